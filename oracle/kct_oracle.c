@@ -1,0 +1,487 @@
+/*
+ * kct_oracle.c -- CPU restatement of oxli's KmerCountTable hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check in
+ * __graft_entry__.py and bench.py's cpu_baseline leg may load it.  The product path
+ * (oxli_amd/, include/kct.h) never links, imports or calls anything in this directory.
+ *
+ * What is restated (all citations relative to /root/reference):
+ *   - KmerCountTable state, consume/count/count_hash/get/add:  src/lib.rs:32-39, 65-81,
+ *     100-104, 145-194, 545-607, 778-837.
+ *   - The arithmetic underneath lives in un-vendored third-party crates and is restated from
+ *     their published algorithms: sourmash 0.23.0 (Cargo.toml:20, Cargo.lock:1200-1203):
+ *     signature::SeqToHashes, encodings::{revcomp, VALID, COMPLEMENT}, _hash_murmur; and
+ *     murmurhash3 0.0.5 (Cargo.lock:628-631): murmurhash3_x64_128 (Appleby's MurmurHash3).
+ *     Call sites in the reference: src/lib.rs:69-76, 576-584.
+ *
+ * Parity pin: the 18 known-answer hashes and the n / len / consumed facts held by the
+ * reference's own tests and docs (tests/golden/reference_kats.json lists each with its
+ * file:line), checked by tests/test_oracle.py.  The Rust reference itself cannot be built
+ * here (no cargo/rustc), so values for k >= 16 (MurmurHash3's 16-byte block loop) are pinned
+ * against an independent canonical MurmurHash3_x64_128 (tests/golden/make_golden.py).
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define ORC_OK 0
+#define ORC_ERR_WRONG_KSIZE 1
+#define ORC_ERR_INVALID_DNA 2
+#define ORC_ERR_BAD_KMER 3
+#define ORC_ERR_KSIZE_MISMATCH 4
+#define ORC_ERR_NOMEM 5
+
+/* ------------------------------------------------------------------------------------------
+ * MurmurHash3_x64_128, low 64 bits.  murmurhash3 0.0.5 `murmurhash3_x64_128(bytes, seed)`;
+ * sourmash `_hash_murmur(kmer, seed)` keeps `.0` (h1).  Used by lib.rs:69-76 / 576-584 with
+ * seed 42.
+ * ---------------------------------------------------------------------------------------- */
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+static inline uint64_t fmix64(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+
+static inline uint64_t load_le64(const uint8_t *p) {
+    uint64_t v = 0;
+    for (int i = 7; i >= 0; --i) v = (v << 8) | p[i];
+    return v;
+}
+
+uint64_t orc_murmur64(const uint8_t *data, size_t len, uint64_t seed) {
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    uint64_t h1 = seed, h2 = seed;
+    size_t nblocks = len / 16;
+    for (size_t i = 0; i < nblocks; ++i) {
+        uint64_t k1 = load_le64(data + 16 * i), k2 = load_le64(data + 16 * i + 8);
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    const uint8_t *tail = data + 16 * nblocks;
+    uint64_t k1 = 0, k2 = 0;
+    size_t rem = len & 15;
+    if (rem > 8) {
+        for (size_t i = rem; i-- > 8;) k2 = (k2 << 8) | tail[i];
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    }
+    if (rem > 0) {
+        size_t top = rem > 8 ? 8 : rem;
+        for (size_t i = top; i-- > 0;) k1 = (k1 << 8) | tail[i];
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    }
+    h1 ^= (uint64_t)len; h2 ^= (uint64_t)len;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2;
+    return h1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * sourmash encodings: VALID (only A C G T after upper-casing), COMPLEMENT / revcomp
+ * (A<->T, C<->G, N->N, everything else -> 0).
+ * ---------------------------------------------------------------------------------------- */
+static inline int valid_base(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+
+static inline uint8_t complement(uint8_t c) {
+    switch (c) {
+        case 'A': return 'T';
+        case 'T': return 'A';
+        case 'C': return 'G';
+        case 'G': return 'C';
+        case 'N': return 'N';
+        default: return 0;
+    }
+}
+
+static inline uint8_t ascii_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+
+/* ------------------------------------------------------------------------------------------
+ * sourmash SeqToHashes (DNA branch) as driven by lib.rs:576-600.
+ * State mirrors the crate's iterator: upper-cased copy made at construction, full-sequence
+ * reverse complement made on the first step, validity checked incrementally from
+ * max(kmer_index, last_position_check).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint8_t *seq;   /* upper-cased copy */
+    uint8_t *rc;    /* reverse complement of the whole sequence (lazy) */
+    size_t len, k, kmer_index, max_index, last_check;
+    int force;
+    uint64_t seed;
+} seq_iter;
+
+static int iter_init(seq_iter *it, const uint8_t *s, size_t len, size_t k, int force, uint64_t seed) {
+    it->seq = (uint8_t *)malloc(len ? len : 1);
+    if (!it->seq) return ORC_ERR_NOMEM;
+    for (size_t i = 0; i < len; ++i) it->seq[i] = ascii_upper(s[i]);
+    it->rc = NULL;
+    it->len = len; it->k = k; it->kmer_index = 0; it->last_check = 0;
+    it->max_index = len >= k ? len - k + 1 : 0;
+    it->force = force; it->seed = seed;
+    return ORC_OK;
+}
+
+static void iter_free(seq_iter *it) { free(it->seq); free(it->rc); }
+
+/* returns 0 = end, 1 = Ok(*out), 2 = Err(InvalidDNA) */
+static int iter_next(seq_iter *it, uint64_t *out) {
+    if (it->kmer_index >= it->max_index) return 0;
+    if (!it->rc) {
+        it->rc = (uint8_t *)malloc(it->len ? it->len : 1);
+        for (size_t i = 0; i < it->len; ++i) it->rc[i] = complement(it->seq[it->len - 1 - i]);
+    }
+    size_t i = it->kmer_index, k = it->k;
+    size_t j0 = i > it->last_check ? i : it->last_check;
+    for (size_t j = j0; j < i + k; ++j) {
+        if (!valid_base(it->seq[j])) {
+            if (!it->force) return 2;
+            it->kmer_index += 1;
+            *out = 0;
+            return 1;
+        }
+        it->last_check += 1;
+    }
+    const uint8_t *fw = it->seq + i;
+    const uint8_t *rv = it->rc + (it->len - k - i);
+    const uint8_t *canon = memcmp(fw, rv, k) <= 0 ? fw : rv;
+    *out = orc_murmur64(canon, k, it->seed);
+    it->kmer_index += 1;
+    return 1;
+}
+
+/* Per-window hashes of `seq` (0 for a skipped window when force).  Returns the number of
+ * values written (<= cap); *err = 1 if iteration stopped on an invalid window (force == 0). */
+size_t orc_seq_to_hashes(const char *seq, size_t len, size_t k, int force, uint64_t *out, size_t cap, int *err) {
+    seq_iter it;
+    *err = 0;
+    if (iter_init(&it, (const uint8_t *)seq, len, k, force, 42) != ORC_OK) { *err = 2; return 0; }
+    size_t n = 0;
+    uint64_t h;
+    int r;
+    while ((r = iter_next(&it, &h)) != 0) {
+        if (r == 2) { *err = 1; break; }
+        if (n < cap) out[n] = h;
+        ++n;
+    }
+    iter_free(&it);
+    return n;
+}
+
+/* lib.rs:65-81 hash_kmer: `(kmer.len() as u8) != ksize` -> "wrong ksize"; else first item of
+ * SeqToHashes(force = false). */
+int orc_hash_kmer(const char *kmer, size_t len, uint8_t ksize, uint64_t *out) {
+    if ((uint8_t)len != ksize) return ORC_ERR_WRONG_KSIZE;
+    seq_iter it;
+    if (iter_init(&it, (const uint8_t *)kmer, len, ksize, 0, 42) != ORC_OK) return ORC_ERR_NOMEM;
+    int r = iter_next(&it, out);
+    iter_free(&it);
+    return r == 1 ? ORC_OK : ORC_ERR_INVALID_DNA;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * u64 -> u64 map standing in for Rust's std HashMap (hashbrown + SipHash-1-3, lib.rs:3,32-33):
+ * SipHash-1-3 of the key with per-table random keys, open addressing, growth by doubling at
+ * 7/8 load.  An occupancy byte array lets key 0 be stored (count_hash(0) is legal, lib.rs:100).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t *keys, *vals;
+    uint8_t *used;
+    size_t cap, len; /* cap is a power of two or 0 */
+    uint64_t k0, k1;
+} u64map;
+
+#define SIPROUND(v0, v1, v2, v3)                                                   \
+    do {                                                                           \
+        v0 += v1; v1 = rotl64(v1, 13); v1 ^= v0; v0 = rotl64(v0, 32);              \
+        v2 += v3; v3 = rotl64(v3, 16); v3 ^= v2;                                   \
+        v0 += v3; v3 = rotl64(v3, 21); v3 ^= v0;                                   \
+        v2 += v1; v1 = rotl64(v1, 17); v1 ^= v2; v2 = rotl64(v2, 32);              \
+    } while (0)
+
+static inline uint64_t siphash13_u64(uint64_t k0, uint64_t k1, uint64_t m) {
+    uint64_t v0 = k0 ^ 0x736f6d6570736575ULL, v1 = k1 ^ 0x646f72616e646f6dULL;
+    uint64_t v2 = k0 ^ 0x6c7967656e657261ULL, v3 = k1 ^ 0x7465646279746573ULL;
+    v3 ^= m; SIPROUND(v0, v1, v2, v3); v0 ^= m;
+    uint64_t b = (uint64_t)8 << 56;
+    v3 ^= b; SIPROUND(v0, v1, v2, v3); v0 ^= b;
+    v2 ^= 0xff;
+    SIPROUND(v0, v1, v2, v3); SIPROUND(v0, v1, v2, v3); SIPROUND(v0, v1, v2, v3);
+    return v0 ^ v1 ^ v2 ^ v3;
+}
+
+static void map_init(u64map *m, uint64_t seed) {
+    memset(m, 0, sizeof *m);
+    m->k0 = 0x0706050403020100ULL ^ seed;
+    m->k1 = 0x0f0e0d0c0b0a0908ULL ^ (seed * 0x9e3779b97f4a7c15ULL);
+}
+
+static void map_free(u64map *m) { free(m->keys); free(m->vals); free(m->used); memset(m, 0, sizeof *m); }
+
+static uint64_t *map_slot(u64map *m, uint64_t key, int *fresh);
+
+static int map_grow(u64map *m) {
+    u64map n = *m;
+    n.cap = m->cap ? m->cap * 2 : 4;
+    n.len = 0;
+    n.keys = (uint64_t *)malloc(n.cap * sizeof(uint64_t));
+    n.vals = (uint64_t *)malloc(n.cap * sizeof(uint64_t));
+    n.used = (uint8_t *)calloc(n.cap, 1);
+    if (!n.keys || !n.vals || !n.used) return ORC_ERR_NOMEM;
+    for (size_t i = 0; i < m->cap; ++i)
+        if (m->used[i]) {
+            int fresh;
+            *map_slot(&n, m->keys[i], &fresh) = m->vals[i];
+        }
+    free(m->keys); free(m->vals); free(m->used);
+    *m = n;
+    return ORC_OK;
+}
+
+/* find-or-insert (value initialised to 0 when fresh) */
+static uint64_t *map_slot(u64map *m, uint64_t key, int *fresh) {
+    if ((m->len + 1) * 8 > m->cap * 7) map_grow(m);
+    size_t mask = m->cap - 1, i = (size_t)siphash13_u64(m->k0, m->k1, key) & mask;
+    while (m->used[i]) {
+        if (m->keys[i] == key) { *fresh = 0; return &m->vals[i]; }
+        i = (i + 1) & mask;
+    }
+    m->used[i] = 1; m->keys[i] = key; m->vals[i] = 0; m->len++;
+    *fresh = 1;
+    return &m->vals[i];
+}
+
+static uint64_t map_get(const u64map *m, uint64_t key) {
+    if (!m->cap) return 0;
+    size_t mask = m->cap - 1, i = (size_t)siphash13_u64(m->k0, m->k1, key) & mask;
+    while (m->used[i]) {
+        if (m->keys[i] == key) return m->vals[i];
+        i = (i + 1) & mask;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * KmerCountTable (lib.rs:32-39) -- counts, ksize, consumed.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct orc_table {
+    u64map counts;
+    uint8_t ksize;
+    uint64_t consumed;
+} orc_table;
+
+orc_table *orc_new(uint8_t ksize) {
+    static uint64_t ctr = 0;
+    orc_table *t = (orc_table *)calloc(1, sizeof *t);
+    if (!t) return NULL;
+    map_init(&t->counts, ++ctr);
+    t->ksize = ksize;
+    return t;
+}
+
+void orc_free(orc_table *t) { if (t) { map_free(&t->counts); free(t); } }
+
+/* lib.rs:100-104 */
+uint64_t orc_count_hash(orc_table *t, uint64_t h) {
+    int fresh;
+    uint64_t *v = map_slot(&t->counts, h, &fresh);
+    return ++*v;
+}
+
+/* lib.rs:185-188 */
+uint64_t orc_get_hash(const orc_table *t, uint64_t h) { return map_get(&t->counts, h); }
+
+/* lib.rs:145-167 (store_kmers == false).  *count_out = new count. */
+int orc_count(orc_table *t, const char *kmer, size_t len, uint64_t *count_out) {
+    if ((uint8_t)len != t->ksize) return ORC_ERR_WRONG_KSIZE;
+    uint64_t h;
+    int st = orc_hash_kmer(kmer, len, t->ksize, &h);
+    if (st != ORC_OK) return st;
+    *count_out = orc_count_hash(t, h);
+    t->consumed += len;
+    return ORC_OK;
+}
+
+/* lib.rs:170-182 */
+int orc_get(const orc_table *t, const char *kmer, size_t len, uint64_t *count_out) {
+    if ((uint8_t)len != t->ksize) return ORC_ERR_WRONG_KSIZE;
+    uint64_t h;
+    int st = orc_hash_kmer(kmer, len, t->ksize, &h);
+    if (st != ORC_OK) return st; /* the reference panics here (lib.rs:176) */
+    *count_out = map_get(&t->counts, h);
+    return ORC_OK;
+}
+
+/* lib.rs:545-607, plain branch (574-601).  On ORC_ERR_BAD_KMER *n_out holds the number of
+ * k-mers counted before the bad window, they stay counted and `consumed` is unchanged. */
+int orc_consume(orc_table *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out) {
+    seq_iter it;
+    uint64_t n = 0, h;
+    int r, st = ORC_OK;
+    if (iter_init(&it, (const uint8_t *)seq, len, t->ksize, skip_bad, 42) != ORC_OK) return ORC_ERR_NOMEM;
+    while ((r = iter_next(&it, &h)) != 0) {
+        if (r == 2) { st = ORC_ERR_BAD_KMER; break; }
+        if (h == 0) continue;
+        orc_count_hash(t, h);
+        ++n;
+    }
+    iter_free(&it);
+    *n_out = n;
+    if (st == ORC_OK) t->consumed += len;
+    return st;
+}
+
+uint64_t orc_len(const orc_table *t) { return t->counts.len; }
+uint64_t orc_consumed(const orc_table *t) { return t->consumed; }
+uint8_t orc_ksize(const orc_table *t) { return t->ksize; }
+
+/* lib.rs:536-539 */
+uint64_t orc_sum_counts(const orc_table *t) {
+    uint64_t s = 0;
+    for (size_t i = 0; i < t->counts.cap; ++i) if (t->counts.used[i]) s += t->counts.vals[i];
+    return s;
+}
+
+typedef struct { uint64_t k, v; } kv;
+static int kv_cmp(const void *a, const void *b) {
+    uint64_t x = ((const kv *)a)->k, y = ((const kv *)b)->k;
+    return x < y ? -1 : x > y;
+}
+
+/* dump(sortkeys=True) (lib.rs:330-381): (hash, count) ascending by hash.  Returns len. */
+uint64_t orc_dump_sorted(const orc_table *t, uint64_t *keys, uint64_t *counts, uint64_t cap) {
+    size_t n = t->counts.len;
+    kv *tmp = (kv *)malloc((n ? n : 1) * sizeof(kv));
+    size_t j = 0;
+    for (size_t i = 0; i < t->counts.cap; ++i)
+        if (t->counts.used[i]) { tmp[j].k = t->counts.keys[i]; tmp[j].v = t->counts.vals[i]; ++j; }
+    qsort(tmp, n, sizeof(kv), kv_cmp);
+    for (size_t i = 0; i < n && i < cap; ++i) { keys[i] = tmp[i].k; counts[i] = tmp[i].v; }
+    free(tmp);
+    return n;
+}
+
+/* lib.rs:778-837 add: per-key sum; (sum of other's counts, keys new to self); consumed sum. */
+int orc_add(orc_table *dst, const orc_table *src, uint64_t *total_added, uint64_t *new_keys) {
+    if (dst->ksize != src->ksize) return ORC_ERR_KSIZE_MISMATCH;
+    uint64_t tot = 0, nk = 0;
+    for (size_t i = 0; i < src->counts.cap; ++i)
+        if (src->counts.used[i]) {
+            int fresh;
+            uint64_t *v = map_slot(&dst->counts, src->counts.keys[i], &fresh);
+            if (*v == 0) ++nk; /* lib.rs:801-803: "new" means current count == 0 */
+            *v += src->counts.vals[i];
+            tot += src->counts.vals[i];
+        }
+    dst->consumed += src->consumed;
+    *total_added = tot; *new_keys = nk;
+    return ORC_OK;
+}
+
+/* add raw (hash, count) pairs -- used by tests to model an owner-side shard merge */
+void orc_add_pairs(orc_table *t, const uint64_t *keys, const uint64_t *counts, uint64_t n) {
+    for (uint64_t i = 0; i < n; ++i) {
+        int fresh;
+        *map_slot(&t->counts, keys[i], &fresh) += counts[i];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic workload (SURVEY.md 8d / DESIGN.md): counter-based so CPU and GPU make the same
+ * bytes.  mix64 = splitmix64's output function applied to (x + golden gamma).
+ * ---------------------------------------------------------------------------------------- */
+static inline uint64_t mix64(uint64_t x) {
+    uint64_t z = x + 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+uint64_t orc_mix64(uint64_t x) { return mix64(x); }
+
+void orc_synth_genome(uint8_t *out, uint64_t G, uint64_t seed_g) {
+    for (uint64_t j = 0; j < G; ++j) out[j] = (uint8_t)"ACGT"[mix64(seed_g + j) & 3];
+}
+
+/* reads [first, first+count) of the stream, each L bases followed by one '\n' separator
+ * (stride L+1) -- the record-separated layout the device consumes. */
+void orc_synth_reads(uint8_t *out, const uint8_t *genome, uint64_t G, uint64_t first, uint64_t count,
+                     uint32_t L, uint64_t seed_r) {
+    for (uint64_t r = 0; r < count; ++r) {
+        uint64_t i = first + r;
+        uint64_t start = mix64(seed_r + 2 * i) % (G - L + 1);
+        int strand = (int)(mix64(seed_r + 2 * i + 1) & 1);
+        uint8_t *dst = out + r * (uint64_t)(L + 1);
+        if (!strand) memcpy(dst, genome + start, L);
+        else for (uint32_t j = 0; j < L; ++j) dst[j] = complement(genome[start + L - 1 - j]);
+        dst[L] = '\n';
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * CPU baseline ("port" of the reference CPU path): one orc_consume per record, exactly as the
+ * README loop does (README.md:96-98); with T threads each thread owns a private table over a
+ * contiguous shard of records and shards are merged with `add` semantics, merge time included.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const uint8_t *reads; uint64_t first, count; uint32_t L; uint8_t k;
+    orc_table *t; uint64_t n;
+} shard_job;
+
+static void *shard_run(void *p) {
+    shard_job *j = (shard_job *)p;
+    j->t = orc_new(j->k);
+    uint64_t n = 0, m;
+    for (uint64_t r = 0; r < j->count; ++r) {
+        orc_consume(j->t, (const char *)(j->reads + (j->first + r) * (uint64_t)(j->L + 1)), j->L, 1, &m);
+        n += m;
+    }
+    j->n = n;
+    return NULL;
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+/* Returns the merged table (caller frees) so the caller can check it; *seconds covers consume
+ * + merge; *kmers = sum of n. */
+orc_table *orc_baseline_consume(const uint8_t *reads, uint64_t nreads, uint32_t L, uint8_t k, int threads,
+                                uint64_t *kmers, double *seconds) {
+    if (threads < 1) threads = 1;
+    shard_job *jobs = (shard_job *)calloc((size_t)threads, sizeof *jobs);
+    pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof *tid);
+    double t0 = now_s();
+    for (int i = 0; i < threads; ++i) {
+        jobs[i].reads = reads; jobs[i].L = L; jobs[i].k = k;
+        jobs[i].first = nreads * (uint64_t)i / (uint64_t)threads;
+        jobs[i].count = nreads * (uint64_t)(i + 1) / (uint64_t)threads - jobs[i].first;
+        if (threads == 1) shard_run(&jobs[i]);
+        else pthread_create(&tid[i], NULL, shard_run, &jobs[i]);
+    }
+    uint64_t n = 0;
+    for (int i = 0; i < threads; ++i) {
+        if (threads > 1) pthread_join(tid[i], NULL);
+        n += jobs[i].n;
+    }
+    orc_table *dst = jobs[0].t;
+    for (int i = 1; i < threads; ++i) {
+        uint64_t a, b;
+        orc_add(dst, jobs[i].t, &a, &b);
+        orc_free(jobs[i].t);
+    }
+    *seconds = now_s() - t0;
+    *kmers = n;
+    free(jobs); free(tid);
+    return dst;
+}
