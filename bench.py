@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/sec through consume (BASELINE.json metric) on N MI355X of one node.
+
+A "step" is one whole job over one batch of synthetic reads already resident in HBM:
+clear the device table, count every k-mer of this rank's reads (kct_consume_device), and -- when
+N > 1 -- the owner-partitioned RCCL all-to-all that turns the per-rank tables into the global
+one (oxli_amd.distributed.merge_across_ranks).  Work per GPU is fixed as N grows (weak scaling):
+rank r counts reads [r*R, (r+1)*R) of the same read stream.
+
+Default workload = BASELINE.json configs[1] ("C2"): R = 1 M reads x 150 bp, k = 21, reads drawn
+from a 5 Mbp synthetic genome (SEED_G 42, SEED_R 1337), device table sized for 5 M distinct keys.
+
+The JSON line also carries
+  roofline     : the dominant kernel (count_windows_kernel), its ALGORITHMIC bytes per launch
+                 (k-mers per launch x (L/(L-k+1) + 24) B) over its average launch
+                 duration measured with HIP events on the table's stream inside the timed region.
+  cpu_baseline : the CPU restatement of the reference path (oracle/, "port") timed on this
+                 host on a bounded sample of the same read stream (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED_G, SEED_R = 42, 1337
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
+    p.add_argument("--read-len", type=int, default=150)
+    p.add_argument("--k", type=int, default=21)
+    p.add_argument("--genome", type=int, default=5_000_000)
+    p.add_argument("--cpu-sample-reads", type=int, default=200_000)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-verify", action="store_true")
+    return p.parse_args()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary (profiles/*.json), else None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(args, log):
+    """Reference-shaped CPU path (oracle 'port') on a bounded sample of the same stream."""
+    import oracle
+    try:
+        oracle.build(native=True)
+        native = True
+    except Exception:  # noqa: BLE001 -- fall back to the portable build that travelled with the repo
+        native = False
+    genome = oracle.synth_genome(args.genome, SEED_G)
+    cores = len(os.sched_getaffinity(0))
+    n1 = min(args.cpu_sample_reads, args.reads)
+    reads1 = oracle.synth_reads(genome, 0, n1, args.read_len, SEED_R)
+    _, km1, s1 = oracle.baseline_consume(reads1, args.read_len, args.k, 1, native)
+    nT = min(args.reads, max(n1, n1 * min(cores, 16) // 2))
+    readsT = reads1 if nT == n1 else oracle.synth_reads(genome, 0, nT, args.read_len, SEED_R)
+    tabT, kmT, sT = oracle.baseline_consume(readsT, args.read_len, args.k, cores, native)
+    log(f"cpu baseline: 1 thread {km1 / s1 / 1e6:.2f} Mk-mers/s on {n1} reads; {cores} threads {kmT / sT / 1e6:.2f} Mk-mers/s on {nT} reads")
+    best_multi = kmT / sT
+    out = {"value": max(best_multi, km1 / s1), "unit": "k-mers/s", "cores": cores if best_multi >= km1 / s1 else 1,
+           "kind": "port",
+           "sample": f"first {nT} reads of the same stream (private table per thread + add() merge, merge timed); "
+                     f"1 thread on first {n1} reads: {km1 / s1:.4g} k-mers/s",
+           "value_1thread": km1 / s1, "value_all_cores": best_multi, "native_build": native}
+    return out, (readsT, tabT)
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from oxli_amd import KmerCountTable, _lib
+    from oxli_amd.distributed import global_scalar_sum, merge_across_ranks
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    lib = _lib.load()
+    L, k, R, G = args.read_len, args.k, args.reads, args.genome
+    kmers_per_step = R * (L - k + 1)
+    stream = torch.cuda.current_stream().cuda_stream
+    genome = torch.empty(G, dtype=torch.uint8, device="cuda")
+    reads = torch.empty(R * (L + 1), dtype=torch.uint8, device="cuda")
+    assert lib.kct_synth_genome_device(genome.data_ptr(), G, SEED_G, stream) == 0
+    assert lib.kct_synth_reads_device(reads.data_ptr(), genome.data_ptr(), G, rank * R, R, L, SEED_R, stream) == 0
+    torch.cuda.synchronize()
+
+    table = KmerCountTable(k, capacity=G, device=local)
+    table.set_stream(stream)
+
+    def step():
+        table.clear()
+        n = table.consume_device(reads.data_ptr(), reads.numel(), R * L)
+        if world > 1:
+            merge_across_ranks(table)
+        return n
+
+    for _ in range(args.warmup):
+        step()
+    table.profile(True)
+    table.profile_reset()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    n_total = 0
+    for _ in range(args.steps):
+        n_total += step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = table.profile_read()
+    table.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        n_all = global_scalar_sum(n_total, "cuda")
+    else:
+        n_all = n_total
+    assert n_total == kmers_per_step * args.steps, (n_total, kmers_per_step * args.steps)
+
+    # invariants of the finished job (cheap, outside the timed region)
+    distinct = global_scalar_sum(len(table), "cuda") if world > 1 else len(table)
+    total_counts = global_scalar_sum(table.sum_counts, "cuda") if world > 1 else table.sum_counts
+    assert total_counts == world * kmers_per_step, (total_counts, world * kmers_per_step)
+
+    value = n_all / elapsed
+    b_alg = L / (L - k + 1) + 24.0
+    dom = "count_windows_kernel"
+    launches, ms = prof.get(dom, (0, 0.0))
+    avg_ms = ms / launches if launches else float("nan")
+    kmers_per_launch = kmers_per_step * args.steps / launches if launches else 0
+    achieved = kmers_per_launch * b_alg / (avg_ms * 1e-3) / 1e9 if launches else float("nan")
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "avg_launch_ms": avg_ms,
+                "launches": launches, "alg_bytes_per_kmer": b_alg, "kmers_per_launch": kmers_per_launch,
+                "kernels_ms": {n: round(v[1], 4) for n, v in prof.items()}}
+
+    result = {
+        "metric": "k-mers/sec (consume) at k=%d, %d bp reads" % (k, L),
+        "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"C2: {R} x {L} bp synthetic reads per GPU, k={k}, genome {G} bp (seed {SEED_G}/{SEED_R}), "
+                               f"device hash table in HBM ({table.capacity} slots x 16 B)",
+                   "reads_per_gpu": R, "read_len": L, "k": k, "genome": G, "distinct_kmers": distinct,
+                   "step": "clear table + consume all reads" + (" + RCCL owner all-to-all merge" if world > 1 else "")},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        base, (sample_reads, sample_table) = cpu_baseline(args, log)
+        result["cpu_baseline"] = base
+        result["speedup_vs_cpu_baseline"] = value / base["value"]
+        if not args.no_verify:
+            # the same sample through the GPU must give the oracle's table bit for bit
+            ns = sample_reads.shape[0]
+            table.clear()
+            n = table.consume_device(reads.data_ptr(), ns * (L + 1), ns * L)
+            dk, dc = table.dump_arrays(1)
+            rk, rc = sample_table.dump_arrays()
+            ok = n == ns * (L - k + 1) and np.array_equal(dk, rk) and np.array_equal(dc, rc)
+            result["verified_vs_oracle"] = bool(ok)
+            assert ok, "GPU table differs from the CPU oracle on the baseline sample"
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+/*
+ * kct.h -- C ABI of the MI355X k-mer counting engine (libkct_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of oxli-bio/oxli: KmerCountTable's
+ * count / consume / get family (reference src/lib.rs:41-194, 545-607, 778-837).  Each entry
+ * point below names the reference interface it replaces.  A Rust `KmerCountTable` would bind
+ * these with `extern "C"` (INTEGRATION.md shows the stub); in this repo the binding is the
+ * ctypes class oxli_amd.KmerCountTable.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  Host pointers unless the name says `_device`.
+ *   - Every function returns a kct_status; results come back through out-parameters.
+ *     Nothing throws or aborts across the boundary.
+ *   - A kct_table is NOT thread-safe: one caller at a time, like the reference's `&mut self`
+ *     under the GIL (lib.rs:546).  All reads observe all earlier writes on the same handle.
+ *   - Input buffers are borrowed for the duration of the call only.
+ *   - There is no CPU fallback: without a usable gfx950 device every call that needs one
+ *     fails with KCT_ERR_NO_DEVICE / KCT_ERR_HIP.
+ */
+#ifndef KCT_H
+#define KCT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kct_table kct_table;
+
+typedef enum kct_status {
+    KCT_OK = 0,
+    KCT_ERR_WRONG_KSIZE = 1,    /* lib.rs:67 "wrong ksize"; lib.rs:147,172 ValueError             */
+    KCT_ERR_INVALID_DNA = 2,    /* lib.rs:79 hash_kmer on a non-ACGT k-mer (RuntimeError)          */
+    KCT_ERR_BAD_KMER = 3,       /* lib.rs:593-596 consume(skip_bad_kmers=False) hit a bad window   */
+    KCT_ERR_KSIZE_MISMATCH = 4, /* lib.rs:780-784 add() of tables with different ksize             */
+    KCT_ERR_NOMEM = 5,          /* host or device allocation failed                                */
+    KCT_ERR_HIP = 6,            /* a HIP runtime call failed; see kct_last_error()                 */
+    KCT_ERR_ARG = 7,            /* null / misaligned / out-of-range argument                       */
+    KCT_ERR_NO_DEVICE = 8       /* no gfx950 device visible                                        */
+} kct_status;
+
+/* Text of the most recent failure on this thread ("" if none). */
+const char *kct_last_error(void);
+
+/* Number of visible HIP devices (0 on a CPU-only machine; never an error). */
+int kct_device_count(void);
+
+/* ---- lifetime ---------------------------------------------------------------------------
+ * KmerCountTable::new(ksize, store_kmers=false)                              lib.rs:44-62
+ * `capacity_hint` = expected number of distinct k-mers (0 = default); the table grows by
+ * itself, the hint only avoids early re-hashes.  `device` = HIP device ordinal. */
+kct_status kct_create(uint8_t ksize, uint64_t capacity_hint, int device, kct_table **out);
+void kct_destroy(kct_table *t);
+
+/* Forget all counts and `consumed`; keeps the allocation. (No reference counterpart: a fresh
+ * KmerCountTable.) */
+kct_status kct_clear(kct_table *t);
+
+/* Ensure room for `distinct` keys without further growth. */
+kct_status kct_reserve(kct_table *t, uint64_t distinct);
+
+/* ---- hashing ----------------------------------------------------------------------------
+ * KmerCountTable::hash_kmer(kmer)                                            lib.rs:65-81
+ * WRONG_KSIZE if (uint8_t)len != ksize (the reference compares `len as u8`), INVALID_DNA if
+ * the first ksize bytes are not all ACGT/acgt. */
+kct_status kct_hash_kmer(kct_table *t, const char *kmer, size_t len, uint64_t *hash_out);
+
+/* sourmash SeqToHashes as consume drives it (lib.rs:576-600): one value per k-window of
+ * `seq`, 0 for a window holding a non-ACGT byte.  Writes min(windows, cap) values, returns
+ * the window count in *n_windows and the index of the first bad window in *first_bad
+ * (== *n_windows if none). */
+kct_status kct_hash_windows(kct_table *t, const char *seq, size_t len, uint64_t *hashes_out, size_t cap,
+                            uint64_t *n_windows, uint64_t *first_bad);
+
+/* ---- point updates and lookups ------------------------------------------------------------
+ * count_hash(hashval) -> new count                                           lib.rs:100-104
+ * count(kmer) -> new count; consumed += len                                  lib.rs:145-167
+ * get(kmer) / get_hash(hashval) / get_hash_array(hash_keys)                  lib.rs:170-194  */
+kct_status kct_count_hash(kct_table *t, uint64_t hash, uint64_t *count_out);
+kct_status kct_count(kct_table *t, const char *kmer, size_t len, uint64_t *count_out);
+kct_status kct_get(kct_table *t, const char *kmer, size_t len, uint64_t *count_out);
+kct_status kct_get_hash(kct_table *t, uint64_t hash, uint64_t *count_out);
+kct_status kct_get_hash_array(kct_table *t, const uint64_t *hashes, size_t n, uint64_t *counts_out);
+
+/* __setitem__(kmer, count) is built from this                                lib.rs:675-681 */
+kct_status kct_set_hash(kct_table *t, uint64_t hash, uint64_t count);
+
+/* ---- bulk ingest: the hot path -------------------------------------------------------------
+ * consume(seq, skip_bad_kmers=true) -> n                                     lib.rs:545-607
+ * *n_out = k-mers counted (valid windows whose hash is not 0).  With skip_bad == 0 and a bad
+ * window present: returns KCT_ERR_BAD_KMER, *n_out = k-mers counted before it (they stay
+ * counted), `consumed` unchanged -- the message is "bad k-mer encountered at position {n}". */
+kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out);
+
+/* The reference is called once per FASTA/FASTQ record (README.md:96-98).  This is the same
+ * loop in one call: record r is bytes[offsets[r] .. offsets[r+1]); k-mers never span records.
+ * *n_total = sum of the per-record n.  With skip_bad == 0 the call stops at the first record
+ * holding a bad window exactly as the per-record loop would: KCT_ERR_BAD_KMER, *bad_record =
+ * its index, *bad_position = the n of that record's own consume ("bad k-mer encountered at
+ * position {n}"), records before it are fully counted, its windows before the bad one are
+ * counted, later records are untouched, and `consumed` covers only the records before it.
+ * Without an error *bad_record = nrec.  bad_record / bad_position may be NULL. */
+kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *offsets, size_t nrec, int skip_bad,
+                             uint64_t *n_total, uint64_t *bad_record, uint64_t *bad_position);
+
+/* Same, for input already resident in HBM: `d_stream` is a 16-byte-aligned device pointer to
+ * `nbytes` bytes in which records are separated by at least one non-ACGT byte (e.g. '\n');
+ * skip_bad semantics.  `consumed` grows by `consumed_bytes` (the caller knows the record
+ * lengths).  Runs on the table's stream and returns after it completes. */
+kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes,
+                              uint64_t *n_total);
+
+/* ---- table attributes ---------------------------------------------------------------------
+ * __len__ lib.rs:665-667; sum_counts lib.rs:536-539; consumed lib.rs:530-533; ksize lib.rs:34 */
+kct_status kct_len(kct_table *t, uint64_t *out);
+kct_status kct_sum_counts(kct_table *t, uint64_t *out);
+kct_status kct_consumed(kct_table *t, uint64_t *out);
+kct_status kct_add_consumed(kct_table *t, uint64_t delta);
+uint8_t kct_ksize(const kct_table *t);
+kct_status kct_capacity(kct_table *t, uint64_t *slots_out);
+
+/* ---- dump / merge ---------------------------------------------------------------------------
+ * dump(file=None, sortcounts, sortkeys) -> [(hash, count)]                   lib.rs:330-381
+ * order: 0 = unspecified (the reference's HashMap order is unspecified too), 1 = by hash,
+ * 2 = by (count, hash).  Writes min(len, cap) pairs; *n_out = len. */
+kct_status kct_dump(kct_table *t, uint64_t *hashes_out, uint64_t *counts_out, size_t cap, int order, uint64_t *n_out);
+
+/* add(other) -> (total_counts_added, new_keys_added); consumed += other.consumed
+ *                                                                            lib.rs:778-837 */
+kct_status kct_add(kct_table *dst, kct_table *src, uint64_t *total_added, uint64_t *new_keys);
+
+/* The two halves of add() for shards that live on different GPUs / ranks: compact the table
+ * into caller-owned device arrays, and fold (hash, count) pairs into a table with add()'s
+ * tallies.  `d_*` are device pointers on the table's device. */
+kct_status kct_export_device(kct_table *t, void *d_hashes, void *d_counts, size_t cap, uint64_t *n_out);
+kct_status kct_merge_device(kct_table *t, const void *d_hashes, const void *d_counts, size_t n,
+                            uint64_t *total_added, uint64_t *new_keys);
+kct_status kct_merge_host(kct_table *t, const uint64_t *hashes, const uint64_t *counts, size_t n,
+                          uint64_t *total_added, uint64_t *new_keys);
+
+/* ---- streams and in-library kernel timing ----------------------------------------------------
+ * The table owns a HIP stream; a caller that has its own (e.g. torch's current stream) can
+ * hand it over as a `hipStream_t` cast to void*. */
+kct_status kct_set_stream(kct_table *t, void *hip_stream);
+void *kct_get_stream(kct_table *t);
+
+/* When enabled, every kernel launch on this table is bracketed by HIP events on the table's
+ * stream.  kct_profile_read(i) returns the i-th kernel name seen since the last reset with
+ * its launch count and summed device time; KCT_ERR_ARG past the end. */
+kct_status kct_profile_enable(kct_table *t, int on);
+kct_status kct_profile_reset(kct_table *t);
+kct_status kct_profile_read(kct_table *t, int index, char *name_out, size_t name_cap, uint64_t *launches,
+                            double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KCT_H */

@@ -1,0 +1,32 @@
+/*
+ * kct_synth.h -- synthetic read generator on the device (measurement infrastructure, exported
+ * by the same libkct_hip.so).  Not part of the reference's interface: it exists so that
+ * bench.py can put BASELINE.json's workloads in HBM without pushing 150 MB - 15 GB over PCIe,
+ * byte-identical to what oracle/kct_oracle.c (orc_synth_genome / orc_synth_reads) makes on the
+ * CPU (tests/test_gpu_parity.py checks that).
+ *
+ *   genome[j] = "ACGT"[ mix64(seed_g + j) & 3 ]
+ *   read i    : start  = mix64(seed_r + 2i)     mod (G - L + 1)
+ *               strand = mix64(seed_r + 2i + 1) & 1      (1 = reverse complement)
+ *               L bases followed by one '\n'  (stride L + 1)
+ *   mix64(x)  = splitmix64 output function of (x + 0x9e3779b97f4a7c15)
+ */
+#ifndef KCT_SYNTH_H
+#define KCT_SYNTH_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* d_genome: device buffer of G bytes.  stream: hipStream_t as void* (NULL = default stream). Returns 0 on success. */
+int kct_synth_genome_device(void *d_genome, uint64_t G, uint64_t seed_g, void *stream);
+
+/* d_reads: device buffer of count * (L + 1) bytes, reads [first, first + count) of the stream. */
+int kct_synth_reads_device(void *d_reads, const void *d_genome, uint64_t G, uint64_t first, uint64_t count, uint32_t L,
+                           uint64_t seed_r, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,87 @@
+"""Loads libkct_hip.so (the C ABI of include/kct.h) with ctypes and declares every entry point.
+
+There is no fallback: if the library is missing this raises, and if no gfx950 device is present
+``kct_create`` fails with KCT_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libkct_hip.so")
+
+KCT_OK = 0
+KCT_ERR_WRONG_KSIZE = 1
+KCT_ERR_INVALID_DNA = 2
+KCT_ERR_BAD_KMER = 3
+KCT_ERR_KSIZE_MISMATCH = 4
+KCT_ERR_NOMEM = 5
+KCT_ERR_HIP = 6
+KCT_ERR_ARG = 7
+KCT_ERR_NO_DEVICE = 8
+
+u8, u64, sz, vp, cp, ci = C.c_uint8, C.c_uint64, C.c_size_t, C.c_void_p, C.c_char_p, C.c_int
+u64p = C.POINTER(C.c_uint64)
+
+# name -> (restype, argtypes); mirrors include/kct.h one to one (tests/test_abi.py checks both ways)
+SIGNATURES = {
+    "kct_last_error": (cp, []),
+    "kct_device_count": (ci, []),
+    "kct_create": (ci, [u8, u64, ci, C.POINTER(vp)]),
+    "kct_destroy": (None, [vp]),
+    "kct_clear": (ci, [vp]),
+    "kct_reserve": (ci, [vp, u64]),
+    "kct_hash_kmer": (ci, [vp, vp, sz, u64p]),
+    "kct_hash_windows": (ci, [vp, vp, sz, vp, sz, u64p, u64p]),
+    "kct_count_hash": (ci, [vp, u64, u64p]),
+    "kct_count": (ci, [vp, vp, sz, u64p]),
+    "kct_get": (ci, [vp, vp, sz, u64p]),
+    "kct_get_hash": (ci, [vp, u64, u64p]),
+    "kct_get_hash_array": (ci, [vp, vp, sz, vp]),
+    "kct_set_hash": (ci, [vp, u64, u64]),
+    "kct_consume": (ci, [vp, vp, sz, ci, u64p]),
+    "kct_consume_batch": (ci, [vp, vp, vp, sz, ci, u64p, u64p, u64p]),
+    "kct_consume_device": (ci, [vp, vp, sz, u64, u64p]),
+    "kct_len": (ci, [vp, u64p]),
+    "kct_sum_counts": (ci, [vp, u64p]),
+    "kct_consumed": (ci, [vp, u64p]),
+    "kct_add_consumed": (ci, [vp, u64]),
+    "kct_ksize": (u8, [vp]),
+    "kct_capacity": (ci, [vp, u64p]),
+    "kct_dump": (ci, [vp, vp, vp, sz, ci, u64p]),
+    "kct_add": (ci, [vp, vp, u64p, u64p]),
+    "kct_export_device": (ci, [vp, vp, vp, sz, u64p]),
+    "kct_merge_device": (ci, [vp, vp, vp, sz, u64p, u64p]),
+    "kct_merge_host": (ci, [vp, vp, vp, sz, u64p, u64p]),
+    "kct_set_stream": (ci, [vp, vp]),
+    "kct_get_stream": (vp, [vp]),
+    "kct_profile_enable": (ci, [vp, ci]),
+    "kct_profile_reset": (ci, [vp]),
+    "kct_profile_read": (ci, [vp, ci, vp, sz, u64p, C.POINTER(C.c_double)]),
+    # include/kct_synth.h (measurement infrastructure)
+    "kct_synth_genome_device": (ci, [vp, u64, u64, vp]),
+    "kct_synth_reads_device": (ci, [vp, vp, u64, u64, u64, C.c_uint32, u64, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the ctypes handle of libkct_hip.so; raises ImportError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  oxli_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export what kct.h declares
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    msg = load().kct_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""

@@ -1,0 +1,280 @@
+// kernels.h -- gfx950 kernels of the consume path.
+//
+// Input layout ("record stream"): the bytes of all records of a batch back to back, each record
+// followed by at least one byte that is not A/C/G/T (the host packer writes '\n').  A k-window
+// is good iff its k bytes are all ACGT (either case), so windows that would span two records
+// are bad by construction and no offsets are needed on the device.
+//
+// Decomposition: one 256-thread workgroup owns a tile of kTile consecutive window START
+// positions.  It stages kTile + k - 1 bytes in LDS with 16-byte coalesced global loads, then
+// every thread walks kWPT consecutive windows with a rolling 2-bit forward word and a rolling
+// reverse-complement word (k - 1 warm-up steps).  Long reads need nothing special: a 10 kbp or
+// 350 kbp record is simply many tiles.
+#pragma once
+#include "kmer_device.h"
+#include "table_device.h"
+
+namespace kct {
+
+constexpr int kBlock = 256;
+constexpr int kWPT = 32;                  // windows per thread
+constexpr int kTile = kBlock * kWPT;      // window start positions per workgroup (8192)
+constexpr int kHaloMax = 256;             // k - 1 <= 254
+constexpr int kCounterShards = 64;        // per-launch tallies are spread over this many 128-B lines
+constexpr int kCounterStride = 16;        // u64 words per shard (128 B)
+enum { CTR_COUNTED = 0, CTR_NEWKEYS = 1, CTR_TOTAL_ADDED = 2, CTR_NEW_BY_ZERO = 3 };
+
+__device__ __forceinline__ u64 wave_sum(u64 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;  // valid in lane 0
+}
+
+// Stage stream[tile_base, tile_base + kTile + k - 1) into LDS; bytes past `nbytes` read as 0.
+__device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ stream, u64 nbytes, u64 tile_base, int k,
+                                           unsigned char *lds) {
+    const int nchunks = (kTile + k - 1 + 15) >> 4;  // <= 512 + 16
+    for (int c = threadIdx.x; c < nchunks; c += kBlock) {
+        const u64 off = tile_base + 16ULL * (u64)c;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (off + 16 <= nbytes) {
+            v = *reinterpret_cast<const uint4 *>(stream + off);
+        } else if (off < nbytes) {
+            unsigned char tmp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tmp[i] = (off + i < nbytes) ? stream[off + i] : (unsigned char)0;
+            v = *reinterpret_cast<uint4 *>(tmp);
+        }
+        *reinterpret_cast<uint4 *>(lds + 16 * c) = v;
+    }
+    __syncthreads();
+}
+
+// Walks this thread's kWPT windows of the staged tile and calls sink(j, good, hash) for each,
+// j = 0..kWPT-1 (window start = tile_base + threadIdx.x * kWPT + j).  KC > 0 fixes k at compile
+// time; KW = 64-bit words of the packed k-mer (k <= 32 * KW).
+template <int KW, int KC, class Sink>
+__device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, int k_rt, Sink &&sink) {
+    const int k = KC > 0 ? KC : k_rt;
+    const unsigned char *p = lds + threadIdx.x * kWPT;
+    Packed<KW> fw, rc;
+#pragma unroll
+    for (int i = 0; i < KW; ++i) { fw.w[i] = 0; rc.w[i] = 0; }
+    int run = 0;  // length of the run of valid bases ending at the current byte
+    for (int j = 0; j < k - 1; ++j) {
+        u32 code = base_code(p[j]);
+        bool ok = code < 4;
+        push_fw(fw, code & 3u);
+        push_rc(rc, 3u - (code & 3u), k);
+        run = ok ? run + 1 : 0;
+    }
+#pragma unroll 4
+    for (int j = 0; j < kWPT; ++j) {
+        u32 code = base_code(p[k - 1 + j]);
+        bool ok = code < 4;
+        push_fw(fw, code & 3u);
+        mask_k(fw, k);
+        push_rc(rc, 3u - (code & 3u), k);
+        run = ok ? run + 1 : 0;
+        const bool good = run >= k;
+        u64 h = 0;
+        if (good) {
+            Packed<KW> c = less_eq(fw, rc) ? fw : rc;
+            left_align(c, k);
+            h = hash_packed(c, k);
+        }
+        sink(j, good, h);
+    }
+}
+
+// Any k (used for k > 64): validity by run length, canonical choice and hashing bytewise.
+template <class Sink>
+__device__ __forceinline__ void walk_windows_bytes(const unsigned char *lds, int k, Sink &&sink) {
+    const unsigned char *p = lds + threadIdx.x * kWPT;
+    int run = 0;
+    for (int j = 0; j < k - 1; ++j) run = base_code(p[j]) < 4 ? run + 1 : 0;
+    for (int j = 0; j < kWPT; ++j) {
+        run = base_code(p[k - 1 + j]) < 4 ? run + 1 : 0;
+        const bool good = run >= k;
+        u64 h = good ? hash_bytes_canonical(p + j, k) : 0;
+        sink(j, good, h);
+    }
+}
+
+template <int KW, int KC, class Sink>
+__device__ __forceinline__ void walk_windows(const unsigned char *lds, int k, Sink &&sink) {
+    if constexpr (KW == 0) walk_windows_bytes(lds, k, sink);
+    else walk_windows_packed<KW, KC>(lds, k, sink);
+}
+
+// ---- hash-only kernel: SeqToHashes as consume drives it (lib.rs:576-600) ------------------------
+// out[p] = hash of the window starting at p (0 if bad), p in [0, nwindows);
+// *first_bad = min index of a bad window (left untouched if none).
+template <int KW, int KC>
+__global__ __launch_bounds__(kBlock) void hash_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
+                                                              u64 nwindows, u64 *__restrict__ out, u64 *first_bad) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kTile + kHaloMax + 16];
+    const u64 tile_base = (u64)blockIdx.x * kTile;
+    stage_tile(stream, nbytes, tile_base, k, lds);
+    const u64 p0 = tile_base + (u64)threadIdx.x * kWPT;
+    u64 my_bad = ~0ULL;
+    walk_windows<KW, KC>(lds, k, [&](int j, bool good, u64 h) {
+        const u64 p = p0 + j;
+        if (p < nwindows) {
+            out[p] = good ? h : 0;
+            if (!good && my_bad == ~0ULL) my_bad = p;
+        }
+    });
+    if (my_bad != ~0ULL) atomicMin(first_bad, my_bad);
+}
+
+// ---- validity-only kernel for skip_bad_kmers == False over a multi-record stream -------------------
+// Finds the smallest stream position q of an invalid byte that lies INSIDE a record of length
+// >= k (separators and records too short to have a window do not raise, lib.rs:593-596 only
+// fires for a window that exists).  rec_off[r] = stream offset of record r, rec_off[nrec] = end;
+// record r spans [rec_off[r], rec_off[r+1] - 1) and is followed by its separator byte.
+__global__ __launch_bounds__(kBlock) void first_bad_byte_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
+                                                                const u64 *__restrict__ rec_off, u64 nrec, u64 *first_bad_q) {
+    const u64 base = ((u64)blockIdx.x * kBlock + threadIdx.x) * 16ULL;
+    if (base >= nbytes) return;
+    unsigned char b[16];
+    if (base + 16 <= nbytes) *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(stream + base);
+    else
+        for (int i = 0; i < 16; ++i) b[i] = base + i < nbytes ? stream[base + i] : (unsigned char)'A';
+    u64 best = ~0ULL;
+    for (int i = 0; i < 16; ++i) {
+        if (base_code(b[i]) < 4) continue;
+        const u64 q = base + i;
+        // record holding q: largest r with rec_off[r] <= q
+        u64 lo = 0, hi = nrec;  // invariant rec_off[lo] <= q < rec_off[hi]
+        while (hi - lo > 1) {
+            u64 mid = (lo + hi) >> 1;
+            if (rec_off[mid] <= q) lo = mid; else hi = mid;
+        }
+        const u64 start = rec_off[lo], end = rec_off[lo + 1] - 1;  // end = separator position
+        if (q < end && end - start >= (u64)k) { best = q; break; }
+    }
+    if (best != ~0ULL) atomicMin(first_bad_q, best);
+}
+
+// ---- the hot kernel: windows -> canonical hash -> scatter-increment -------------------------------
+// consume's loop body (lib.rs:586-600) for every window of the stream at once.
+template <int KW, int KC>
+__global__ __launch_bounds__(kBlock) void count_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
+                                                               TableView table, u64 *counters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kTile + kHaloMax + 16];
+    __shared__ u64 s_counted, s_new;
+    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
+    const u64 tile_base = (u64)blockIdx.x * kTile;
+    stage_tile(stream, nbytes, tile_base, k, lds);
+    const int lane = threadIdx.x & 63;
+    int counted = 0;  // signed: a leader whose folded add spills takes back the folded lanes' tallies
+    int newkeys = 0;
+    walk_windows<KW, KC>(lds, k, [&](int, bool good, u64 h) {
+        bool active = good && h != 0;  // lib.rs:589: a hash of 0 is skipped and not tallied
+        u64 c = 1;
+        int tally = 0;
+        // Wavefront combining: lanes whose hash equals the first active lane's hash fold into
+        // one add.  Tandem repeats and homopolymers put the same k-mer in every lane at once
+        // (lanes are kWPT windows apart), which would otherwise serialise on one HBM atomic.
+        const u64 act = __ballot(active);
+        if (act) {
+            const int leader = __ffsll((long long)act) - 1;
+            const u64 hl = __shfl(h, leader);
+            const u64 same = __ballot(active && h == hl);
+            if (same != (1ULL << leader)) {
+                if (lane == leader) c = (u64)__popcll(same);
+                else if ((same >> lane) & 1ULL) { active = false; tally = 1; }
+            }
+        }
+        if (active) {
+            const AddResult r = table_add<false>(table, h, c);
+            // spilled entries are tallied when the host replays them: a leader whose folded
+            // add spilled also takes back the folded lanes' tallies (the replay adds c)
+            tally = r.spilled ? 1 - (int)c : 1;
+            newkeys += r.claimed ? 1 : 0;
+        }
+        counted += tally;
+    });
+    u64 wc = wave_sum((u64)(long long)counted), wn = wave_sum((u64)newkeys);
+    if (lane == 0) { atomicAdd(&s_counted, wc); atomicAdd(&s_new, wn); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_counted) atomicAdd(shard + CTR_COUNTED, s_counted);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+    }
+}
+
+// ---- (hash, count) pairs -> table: add()'s inner loop (lib.rs:798-806), spill replay, re-hash --------
+// pairs are read as keys[i * key_stride], counts[i * count_stride] so that the same kernel folds
+// separate arrays (stride 1) and an old slot array (stride 2, keys = slots, counts = slots + 1).
+__global__ __launch_bounds__(kBlock) void merge_pairs_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ counts,
+                                                             u64 n, int stride, TableView table, u64 *counters) {
+    __shared__ u64 s_tot, s_new, s_zero;
+    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; s_zero = 0; }
+    __syncthreads();
+    u64 tot = 0, nk = 0, nz = 0;
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
+        const u64 h = keys[i * stride];
+        if (h == 0) continue;
+        const u64 c = counts[i * stride];
+        const AddResult r = table_add<true>(table, h, c);
+        if (!r.spilled) {
+            tot += c;
+            nk += r.claimed;
+            nz += (r.old == 0);  // lib.rs:801-803: a key counts as new when its current count is 0
+        }
+    }
+    tot = wave_sum(tot); nk = wave_sum(nk); nz = wave_sum(nz);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); atomicAdd(&s_zero, nz); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+        if (s_zero) atomicAdd(shard + CTR_NEW_BY_ZERO, s_zero);
+    }
+}
+
+// ---- lookups / point update ---------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void get_hashes_kernel(const u64 *__restrict__ slots, u64 mask,
+                                                            const u64 *__restrict__ hashes, u64 n, u64 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = hashes[i] ? table_get(slots, mask, hashes[i]) : 0;
+}
+
+// set the count of an existing key (returns 1 in *found) -- __setitem__ (lib.rs:675-681)
+__global__ void set_hash_kernel(u64 *slots, u64 mask, u64 h, u64 value, u64 *found) {
+    u64 s = h & mask;
+    *found = 0;
+    for (u64 probe = 0; probe <= mask; ++probe) {
+        u64 key = slots[2 * s];
+        if (key == h) { slots[2 * s + 1] = value; *found = 1; return; }
+        if (key == 0) return;
+        s = (s + 1) & mask;
+    }
+}
+
+// ---- whole-table scans ---------------------------------------------------------------------------
+// compaction for dump / export: out_n must be zero on entry
+__global__ __launch_bounds__(kBlock) void compact_kernel(const u64 *__restrict__ slots, u64 cap, u64 *__restrict__ out_keys,
+                                                         u64 *__restrict__ out_counts, u64 out_cap, u64 *out_n) {
+    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock) {
+        const u64 key = slots[2 * s];
+        if (key != 0) {
+            const u64 i = atomicAdd(out_n, 1ULL);  // hipcc folds this into one add per wave
+            if (i < out_cap) { out_keys[i] = key; out_counts[i] = slots[2 * s + 1]; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void sum_counts_kernel(const u64 *__restrict__ slots, u64 cap, u64 *out) {
+    u64 acc = 0;
+    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock)
+        if (slots[2 * s] != 0) acc += slots[2 * s + 1];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+}  // namespace kct

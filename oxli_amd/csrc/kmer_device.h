@@ -1,0 +1,201 @@
+// kmer_device.h -- device-side k-mer arithmetic for gfx950 (wave64).
+//
+// What is computed (bit-exact with the reference path):
+//   window good  <=>  all k bytes are A/C/G/T after ASCII upper-casing   (sourmash VALID)
+//   canonical    =   bytewise min(forward, reverse complement)           (sourmash SeqToHashes)
+//   hash         =   MurmurHash3_x64_128(canonical ASCII bytes, seed 42).h1
+//                                                                        (lib.rs:69-76, 576-584)
+// How: bases are held 2 bits each, A<C<G<T = 0<1<2<3, first base in the most significant
+// position, so lexicographic min of the byte strings == integer min of the packed words.  The
+// chosen strand is re-expanded to upper-case ASCII in registers (v_bfrev + two shift/mask
+// steps + one v_perm_b32 byte-LUT per four bases) because the hash input is the ASCII text.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kct {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr u64 kSeed = 42;  // lib.rs:75, 582
+constexpr u64 kC1 = 0x87c37b91114253d5ULL;
+constexpr u64 kC2 = 0x4cf5ad432745937fULL;
+
+__device__ __forceinline__ u64 rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+
+__device__ __forceinline__ u64 fmix64(u64 k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+
+struct Murmur {
+    u64 h1, h2;
+    __device__ __forceinline__ Murmur() : h1(kSeed), h2(kSeed) {}
+    __device__ __forceinline__ void block(u64 k1, u64 k2) {
+        k1 *= kC1; k1 = rotl64(k1, 31); k1 *= kC2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= kC2; k2 = rotl64(k2, 33); k2 *= kC1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    // rem = number of tail bytes (1..15); k1/k2 already hold only those bytes (rest zero)
+    __device__ __forceinline__ void tail(u64 k1, u64 k2, int rem) {
+        if (rem > 8) { k2 *= kC2; k2 = rotl64(k2, 33); k2 *= kC1; h2 ^= k2; }
+        k1 *= kC1; k1 = rotl64(k1, 31); k1 *= kC2; h1 ^= k1;
+    }
+    __device__ __forceinline__ u64 finish(u64 len) {
+        h1 ^= len; h2 ^= len;
+        h1 += h2; h2 += h1;
+        h1 = fmix64(h1); h2 = fmix64(h2);
+        return h1 + h2;
+    }
+};
+
+// low `n` bytes kept (n in 0..8), n wave-uniform
+__device__ __forceinline__ u64 keep_bytes(u64 v, int n) { return n >= 8 ? v : (v & ((1ULL << (8 * n)) - 1ULL)); }
+
+// ---- base classification --------------------------------------------------------------------
+// returns 0..3 for A/C/G/T (either case), 4 otherwise
+__device__ __forceinline__ u32 base_code(u32 c) {
+    const u32 letters = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20);  // a c g t, as (c & 31)
+    bool ok = ((c & 0xC0u) == 0x40u) && ((letters >> (c & 31u)) & 1u);
+    u32 x = (c >> 1) & 3u;  // A0 C1 G3 T2
+    x ^= x >> 1;            // A0 C1 G2 T3
+    return ok ? x : 4u;
+}
+
+// four 2-bit codes (bit-swapped within each pair by v_bfrev) -> four ASCII bytes
+__device__ __forceinline__ u32 expand4(u32 v8) {
+    u32 s = (v8 | (v8 << 12)) & 0x000F000Fu;
+    s = (s | (s << 6)) & 0x03030303u;
+    return __builtin_amdgcn_perm(0u, 0x54434741u /* 'A','G','C','T' for swapped codes 0,1,2,3 */, s);
+}
+
+// 16 bases held in one dword, first base in bits 31:30 -> 16 ASCII bytes as two LE u64
+__device__ __forceinline__ void expand16(u32 chunk, u64 &lo, u64 &hi) {
+    u32 r = __builtin_bitreverse32(chunk);  // base j now in bits 2j+1:2j, its two bits swapped
+    u32 d0 = expand4(r & 0xFFu), d1 = expand4((r >> 8) & 0xFFu);
+    u32 d2 = expand4((r >> 16) & 0xFFu), d3 = expand4(r >> 24);
+    lo = (u64)d0 | ((u64)d1 << 32);
+    hi = (u64)d2 | ((u64)d3 << 32);
+}
+
+// ---- packed k-mers of KW 64-bit words (k <= 32*KW); w[0] is most significant ------------------
+template <int KW>
+struct Packed {
+    u64 w[KW];
+};
+
+template <int KW>
+__device__ __forceinline__ void push_fw(Packed<KW> &a, u32 code) {  // a = (a << 2) | code
+#pragma unroll
+    for (int i = 0; i < KW - 1; ++i) a.w[i] = (a.w[i] << 2) | (a.w[i + 1] >> 62);
+    a.w[KW - 1] = (a.w[KW - 1] << 2) | code;
+}
+
+template <int KW>
+__device__ __forceinline__ void push_rc(Packed<KW> &a, u32 ccode, int k) {  // a = (a >> 2) | ccode << (2k-2)
+#pragma unroll
+    for (int i = KW - 1; i > 0; --i) a.w[i] = (a.w[i] >> 2) | (a.w[i - 1] << 62);
+    a.w[0] >>= 2;
+    const int pos = 2 * k - 2;  // bit position counted from the LSB of w[KW-1]
+#pragma unroll
+    for (int i = 0; i < KW; ++i) {
+        const int base = 64 * (KW - 1 - i);
+        if (pos >= base && pos < base + 64) a.w[i] |= (u64)ccode << (pos - base);
+    }
+}
+
+template <int KW>
+__device__ __forceinline__ void mask_k(Packed<KW> &a, int k) {  // keep the low 2k bits
+#pragma unroll
+    for (int i = 0; i < KW; ++i) {
+        const int base = 64 * (KW - 1 - i);
+        const int bits = 2 * k - base;
+        if (bits <= 0) a.w[i] = 0;
+        else if (bits < 64) a.w[i] &= (1ULL << bits) - 1ULL;
+    }
+}
+
+template <int KW>
+__device__ __forceinline__ bool less_eq(const Packed<KW> &a, const Packed<KW> &b) {
+    if (KW == 1) return a.w[0] <= b.w[0];
+    bool le = a.w[KW - 1] <= b.w[KW - 1];
+#pragma unroll
+    for (int i = KW - 2; i >= 0; --i) le = a.w[i] < b.w[i] || (a.w[i] == b.w[i] && le);
+    return le;
+}
+
+// shift left so that base 0 sits in bits 63:62 of w[0]
+template <int KW>
+__device__ __forceinline__ void left_align(Packed<KW> &a, int k) {
+    const int s = 64 * KW - 2 * k;  // wave-uniform
+    const int ws = s >> 6, bs = s & 63;
+    Packed<KW> o;
+#pragma unroll
+    for (int i = 0; i < KW; ++i) {
+        u64 hi = 0, lo = 0;
+#pragma unroll
+        for (int j = 0; j < KW; ++j) {
+            if (j == i + ws) hi = a.w[j];
+            if (j == i + ws + 1) lo = a.w[j];
+        }
+        o.w[i] = bs ? ((hi << bs) | (lo >> (64 - bs))) : hi;
+    }
+    a = o;
+}
+
+// MurmurHash3_x64_128(seed 42).h1 of the ASCII text of a left-aligned packed k-mer.
+// One 32-bit chunk of the packed form = 16 bases = exactly one 16-byte murmur block.
+template <int KW>
+__device__ __forceinline__ u64 hash_packed(const Packed<KW> &a, int k) {
+    Murmur m;
+    const int nblocks = k >> 4, rem = k & 15;
+#pragma unroll
+    for (int b = 0; b < 2 * KW; ++b) {
+        if (b * 16 < k) {
+            u32 chunk = (b & 1) ? (u32)a.w[b >> 1] : (u32)(a.w[b >> 1] >> 32);
+            u64 k1, k2;
+            expand16(chunk, k1, k2);
+            if (b < nblocks) m.block(k1, k2);
+            else m.tail(keep_bytes(k1, rem), keep_bytes(k2, rem - 8), rem);
+        }
+    }
+    return m.finish((u64)k);
+}
+
+// ---- generic path for any k (1..255): works on upper-casing bytes in LDS -----------------------
+__device__ __forceinline__ u32 upper(u32 c) { return (c >= 'a' && c <= 'z') ? c - 32u : c; }
+__device__ __forceinline__ u32 comp_ascii(u32 c) {  // c is one of ACGT (upper case)
+    return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+}
+
+// s points at the first byte of a window known to be all-ACGT (any case)
+__device__ __forceinline__ u64 hash_bytes_canonical(const unsigned char *s, int k) {
+    bool use_rc = false;
+    for (int i = 0; i < k; ++i) {
+        u32 f = upper(s[i]), r = comp_ascii(upper(s[k - 1 - i]));
+        if (f != r) { use_rc = r < f; break; }
+    }
+    Murmur m;
+    const int nblocks = k >> 4, rem = k & 15;
+    auto byte_at = [&](int i) -> u64 { return use_rc ? comp_ascii(upper(s[k - 1 - i])) : upper(s[i]); };
+    for (int b = 0; b < nblocks; ++b) {
+        u64 k1 = 0, k2 = 0;
+        for (int i = 7; i >= 0; --i) { k1 = (k1 << 8) | byte_at(16 * b + i); k2 = (k2 << 8) | byte_at(16 * b + 8 + i); }
+        m.block(k1, k2);
+    }
+    if (rem) {
+        u64 k1 = 0, k2 = 0;
+        for (int i = rem - 1; i >= 8; --i) k2 = (k2 << 8) | byte_at(16 * nblocks + i);
+        for (int i = (rem > 8 ? 8 : rem) - 1; i >= 0; --i) k1 = (k1 << 8) | byte_at(16 * nblocks + i);
+        m.tail(k1, k2, rem);
+    }
+    return m.finish((u64)k);
+}
+
+}  // namespace kct

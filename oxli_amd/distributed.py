@@ -1,0 +1,110 @@
+"""Multi-GPU shard merge for ``KmerCountTable`` -- one process per GPU, ``torch.distributed``
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+The reference defines how two shards combine: ``add`` (lib.rs:778-837) -- per-key sum of counts,
+sum of ``consumed``.  Records are independent (one ``consume`` per record, README.md:96-98), so
+each rank counts its own records into its own device table with no communication, and ONE
+exchange at the end makes the result global:
+
+    owner(hash) = floor(hi32(hash) * world / 2^32)          (a contiguous slice of hash space)
+    every rank sends each owner the (hash, count) pairs it holds for that owner's slice
+    (all-to-all: all 7 xGMI links of a GPU carry traffic at once), and each owner folds what it
+    receives into a fresh table.  Afterwards rank r holds exactly the keys of slice r with their
+    global counts; the global table is the disjoint union over ranks.
+
+An element-wise all-reduce of the raw tables would be wrong: open addressing places a key
+wherever its probe sequence found room, so slot layouts differ between ranks.
+
+Only plumbing lives here (bucketing with torch ops, the collective); hashing and counting stay
+in the HIP library.
+"""
+import torch
+import torch.distributed as dist
+
+__all__ = ["owner_of", "partition_by_owner", "exchange_pairs", "merge_across_ranks", "global_scalar_sum"]
+
+
+def owner_of(hashes_i64: torch.Tensor, world: int) -> torch.Tensor:
+    """Owner rank of each hash (hashes carried as int64 bit patterns)."""
+    hi32 = (hashes_i64 >> 32) & 0xFFFFFFFF
+    return (hi32 * world) >> 32
+
+
+def partition_by_owner(hashes_i64, counts_i64, world):
+    """Sorts the pairs by owner.  Returns (hashes, counts, send_counts[world])."""
+    if hashes_i64.numel() == 0:
+        return hashes_i64, counts_i64, torch.zeros(world, dtype=torch.int64)
+    own = owner_of(hashes_i64, world)
+    order = torch.argsort(own, stable=True)
+    send_counts = torch.bincount(own, minlength=world).to(torch.int64).cpu()
+    return hashes_i64[order].contiguous(), counts_i64[order].contiguous(), send_counts
+
+
+def exchange_pairs(hashes, counts, send_counts, zero_count=0, group=None):
+    """All-to-all of owner-bucketed pairs.  Returns (recv_hashes, recv_counts, zero_total).
+
+    ``zero_count`` is this rank's count for hash 0, which the library keeps outside the device
+    table (0 is its EMPTY sentinel); it rides along with the size exchange to its owner, rank 0.
+    """
+    world = dist.get_world_size(group)
+    assert world == send_counts.numel()
+    dev = hashes.device
+    # 1) how much will I receive from each peer (tiny fixed-layout exchange)
+    meta = torch.zeros((world, 2), dtype=torch.int64)
+    meta[:, 0] = send_counts
+    meta[0, 1] = int(zero_count)
+    meta = meta.to(dev)
+    got = torch.empty_like(meta)
+    dist.all_to_all_single(got, meta, group=group)
+    got = got.cpu()
+    recv_counts = got[:, 0]
+    zero_total = int(got[:, 1].sum())
+    n_recv = int(recv_counts.sum())
+    # 2) the pairs: hashes and counts interleaved so that one collective moves both
+    payload = torch.stack([hashes, counts], dim=1).contiguous()  # [n, 2] int64
+    out = torch.empty((n_recv, 2), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(out, payload, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(),
+                           group=group)
+    return out[:, 0].contiguous(), out[:, 1].contiguous(), zero_total
+
+
+def global_scalar_sum(value: int, device, group=None) -> int:
+    t = torch.tensor([value], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
+
+
+def merge_across_ranks(table, group=None):
+    """Turns per-rank tables into the owner-partitioned global table, in place.
+
+    After the call ``table`` on rank r holds every key of hash-slice r with its global count;
+    ``len`` / ``sum_counts`` / ``consumed`` of the global table are the sums over ranks
+    (``global_scalar_sum``).  ``table.consumed`` keeps this rank's own share.
+    Returns the number of pairs this rank received.
+    """
+    import ctypes as C
+
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 0
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n = len(table)
+    hashes = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    counts = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    got = C.c_uint64()
+    table._check(table._lib.kct_export_device(table._h, C.c_void_p(hashes.data_ptr()), C.c_void_p(counts.data_ptr()), n, C.byref(got)))
+    hashes, counts = hashes[: got.value], counts[: got.value]
+    hashes, counts, send_counts = partition_by_owner(hashes, counts, world)
+    rh, rc, zero = exchange_pairs(hashes, counts, send_counts, table.get_hash(0), group)
+    torch.cuda.synchronize()
+    consumed = table.consumed
+    table.clear()
+    if zero:
+        import numpy as np
+        zk, zc = np.zeros(1, dtype=np.uint64), np.array([zero], dtype=np.uint64)
+        table._check(table._lib.kct_merge_host(table._h, zk.ctypes.data, zc.ctypes.data, 1, None, None))
+    a, b = C.c_uint64(), C.c_uint64()
+    table._check(table._lib.kct_merge_device(table._h, C.c_void_p(rh.data_ptr()), C.c_void_p(rc.data_ptr()), rh.numel(),
+                                             C.byref(a), C.byref(b)))
+    table._check(table._lib.kct_add_consumed(table._h, consumed))
+    return rh.numel()

@@ -1,0 +1,401 @@
+"""Parity of the HIP path against the CPU oracle and the reference's known answers.  All tests
+here need a real MI355X (``-m gpu``) and go through the C ABI (ctypes -> libkct_hip.so).
+
+Bar: bit-exact -- every hash, every count, n, len, consumed, sum_counts.
+The tests re-express the reference's own tests for this path (src/python/tests/test_basic.py,
+test_kmers_and_hashes.py, test_attr.py, test_add.py, test_dunders.py, test_dump.py) plus the
+edge cases the domain has: empty / short / ragged records, bad bases, lower case, non-ASCII
+bytes, heavy hitters, table growth from a tiny capacity, every k from 1 to 255.
+"""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402  (the checker)
+from oracle import OracleTable  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def KCT():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from oxli_amd import KmerCountTable
+    return KmerCountTable
+
+
+def assert_same_table(dev, ref):
+    dk, dc = dev.dump_arrays(1)
+    rk, rc = ref.dump_arrays()
+    assert dk.size == rk.size, (dk.size, rk.size)
+    assert np.array_equal(dk, rk), "hash sets differ"
+    assert np.array_equal(dc, rc), "counts differ"
+    assert len(dev) == len(ref)
+    assert dev.sum_counts == ref.sum_counts
+    assert dev.consumed == ref.consumed
+
+
+def rand_dna(rng, n, alphabet="ACGT"):
+    return "".join(rng.choice(alphabet) for _ in range(n))
+
+
+# ---- hashes ---------------------------------------------------------------------------------------
+def test_reference_hash_kats(KCT, kats):
+    tables = {}
+    for e in kats["hashes"]:
+        k = len(e["kmer"])
+        t = tables.setdefault(k, KCT(k))
+        assert t.hash_kmer(e["kmer"]) == e["hash"], e
+        assert t.hash_kmer(e["kmer"].lower()) == e["hash"], e
+
+
+def test_reference_window_hash_lists(KCT, kats):
+    for e in kats["window_hashes"]:
+        assert KCT(e["k"]).hash_windows(e["seq"]).tolist() == e["hashes"], e
+
+
+def test_hash_windows_equal_oracle_every_k(KCT):
+    rng = random.Random(11)
+    seq = rand_dna(rng, 3000)
+    noisy = list(seq)
+    for pos in rng.sample(range(len(noisy)), 25):
+        noisy[pos] = rng.choice("NnXx-*RYacgt")
+    noisy = "".join(noisy)
+    for k in list(range(1, 70)) + [95, 96, 97, 127, 128, 129, 200, 254, 255]:
+        t = KCT(k)
+        for s in (seq, noisy):
+            want, _ = oracle.seq_to_hashes(s, k, force=True)
+            got = t.hash_windows(s)
+            assert np.array_equal(got, want), f"k={k}"
+
+
+def test_hash_kmer_errors(KCT):
+    t = KCT(4)
+    with pytest.raises(RuntimeError, match="wrong ksize"):
+        t.hash_kmer("ACG")
+    with pytest.raises(RuntimeError):
+        t.hash_kmer("ACGN")
+    # the reference compares `len as u8` (lib.rs:66): a 260-byte string passes a ksize-4 check
+    long = "ACGT" + "T" * 256
+    assert t.hash_kmer(long) == oracle.hash_kmer(long, 4) == oracle.hash_kmer("ACGT")
+
+
+# ---- reference test_basic.py ------------------------------------------------------------------------
+def test_count_get(KCT):
+    cg = KCT(4)
+    assert cg.get("ATCG") == 0
+    assert cg.count("ATCG") == 1
+    assert cg.get("ATCG") == 1
+    assert cg["ATCG"] == 1
+
+
+def test_count_hash_and_count_agree(KCT):
+    kmer = "TAAACCCTAACCCTAACCCTAACCCTAACCC"
+    cg = KCT(ksize=31)
+    h = cg.hash_kmer(kmer)
+    assert h == oracle.hash_kmer(kmer)
+    assert cg.get_hash(h) == 0 and cg.get(kmer) == 0
+    assert cg.count(kmer) == 1 and cg.count(kmer) == 2 and cg.get(kmer) == 2
+    assert cg.count_hash(h) == 3 and cg.get(kmer) == 3 and cg.get_hash(h) == 3
+    assert cg.consumed == 62 and cg.sum_counts == 3 and len(cg) == 1
+
+
+def test_wrong_ksize(KCT):
+    cg = KCT(3)
+    with pytest.raises(ValueError):
+        cg.count("ATCG")
+    with pytest.raises(ValueError):
+        cg.get("ATCG")
+
+
+def test_reference_consume_facts(KCT, kats):
+    for e in kats["consume"]:
+        t = KCT(e["k"])
+        assert t.consume(e["seq"]) == e["n"], e
+        for kmer, c in e.get("get", {}).items():
+            assert t.get(kmer) == c, (e, kmer)
+        if "len" in e:
+            assert len(t) == e["len"]
+        if "sum_counts" in e:
+            assert t.sum_counts == e["sum_counts"]
+        assert t.consumed == len(e["seq"])
+
+
+def test_reference_consume_errors(KCT, kats):
+    for e in kats["consume_errors"]:
+        t = KCT(e["k"])
+        with pytest.raises(ValueError, match=f"bad k-mer encountered at position {e['position']}$"):
+            t.consume(e["seq"], skip_bad_kmers=False)
+        assert t.consumed == 0
+        assert t.sum_counts == e["position"]
+
+
+def test_get_hash_array_order(KCT):
+    t = KCT(3)
+    for k in ["AAA", "TTT", "AAC"]:
+        t.count(k)
+    hs = [t.hash_kmer("AAA"), t.hash_kmer("AAC"), t.hash_kmer("GGG")]
+    assert t.get_hash_array(hs) == [2, 1, 0]
+    assert t.get_hash_array(hs[::-1]) == [0, 1, 2]
+
+
+# ---- reference doc/api.md + README on doc/example.fa ------------------------------------------------
+def test_example_fa(KCT, kats, example_seq, example_digests):
+    for e in kats["example_fa"]:
+        t = KCT(e["k"])
+        assert t.consume(example_seq) == e["n"]
+        for kmer, c in e.get("get", {}).items():
+            assert t.get(kmer) == c
+        if "then_consume_skip" in e:
+            x = e["then_consume_skip"]
+            with pytest.raises(ValueError, match="bad k-mer encountered at position 0"):
+                t.consume(x["seq"], skip_bad_kmers=False)
+            assert t.consume(x["seq"]) == x["n"]
+            for kmer, c in x["get"].items():
+                assert t.get(kmer) == c
+    for k, d in example_digests["k"].items():
+        t = KCT(int(k))
+        assert t.consume(example_seq) == d["n"]
+        keys, counts = t.dump_arrays(1)
+        assert len(t) == d["distinct"] and int(counts.max()) == d["max"] and t.consumed == d["consumed"]
+        tsv = "".join(f"{h}\t{c}\n" for h, c in zip(keys.tolist(), counts.tolist()))
+        assert hashlib.sha256(tsv.encode()).hexdigest() == d["sha256_dump_sortkeys_tsv"]
+        assert t.hash_windows(example_seq[:100])[:3].tolist() == d["first3"]
+
+
+# ---- consume == oracle on seeded inputs --------------------------------------------------------------
+@pytest.mark.parametrize("k", [1, 4, 15, 16, 17, 21, 31, 32, 33, 51, 64, 65, 100, 255])
+def test_consume_matches_oracle(KCT, k):
+    rng = random.Random(1000 + k)
+    dev, ref = KCT(k), OracleTable(k)
+    seqs = [rand_dna(rng, rng.choice([0, 1, k - 1, k, k + 1, 2 * k, 150, 1000, 9000])) for _ in range(12)]
+    seqs.append(rand_dna(rng, 4000, "ACGTN"))
+    seqs.append(rand_dna(rng, 2000, "acgtACGT"))
+    seqs.append("A" * 3000)
+    seqs.append("AC" * 1500)
+    for s in seqs:
+        assert dev.consume(s) == ref.consume(s), (k, len(s))
+    assert_same_table(dev, ref)
+
+
+def test_consume_error_mode_matches_oracle(KCT):
+    rng = random.Random(5)
+    for k in (4, 21, 33):
+        for trial in range(8):
+            s = list(rand_dna(rng, rng.randint(k, 400)))
+            if trial % 4 != 3:
+                s[rng.randrange(len(s))] = "N"
+            s = "".join(s)
+            dev, ref = KCT(k), OracleTable(k)
+            outcomes = []
+            for t in (dev, ref):
+                try:
+                    outcomes.append(("ok", t.consume(s, skip_bad_kmers=False)))
+                except ValueError as e:
+                    outcomes.append(("err", str(e)))
+            assert outcomes[0] == outcomes[1], (k, s)
+            assert_same_table(dev, ref)
+
+
+def test_non_ascii_and_byte_semantics(KCT):
+    dev, ref = KCT(4), OracleTable(4)
+    for s in ["ACGTéACGT", "ACGT\x00ACGT", "\nACGTAC\r\nGGTTAA\n", "ACGT" * 3 + "中" + "TTGCA"]:
+        assert dev.consume(s) == ref.consume(s)
+    assert_same_table(dev, ref)  # consumed counts UTF-8 bytes (lib.rs:548)
+
+
+def test_heavy_hitters(KCT, kats):
+    s = kats["stress"]
+    seq = s["unit"] * s["repeat"]
+    a, b = KCT(s["k"]), KCT(s["k"])
+    assert a.consume(seq) == s["n"]
+    assert b.consume(seq) == s["n"]
+    assert a.add(b) == (s["add_counts_added"], s["add_new_keys"])
+    assert a.sum_counts == s["sum_counts_after_add"]
+    ref = OracleTable(s["k"])
+    ref.consume(seq); ref.consume(seq)
+    dk, dc = a.dump_arrays(1)
+    rk, rc = ref.dump_arrays()
+    assert np.array_equal(dk, rk) and np.array_equal(dc, rc)
+    # homopolymer: one key, every lane of every wave folds into it
+    t = KCT(21)
+    assert t.consume("A" * 100000) == 100000 - 20
+    assert len(t) == 1 and t.get("T" * 21) == 100000 - 20
+
+
+def test_growth_from_tiny_capacity(KCT):
+    rng = random.Random(3)
+    seq = rand_dna(rng, 300000)
+    dev, ref = KCT(25, capacity=16), OracleTable(25)
+    cap0 = dev.capacity
+    assert dev.consume(seq) == ref.consume(seq)
+    assert dev.capacity > cap0
+    for _ in range(3):
+        s = rand_dna(rng, 50000)
+        assert dev.consume(s) == ref.consume(s)
+    assert_same_table(dev, ref)
+
+
+# ---- batch API == the per-record loop -----------------------------------------------------------------
+def test_consume_batch_equals_loop(KCT):
+    rng = random.Random(21)
+    recs = [rand_dna(rng, rng.choice([0, 5, 20, 21, 22, 150, 151, 3000]), "ACGTACGTACGTN") for _ in range(300)]
+    for k in (21, 40):
+        dev, ref = KCT(k), OracleTable(k)
+        n = dev.consume_batch(recs)
+        assert n == sum(ref.consume(r) for r in recs)
+        assert_same_table(dev, ref)
+        # CSR form
+        dev2 = KCT(k)
+        data = "".join(recs).encode()
+        offs = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+        assert dev2.consume_batch((data, offs)) == n
+        assert_same_table(dev2, ref)
+    assert KCT(21).consume_batch([]) == 0
+
+
+def test_consume_batch_error_mode(KCT):
+    rng = random.Random(22)
+    k = 21
+    recs = [rand_dna(rng, 150) for _ in range(50)]
+    recs[10] = "ACGTN"                      # too short to have a window: must NOT raise
+    recs[30] = recs[30][:70] + "N" + recs[30][71:]
+    dev, ref = KCT(k), OracleTable(k)
+    n_ref, err_ref = 0, None
+    for r in recs:
+        try:
+            n_ref += ref.consume(r, skip_bad_kmers=False)
+        except ValueError as e:
+            err_ref = str(e)
+            break
+    with pytest.raises(ValueError) as ei:
+        dev.consume_batch(recs, skip_bad_kmers=False)
+    assert str(ei.value) == err_ref == "bad k-mer encountered at position 50"
+    assert ei.value.record == 30
+    assert_same_table(dev, ref)
+    # no bad window anywhere: plain success
+    clean = [rand_dna(rng, 100) for _ in range(20)]
+    dev, ref = KCT(k), OracleTable(k)
+    assert dev.consume_batch(clean, skip_bad_kmers=False) == sum(ref.consume(r, False) for r in clean)
+    assert_same_table(dev, ref)
+
+
+# ---- merge (reference test_add.py) -----------------------------------------------------------------------
+def test_reference_add_facts(KCT, kats):
+    for e in kats["add"]:
+        a, b = KCT(e["k"]), KCT(e["k"])
+        if e["a"]:
+            a.consume(e["a"])
+        b.consume(e["b"])
+        assert a.add(b) == (e["counts_added"], e["new_keys"]), e
+        assert a.sum_counts == e["sum_counts"]
+        if "len" in e:
+            assert len(a) == e["len"]
+        assert a.consumed == len(e["a"]) + len(e["b"])
+    with pytest.raises(ValueError):
+        KCT(5).add(KCT(6))
+
+
+def test_add_matches_oracle_and_counts_zero_valued_keys_as_new(KCT):
+    rng = random.Random(8)
+    g = rand_dna(rng, 5000)
+    a, b, ra, rb = KCT(17), KCT(17), OracleTable(17), OracleTable(17)
+    for t in (a, ra):
+        t.consume(g[:3000])
+    for t in (b, rb):
+        t.consume(g[2000:])
+    assert a.add(b) == ra.add(rb)
+    assert_same_table(a, ra)
+    # __setitem__(kmer, 0) leaves a key whose count is 0; add() reports it as new (lib.rs:801-803)
+    x, y = KCT(4), KCT(4)
+    x["ACGT"] = 0
+    assert len(x) == 1 and x.get("ACGT") == 0
+    y.count("ACGT")
+    assert x.add(y) == (1, 1)
+    x["AAAA"] = 7
+    assert x.get("TTTT") == 7 and x.sum_counts == 8
+
+
+def test_dump_orders(KCT):
+    t = KCT(4)
+    t.count("AAAA"); t.count("TTTT"); t.count("AATT"); t.count("GGGG"); t.count("GGGG")
+    assert t.dump(sortkeys=True) == [(73459868045630124, 2), (382727017318141683, 1), (17832910516274425539, 2)]
+    assert t.dump(sortcounts=True) == [(382727017318141683, 1), (73459868045630124, 2), (17832910516274425539, 2)]
+    assert sorted(t.dump()) == t.dump(sortkeys=True)
+    with pytest.raises(ValueError):
+        t.dump(sortcounts=True, sortkeys=True)
+    assert KCT(4).dump() == []
+
+
+def test_hash_zero_is_a_legal_key_for_count_hash(KCT):
+    t = KCT(4)
+    assert t.get_hash(0) == 0 and len(t) == 0
+    assert t.count_hash(0) == 1 and t.count_hash(0) == 2
+    assert t.get_hash(0) == 2 and len(t) == 1 and t.sum_counts == 2
+    assert t.get_hash_array([0, 5]) == [2, 0]
+    assert t.dump(sortkeys=True) == [(0, 2)]
+
+
+# ---- device-resident input + synthetic workload ------------------------------------------------------------
+def test_device_generator_matches_oracle_and_consume_device(KCT):
+    import ctypes as C
+
+    import torch
+
+    from oxli_amd import _lib
+    lib = _lib.load()
+    G, L, N, k = 50000, 150, 4096, 21
+    g = torch.empty(G, dtype=torch.uint8, device="cuda")
+    r = torch.empty(N * (L + 1), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.kct_synth_genome_device(g.data_ptr(), G, 42, stream) == 0
+    assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), G, 100, N, L, 1337, stream) == 0
+    torch.cuda.synchronize()
+    genome = oracle.synth_genome(G)
+    reads = oracle.synth_reads(genome, 100, N, L)
+    assert np.array_equal(g.cpu().numpy(), genome)
+    assert np.array_equal(r.cpu().numpy().reshape(N, L + 1), reads)
+    dev, ref = KCT(k, capacity=G), OracleTable(k)
+    n = dev.consume_device(r.data_ptr(), r.numel(), N * L)
+    assert n == sum(ref.consume(reads[i, :L]) for i in range(N)) == N * (L - k + 1)
+    assert_same_table(dev, ref)
+
+
+def test_full_size_properties_1M_reads(KCT):
+    """BASELINE config C2 at full size (1 M x 150 bp, k=21): properties that need no oracle run.
+    sum_counts == n == reads * 130; consumed == reads * 150; consuming the same reads again
+    doubles every count and adds no key; counts of a sampled read's k-mers are >= 1."""
+    import torch
+
+    from oxli_amd import _lib
+    lib = _lib.load()
+    G, L, N, k = 5_000_000, 150, 1_000_000, 21
+    g = torch.empty(G, dtype=torch.uint8, device="cuda")
+    r = torch.empty(N * (L + 1), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.kct_synth_genome_device(g.data_ptr(), G, 42, stream) == 0
+    assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), G, 0, N, L, 1337, stream) == 0
+    torch.cuda.synchronize()
+    t = KCT(k, capacity=G)
+    n = t.consume_device(r.data_ptr(), r.numel(), N * L)
+    assert n == N * (L - k + 1) == t.sum_counts
+    assert t.consumed == N * L
+    distinct = len(t)
+    assert 0.9 * G < distinct <= G - k + 1
+    keys, counts = t.dump_arrays(1)
+    assert np.all(keys[:-1] < keys[1:]) and int(counts.sum()) == n
+    assert t.consume_device(r.data_ptr(), r.numel(), N * L) == n
+    assert len(t) == distinct
+    keys2, counts2 = t.dump_arrays(1)
+    assert np.array_equal(keys, keys2) and np.array_equal(counts2, 2 * counts)
+    # a slice of the same reads through the oracle: every one of its keys is present with count >= oracle's
+    sub = r[: 2000 * (L + 1)].cpu().numpy().reshape(2000, L + 1)
+    ref = OracleTable(k)
+    for i in range(2000):
+        ref.consume(sub[i, :L])
+    rk, rc = ref.dump_arrays()
+    got = np.array(t.get_hash_array(rk), dtype=np.uint64)
+    assert np.all(got >= 2 * rc)
