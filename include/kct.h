@@ -140,6 +140,12 @@ kct_status kct_merge_device(kct_table *t, const void *d_hashes, const void *d_co
 kct_status kct_merge_host(kct_table *t, const uint64_t *hashes, const uint64_t *counts, size_t n,
                           uint64_t *total_added, uint64_t *new_keys);
 
+/* Which device path bulk ingest uses: 0 = chosen per pass (default), 1 = direct path only (one
+ * HBM atomic per k-mer), 2 = partitioned path whenever the table geometry allows (radix-partition
+ * the hashes by 128-KiB table block, count each block in LDS).  Results are identical; this
+ * exists for tests and measurement. */
+kct_status kct_set_path(kct_table *t, int mode);
+
 /* ---- streams and in-library kernel timing ----------------------------------------------------
  * The table owns a HIP stream; a caller that has its own (e.g. torch's current stream) can
  * hand it over as a `hipStream_t` cast to void*. */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "kct_export_device": (ci, [vp, vp, vp, sz, u64p]),
     "kct_merge_device": (ci, [vp, vp, vp, sz, u64p, u64p]),
     "kct_merge_host": (ci, [vp, vp, vp, sz, u64p, u64p]),
+    "kct_set_path": (ci, [vp, ci]),
     "kct_set_stream": (ci, [vp, vp]),
     "kct_get_stream": (vp, [vp]),
     "kct_profile_enable": (ci, [vp, ci]),

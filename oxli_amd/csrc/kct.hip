@@ -47,7 +47,7 @@ void set_err(const char *fmt, ...) {
 
 constexpr u64 kDefaultSlots = 1ULL << 16;
 constexpr u64 kMinSlots = 1ULL << 10;
-constexpr double kMaxLoad = 0.5;                 // grow between launches once load exceeds this
+constexpr double kMaxLoad = 0.65;                // grow between launches once load exceeds this
 constexpr u64 kChunkPositions = 1ULL << 28;      // stream bytes per launch (bounds the spill list)
 constexpr int kNumCounters = kct::kCounterShards * kct::kCounterStride;
 
@@ -100,6 +100,10 @@ struct kct_table {
 
     du64 *slots = nullptr;  // 2 * cap words (device)
     u64 cap = 0;
+    int block_bits = 0;     // log2(slots per probing block) = min(13, log2 cap)
+    bool lazy_empty = false;  // kct_clear() was called and the memset has not been issued yet
+    int num_cus = 256;
+    int force_path = 0;     // 0 = choose per pass, 1 = direct atomic kernel only, 2 = partitioned whenever the geometry allows
     u64 n_keys = 0;        // distinct non-zero hashes in `slots`
     u64 consumed = 0;      // lib.rs:36
     bool zero_present = false;  // key 0 lives host-side (0 is the EMPTY sentinel on the device)
@@ -107,7 +111,7 @@ struct kct_table {
 
     du64 *d_counters = nullptr;  // kNumCounters tallies + 8 scratch words (device)
     u64 *h_counters = nullptr;   // pinned mirror
-    DevBuf d_stream, d_spill, d_aux, d_aux2;
+    DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr;
     PinnedBuf h_stage;
 
     bool prof_on = false;
@@ -167,10 +171,25 @@ kct::TableView view(kct_table *t, u64 spill_cap) {
     kct::TableView v;
     v.slots = t->slots;
     v.mask = t->cap - 1;
+    v.block_mask = (1ULL << t->block_bits) - 1;
     v.spill = (du64 *)t->d_spill.p;
     v.spill_cap = spill_cap;
     v.spill_n = t->d_counters + kNumCounters;  // scratch word 0
     return v;
+}
+
+int log2_u64(u64 v) { int b = 0; while ((1ULL << b) < v) ++b; return b; }
+
+void set_geometry(kct_table *t) { t->block_bits = std::min(kct::kBlockBitsMax, log2_u64(t->cap)); }
+
+// kct_clear() defers its memset: the partitioned path rewrites every block from zeros anyway.
+// Anything else that touches `slots` calls this first.
+kct_status materialize(kct_table *t) {
+    if (t->lazy_empty) {
+        HIP_TRY(hipMemsetAsync(t->slots, 0, t->cap * 16, t->stream));
+        t->lazy_empty = false;
+    }
+    return KCT_OK;
 }
 
 kct_status zero_counters(kct_table *t) {
@@ -205,13 +224,14 @@ int merge_grid(u64 n) { return (int)std::min<u64>((n + kct::kBlock - 1) / kct::k
 kct_status grow_to(kct_table *t, u64 new_cap);
 
 kct_status merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n, int stride, u64 tallies[4]) {
+    KCT_TRY(materialize(t));
     while (n > 0) {
         KCT_TRY(t->d_spill.reserve(n * 16));
         KCT_TRY(zero_counters(t));
         {
             ProfScope ps(t, "merge_pairs_kernel");
             hipLaunchKernelGGL(kct::merge_pairs_kernel, dim3(merge_grid(n)), dim3(kct::kBlock), 0, t->stream, d_keys, d_counts, n,
-                               stride, view(t, n), t->d_counters);
+                               (const du64 *)nullptr, (const du64 *)nullptr, stride, view(t, n), t->d_counters);
         }
         HIP_TRY(hipGetLastError());
         u64 c[4], spilled;
@@ -241,7 +261,9 @@ kct_status grow_to(kct_table *t, u64 new_cap) {
     KCT_TRY(alloc_slots(t->device, new_cap, t->stream, &fresh));
     t->slots = fresh;
     t->cap = new_cap;
+    set_geometry(t);
     t->n_keys = 0;
+    if (t->lazy_empty) t->lazy_empty = false;  // the old array was never cleaned, but it holds no keys: drop it
     if (old && old_keys > 0) {
         // re-insert every occupied slot; the new table is at most half full so nothing spills
         KCT_TRY(t->d_spill.reserve(16));
@@ -249,7 +271,7 @@ kct_status grow_to(kct_table *t, u64 new_cap) {
         {
             ProfScope ps(t, "merge_pairs_kernel(rehash)");
             hipLaunchKernelGGL(kct::merge_pairs_kernel, dim3(merge_grid(old_cap)), dim3(kct::kBlock), 0, t->stream, old, old + 1,
-                               old_cap, 2, view(t, 0), t->d_counters);
+                               old_cap, (const du64 *)nullptr, (const du64 *)nullptr, 2, view(t, 0), t->d_counters);
         }
         HIP_TRY(hipGetLastError());
         u64 c[4], spilled;
@@ -300,6 +322,94 @@ struct HashLauncher {
     }
 };
 
+template <int KW, int KC>
+struct PartitionLauncher {
+    static void run(hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, int k, u64 ntiles, kct::PartitionArgs a) {
+        hipLaunchKernelGGL((kct::partition_windows_kernel<KW, KC>), dim3(grid), dim3(kct::kPartThreads), 0, s, stream, nbytes, k, ntiles, a);
+    }
+};
+
+// Replays a spill list (already copied to d_aux2) after growing; adds what it counted to *n_out.
+kct_status replay_spill(kct_table *t, u64 spilled, u64 *n_out) {
+    KCT_TRY(grow_to(t, next_pow2((u64)((double)(t->n_keys + spilled) / kMaxLoad) + 1)));
+    u64 tl[4] = {0, 0, 0, 0};
+    KCT_TRY(merge_pairs(t, (const du64 *)t->d_aux2.p, (const du64 *)t->d_aux2.p + 1, spilled, 2, tl));
+    *n_out += tl[kct::CTR_TOTAL_ADDED];
+    return KCT_OK;
+}
+
+// The partitioned path pays 16 B of streaming scratch traffic per k-mer plus 32 B per table
+// slot per pass; the direct path pays one memory-side atomic per k-mer.  It wins once a pass
+// brings at least ~a quarter as many windows as the table has slots.
+bool partition_pays(const kct_table *t, u64 npos) {
+    const u64 nblocks = t->cap >> t->block_bits;
+    return nblocks >= 16 && nblocks <= 1024 && npos >= (1ULL << 20) && npos >= t->cap / 4;
+}
+
+// One pass of the partitioned path over window starts [0, npos) of d_stream.  *handled = false
+// (and nothing counted) if the pass had to be abandoned; the caller then uses the direct path.
+kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled) {
+    *handled = false;
+    const int k = t->k;
+    const int pbits = log2_u64(t->cap >> t->block_bits);
+    const u64 P = 1ULL << pbits;
+    const int nwg = t->num_cus;
+    const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
+    const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
+    const double avg = (double)(tiles_per_wg * kct::kPartTile) / (double)P;
+    const unsigned int region_cap = (unsigned int)((((u64)(avg * 1.15 + 8.0 * __builtin_sqrt(avg) + 64.0)) + 7) & ~7ULL);
+    const u64 irr_cap = npos / 8 + 65536;
+    KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 8));
+    KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
+    KCT_TRY(t->d_irr.reserve(irr_cap * 16));
+    KCT_TRY(t->d_spill.reserve(npos * 16));
+    KCT_TRY(zero_counters(t));
+    du64 *d_irr_n = t->d_counters + kNumCounters + 5, *d_overflow = t->d_counters + kNumCounters + 6;
+    const bool fresh = t->lazy_empty;
+
+    kct::PartitionArgs pa;
+    pa.mask = t->cap - 1; pa.block_bits = t->block_bits; pa.pbits = pbits;
+    pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
+    pa.irr = (du64 *)t->d_irr.p; pa.irr_cap = irr_cap; pa.irr_n = d_irr_n; pa.overflow = d_overflow;
+    {
+        ProfScope ps(t, "partition_windows_kernel");
+        dispatch_k<PartitionLauncher>(k, t->stream, nwg, d_stream, chunk_bytes, k, ntiles, pa);
+    }
+    HIP_TRY(hipGetLastError());
+
+    kct::AggregateArgs aa;
+    aa.slots = t->slots; aa.block_bits = t->block_bits; aa.pbits = pbits;
+    aa.scratch = (const du64 *)t->d_scratch.p; aa.region_cap = region_cap; aa.region_count = (const unsigned int *)t->d_regions.p;
+    aa.nwg = nwg; aa.fresh = fresh ? 1 : 0; aa.overflow = d_overflow;
+    aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
+    {
+        ProfScope ps(t, "aggregate_blocks_kernel");
+        hipLaunchKernelGGL(kct::aggregate_blocks_kernel, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, aa);
+    }
+    HIP_TRY(hipGetLastError());
+    {
+        // fold the irregular side list with the direct atomic kernel; it reads its length and the
+        // abandon flag from device memory, so no host round trip sits between the three launches
+        ProfScope ps(t, "merge_pairs_kernel(irregular)");
+        hipLaunchKernelGGL(kct::merge_pairs_kernel, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
+                           (const du64 *)t->d_irr.p + 1, irr_cap, (const du64 *)d_irr_n, (const du64 *)d_overflow, 2, view(t, npos), t->d_counters);
+    }
+    HIP_TRY(hipGetLastError());
+    u64 c[4], spilled;
+    KCT_TRY(read_counters(t, c, &spilled));
+    if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // abandoned: K2 and the merge exited early, nothing was touched
+    t->lazy_empty = false;
+    *handled = true;
+    *n_out += c[kct::CTR_COUNTED] + c[kct::CTR_TOTAL_ADDED];
+    t->n_keys += c[kct::CTR_NEWKEYS];
+    if (spilled) {
+        KCT_TRY(t->d_aux2.reserve(spilled * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(replay_spill(t, spilled, n_out));
+    }
+    return KCT_OK;
+}
+
 // Counts every good window of a device-resident record stream.  *n_out = k-mers counted.
 kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 *n_out) {
     *n_out = 0;
@@ -312,6 +422,14 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         // a chunk owns window starts [done, done + npos); its loads reach k-1 bytes further
         const u64 npos = std::min<u64>(kChunkPositions, last_start + 1 - done);
         const u64 chunk_bytes = std::min<u64>(nbytes - done, npos + k - 1);
+        const u64 nblocks = t->cap >> t->block_bits;
+        const bool geometry_ok = nblocks >= 16 && nblocks <= 1024;
+        if (geometry_ok && t->force_path != 1 && (t->force_path == 2 || partition_pays(t, npos))) {
+            bool handled = false;
+            KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled));
+            if (handled) { done += npos; continue; }
+        }
+        KCT_TRY(materialize(t));
         KCT_TRY(t->d_spill.reserve(npos * 16));
         KCT_TRY(zero_counters(t));
         const int grid = (int)((npos + kct::kTile - 1) / kct::kTile);
@@ -329,10 +447,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         if (spilled) {
             KCT_TRY(t->d_aux2.reserve(spilled * 16));
             HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
-            KCT_TRY(grow_to(t, next_pow2((u64)((double)(t->n_keys + spilled) / kMaxLoad) + 1)));
-            u64 tl[4] = {0, 0, 0, 0};
-            KCT_TRY(merge_pairs(t, (const du64 *)t->d_aux2.p, (const du64 *)t->d_aux2.p + 1, spilled, 2, tl));
-            *n_out += tl[kct::CTR_TOTAL_ADDED];
+            KCT_TRY(replay_spill(t, spilled, n_out));
         }
         done += npos;
     }
@@ -433,6 +548,8 @@ kct_status kct_create(uint8_t ksize, uint64_t capacity_hint, int device, kct_tab
     st = alloc_slots(device, cap, t->stream, &t->slots);
     if (st != KCT_OK) return fail(st);
     t->cap = cap;
+    set_geometry(t);
+    t->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamSynchronize(t->stream) != hipSuccess) { set_err("stream sync failed"); return fail(KCT_ERR_HIP); }
     *out = t;
     return KCT_OK;
@@ -448,6 +565,7 @@ void kct_destroy(kct_table *t) {
     if (t->d_counters) (void)hipFree(t->d_counters);
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     t->d_stream.release(); t->d_spill.release(); t->d_aux.release(); t->d_aux2.release();
+    t->d_scratch.release(); t->d_regions.release(); t->d_irr.release();
     t->h_stage.release();
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
@@ -455,8 +573,7 @@ void kct_destroy(kct_table *t) {
 
 kct_status kct_clear(kct_table *t) {
     KCT_TRY(use(t));
-    ProfScope ps(t, "clear(memset)");
-    HIP_TRY(hipMemsetAsync(t->slots, 0, t->cap * 16, t->stream));
+    t->lazy_empty = true;  // the memset is issued by materialize() only if something needs it
     t->n_keys = 0; t->consumed = 0; t->zero_present = false; t->zero_count = 0;
     return KCT_OK;
 }
@@ -518,13 +635,14 @@ kct_status kct_get_hash_array(kct_table *t, const uint64_t *hashes, size_t n, ui
     KCT_TRY(use(t));
     if (n == 0) return KCT_OK;
     if (!hashes || !counts_out) { set_err("null argument"); return KCT_ERR_ARG; }
+    KCT_TRY(materialize(t));
     KCT_TRY(t->d_aux.reserve(n * 16));
     du64 *d_in = (du64 *)t->d_aux.p, *d_out = d_in + n;
     HIP_TRY(hipMemcpyAsync(d_in, hashes, n * 8, hipMemcpyHostToDevice, t->stream));
     {
         ProfScope ps(t, "get_hashes_kernel");
         hipLaunchKernelGGL(kct::get_hashes_kernel, dim3((unsigned)((n + kct::kBlock - 1) / kct::kBlock)), dim3(kct::kBlock), 0, t->stream,
-                           t->slots, t->cap - 1, d_in, (u64)n, d_out);
+                           t->slots, t->cap - 1, (1ULL << t->block_bits) - 1, d_in, (u64)n, d_out);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(counts_out, d_out, n * 8, hipMemcpyDeviceToHost, t->stream));
@@ -561,7 +679,7 @@ kct_status kct_set_hash(kct_table *t, uint64_t hash, uint64_t count) {
     u64 tl[4] = {0, 0, 0, 0};
     KCT_TRY(merge_pairs(t, (const du64 *)t->d_aux.p, (const du64 *)t->d_aux.p + 1, 1, 1, tl));
     du64 *d_found = t->d_counters + kNumCounters + 2;
-    hipLaunchKernelGGL(kct::set_hash_kernel, dim3(1), dim3(1), 0, t->stream, t->slots, t->cap - 1, (u64)hash, (u64)count, d_found);
+    hipLaunchKernelGGL(kct::set_hash_kernel, dim3(1), dim3(1), 0, t->stream, t->slots, t->cap - 1, (1ULL << t->block_bits) - 1, (u64)hash, (u64)count, d_found);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));
     return KCT_OK;
@@ -675,6 +793,7 @@ kct_status kct_len(kct_table *t, uint64_t *out) {
 
 kct_status kct_sum_counts(kct_table *t, uint64_t *out) {
     KCT_TRY(use(t));
+    KCT_TRY(materialize(t));
     du64 *d_sum = t->d_counters + kNumCounters + 3;
     HIP_TRY(hipMemsetAsync(d_sum, 0, 8, t->stream));
     {
@@ -696,6 +815,7 @@ kct_status kct_capacity(kct_table *t, uint64_t *slots_out) { KCT_TRY(use(t)); *s
 kct_status kct_export_device(kct_table *t, void *d_hashes, void *d_counts, size_t cap, uint64_t *n_out) {
     KCT_TRY(use(t));
     if (!n_out || (cap && (!d_hashes || !d_counts))) { set_err("null argument"); return KCT_ERR_ARG; }
+    KCT_TRY(materialize(t));
     du64 *d_n = t->d_counters + kNumCounters + 4;
     HIP_TRY(hipMemsetAsync(d_n, 0, 8, t->stream));
     {
@@ -809,6 +929,13 @@ kct_status kct_set_stream(kct_table *t, void *hip_stream) {
 }
 
 void *kct_get_stream(kct_table *t) { return t ? (void *)t->stream : nullptr; }
+
+kct_status kct_set_path(kct_table *t, int mode) {
+    KCT_TRY(use(t));
+    if (mode < 0 || mode > 2) { set_err("mode must be 0, 1 or 2"); return KCT_ERR_ARG; }
+    t->force_path = mode;
+    return KCT_OK;
+}
 
 kct_status kct_profile_enable(kct_table *t, int on) { KCT_TRY(use(t)); t->prof_on = on != 0; return KCT_OK; }
 

@@ -17,9 +17,14 @@
 namespace kct {
 
 constexpr int kBlock = 256;
-constexpr int kWPT = 32;                  // windows per thread
+constexpr int kWPT = 32;                  // windows per thread (direct kernels)
 constexpr int kTile = kBlock * kWPT;      // window start positions per workgroup (8192)
 constexpr int kHaloMax = 256;             // k - 1 <= 254
+constexpr int kPartThreads = 1024;        // partitioned path: one 16-wave workgroup per CU
+constexpr int kPartWPT = 16;
+constexpr int kPartTile = kPartThreads * kPartWPT;  // 16384 window starts per tile
+constexpr int kRingEntries = 16384;       // LDS write-combining ring: 128 KiB of u64, split over the bins
+constexpr int kChunk = 8;                 // entries per flush = one 64-byte line
 constexpr int kCounterShards = 64;        // per-launch tallies are spread over this many 128-B lines
 constexpr int kCounterStride = 16;        // u64 words per shard (128 B)
 enum { CTR_COUNTED = 0, CTR_NEWKEYS = 1, CTR_TOTAL_ADDED = 2, CTR_NEW_BY_ZERO = 3 };
@@ -30,11 +35,12 @@ __device__ __forceinline__ u64 wave_sum(u64 v) {
     return v;  // valid in lane 0
 }
 
-// Stage stream[tile_base, tile_base + kTile + k - 1) into LDS; bytes past `nbytes` read as 0.
+// Stage stream[tile_base, tile_base + TILE + k - 1) into LDS; bytes past `nbytes` read as 0.
+template <int BLOCK, int TILE>
 __device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ stream, u64 nbytes, u64 tile_base, int k,
                                            unsigned char *lds) {
-    const int nchunks = (kTile + k - 1 + 15) >> 4;  // <= 512 + 16
-    for (int c = threadIdx.x; c < nchunks; c += kBlock) {
+    const int nchunks = (TILE + k - 1 + 15) >> 4;
+    for (int c = threadIdx.x; c < nchunks; c += BLOCK) {
         const u64 off = tile_base + 16ULL * (u64)c;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (off + 16 <= nbytes) {
@@ -50,13 +56,14 @@ __device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ str
     __syncthreads();
 }
 
-// Walks this thread's kWPT windows of the staged tile and calls sink(j, good, hash) for each,
-// j = 0..kWPT-1 (window start = tile_base + threadIdx.x * kWPT + j).  KC > 0 fixes k at compile
-// time; KW = 64-bit words of the packed k-mer (k <= 32 * KW).
-template <int KW, int KC, class Sink>
+// Walks this thread's WPT windows of the staged tile and calls sink(j, good, hash) for each,
+// j = 0..WPT-1 (window start = tile_base + threadIdx.x * WPT + j).  KC > 0 fixes k at compile
+// time; KW = 64-bit words of the packed k-mer (k <= 32 * KW).  Every thread of the workgroup
+// makes the same WPT calls, so a sink may use wave collectives and workgroup barriers.
+template <int KW, int KC, int WPT, class Sink>
 __device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, int k_rt, Sink &&sink) {
     const int k = KC > 0 ? KC : k_rt;
-    const unsigned char *p = lds + threadIdx.x * kWPT;
+    const unsigned char *p = lds + threadIdx.x * WPT;
     Packed<KW> fw, rc;
 #pragma unroll
     for (int i = 0; i < KW; ++i) { fw.w[i] = 0; rc.w[i] = 0; }
@@ -69,7 +76,7 @@ __device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, in
         run = ok ? run + 1 : 0;
     }
 #pragma unroll 4
-    for (int j = 0; j < kWPT; ++j) {
+    for (int j = 0; j < WPT; ++j) {
         u32 code = base_code(p[k - 1 + j]);
         bool ok = code < 4;
         push_fw(fw, code & 3u);
@@ -88,12 +95,12 @@ __device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, in
 }
 
 // Any k (used for k > 64): validity by run length, canonical choice and hashing bytewise.
-template <class Sink>
+template <int WPT, class Sink>
 __device__ __forceinline__ void walk_windows_bytes(const unsigned char *lds, int k, Sink &&sink) {
-    const unsigned char *p = lds + threadIdx.x * kWPT;
+    const unsigned char *p = lds + threadIdx.x * WPT;
     int run = 0;
     for (int j = 0; j < k - 1; ++j) run = base_code(p[j]) < 4 ? run + 1 : 0;
-    for (int j = 0; j < kWPT; ++j) {
+    for (int j = 0; j < WPT; ++j) {
         run = base_code(p[k - 1 + j]) < 4 ? run + 1 : 0;
         const bool good = run >= k;
         u64 h = good ? hash_bytes_canonical(p + j, k) : 0;
@@ -101,10 +108,10 @@ __device__ __forceinline__ void walk_windows_bytes(const unsigned char *lds, int
     }
 }
 
-template <int KW, int KC, class Sink>
+template <int KW, int KC, int WPT, class Sink>
 __device__ __forceinline__ void walk_windows(const unsigned char *lds, int k, Sink &&sink) {
-    if constexpr (KW == 0) walk_windows_bytes(lds, k, sink);
-    else walk_windows_packed<KW, KC>(lds, k, sink);
+    if constexpr (KW == 0) walk_windows_bytes<WPT>(lds, k, sink);
+    else walk_windows_packed<KW, KC, WPT>(lds, k, sink);
 }
 
 // ---- hash-only kernel: SeqToHashes as consume drives it (lib.rs:576-600) ------------------------
@@ -115,10 +122,10 @@ __global__ __launch_bounds__(kBlock) void hash_windows_kernel(const unsigned cha
                                                               u64 nwindows, u64 *__restrict__ out, u64 *first_bad) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kTile + kHaloMax + 16];
     const u64 tile_base = (u64)blockIdx.x * kTile;
-    stage_tile(stream, nbytes, tile_base, k, lds);
+    stage_tile<kBlock, kTile>(stream, nbytes, tile_base, k, lds);
     const u64 p0 = tile_base + (u64)threadIdx.x * kWPT;
     u64 my_bad = ~0ULL;
-    walk_windows<KW, KC>(lds, k, [&](int j, bool good, u64 h) {
+    walk_windows<KW, KC, kWPT>(lds, k, [&](int j, bool good, u64 h) {
         const u64 p = p0 + j;
         if (p < nwindows) {
             out[p] = good ? h : 0;
@@ -166,11 +173,11 @@ __global__ __launch_bounds__(kBlock) void count_windows_kernel(const unsigned ch
     __shared__ u64 s_counted, s_new;
     if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
     const u64 tile_base = (u64)blockIdx.x * kTile;
-    stage_tile(stream, nbytes, tile_base, k, lds);
+    stage_tile<kBlock, kTile>(stream, nbytes, tile_base, k, lds);
     const int lane = threadIdx.x & 63;
     int counted = 0;  // signed: a leader whose folded add spills takes back the folded lanes' tallies
     int newkeys = 0;
-    walk_windows<KW, KC>(lds, k, [&](int, bool good, u64 h) {
+    walk_windows<KW, KC, kWPT>(lds, k, [&](int, bool good, u64 h) {
         bool active = good && h != 0;  // lib.rs:589: a hash of 0 is skipped and not tallied
         u64 c = 1;
         int tally = 0;
@@ -206,12 +213,195 @@ __global__ __launch_bounds__(kBlock) void count_windows_kernel(const unsigned ch
     }
 }
 
+// =================================================================================================
+// Partitioned path: the same consume loop, without one HBM atomic per k-mer.
+//
+// The direct kernel above is bound by the memory-side atomic rate (~2.3e10 64-byte atomic
+// requests/s measured on MI355X, profiles/r01a_*), not by HBM bandwidth.  Because probing is
+// confined to 128-KiB table blocks (table_device.h), a block can be owned by ONE workgroup:
+//
+//   K1 partition_windows_kernel  hash every window (same arithmetic as above) and radix-partition
+//        the 8-byte hashes by table block into HBM scratch.  Each persistent 1024-thread
+//        workgroup keeps a software write-combining ring per block in LDS (128 KiB in all) and
+//        flushes 64-byte lines to its own private region of every block's scratch, so the
+//        scatter costs no global atomics and every store is a whole line.
+//   K2 aggregate_blocks_kernel   one workgroup per table block: load the block (128 KiB) into
+//        LDS -- or start from zeros if the table is known empty -- stream the block's hashes,
+//        count them with LDS atomics (ds_cmpst_rtn_b64 claim + ds_add_u64), store the block back.
+//
+// HBM traffic per k-mer: 1.15 B bases + 8 B scratch write + 8 B scratch read, plus 32 B per table
+// slot per pass -- all of it coalesced streaming.  Anything irregular (a wavefront full of one
+// repeated k-mer, a ring or region that is full) goes to a small (hash, count) side list that
+// the host folds in afterwards with the direct atomic kernel, so results are identical.
+// =================================================================================================
+
+struct PartitionArgs {
+    u64 mask;            // table capacity - 1
+    int block_bits;      // log2(slots per block)
+    int pbits;           // log2(number of blocks P); P * D = kRingEntries, D >= 16
+    u64 *scratch;        // [nwg][P][region_cap] hashes
+    u32 region_cap;      // entries per (workgroup, block) region, multiple of kChunk
+    u32 *region_count;   // [nwg][P] entries written (multiple of kChunk, zero-padded)
+    u64 *irr;            // irregular (hash, count) pairs
+    u64 irr_cap;
+    u64 *irr_n;          // device counter
+    u64 *overflow;       // set to 1 if the irregular list overflowed: the pass is abandoned
+};
+
+__device__ __forceinline__ void irregular_pair(const PartitionArgs &a, u64 h, u64 c) {
+    u64 i = atomicAdd(a.irr_n, 1ULL);
+    if (i < a.irr_cap) { a.irr[2 * i] = h; a.irr[2 * i + 1] = c; }
+    else *a.overflow = 1ULL;
+}
+
+template <int KW, int KC>
+__global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
+                                                                         u64 ntiles, PartitionArgs a) {
+    __shared__ __attribute__((aligned(16))) u64 ring[kRingEntries];
+    __shared__ u32 fill[1024], flushed[1024];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kPartTile + kHaloMax + 16];
+    const int P = 1 << a.pbits;
+    const u32 D = (u32)(kRingEntries >> a.pbits), dmask = D - 1;
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < kRingEntries; i += kPartThreads) ring[i] = 0;
+    for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
+    u64 *my_scratch = a.scratch + (u64)blockIdx.x * P * a.region_cap;
+
+    // one thread moves one 64-byte line of a block's ring to this workgroup's region of that block
+    auto flush_chunk = [&](int b, u32 f) {
+        uint4 *src = reinterpret_cast<uint4 *>(&ring[(u32)b * D + (f & dmask)]);
+        uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        src[0] = z; src[1] = z; src[2] = z; src[3] = z;
+        if (f + kChunk <= a.region_cap) {
+            uint4 *dst = reinterpret_cast<uint4 *>(my_scratch + (u64)b * a.region_cap + f);
+            dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+        } else {  // region full (badly skewed input): hand the line to the side list
+            const u64 e[8] = {((u64)v0.y << 32) | v0.x, ((u64)v0.w << 32) | v0.z, ((u64)v1.y << 32) | v1.x, ((u64)v1.w << 32) | v1.z,
+                              ((u64)v2.y << 32) | v2.x, ((u64)v2.w << 32) | v2.z, ((u64)v3.y << 32) | v3.x, ((u64)v3.w << 32) | v3.z};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (e[i]) irregular_pair(a, e[i], 1);
+        }
+    };
+
+    for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();  // the previous tile's readers are done with `lds`; ring/fill init is visible
+        stage_tile<kPartThreads, kPartTile>(stream, nbytes, tile * kPartTile, k, lds);
+        walk_windows<KW, KC, kPartWPT>(lds, k, [&](int j, bool good, u64 h) {
+            bool active = good && h != 0;
+            // a wavefront full of one k-mer (homopolymer, tandem repeat) would overrun one ring:
+            // fold those lanes into a single (hash, count) pair on the side list instead
+            const u64 act = __ballot(active);
+            if (act) {
+                const int leader = __ffsll((long long)act) - 1;
+                const u64 hl = __shfl(h, leader);
+                const u64 same = __ballot(active && h == hl);
+                if (__popcll(same) >= 8) {
+                    if (lane == leader) irregular_pair(a, hl, (u64)__popcll(same));
+                    if ((same >> lane) & 1ULL) active = false;
+                }
+            }
+            if (active) {
+                const u32 b = (u32)((h & a.mask) >> a.block_bits);
+                const u32 pos = atomicAdd(&fill[b], 1u);
+                if (pos - flushed[b] < D) ring[b * D + (pos & dmask)] = h;  // slot's previous tenant is flushed
+                else irregular_pair(a, h, 1);                               // ring full: position stays a 0 hole
+            }
+            if (j & 1) {  // every second step: move every full line out
+                __syncthreads();
+                for (int b = threadIdx.x; b < P; b += kPartThreads) {
+                    u32 f = flushed[b];
+                    const u32 top = fill[b];
+                    while (top - f >= kChunk) { flush_chunk(b, f); f += kChunk; }
+                    flushed[b] = f;
+                }
+                __syncthreads();
+            }
+        });
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < P; b += kPartThreads) {  // drain: partial lines go out zero-padded
+        u32 f = flushed[b];
+        const u32 top = fill[b];
+        while ((int)(top - f) > 0) { flush_chunk(b, f); f += kChunk; }
+        a.region_count[(u64)blockIdx.x * P + b] = f < a.region_cap ? f : a.region_cap;
+    }
+}
+
+struct AggregateArgs {
+    u64 *slots;
+    int block_bits;
+    int pbits;
+    const u64 *scratch;
+    u32 region_cap;
+    const u32 *region_count;
+    int nwg;             // workgroups K1 ran with (= regions per block)
+    int fresh;           // table known empty: start every block from zeros instead of loading it
+    const u64 *overflow; // K1's abandon flag
+    u64 *spill; u64 spill_cap; u64 *spill_n;
+    u64 *counters;
+};
+
+__global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(AggregateArgs a) {
+    __shared__ __attribute__((aligned(16))) u64 tab[2 << kBlockBitsMax];  // {key, count} x 8192 = 128 KiB
+    __shared__ u64 s_counted, s_new;
+    if (*a.overflow) return;  // wave-uniform: K1 gave up, the host reruns the batch on the direct path
+    const int P = 1 << a.pbits, b = blockIdx.x;
+    const u32 S = 1u << a.block_bits, smask = S - 1;
+    u64 *gblock = a.slots + 2 * ((u64)b << a.block_bits);
+    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
+    uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+    if (a.fresh) for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
+    else for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32 counted = 0, newkeys = 0;
+    for (int seg = wave; seg < a.nwg; seg += kPartThreads / 64) {
+        const u32 cnt = a.region_count[(u64)seg * P + b];
+        const u64 *src = a.scratch + ((u64)seg * P + b) * a.region_cap;
+        for (u32 i = lane; i < cnt; i += 64) {
+            const u64 h = src[i];
+            if (h == 0) continue;  // zero padding / ring hole
+            u32 off = (u32)h & smask;
+            bool placed = false;
+            for (u32 probe = 0; probe < S; ++probe) {
+                u64 key = tab[2 * off];
+                if (key == 0) {
+                    key = atomicCAS(&tab[2 * off], 0ULL, h);
+                    if (key == 0) { ++newkeys; key = h; }
+                }
+                if (key == h) { atomicAdd(&tab[2 * off + 1], 1ULL); placed = true; break; }
+                off = (off + 1) & smask;
+            }
+            if (placed) ++counted;
+            else {  // block full: grow-and-replay list, tallied when replayed
+                u64 si = atomicAdd(a.spill_n, 1ULL);
+                if (si < a.spill_cap) { a.spill[2 * si] = h; a.spill[2 * si + 1] = 1; }
+            }
+        }
+    }
+    u64 wc = wave_sum(counted), wn = wave_sum(newkeys);
+    if (lane == 0) { atomicAdd(&s_counted, wc); atomicAdd(&s_new, wn); }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
+    if (threadIdx.x == 0) {
+        u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_counted) atomicAdd(shard + CTR_COUNTED, s_counted);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+    }
+}
+
 // ---- (hash, count) pairs -> table: add()'s inner loop (lib.rs:798-806), spill replay, re-hash --------
 // pairs are read as keys[i * key_stride], counts[i * count_stride] so that the same kernel folds
 // separate arrays (stride 1) and an old slot array (stride 2, keys = slots, counts = slots + 1).
+// n_dev (if not null) holds the pair count in device memory, clamped to n; a non-zero *abort
+// (if not null) turns the launch into a no-op.
 __global__ __launch_bounds__(kBlock) void merge_pairs_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ counts,
-                                                             u64 n, int stride, TableView table, u64 *counters) {
+                                                             u64 n, const u64 *n_dev, const u64 *abort, int stride, TableView table,
+                                                             u64 *counters) {
     __shared__ u64 s_tot, s_new, s_zero;
+    if (abort && *abort) return;
+    if (n_dev) { const u64 nd = *n_dev; n = nd < n ? nd : n; }
     if (threadIdx.x == 0) { s_tot = 0; s_new = 0; s_zero = 0; }
     __syncthreads();
     u64 tot = 0, nk = 0, nz = 0;
@@ -238,21 +428,21 @@ __global__ __launch_bounds__(kBlock) void merge_pairs_kernel(const u64 *__restri
 }
 
 // ---- lookups / point update ---------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void get_hashes_kernel(const u64 *__restrict__ slots, u64 mask,
+__global__ __launch_bounds__(kBlock) void get_hashes_kernel(const u64 *__restrict__ slots, u64 mask, u64 block_mask,
                                                             const u64 *__restrict__ hashes, u64 n, u64 *__restrict__ out) {
     const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) out[i] = hashes[i] ? table_get(slots, mask, hashes[i]) : 0;
+    if (i < n) out[i] = hashes[i] ? table_get(slots, mask, block_mask, hashes[i]) : 0;
 }
 
 // set the count of an existing key (returns 1 in *found) -- __setitem__ (lib.rs:675-681)
-__global__ void set_hash_kernel(u64 *slots, u64 mask, u64 h, u64 value, u64 *found) {
+__global__ void set_hash_kernel(u64 *slots, u64 mask, u64 block_mask, u64 h, u64 value, u64 *found) {
     u64 s = h & mask;
     *found = 0;
-    for (u64 probe = 0; probe <= mask; ++probe) {
+    for (u64 probe = 0; probe <= block_mask; ++probe) {
         u64 key = slots[2 * s];
         if (key == h) { slots[2 * s + 1] = value; *found = 1; return; }
         if (key == 0) return;
-        s = (s + 1) & mask;
+        s = next_slot(s, block_mask);
     }
 }
 

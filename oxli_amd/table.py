@@ -255,6 +255,10 @@ class KmerCountTable:
     def clear(self):
         self._check(self._lib.kct_clear(self._h))
 
+    def set_path(self, mode):
+        """0 = choose per pass, 1 = direct atomic path only, 2 = partitioned path whenever possible."""
+        self._check(self._lib.kct_set_path(self._h, {"auto": 0, "direct": 1, "partitioned": 2}.get(mode, mode)))
+
     # ---- in-library kernel timing (bench.py) ----------------------------------------------------------
     def set_stream(self, stream_ptr):
         self._check(self._lib.kct_set_stream(self._h, C.c_void_p(int(stream_ptr))))

@@ -399,3 +399,78 @@ def test_full_size_properties_1M_reads(KCT):
     rk, rc = ref.dump_arrays()
     got = np.array(t.get_hash_array(rk), dtype=np.uint64)
     assert np.all(got >= 2 * rc)
+
+
+# ---- the partitioned path (radix-partition by table block + LDS counting) == the direct path == oracle ----
+def _mixed_inputs(rng, k):
+    seqs = [rand_dna(rng, n) for n in (k, 2 * k, 150, 5000, 40000)]
+    seqs.append(rand_dna(rng, 300000))
+    seqs.append(rand_dna(rng, 20000, "ACGTN"))
+    seqs.append(rand_dna(rng, 20000, "acgtACGT"))
+    seqs.append("A" * 50000)                       # every lane of every wave holds the same k-mer
+    seqs.append("AC" * 30000 + "ACG" * 30000)      # tandem repeats: a handful of k-mers, ring overruns
+    seqs.append(rand_dna(rng, 1000) * 60)          # a 1 kbp unit repeated: every k-mer 60 times
+    return seqs
+
+
+@pytest.mark.parametrize("k", [21, 31, 32, 33, 51, 100])
+def test_partitioned_path_matches_oracle(KCT, k):
+    rng = random.Random(4000 + k)
+    seqs = _mixed_inputs(rng, k)
+    ref = OracleTable(k)
+    n_ref = [ref.consume(s) for s in seqs]
+    for path in ("partitioned", "direct", "auto"):
+        dev = KCT(k, capacity=400000)
+        dev.set_path(path)
+        assert [dev.consume(s) for s in seqs] == n_ref, path
+        assert_same_table(dev, ref)
+    # one batch call (all records in one pass of the pipeline)
+    dev = KCT(k, capacity=400000)
+    dev.set_path("partitioned")
+    assert dev.consume_batch(seqs) == sum(n_ref)
+    assert_same_table(dev, ref)
+
+
+def test_partitioned_path_updates_a_live_table(KCT):
+    """Second and later passes load each table block into LDS instead of starting from zeros; point
+    updates made through the atomic path in between must be seen and kept."""
+    rng = random.Random(77)
+    k = 25
+    a, b, c = rand_dna(rng, 200000), rand_dna(rng, 200000), rand_dna(rng, 1000)
+    dev, ref = KCT(k, capacity=600000), OracleTable(k)
+    dev.set_path("partitioned")
+    for t in (dev, ref):
+        t.consume(a)
+        t.count(c[:k]); t.count(c[:k]); t.count_hash(12345)
+        t.consume(b)
+        t.consume(a[:100000])
+    assert_same_table(dev, ref)
+    dev.clear()
+    ref = OracleTable(k)
+    assert dev.consume(b) == ref.consume(b)   # lazy clear -> fresh pass
+    assert_same_table(dev, ref)
+    dev.clear()
+    assert len(dev) == 0 and dev.sum_counts == 0 and dev.get(c[:k]) == 0 and dev.dump() == []
+
+
+def test_partitioned_path_grows_when_blocks_fill(KCT):
+    rng = random.Random(78)
+    k = 27
+    s = rand_dna(rng, 1500000)       # ~1.5 M distinct k-mers into a table sized for 100 k
+    dev, ref = KCT(k, capacity=100000), OracleTable(k)
+    dev.set_path("partitioned")
+    cap0 = dev.capacity
+    assert dev.consume(s) == ref.consume(s)
+    assert dev.capacity > cap0
+    assert_same_table(dev, ref)
+
+
+def test_partitioned_path_abandons_on_pathological_input(KCT):
+    """Period-3 repeats keep overrunning one ring; the side list overflows, the pass is abandoned
+    and the batch is recounted on the direct path -- same answer."""
+    k = 21
+    s = "ACG" * 1000000
+    dev, ref = KCT(k, capacity=200000), OracleTable(k)
+    dev.set_path("partitioned")
+    assert dev.consume(s) == ref.consume(s)
+    assert_same_table(dev, ref)
