@@ -152,12 +152,13 @@ def main():
         n_all = global_scalar_sum(n_total, "cuda")
     else:
         n_all = n_total
-    assert n_total == kmers_per_step * args.steps, (n_total, kmers_per_step * args.steps)
+    ablate = bool(os.environ.get("KCT_ABLATE"))  # timing experiments that deliberately skip work: no result checks
+    assert ablate or n_total == kmers_per_step * args.steps, (n_total, kmers_per_step * args.steps)
 
     # invariants of the finished job (cheap, outside the timed region)
     distinct = global_scalar_sum(len(table), "cuda") if world > 1 else len(table)
     total_counts = global_scalar_sum(table.sum_counts, "cuda") if world > 1 else table.sum_counts
-    assert total_counts == world * kmers_per_step, (total_counts, world * kmers_per_step)
+    assert ablate or total_counts == world * kmers_per_step, (total_counts, world * kmers_per_step)
 
     value = n_all / elapsed
     b_alg = L / (L - k + 1) + 24.0
@@ -181,7 +182,7 @@ def main():
         "metric": "k-mers/sec (consume) at k=%d, %d bp reads" % (k, L),
         "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64", "data": "synthetic",
+        "dtype": "u64", "data": "synthetic" if not ablate else "INVALID (KCT_ABLATE set: work skipped)",
         "config": {"workload": f"C2: {R} x {L} bp synthetic reads per GPU, k={k}, genome {G} bp (seed {SEED_G}/{SEED_R}), "
                                f"device hash table in HBM ({table.capacity} slots x 16 B)",
                    "reads_per_gpu": R, "read_len": L, "k": k, "genome": G, "distinct_kmers": distinct,

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -167,11 +168,17 @@ kct_status use(kct_table *t) {
     return KCT_OK;
 }
 
+kct::TableGeom geom(const kct_table *t) {
+    kct::TableGeom g;
+    g.mask = t->cap - 1;
+    g.block_bits = t->block_bits;
+    return g;
+}
+
 kct::TableView view(kct_table *t, u64 spill_cap) {
     kct::TableView v;
-    v.slots = t->slots;
-    v.mask = t->cap - 1;
-    v.block_mask = (1ULL << t->block_bits) - 1;
+    v.words = t->slots;
+    v.g = geom(t);
     v.spill = (du64 *)t->d_spill.p;
     v.spill_cap = spill_cap;
     v.spill_n = t->d_counters + kNumCounters;  // scratch word 0
@@ -180,7 +187,7 @@ kct::TableView view(kct_table *t, u64 spill_cap) {
 
 int log2_u64(u64 v) { int b = 0; while ((1ULL << b) < v) ++b; return b; }
 
-void set_geometry(kct_table *t) { t->block_bits = std::min(kct::kBlockBitsMax, log2_u64(t->cap)); }
+void set_geometry(kct_table *t) { t->block_bits = std::min(kct::kBlockBitsMax, log2_u64(t->cap)); }  // cap >= kMinSlots = 1024 > one group
 
 // kct_clear() defers its memset: the partitioned path rewrites every block from zeros anyway.
 // Anything else that touches `slots` calls this first.
@@ -257,6 +264,7 @@ kct_status grow_to(kct_table *t, u64 new_cap) {
     if (new_cap <= t->cap) new_cap = t->cap * 2;
     du64 *old = t->slots;
     const u64 old_cap = t->cap, old_keys = t->n_keys;
+    const kct::TableGeom old_g = geom(t);
     du64 *fresh = nullptr;
     KCT_TRY(alloc_slots(t->device, new_cap, t->stream, &fresh));
     t->slots = fresh;
@@ -265,13 +273,13 @@ kct_status grow_to(kct_table *t, u64 new_cap) {
     t->n_keys = 0;
     if (t->lazy_empty) t->lazy_empty = false;  // the old array was never cleaned, but it holds no keys: drop it
     if (old && old_keys > 0) {
-        // re-insert every occupied slot; the new table is at most half full so nothing spills
+        // re-insert every occupied slot; the new table is at most ~half full so nothing spills
         KCT_TRY(t->d_spill.reserve(16));
         KCT_TRY(zero_counters(t));
         {
-            ProfScope ps(t, "merge_pairs_kernel(rehash)");
-            hipLaunchKernelGGL(kct::merge_pairs_kernel, dim3(merge_grid(old_cap)), dim3(kct::kBlock), 0, t->stream, old, old + 1,
-                               old_cap, (const du64 *)nullptr, (const du64 *)nullptr, 2, view(t, 0), t->d_counters);
+            ProfScope ps(t, "rehash_kernel");
+            hipLaunchKernelGGL(kct::rehash_kernel, dim3(merge_grid(old_cap)), dim3(kct::kBlock), 0, t->stream, (const du64 *)old, old_g,
+                               view(t, 0), t->d_counters);
         }
         HIP_TRY(hipGetLastError());
         u64 c[4], spilled;
@@ -371,6 +379,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     pa.mask = t->cap - 1; pa.block_bits = t->block_bits; pa.pbits = pbits;
     pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
     pa.irr = (du64 *)t->d_irr.p; pa.irr_cap = irr_cap; pa.irr_n = d_irr_n; pa.overflow = d_overflow;
+    pa.ablate = getenv("KCT_ABLATE") ? atoi(getenv("KCT_ABLATE")) : 0;  // measurement only; wrong counts when set
     {
         ProfScope ps(t, "partition_windows_kernel");
         dispatch_k<PartitionLauncher>(k, t->stream, nwg, d_stream, chunk_bytes, k, ntiles, pa);
@@ -378,9 +387,9 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     HIP_TRY(hipGetLastError());
 
     kct::AggregateArgs aa;
-    aa.slots = t->slots; aa.block_bits = t->block_bits; aa.pbits = pbits;
+    aa.words = t->slots; aa.block_bits = t->block_bits; aa.pbits = pbits;
     aa.scratch = (const du64 *)t->d_scratch.p; aa.region_cap = region_cap; aa.region_count = (const unsigned int *)t->d_regions.p;
-    aa.nwg = nwg; aa.fresh = fresh ? 1 : 0; aa.overflow = d_overflow;
+    aa.nwg = nwg; aa.fresh = fresh ? 1 : 0; aa.overflow = d_overflow; aa.ablate = pa.ablate;
     aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
     {
         ProfScope ps(t, "aggregate_blocks_kernel");
@@ -642,7 +651,7 @@ kct_status kct_get_hash_array(kct_table *t, const uint64_t *hashes, size_t n, ui
     {
         ProfScope ps(t, "get_hashes_kernel");
         hipLaunchKernelGGL(kct::get_hashes_kernel, dim3((unsigned)((n + kct::kBlock - 1) / kct::kBlock)), dim3(kct::kBlock), 0, t->stream,
-                           t->slots, t->cap - 1, (1ULL << t->block_bits) - 1, d_in, (u64)n, d_out);
+                           (const du64 *)t->slots, geom(t), (const du64 *)d_in, (u64)n, d_out);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(counts_out, d_out, n * 8, hipMemcpyDeviceToHost, t->stream));
@@ -679,7 +688,7 @@ kct_status kct_set_hash(kct_table *t, uint64_t hash, uint64_t count) {
     u64 tl[4] = {0, 0, 0, 0};
     KCT_TRY(merge_pairs(t, (const du64 *)t->d_aux.p, (const du64 *)t->d_aux.p + 1, 1, 1, tl));
     du64 *d_found = t->d_counters + kNumCounters + 2;
-    hipLaunchKernelGGL(kct::set_hash_kernel, dim3(1), dim3(1), 0, t->stream, t->slots, t->cap - 1, (1ULL << t->block_bits) - 1, (u64)hash, (u64)count, d_found);
+    hipLaunchKernelGGL(kct::set_hash_kernel, dim3(1), dim3(1), 0, t->stream, t->slots, geom(t), (u64)hash, (u64)count, d_found);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));
     return KCT_OK;
@@ -798,7 +807,7 @@ kct_status kct_sum_counts(kct_table *t, uint64_t *out) {
     HIP_TRY(hipMemsetAsync(d_sum, 0, 8, t->stream));
     {
         ProfScope ps(t, "sum_counts_kernel");
-        hipLaunchKernelGGL(kct::sum_counts_kernel, dim3(merge_grid(t->cap)), dim3(kct::kBlock), 0, t->stream, t->slots, t->cap, d_sum);
+        hipLaunchKernelGGL(kct::sum_counts_kernel, dim3(merge_grid(t->cap)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->slots, geom(t), d_sum);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(t->h_counters, d_sum, 8, hipMemcpyDeviceToHost, t->stream));
@@ -820,7 +829,7 @@ kct_status kct_export_device(kct_table *t, void *d_hashes, void *d_counts, size_
     HIP_TRY(hipMemsetAsync(d_n, 0, 8, t->stream));
     {
         ProfScope ps(t, "compact_kernel");
-        hipLaunchKernelGGL(kct::compact_kernel, dim3(merge_grid(t->cap)), dim3(kct::kBlock), 0, t->stream, t->slots, t->cap, (du64 *)d_hashes,
+        hipLaunchKernelGGL(kct::compact_kernel, dim3(merge_grid(t->cap)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->slots, geom(t), (du64 *)d_hashes,
                            (du64 *)d_counts, (u64)cap, d_n);
     }
     HIP_TRY(hipGetLastError());

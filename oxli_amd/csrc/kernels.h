@@ -25,6 +25,7 @@ constexpr int kPartWPT = 16;
 constexpr int kPartTile = kPartThreads * kPartWPT;  // 16384 window starts per tile
 constexpr int kRingEntries = 16384;       // LDS write-combining ring: 128 KiB of u64, split over the bins
 constexpr int kChunk = 8;                 // entries per flush = one 64-byte line
+constexpr int kWaveQueue = 160;           // K2: deferred entries per wave
 constexpr int kCounterShards = 64;        // per-launch tallies are spread over this many 128-B lines
 constexpr int kCounterStride = 16;        // u64 words per shard (128 B)
 enum { CTR_COUNTED = 0, CTR_NEWKEYS = 1, CTR_TOTAL_ADDED = 2, CTR_NEW_BY_ZERO = 3 };
@@ -241,7 +242,8 @@ struct PartitionArgs {
     int pbits;           // log2(number of blocks P); P * D = kRingEntries, D >= 16
     u64 *scratch;        // [nwg][P][region_cap] hashes
     u32 region_cap;      // entries per (workgroup, block) region, multiple of kChunk
-    u32 *region_count;   // [nwg][P] entries written (multiple of kChunk, zero-padded)
+    u32 *region_count;   // [P][nwg] entries written (multiple of kChunk, zero-padded)
+    int ablate;          // measurement only: bit 0 = skip the ring append, bit 1 = skip the flush phases
     u64 *irr;            // irregular (hash, count) pairs
     u64 irr_cap;
     u64 *irr_n;          // device counter
@@ -301,13 +303,13 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
                     if ((same >> lane) & 1ULL) active = false;
                 }
             }
-            if (active) {
+            if (active && !(a.ablate & 1)) {
                 const u32 b = (u32)((h & a.mask) >> a.block_bits);
                 const u32 pos = atomicAdd(&fill[b], 1u);
                 if (pos - flushed[b] < D) ring[b * D + (pos & dmask)] = h;  // slot's previous tenant is flushed
                 else irregular_pair(a, h, 1);                               // ring full: position stays a 0 hole
             }
-            if (j & 1) {  // every second step: move every full line out
+            if ((j & 3) == 3 && !(a.ablate & 2)) {  // every fourth step: move every full line out
                 __syncthreads();
                 for (int b = threadIdx.x; b < P; b += kPartThreads) {
                     u32 f = flushed[b];
@@ -324,12 +326,12 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         u32 f = flushed[b];
         const u32 top = fill[b];
         while ((int)(top - f) > 0) { flush_chunk(b, f); f += kChunk; }
-        a.region_count[(u64)blockIdx.x * P + b] = f < a.region_cap ? f : a.region_cap;
+        a.region_count[(u64)b * gridDim.x + blockIdx.x] = f < a.region_cap ? f : a.region_cap;
     }
 }
 
 struct AggregateArgs {
-    u64 *slots;
+    u64 *words;          // the table (block-SoA)
     int block_bits;
     int pbits;
     const u64 *scratch;
@@ -338,48 +340,132 @@ struct AggregateArgs {
     int nwg;             // workgroups K1 ran with (= regions per block)
     int fresh;           // table known empty: start every block from zeros instead of loading it
     const u64 *overflow; // K1's abandon flag
+    int ablate;          // measurement only: bit 2 = no count add, bit 4 = loads only
     u64 *spill; u64 spill_cap; u64 *spill_n;
     u64 *counters;
 };
 
 __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(AggregateArgs a) {
-    __shared__ __attribute__((aligned(16))) u64 tab[2 << kBlockBitsMax];  // {key, count} x 8192 = 128 KiB
+    __shared__ __attribute__((aligned(16))) u64 tab[2 << kBlockBitsMax];  // S keys then S counts = 128 KiB
+    __shared__ u64 wq[(kPartThreads / 64) * kWaveQueue];                  // per-wave queues of deferred entries, 20 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char tags[1 << kBlockBitsMax];  // one fingerprint byte per slot, 8 KiB
     __shared__ u64 s_counted, s_new;
     if (*a.overflow) return;  // wave-uniform: K1 gave up, the host reruns the batch on the direct path
     const int P = 1 << a.pbits, b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
-    u64 *gblock = a.slots + 2 * ((u64)b << a.block_bits);
+    u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
+    u64 *keys = tab, *cnts = tab + S;
     if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
-    if (a.fresh) for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
-    else for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
+    // fingerprint of a key: a hash byte that neither the slot index (low bits) nor the multi-GPU
+    // owner (top bits) uses; 0 is reserved for "empty slot"
+    auto tag_of = [](u64 h) -> u32 { const u32 t = (u32)(h >> 32) & 0xFFu; return t ? t : 1u; };
+    if (a.fresh) {
+        for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
+        for (u32 i = threadIdx.x; i < S / 16; i += kPartThreads) reinterpret_cast<uint4 *>(tags)[i] = make_uint4(0, 0, 0, 0);
+    } else {
+        for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < S; i += kPartThreads) { const u64 kk = keys[i]; tags[i] = (unsigned char)(kk ? tag_of(kk) : 0u); }
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32 counted = 0, newkeys = 0;
-    for (int seg = wave; seg < a.nwg; seg += kPartThreads / 64) {
-        const u32 cnt = a.region_count[(u64)seg * P + b];
-        const u64 *src = a.scratch + ((u64)seg * P + b) * a.region_cap;
-        for (u32 i = lane; i < cnt; i += 64) {
-            const u64 h = src[i];
-            if (h == 0) continue;  // zero padding / ring hole
-            u32 off = (u32)h & smask;
-            bool placed = false;
-            for (u32 probe = 0; probe < S; ++probe) {
-                u64 key = tab[2 * off];
-                if (key == 0) {
-                    key = atomicCAS(&tab[2 * off], 0ULL, h);
-                    if (key == 0) { ++newkeys; key = h; }
+    // General insert.  One probe round = the 8 keys of a group = one 64-byte LDS line
+    // (4 x ds_read_b128), examined in slot order so a new key lands in the first empty slot of
+    // its sequence -- the same arrangement the direct path builds.
+    auto insert = [&](u64 h) {
+        u32 g = (u32)h & smask & ~(u32)(kGroup - 1);
+        bool placed = false;
+        for (u32 round = 0; round < (S >> kGroupBits) && !placed; ++round) {
+            const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(keys + g);
+            const ulonglong2 q0 = kp[0], q1 = kp[1], q2 = kp[2], q3 = kp[3];
+            const u64 k[kGroup] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+            int sel = kGroup;  // first slot that holds h or is empty
+#pragma unroll
+            for (int i = kGroup - 1; i >= 0; --i) if (k[i] == h || k[i] == 0) sel = i;
+            while (sel < kGroup) {
+                u64 ks = keys[g + sel];
+                if (ks == 0) {
+                    ks = atomicCAS(&keys[g + sel], 0ULL, h);
+                    if (ks == 0) { ++newkeys; ks = h; tags[g + sel] = (unsigned char)tag_of(h); }
                 }
-                if (key == h) { atomicAdd(&tab[2 * off + 1], 1ULL); placed = true; break; }
-                off = (off + 1) & smask;
+                if (ks == h) {
+                    if (!(a.ablate & 4)) atomicAdd(&cnts[g + sel], 1ULL);
+                    placed = true;
+                    break;
+                }
+                ++sel;  // another lane claimed that slot for a different key: try the following slots
+                while (sel < kGroup) { const u64 kk = keys[g + sel]; if (kk == h || kk == 0) break; ++sel; }
             }
-            if (placed) ++counted;
-            else {  // block full: grow-and-replay list, tallied when replayed
-                u64 si = atomicAdd(a.spill_n, 1ULL);
-                if (si < a.spill_cap) { a.spill[2 * si] = h; a.spill[2 * si + 1] = 1; }
+            g = (g + kGroup) & smask;
+        }
+        if (placed) ++counted;
+        else {  // block full: grow-and-replay list, tallied when replayed
+            u64 si = atomicAdd(a.spill_n, 1ULL);
+            if (si < a.spill_cap) { a.spill[2 * si] = h; a.spill[2 * si + 1] = 1; }
+        }
+    };
+    // Fast path: ~93 % of a block's entries are repeat sightings of a key that already sits in
+    // its home group.  Those cost one 8-byte read of the group's fingerprints, a SWAR byte match,
+    // one 8-byte key read to confirm and one ds_add_u64 -- 24 bytes of LDS traffic, no loops.
+    // Everything else (first sightings, keys pushed to a later group, fingerprint collisions) is
+    // parked in a per-wave queue and run through the general insert 64 at a time, so the branchy
+    // code always runs with full lanes.  A fingerprint written late only costs a detour through
+    // the queue; the general insert never trusts fingerprints.
+    u64 *myq = wq + wave * kWaveQueue;
+    u32 qn = 0;  // wave-uniform
+    auto drain = [&](u32 keep_below) {
+        while (qn > keep_below) {
+            const u32 take = qn < 64 ? qn : 64;
+            qn -= take;
+            if ((u32)lane < take) insert(myq[qn + lane]);
+        }
+    };
+    auto fast = [&](u64 h) {
+        bool miss = h != 0;
+        if (h != 0) {
+            const u32 g = (u32)h & smask & ~(u32)(kGroup - 1);
+            const u64 t8 = *reinterpret_cast<const u64 *>(tags + g);
+            const u64 x = t8 ^ ((u64)tag_of(h) * 0x0101010101010101ULL);
+            const u64 z = (x - 0x0101010101010101ULL) & ~x & 0x8080808080808080ULL;  // lowest set bit marks the first equal byte
+            if (z) {
+                const u32 idx = (u32)__builtin_ctzll(z) >> 3;
+                if (keys[g + idx] == h) {
+                    if (!(a.ablate & 4)) atomicAdd(&cnts[g + idx], 1ULL);
+                    ++counted;
+                    miss = false;
+                }
             }
         }
+        const u64 m = __ballot(miss);
+        if (m) {
+            const u32 pos = qn + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+            if (miss) myq[pos] = h;
+            qn += (u32)__popcll(m);
+            if (qn > kWaveQueue - 64) drain(31);
+        }
+    };
+    // One wave per source region.  All of a lane's loads for the region are issued before the
+    // first insert so that ~10 x 512 B are in flight per wave instead of one dependent load.
+    constexpr int kInFlight = 12;
+    const u32 *my_counts = a.region_count + (u64)b * a.nwg;
+    for (int seg = wave; seg < a.nwg; seg += kPartThreads / 64) {
+        const u32 cnt = my_counts[seg];
+        const u64 *src = a.scratch + ((u64)seg * P + b) * a.region_cap;
+        u64 v[kInFlight];
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) { const u32 i = lane + 64 * j; v[j] = i < cnt ? src[i] : 0ULL; }
+        if (a.ablate & 16) {
+#pragma unroll
+            for (int j = 0; j < kInFlight; ++j) counted += (u32)v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < kInFlight; ++j) fast(v[j]);
+        }
+        for (u32 i0 = 64 * kInFlight; i0 < cnt; i0 += 64) { const u32 i = i0 + lane; fast(i < cnt ? src[i] : 0ULL); }
     }
+    drain(0);
     u64 wc = wave_sum(counted), wn = wave_sum(newkeys);
     if (lane == 0) { atomicAdd(&s_counted, wc); atomicAdd(&s_new, wn); }
     __syncthreads();
@@ -427,42 +513,65 @@ __global__ __launch_bounds__(kBlock) void merge_pairs_kernel(const u64 *__restri
     }
 }
 
+// ---- re-hash: every occupied slot of an old table -> the new table (growth) ------------------------
+__global__ __launch_bounds__(kBlock) void rehash_kernel(const u64 *__restrict__ old_words, TableGeom old_g, TableView table,
+                                                        u64 *counters) {
+    __shared__ u64 s_new;
+    if (threadIdx.x == 0) s_new = 0;
+    __syncthreads();
+    const u64 cap = old_g.mask + 1, S = block_slots(old_g);
+    u64 nk = 0;
+    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock) {
+        const u64 kw = key_word(old_g, s);
+        const u64 h = old_words[kw];
+        if (h == 0) continue;
+        const AddResult r = table_add<false>(table, h, old_words[kw + S]);
+        nk += (r.claimed && !r.spilled) ? 1 : 0;
+    }
+    nk = wave_sum(nk);
+    if ((threadIdx.x & 63) == 0 && nk) atomicAdd(&s_new, nk);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_new) atomicAdd(counters + (blockIdx.x % kCounterShards) * kCounterStride + CTR_NEWKEYS, s_new);
+}
+
 // ---- lookups / point update ---------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void get_hashes_kernel(const u64 *__restrict__ slots, u64 mask, u64 block_mask,
+__global__ __launch_bounds__(kBlock) void get_hashes_kernel(const u64 *__restrict__ words, TableGeom g,
                                                             const u64 *__restrict__ hashes, u64 n, u64 *__restrict__ out) {
     const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) out[i] = hashes[i] ? table_get(slots, mask, block_mask, hashes[i]) : 0;
+    if (i >= n) return;
+    const u64 w = hashes[i] ? table_find(words, g, hashes[i]) : ~0ULL;
+    out[i] = w == ~0ULL ? 0 : words[w + block_slots(g)];
 }
 
 // set the count of an existing key (returns 1 in *found) -- __setitem__ (lib.rs:675-681)
-__global__ void set_hash_kernel(u64 *slots, u64 mask, u64 block_mask, u64 h, u64 value, u64 *found) {
-    u64 s = h & mask;
-    *found = 0;
-    for (u64 probe = 0; probe <= block_mask; ++probe) {
-        u64 key = slots[2 * s];
-        if (key == h) { slots[2 * s + 1] = value; *found = 1; return; }
-        if (key == 0) return;
-        s = next_slot(s, block_mask);
-    }
+__global__ void set_hash_kernel(u64 *words, TableGeom g, u64 h, u64 value, u64 *found) {
+    const u64 w = table_find(words, g, h);
+    *found = w != ~0ULL;
+    if (w != ~0ULL) words[w + block_slots(g)] = value;
 }
 
 // ---- whole-table scans ---------------------------------------------------------------------------
 // compaction for dump / export: out_n must be zero on entry
-__global__ __launch_bounds__(kBlock) void compact_kernel(const u64 *__restrict__ slots, u64 cap, u64 *__restrict__ out_keys,
+__global__ __launch_bounds__(kBlock) void compact_kernel(const u64 *__restrict__ words, TableGeom g, u64 *__restrict__ out_keys,
                                                          u64 *__restrict__ out_counts, u64 out_cap, u64 *out_n) {
+    const u64 cap = g.mask + 1, S = block_slots(g);
     for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock) {
-        const u64 key = slots[2 * s];
+        const u64 kw = key_word(g, s);
+        const u64 key = words[kw];
         if (key != 0) {
             const u64 i = atomicAdd(out_n, 1ULL);  // hipcc folds this into one add per wave
-            if (i < out_cap) { out_keys[i] = key; out_counts[i] = slots[2 * s + 1]; }
+            if (i < out_cap) { out_keys[i] = key; out_counts[i] = words[kw + S]; }
         }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void sum_counts_kernel(const u64 *__restrict__ slots, u64 cap, u64 *out) {
+__global__ __launch_bounds__(kBlock) void sum_counts_kernel(const u64 *__restrict__ words, TableGeom g, u64 *out) {
+    const u64 cap = g.mask + 1, S = block_slots(g);
     u64 acc = 0;
-    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock)
-        if (slots[2 * s] != 0) acc += slots[2 * s + 1];
+    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock) {
+        const u64 kw = key_word(g, s);
+        if (words[kw] != 0) acc += words[kw + S];
+    }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
