@@ -366,19 +366,20 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
     const double avg = (double)(tiles_per_wg * kct::kPartTile) / (double)P;
     const unsigned int region_cap = (unsigned int)((((u64)(avg * 1.15 + 8.0 * __builtin_sqrt(avg) + 64.0)) + 7) & ~7ULL);
-    const u64 irr_cap = npos / 8 + 65536;
+    const unsigned int ovf_cap = (unsigned int)std::max<u64>(4096, tiles_per_wg * kct::kPartTile / 8);
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 8));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
-    KCT_TRY(t->d_irr.reserve(irr_cap * 16));
+    KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
     KCT_TRY(t->d_spill.reserve(npos * 16));
     KCT_TRY(zero_counters(t));
-    du64 *d_irr_n = t->d_counters + kNumCounters + 5, *d_overflow = t->d_counters + kNumCounters + 6;
+    du64 *d_overflow = t->d_counters + kNumCounters + 6;
+    unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
     const bool fresh = t->lazy_empty;
 
     kct::PartitionArgs pa;
     pa.mask = t->cap - 1; pa.block_bits = t->block_bits; pa.pbits = pbits;
     pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
-    pa.irr = (du64 *)t->d_irr.p; pa.irr_cap = irr_cap; pa.irr_n = d_irr_n; pa.overflow = d_overflow;
+    pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
     pa.ablate = getenv("KCT_ABLATE") ? atoi(getenv("KCT_ABLATE")) : 0;  // measurement only; wrong counts when set
     {
         ProfScope ps(t, "partition_windows_kernel");
@@ -397,15 +398,24 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     }
     HIP_TRY(hipGetLastError());
     {
-        // fold the irregular side list with the direct atomic kernel; it reads its length and the
-        // abandon flag from device memory, so no host round trip sits between the three launches
-        ProfScope ps(t, "merge_pairs_kernel(irregular)");
-        hipLaunchKernelGGL(kct::merge_pairs_kernel, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
-                           (const du64 *)t->d_irr.p + 1, irr_cap, (const du64 *)d_irr_n, (const du64 *)d_overflow, 2, view(t, npos), t->d_counters);
+        // fold the overflow regions with the direct atomic path; the kernel reads the region lengths
+        // and the abandon flag from device memory, so no host round trip sits between the launches
+        ProfScope ps(t, "merge_overflow_kernel");
+        hipLaunchKernelGGL(kct::merge_overflow_kernel, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
+                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, view(t, npos), t->d_counters);
     }
     HIP_TRY(hipGetLastError());
     u64 c[4], spilled;
     KCT_TRY(read_counters(t, c, &spilled));
+    if (getenv("KCT_DEBUG")) {
+        std::vector<unsigned int> oc(nwg);
+        (void)hipMemcpy(oc.data(), d_ovf_count, nwg * 4, hipMemcpyDeviceToHost);
+        u64 tot = 0; unsigned int mx = 0;
+        for (auto v : oc) { tot += v; mx = std::max(mx, v); }
+        fprintf(stderr, "[kct] partitioned pass: npos=%llu P=%llu region_cap=%u ovf_cap=%u overflow entries total=%llu max/wg=%u counted=%llu merged=%llu spilled=%llu abandon=%llu\n",
+                (unsigned long long)npos, (unsigned long long)P, region_cap, ovf_cap, (unsigned long long)tot, mx, (unsigned long long)c[kct::CTR_COUNTED],
+                (unsigned long long)c[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled, (unsigned long long)t->h_counters[kNumCounters + 6]);
+    }
     if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // abandoned: K2 and the merge exited early, nothing was touched
     t->lazy_empty = false;
     *handled = true;

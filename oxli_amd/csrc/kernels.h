@@ -30,6 +30,13 @@ constexpr int kCounterShards = 64;        // per-launch tallies are spread over 
 constexpr int kCounterStride = 16;        // u64 words per shard (128 B)
 enum { CTR_COUNTED = 0, CTR_NEWKEYS = 1, CTR_TOTAL_ADDED = 2, CTR_NEW_BY_ZERO = 3 };
 
+// 64-bit value of lane `src` (wave-uniform index) broadcast through SGPRs: two v_readlane_b32,
+// no LDS round trip (what __shfl would cost).
+__device__ __forceinline__ u64 read_lane64(u64 v, int src) {
+    const u32 lo = __builtin_amdgcn_readlane((u32)v, src), hi = __builtin_amdgcn_readlane((u32)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+
 __device__ __forceinline__ u64 wave_sum(u64 v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void count_windows_kernel(const unsigned ch
         const u64 act = __ballot(active);
         if (act) {
             const int leader = __ffsll((long long)act) - 1;
-            const u64 hl = __shfl(h, leader);
+            const u64 hl = read_lane64(h, leader);
             const u64 same = __ballot(active && h == hl);
             if (same != (1ULL << leader)) {
                 if (lane == leader) c = (u64)__popcll(same);
@@ -243,32 +250,39 @@ struct PartitionArgs {
     u64 *scratch;        // [nwg][P][region_cap] hashes
     u32 region_cap;      // entries per (workgroup, block) region, multiple of kChunk
     u32 *region_count;   // [P][nwg] entries written (multiple of kChunk, zero-padded)
+    u64 *ovf;            // [nwg][ovf_cap] hashes that found their ring (or region) full
+    u32 ovf_cap;
+    u32 *ovf_count;      // [nwg]
+    u64 *overflow;       // set to 1 if an overflow region itself overflowed: the pass is abandoned
     int ablate;          // measurement only: bit 0 = skip the ring append, bit 1 = skip the flush phases
-    u64 *irr;            // irregular (hash, count) pairs
-    u64 irr_cap;
-    u64 *irr_n;          // device counter
-    u64 *overflow;       // set to 1 if the irregular list overflowed: the pass is abandoned
 };
-
-__device__ __forceinline__ void irregular_pair(const PartitionArgs &a, u64 h, u64 c) {
-    u64 i = atomicAdd(a.irr_n, 1ULL);
-    if (i < a.irr_cap) { a.irr[2 * i] = h; a.irr[2 * i + 1] = c; }
-    else *a.overflow = 1ULL;
-}
 
 template <int KW, int KC>
 __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
                                                                          u64 ntiles, PartitionArgs a) {
     __shared__ __attribute__((aligned(16))) u64 ring[kRingEntries];
     __shared__ u32 fill[1024], flushed[1024];
+    __shared__ u32 ovf_n;
     __shared__ __attribute__((aligned(16))) unsigned char lds[kPartTile + kHaloMax + 16];
     const int P = 1 << a.pbits;
     const u32 D = (u32)(kRingEntries >> a.pbits), dmask = D - 1;
-    const int lane = threadIdx.x & 63;
+    const int fmask = (a.ablate >> 8) ? (a.ablate >> 8) - 1 : 3;  // flush interval - 1 (measurement knob in bits 8+)
     for (int i = threadIdx.x; i < kRingEntries; i += kPartThreads) ring[i] = 0;
     for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
+    if (threadIdx.x == 0) ovf_n = 0;
     u64 *my_scratch = a.scratch + (u64)blockIdx.x * P * a.region_cap;
 
+    // A hash whose ring slot is still occupied (many lanes hitting one block in the same few steps:
+    // homopolymers, tandem repeats) or whose region is full goes to this workgroup's overflow
+    // region: an LDS cursor and a plain 8-byte store, no global atomic, no cross-lane traffic.
+    // The host folds those regions in afterwards with the direct atomic kernel, which combines
+    // equal neighbours -- so the hot loop needs no duplicate detection at all.
+    u64 *my_ovf = a.ovf + (u64)blockIdx.x * a.ovf_cap;
+    auto overflow_hash = [&](u64 h) {
+        const u32 i = atomicAdd(&ovf_n, 1u);
+        if (i < a.ovf_cap) my_ovf[i] = h;
+        else *a.overflow = 1ULL;
+    };
     // one thread moves one 64-byte line of a block's ring to this workgroup's region of that block
     auto flush_chunk = [&](int b, u32 f) {
         uint4 *src = reinterpret_cast<uint4 *>(&ring[(u32)b * D + (f & dmask)]);
@@ -282,34 +296,48 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
             const u64 e[8] = {((u64)v0.y << 32) | v0.x, ((u64)v0.w << 32) | v0.z, ((u64)v1.y << 32) | v1.x, ((u64)v1.w << 32) | v1.z,
                               ((u64)v2.y << 32) | v2.x, ((u64)v2.w << 32) | v2.z, ((u64)v3.y << 32) | v3.x, ((u64)v3.w << 32) | v3.z};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) if (e[i]) irregular_pair(a, e[i], 1);
+            for (int i = 0; i < 8; ++i) if (e[i]) overflow_hash(e[i]);
         }
     };
 
+    // A tile is kPartTile + k - 1 <= 1024 + 16 sixteen-byte chunks: one per thread plus a halo that
+    // the first 16 threads carry.  The NEXT tile's chunks are loaded into registers before the
+    // current tile is hashed, so the HBM latency hides under ~100 us of hashing.
+    auto load_chunk = [&](u64 tile_base, int c) -> uint4 {
+        const u64 off = tile_base + 16ULL * (u64)c;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (off + 16 <= nbytes) v = *reinterpret_cast<const uint4 *>(stream + off);
+        else if (off < nbytes) {
+            unsigned char tmp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tmp[i] = (off + i < nbytes) ? stream[off + i] : (unsigned char)0;
+            v = *reinterpret_cast<uint4 *>(tmp);
+        }
+        return v;
+    };
+    uint4 pre_main = make_uint4(0, 0, 0, 0), pre_halo = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x < ntiles) {
+        pre_main = load_chunk((u64)blockIdx.x * kPartTile, threadIdx.x);
+        if (threadIdx.x < 16) pre_halo = load_chunk((u64)blockIdx.x * kPartTile, kPartThreads + threadIdx.x);
+    }
     for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();  // the previous tile's readers are done with `lds`; ring/fill init is visible
-        stage_tile<kPartThreads, kPartTile>(stream, nbytes, tile * kPartTile, k, lds);
+        reinterpret_cast<uint4 *>(lds)[threadIdx.x] = pre_main;
+        if (threadIdx.x < 16) reinterpret_cast<uint4 *>(lds)[kPartThreads + threadIdx.x] = pre_halo;
+        __syncthreads();
+        const u64 next = tile + gridDim.x;
+        if (next < ntiles) {
+            pre_main = load_chunk(next * kPartTile, threadIdx.x);
+            if (threadIdx.x < 16) pre_halo = load_chunk(next * kPartTile, kPartThreads + threadIdx.x);
+        }
         walk_windows<KW, KC, kPartWPT>(lds, k, [&](int j, bool good, u64 h) {
-            bool active = good && h != 0;
-            // a wavefront full of one k-mer (homopolymer, tandem repeat) would overrun one ring:
-            // fold those lanes into a single (hash, count) pair on the side list instead
-            const u64 act = __ballot(active);
-            if (act) {
-                const int leader = __ffsll((long long)act) - 1;
-                const u64 hl = __shfl(h, leader);
-                const u64 same = __ballot(active && h == hl);
-                if (__popcll(same) >= 8) {
-                    if (lane == leader) irregular_pair(a, hl, (u64)__popcll(same));
-                    if ((same >> lane) & 1ULL) active = false;
-                }
-            }
-            if (active && !(a.ablate & 1)) {
+            if (good && h != 0 && !(a.ablate & 1)) {
                 const u32 b = (u32)((h & a.mask) >> a.block_bits);
                 const u32 pos = atomicAdd(&fill[b], 1u);
                 if (pos - flushed[b] < D) ring[b * D + (pos & dmask)] = h;  // slot's previous tenant is flushed
-                else irregular_pair(a, h, 1);                               // ring full: position stays a 0 hole
+                else overflow_hash(h);                                      // ring full: position stays a 0 hole
             }
-            if ((j & 3) == 3 && !(a.ablate & 2)) {  // every fourth step: move every full line out
+            if ((j & fmask) == fmask && !(a.ablate & 2)) {  // every (fmask+1)-th step: move every full line out
                 __syncthreads();
                 for (int b = threadIdx.x; b < P; b += kPartThreads) {
                     u32 f = flushed[b];
@@ -328,6 +356,8 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         while ((int)(top - f) > 0) { flush_chunk(b, f); f += kChunk; }
         a.region_count[(u64)b * gridDim.x + blockIdx.x] = f < a.region_cap ? f : a.region_cap;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) a.ovf_count[blockIdx.x] = ovf_n < a.ovf_cap ? ovf_n : a.ovf_cap;
 }
 
 struct AggregateArgs {
@@ -510,6 +540,51 @@ __global__ __launch_bounds__(kBlock) void merge_pairs_kernel(const u64 *__restri
         if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
         if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
         if (s_zero) atomicAdd(shard + CTR_NEW_BY_ZERO, s_zero);
+    }
+}
+
+// ---- overflow regions of the partitioned path -> table ---------------------------------------------
+// regions[r] holds counts[r] hashes (each standing for one k-mer).  Neighbouring entries are often
+// equal (that is why they overflowed), so every wave first folds equal hashes: the lowest active
+// lane is the leader, all lanes holding the leader's hash retire into one add, repeat.
+__global__ __launch_bounds__(kBlock) void merge_overflow_kernel(const u64 *__restrict__ regions, const u32 *__restrict__ counts,
+                                                                int nregions, u32 region_cap, const u64 *abort, TableView table,
+                                                                u64 *counters) {
+    __shared__ u64 s_tot, s_new;
+    if (abort && *abort) return;
+    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64 tot = 0, nk = 0;
+    for (int r = blockIdx.x; r < nregions; r += gridDim.x) {  // one workgroup per region
+        const u32 cnt = counts[r];
+        const u64 *src = regions + (u64)r * region_cap;
+        for (u32 base = 64u * wave; base < cnt; base += kBlock) {
+            const u32 i = base + lane;
+            const u64 h = i < cnt ? src[i] : 0ULL;
+            // group equal hashes (registers and SGPRs only), then let every group leader add at once
+            bool pending = h != 0, is_leader = false;
+            u64 c = 0, act;
+            while ((act = __ballot(pending)) != 0) {
+                const int leader = __ffsll((long long)act) - 1;
+                const u64 hl = read_lane64(h, leader);
+                const u64 same = __ballot(pending && h == hl);
+                if (lane == leader) { is_leader = true; c = (u64)__popcll(same); }
+                if ((same >> lane) & 1ULL) pending = false;
+            }
+            if (is_leader) {
+                const AddResult res = table_add<false>(table, h, c);
+                if (!res.spilled) { tot += c; nk += res.claimed; }
+            }
+        }
+    }
+    tot = wave_sum(tot); nk = wave_sum(nk);
+    if (lane == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
     }
 }
 
