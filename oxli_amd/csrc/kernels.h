@@ -102,6 +102,89 @@ __device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, in
     }
 }
 
+// Same contract as walk_windows_packed, over a PRE-ENCODED tile (kmer_device.h encode16):
+// codes[c] / valid[c] describe bases 16c .. 16c+15 of the tile.  The first window is assembled
+// directly from the packed words (no k-1 warm-up steps); the WPT-1 following bases come out of two
+// shift registers.  WPT must be 16 (one code word per thread).
+template <int KW, int KC, class Sink>
+__device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const unsigned short *valid, int k_rt, Sink &&sink) {
+    constexpr int WPT = 16, NW = 2 * KW + 1;  // code words covering bases 0 .. 15 + k
+    const int k = KC > 0 ? KC : k_rt;
+    u32 w[NW];
+    u64 vbits = 0;  // validity of the first 64 bases, base n in bit 63 - n (KW = 1 needs 47, KW = 2 needs 79)
+    u32 vtail = 0;  // ... bases 64..79 in bits 15..0 (KW = 2 only)
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        w[i] = codes[threadIdx.x + i];
+        const u64 v = valid[threadIdx.x + i];
+        if (i < 4) vbits |= v << (48 - 16 * i);
+        else vtail = (u32)v;
+    }
+    // ---- window 0: bases 0 .. k-1
+    Packed<KW> fw;
+#pragma unroll
+    for (int i = 0; i < KW; ++i) fw.w[i] = ((u64)w[2 * i] << 32) | w[2 * i + 1];
+    {   // shift right so that base k-1 sits in the low 2 bits
+        const int s = 64 * KW - 2 * k, ws = s >> 6, bs = s & 63;
+        Packed<KW> o;
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+            u64 lo = 0, hi = 0;
+#pragma unroll
+            for (int j = 0; j < KW; ++j) {
+                if (j == i - ws) lo = fw.w[j];
+                if (j == i - ws - 1) hi = fw.w[j];
+            }
+            o.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+        }
+        fw = o;
+    }
+    Packed<KW> rc = revcomp_packed(fw, k);
+    // run = valid bases in a row ending at base k-1
+    int run;
+    {
+        u64 inv_hi = ~vbits;                 // invalid bases among 0..63
+        if (k < 64) inv_hi &= ~0ULL << (64 - k);  // keep bases 0..k-1 only
+        // the last invalid base before k: its distance to base k-1
+        run = inv_hi ? (int)__builtin_ctzll(inv_hi) - (64 - k) : k;
+        if (k > 64) run = k;  // unreachable for KW <= 2 (k <= 64)
+    }
+    // ---- streams of the WPT-1 bases k .. k+WPT-2 (and their validity), next one in the top bits
+    u32 cs, vs;
+    {
+        const int idx = k >> 4, sh = 2 * (k & 15);
+        u32 a = 0, b = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { if (i == idx) a = w[i]; if (i == idx + 1) b = w[i]; }
+        cs = sh ? ((a << sh) | (b >> (32 - sh))) : a;
+        // validity of base n: n < 64 -> vbits bit 63-n, else vtail bit 79-n
+        const u64 v_lo = k < 64 ? (vbits << k) : 0ULL;                       // base k at bit 63
+        const u64 v_hi = k < 64 ? ((u64)vtail << 48) >> (64 - k) : (u64)vtail << 48;  // bases 64.. follow
+        vs = (u32)((v_lo | (k ? v_hi : 0ULL)) >> 32);
+    }
+#pragma unroll 4
+    for (int j = 0; j < WPT; ++j) {
+        const bool good = run >= k;
+        u64 h = 0;
+        if (good) {
+            Packed<KW> c = less_eq(fw, rc) ? fw : rc;
+            left_align(c, k);
+            h = hash_packed(c, k);
+        }
+        sink(j, good, h);
+        if (j + 1 < WPT) {
+            const u32 code = cs >> 30;
+            cs <<= 2;
+            const bool ok = (int)vs < 0;
+            vs <<= 1;
+            push_fw(fw, code);
+            mask_k(fw, k);
+            push_rc(rc, 3u - code, k);
+            run = ok ? run + 1 : 0;
+        }
+    }
+}
+
 // Any k (used for k > 64): validity by run length, canonical choice and hashing bytewise.
 template <int WPT, class Sink>
 __device__ __forceinline__ void walk_windows_bytes(const unsigned char *lds, int k, Sink &&sink) {
@@ -263,10 +346,14 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     __shared__ __attribute__((aligned(16))) u64 ring[kRingEntries];
     __shared__ u32 fill[1024], flushed[1024];
     __shared__ u32 ovf_n;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kPartTile + kHaloMax + 16];
+    // the staged tile: raw bytes for the bytewise path (k > 64), pre-encoded 2-bit words otherwise
+    constexpr int kTileBytes = KW == 0 ? kPartTile + kHaloMax + 16 : 16;
+    constexpr int kTileWords = KW == 0 ? 4 : kPartThreads + 16;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kTileBytes];
+    __shared__ u32 tcodes[kTileWords];
+    __shared__ unsigned short tvalid[kTileWords];
     const int P = 1 << a.pbits;
     const u32 D = (u32)(kRingEntries >> a.pbits), dmask = D - 1;
-    const int fmask = (a.ablate >> 8) ? (a.ablate >> 8) - 1 : 3;  // flush interval - 1 (measurement knob in bits 8+)
     for (int i = threadIdx.x; i < kRingEntries; i += kPartThreads) ring[i] = 0;
     for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
     if (threadIdx.x == 0) ovf_n = 0;
@@ -322,22 +409,32 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     }
     for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();  // the previous tile's readers are done with `lds`; ring/fill init is visible
-        reinterpret_cast<uint4 *>(lds)[threadIdx.x] = pre_main;
-        if (threadIdx.x < 16) reinterpret_cast<uint4 *>(lds)[kPartThreads + threadIdx.x] = pre_halo;
+        if constexpr (KW == 0) {
+            reinterpret_cast<uint4 *>(lds)[threadIdx.x] = pre_main;
+            if (threadIdx.x < 16) reinterpret_cast<uint4 *>(lds)[kPartThreads + threadIdx.x] = pre_halo;
+        } else {
+            u32 c, v;
+            encode16(pre_main, c, v);
+            tcodes[threadIdx.x] = c; tvalid[threadIdx.x] = (unsigned short)v;
+            if (threadIdx.x < 16) {
+                encode16(pre_halo, c, v);
+                tcodes[kPartThreads + threadIdx.x] = c; tvalid[kPartThreads + threadIdx.x] = (unsigned short)v;
+            }
+        }
         __syncthreads();
         const u64 next = tile + gridDim.x;
         if (next < ntiles) {
             pre_main = load_chunk(next * kPartTile, threadIdx.x);
             if (threadIdx.x < 16) pre_halo = load_chunk(next * kPartTile, kPartThreads + threadIdx.x);
         }
-        walk_windows<KW, KC, kPartWPT>(lds, k, [&](int j, bool good, u64 h) {
+        auto sink = [&](int j, bool good, u64 h) {
             if (good && h != 0 && !(a.ablate & 1)) {
                 const u32 b = (u32)((h & a.mask) >> a.block_bits);
                 const u32 pos = atomicAdd(&fill[b], 1u);
                 if (pos - flushed[b] < D) ring[b * D + (pos & dmask)] = h;  // slot's previous tenant is flushed
                 else overflow_hash(h);                                      // ring full: position stays a 0 hole
             }
-            if ((j & fmask) == fmask && !(a.ablate & 2)) {  // every (fmask+1)-th step: move every full line out
+            if ((j & 3) == 3 && !(a.ablate & 2)) {  // every fourth step: move every full line out
                 __syncthreads();
                 for (int b = threadIdx.x; b < P; b += kPartThreads) {
                     u32 f = flushed[b];
@@ -347,7 +444,9 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
                 }
                 __syncthreads();
             }
-        });
+        };
+        if constexpr (KW == 0) walk_windows<0, 0, kPartWPT>(lds, k, sink);
+        else walk_windows_encoded<KW, KC>(tcodes, tvalid, k, sink);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < P; b += kPartThreads) {  // drain: partial lines go out zero-padded

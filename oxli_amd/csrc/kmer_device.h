@@ -168,6 +168,46 @@ __device__ __forceinline__ u64 hash_packed(const Packed<KW> &a, int k) {
     return m.finish((u64)k);
 }
 
+// ---- tile pre-encoding (partitioned path, k <= 64) -------------------------------------------------
+// Sixteen ASCII bases held in a uint4 (byte 0 = first base) -> one 32-bit word of 2-bit codes with
+// the first base in bits 31:30, plus a 16-bit validity word with the first base in bit 15.
+// SWAR on whole dwords: every base is classified exactly once per tile instead of once per
+// window that touches it.
+__device__ __forceinline__ void encode4(u32 w, u32 &codes8, u32 &valid4) {
+    u32 x = (w >> 1) & 0x03030303u;          // A0 C1 G3 T2 per byte
+    x ^= (x >> 1) & 0x01010101u;             // A0 C1 G2 T3
+    // the byte must equal the letter its code stands for (case folded); anything else is invalid
+    const u32 d = (w | 0x20202020u) ^ __builtin_amdgcn_perm(0u, 0x74676361u /* 'a','c','g','t' */, x);
+    u32 t = (d & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+    t = ~(t | d | 0x7f7f7f7fu);              // 0x80 in every byte of d that is zero
+    codes8 = (x * ((1u << 30) | (1u << 20) | (1u << 10) | 1u)) >> 24;             // byte0 -> bits 7:6 ... byte3 -> bits 1:0
+    valid4 = ((t >> 7) * ((1u << 27) | (1u << 18) | (1u << 9) | 1u)) >> 24 & 0xFu; // byte0 -> bit 3 ... byte3 -> bit 0
+}
+
+__device__ __forceinline__ void encode16(uint4 v, u32 &codes, u32 &valid) {
+    u32 c0, c1, c2, c3, v0, v1, v2, v3;
+    encode4(v.x, c0, v0); encode4(v.y, c1, v1); encode4(v.z, c2, v2); encode4(v.w, c3, v3);
+    codes = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
+    valid = (v0 << 12) | (v1 << 8) | (v2 << 4) | v3;
+}
+
+// reverse the order of the 2-bit groups of a 64-bit word
+__device__ __forceinline__ u64 reverse_pairs64(u64 x) {
+    const u64 y = __builtin_bitreverse64(x);
+    return ((y >> 1) & 0x5555555555555555ULL) | ((y & 0x5555555555555555ULL) << 1);
+}
+
+// reverse complement of a packed k-mer: complement every base, reverse their order
+template <int KW>
+__device__ __forceinline__ Packed<KW> revcomp_packed(Packed<KW> a, int k) {
+    left_align(a, k);
+    Packed<KW> r;
+#pragma unroll
+    for (int i = 0; i < KW; ++i) r.w[i] = ~reverse_pairs64(a.w[KW - 1 - i]);
+    mask_k(r, k);
+    return r;
+}
+
 // ---- generic path for any k (1..255): works on upper-casing bytes in LDS -----------------------
 __device__ __forceinline__ u32 upper(u32 c) { return (c >= 'a' && c <= 'z') ? c - 32u : c; }
 __device__ __forceinline__ u32 comp_ascii(u32 c) {  // c is one of ACGT (upper case)
