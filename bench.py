@@ -70,16 +70,28 @@ def cpu_baseline(args, log):
     n1 = min(args.cpu_sample_reads, args.reads)
     reads1 = oracle.synth_reads(genome, 0, n1, args.read_len, SEED_R)
     _, km1, s1 = oracle.baseline_consume(reads1, args.read_len, args.k, 1, native)
-    nT = min(args.reads, max(n1, n1 * min(cores, 16) // 2))
+    log(f"cpu baseline: 1 thread {km1 / s1 / 1e6:.2f} Mk-mers/s on {n1} reads")
+    # "rayon-style" best case: private table per thread over contiguous shards + parallel tree merge;
+    # the best thread count is found by trying a few (more threads = more duplicate keys to merge)
+    nT = min(args.reads, 1_000_000)
     readsT = reads1 if nT == n1 else oracle.synth_reads(genome, 0, nT, args.read_len, SEED_R)
-    tabT, kmT, sT = oracle.baseline_consume(readsT, args.read_len, args.k, cores, native)
-    log(f"cpu baseline: 1 thread {km1 / s1 / 1e6:.2f} Mk-mers/s on {n1} reads; {cores} threads {kmT / sT / 1e6:.2f} Mk-mers/s on {nT} reads")
-    best_multi = kmT / sT
-    out = {"value": max(best_multi, km1 / s1), "unit": "k-mers/s", "cores": cores if best_multi >= km1 / s1 else 1,
-           "kind": "port",
-           "sample": f"first {nT} reads of the same stream (private table per thread + add() merge, merge timed); "
+    tried, tabT = {}, None
+    for T in sorted({t for t in (8, 32, 128, cores) if 1 < t <= cores}):
+        tabT, km, s = oracle.baseline_consume(readsT, args.read_len, args.k, T, native)
+        tried[T] = km / s
+        log(f"cpu baseline: {T} threads {km / s / 1e6:.2f} Mk-mers/s on {nT} reads")
+    if tabT is None:  # single-core host: the verification table still has to cover the nT-read sample
+        tabT, _, _ = oracle.baseline_consume(readsT, args.read_len, args.k, 1, native)
+    rates = dict(tried)
+    rates[1] = km1 / s1
+    best_T = max(rates, key=rates.get)
+    best = (rates[best_T], best_T)
+    out = {"value": best[0], "unit": "k-mers/s", "cores": best[1], "kind": "port",
+           "sample": f"first {nT} reads of the same stream; private table per thread + parallel tree merge with add() "
+                     f"semantics, merge timed; thread counts tried {sorted(tried)} of {cores} host cores; "
                      f"1 thread on first {n1} reads: {km1 / s1:.4g} k-mers/s",
-           "value_1thread": km1 / s1, "value_all_cores": best_multi, "native_build": native}
+           "value_1thread": km1 / s1, "by_threads": {str(k): v for k, v in tried.items()}, "host_cores": cores,
+           "native_build": native}
     return out, (readsT, tabT)
 
 

@@ -448,6 +448,16 @@ static void *shard_run(void *p) {
     return NULL;
 }
 
+typedef struct { orc_table *dst, *src; } merge_job;
+
+static void *merge_run(void *p) {
+    merge_job *m = (merge_job *)p;
+    uint64_t a, b;
+    orc_add(m->dst, m->src, &a, &b);
+    orc_free(m->src);
+    return NULL;
+}
+
 static double now_s(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -474,12 +484,21 @@ orc_table *orc_baseline_consume(const uint8_t *reads, uint64_t nreads, uint32_t 
         if (threads > 1) pthread_join(tid[i], NULL);
         n += jobs[i].n;
     }
-    orc_table *dst = jobs[0].t;
-    for (int i = 1; i < threads; ++i) {
-        uint64_t a, b;
-        orc_add(dst, jobs[i].t, &a, &b);
-        orc_free(jobs[i].t);
+    /* merge the shards with add() semantics as a binary tree, each level's pair-merges in parallel
+     * (the reference's add() is serial under a mutex, lib.rs:798-806; this is the kindest reading
+     * of "rayon-style") */
+    merge_job *mj = (merge_job *)calloc((size_t)threads, sizeof *mj);
+    for (int stride = 1; stride < threads; stride *= 2) {
+        int nm = 0;
+        for (int i = 0; i + stride < threads; i += 2 * stride) {
+            mj[nm].dst = jobs[i].t; mj[nm].src = jobs[i + stride].t;
+            pthread_create(&tid[nm], NULL, merge_run, &mj[nm]);
+            ++nm;
+        }
+        for (int i = 0; i < nm; ++i) pthread_join(tid[i], NULL);
     }
+    free(mj);
+    orc_table *dst = jobs[0].t;
     *seconds = now_s() - t0;
     *kmers = n;
     free(jobs); free(tid);
