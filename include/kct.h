@@ -140,6 +140,15 @@ kct_status kct_merge_device(kct_table *t, const void *d_hashes, const void *d_co
 kct_status kct_merge_host(kct_table *t, const uint64_t *hashes, const uint64_t *counts, size_t n,
                           uint64_t *total_added, uint64_t *new_keys);
 
+/* The same two halves shaped for an all-to-all between ranks: the export writes interleaved
+ * {hash, count} pairs (2 * cap u64 words at d_pairs) bucketed by owner rank,
+ * owner(hash) = floor(hi32(hash) * nparts / 2^32), owner p's pairs contiguous and in rank order;
+ * part_counts[p] (host, nparts entries) = pairs of owner p; *n_out = their sum.  nparts <= 256.
+ * kct_merge_pairs_device folds n interleaved pairs with add()'s tallies. */
+kct_status kct_export_by_owner_device(kct_table *t, uint32_t nparts, void *d_pairs, size_t cap, uint64_t *part_counts,
+                                      uint64_t *n_out);
+kct_status kct_merge_pairs_device(kct_table *t, const void *d_pairs, size_t n, uint64_t *total_added, uint64_t *new_keys);
+
 /* Which device path bulk ingest uses: 0 = chosen per pass (default), 1 = direct path only (one
  * HBM atomic per k-mer), 2 = partitioned path whenever the table geometry allows (radix-partition
  * the hashes by 128-KiB table block, count each block in LDS).  Results are identical; this

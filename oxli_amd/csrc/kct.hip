@@ -849,6 +849,53 @@ kct_status kct_export_device(kct_table *t, void *d_hashes, void *d_counts, size_
     return KCT_OK;
 }
 
+kct_status kct_export_by_owner_device(kct_table *t, uint32_t nparts, void *d_pairs, size_t cap, uint64_t *part_counts, uint64_t *n_out) {
+    KCT_TRY(use(t));
+    if (!n_out || !part_counts || (cap && !d_pairs)) { set_err("null argument"); return KCT_ERR_ARG; }
+    if (nparts == 0 || nparts > (uint32_t)kct::kMaxParts) { set_err("nparts must be 1..%d", kct::kMaxParts); return KCT_ERR_ARG; }
+    KCT_TRY(materialize(t));
+    KCT_TRY(t->d_aux.reserve((size_t)nparts * 16));
+    du64 *d_counts = (du64 *)t->d_aux.p, *d_cursor = d_counts + nparts;
+    HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nparts * 8, t->stream));
+    {
+        ProfScope ps(t, "count_owners_kernel");
+        hipLaunchKernelGGL(kct::count_owners_kernel, dim3(merge_grid(t->cap)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->slots, geom(t),
+                           (unsigned int)nparts, d_counts);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(t->h_counters, d_counts, (size_t)nparts * 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    u64 total = 0;
+    std::vector<u64> base(nparts);
+    for (uint32_t p = 0; p < nparts; ++p) { part_counts[p] = t->h_counters[p]; base[p] = total; total += part_counts[p]; }
+    *n_out = total;
+    if (total == 0 || cap == 0) return KCT_OK;
+    for (uint32_t p = 0; p < nparts; ++p) t->h_counters[p] = base[p];
+    HIP_TRY(hipMemcpyAsync(d_cursor, t->h_counters, (size_t)nparts * 8, hipMemcpyHostToDevice, t->stream));
+    {
+        ProfScope ps(t, "scatter_owners_kernel");
+        const unsigned grid = (unsigned)std::min<u64>((t->cap + 16 * kct::kBlock - 1) / (16 * kct::kBlock), 2048);
+        hipLaunchKernelGGL(kct::scatter_owners_kernel, dim3(grid), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->slots, geom(t),
+                           (unsigned int)nparts, d_cursor, (du64 *)d_pairs, (u64)cap);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return KCT_OK;
+}
+
+kct_status kct_merge_pairs_device(kct_table *t, const void *d_pairs, size_t n, uint64_t *total_added, uint64_t *new_keys) {
+    KCT_TRY(use(t));
+    u64 tl[4] = {0, 0, 0, 0};
+    if (n) {
+        if (!d_pairs) { set_err("null argument"); return KCT_ERR_ARG; }
+        if ((double)(t->n_keys + n) > kMaxLoad * (double)t->cap) KCT_TRY(grow_to(t, next_pow2((u64)((double)(t->n_keys + n) / kMaxLoad) + 1)));
+        KCT_TRY(merge_pairs(t, (const du64 *)d_pairs, (const du64 *)d_pairs + 1, n, 2, tl));
+    }
+    if (total_added) *total_added = tl[kct::CTR_TOTAL_ADDED];
+    if (new_keys) *new_keys = tl[kct::CTR_NEW_BY_ZERO];
+    return KCT_OK;
+}
+
 kct_status kct_dump(kct_table *t, uint64_t *hashes_out, uint64_t *counts_out, size_t cap, int order, uint64_t *n_out) {
     KCT_TRY(use(t));
     if (!n_out) { set_err("null argument"); return KCT_ERR_ARG; }

@@ -739,6 +739,64 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const u64 *__restrict__
     }
 }
 
+// ---- export bucketed by owner rank (multi-GPU merge) -------------------------------------------------
+// owner(h) = floor(hi32(h) * nparts / 2^32): a contiguous slice of hash space per rank.
+__device__ __forceinline__ u32 owner_of(u64 h, u32 nparts) { return (u32)(((h >> 32) * (u64)nparts) >> 32); }
+
+constexpr int kMaxParts = 256;
+
+// pass 1: how many occupied slots belong to each owner
+__global__ __launch_bounds__(kBlock) void count_owners_kernel(const u64 *__restrict__ words, TableGeom g, u32 nparts, u64 *part_counts) {
+    __shared__ u32 hist[kMaxParts];
+    for (u32 i = threadIdx.x; i < nparts; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const u64 cap = g.mask + 1;
+    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock) {
+        const u64 key = words[key_word(g, s)];
+        if (key != 0) atomicAdd(&hist[owner_of(key, nparts)], 1u);
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < nparts; i += kBlock) if (hist[i]) atomicAdd(part_counts + i, (u64)hist[i]);
+}
+
+// pass 2: write interleaved {hash, count} pairs, owner p's pairs contiguous from part_base[p].
+// Each workgroup reserves one range per owner per chunk of slots, so the global cursors see
+// (chunks x nparts) atomics instead of one per key.
+__global__ __launch_bounds__(kBlock) void scatter_owners_kernel(const u64 *__restrict__ words, TableGeom g, u32 nparts,
+                                                                u64 *part_cursor /* starts at part_base */, u64 *__restrict__ out_pairs,
+                                                                u64 out_cap) {
+    __shared__ u32 hist[kMaxParts];
+    __shared__ u64 base[kMaxParts];
+    const u64 cap = g.mask + 1, S = block_slots(g);
+    constexpr u64 kChunkSlots = 16 * kBlock;
+    for (u64 c0 = (u64)blockIdx.x * kChunkSlots; c0 < cap; c0 += (u64)gridDim.x * kChunkSlots) {
+        for (u32 i = threadIdx.x; i < nparts; i += kBlock) hist[i] = 0;
+        __syncthreads();
+        u64 keys[16], cnts[16];
+        u32 rank[16], own[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u64 s = c0 + (u64)j * kBlock + threadIdx.x;
+            keys[j] = 0;
+            if (s < cap) {
+                const u64 kw = key_word(g, s);
+                keys[j] = words[kw];
+                if (keys[j]) { cnts[j] = words[kw + S]; own[j] = owner_of(keys[j], nparts); rank[j] = atomicAdd(&hist[own[j]], 1u); }
+            }
+        }
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < nparts; i += kBlock) base[i] = hist[i] ? atomicAdd(part_cursor + i, (u64)hist[i]) : 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (keys[j]) {
+                const u64 pos = base[own[j]] + rank[j];
+                if (pos < out_cap) { out_pairs[2 * pos] = keys[j]; out_pairs[2 * pos + 1] = cnts[j]; }
+            }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void sum_counts_kernel(const u64 *__restrict__ words, TableGeom g, u64 *out) {
     const u64 cap = g.mask + 1, S = block_slots(g);
     u64 acc = 0;

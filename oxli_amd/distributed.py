@@ -31,24 +31,25 @@ def owner_of(hashes_i64: torch.Tensor, world: int) -> torch.Tensor:
 
 
 def partition_by_owner(hashes_i64, counts_i64, world):
-    """Sorts the pairs by owner.  Returns (hashes, counts, send_counts[world])."""
+    """Buckets the pairs by owner.  Returns (pairs [n, 2] with owner p's rows contiguous, send_counts[world])."""
     if hashes_i64.numel() == 0:
-        return hashes_i64, counts_i64, torch.zeros(world, dtype=torch.int64)
+        return torch.empty((0, 2), dtype=torch.int64, device=hashes_i64.device), torch.zeros(world, dtype=torch.int64)
     own = owner_of(hashes_i64, world)
     order = torch.argsort(own, stable=True)
     send_counts = torch.bincount(own, minlength=world).to(torch.int64).cpu()
-    return hashes_i64[order].contiguous(), counts_i64[order].contiguous(), send_counts
+    return torch.stack([hashes_i64[order], counts_i64[order]], dim=1).contiguous(), send_counts
 
 
-def exchange_pairs(hashes, counts, send_counts, zero_count=0, group=None):
-    """All-to-all of owner-bucketed pairs.  Returns (recv_hashes, recv_counts, zero_total).
+def exchange_pairs(pairs, send_counts, zero_count=0, group=None):
+    """All-to-all of owner-bucketed pairs.  ``pairs`` is an int64 tensor [n, 2] = (hash, count),
+    owner p's rows contiguous and in rank order.  Returns (recv_pairs [m, 2], zero_total).
 
     ``zero_count`` is this rank's count for hash 0, which the library keeps outside the device
     table (0 is its EMPTY sentinel); it rides along with the size exchange to its owner, rank 0.
     """
     world = dist.get_world_size(group)
     assert world == send_counts.numel()
-    dev = hashes.device
+    dev = pairs.device
     # 1) how much will I receive from each peer (tiny fixed-layout exchange)
     meta = torch.zeros((world, 2), dtype=torch.int64)
     meta[:, 0] = send_counts
@@ -59,13 +60,11 @@ def exchange_pairs(hashes, counts, send_counts, zero_count=0, group=None):
     got = got.cpu()
     recv_counts = got[:, 0]
     zero_total = int(got[:, 1].sum())
-    n_recv = int(recv_counts.sum())
-    # 2) the pairs: hashes and counts interleaved so that one collective moves both
-    payload = torch.stack([hashes, counts], dim=1).contiguous()  # [n, 2] int64
-    out = torch.empty((n_recv, 2), dtype=torch.int64, device=dev)
-    dist.all_to_all_single(out, payload, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(),
+    # 2) the pairs themselves: one collective moves hashes and counts together
+    out = torch.empty((int(recv_counts.sum()), 2), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(out, pairs, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(),
                            group=group)
-    return out[:, 0].contiguous(), out[:, 1].contiguous(), zero_total
+    return out, zero_total
 
 
 def global_scalar_sum(value: int, device, group=None) -> int:
@@ -81,30 +80,34 @@ def merge_across_ranks(table, group=None):
     ``len`` / ``sum_counts`` / ``consumed`` of the global table are the sums over ranks
     (``global_scalar_sum``).  ``table.consumed`` keeps this rank's own share.
     Returns the number of pairs this rank received.
+
+    Device work is native: ``kct_export_by_owner_device`` buckets the table by owner in two
+    kernels, ``kct_merge_pairs_device`` folds what arrives.  ``partition_by_owner`` above is the
+    same bucketing in torch ops (what the CPU gloo test exercises).
     """
     import ctypes as C
+
+    import numpy as np
 
     world = dist.get_world_size(group)
     if world == 1:
         return 0
     dev = torch.device("cuda", torch.cuda.current_device())
     n = len(table)
-    hashes = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
-    counts = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    pairs = torch.empty((max(n, 1), 2), dtype=torch.int64, device=dev)
+    part_counts = np.zeros(world, dtype=np.uint64)
     got = C.c_uint64()
-    table._check(table._lib.kct_export_device(table._h, C.c_void_p(hashes.data_ptr()), C.c_void_p(counts.data_ptr()), n, C.byref(got)))
-    hashes, counts = hashes[: got.value], counts[: got.value]
-    hashes, counts, send_counts = partition_by_owner(hashes, counts, world)
-    rh, rc, zero = exchange_pairs(hashes, counts, send_counts, table.get_hash(0), group)
+    table._check(table._lib.kct_export_by_owner_device(table._h, world, C.c_void_p(pairs.data_ptr()), n, part_counts.ctypes.data,
+                                                       C.byref(got)))
+    send_counts = torch.from_numpy(part_counts.astype(np.int64))
+    recv, zero = exchange_pairs(pairs[: got.value], send_counts, table.get_hash(0), group)
     torch.cuda.synchronize()
     consumed = table.consumed
     table.clear()
     if zero:
-        import numpy as np
         zk, zc = np.zeros(1, dtype=np.uint64), np.array([zero], dtype=np.uint64)
         table._check(table._lib.kct_merge_host(table._h, zk.ctypes.data, zc.ctypes.data, 1, None, None))
     a, b = C.c_uint64(), C.c_uint64()
-    table._check(table._lib.kct_merge_device(table._h, C.c_void_p(rh.data_ptr()), C.c_void_p(rc.data_ptr()), rh.numel(),
-                                             C.byref(a), C.byref(b)))
+    table._check(table._lib.kct_merge_pairs_device(table._h, C.c_void_p(recv.data_ptr()), recv.shape[0], C.byref(a), C.byref(b)))
     table._check(table._lib.kct_add_consumed(table._h, consumed))
-    return rh.numel()
+    return recv.shape[0]

@@ -40,14 +40,14 @@ def _worker(rank, world, port, outdir):
     keys, counts = mine.dump_arrays()
     h = torch.from_numpy(keys.view(np.int64).copy())
     c = torch.from_numpy(counts.view(np.int64).copy())
-    h, c, send = partition_by_owner(h, c, world)
+    pairs, send = partition_by_owner(h, c, world)
     assert int(send.sum()) == keys.size
-    assert torch.all(owner_of(h, world)[1:] >= owner_of(h, world)[:-1])
-    rh, rc, zero_total = exchange_pairs(h, c, send, zero)
-    assert torch.all(owner_of(rh, world) == rank)
+    assert torch.all(owner_of(pairs[:, 0], world)[1:] >= owner_of(pairs[:, 0], world)[:-1])
+    recv, zero_total = exchange_pairs(pairs, send, zero)
+    assert torch.all(owner_of(recv[:, 0], world) == rank)
     assert zero_total == (3 if rank == 0 else 0)
     owned = oracle.OracleTable(k)
-    owned.add_pairs(rh.numpy().view(np.uint64), rc.numpy().view(np.uint64))
+    owned.add_pairs(recv[:, 0].contiguous().numpy().view(np.uint64), recv[:, 1].contiguous().numpy().view(np.uint64))
     ok, oc = owned.dump_arrays()
     np.save(os.path.join(outdir, f"keys{rank}.npy"), ok)
     np.save(os.path.join(outdir, f"counts{rank}.npy"), oc)

@@ -474,3 +474,61 @@ def test_partitioned_path_abandons_on_pathological_input(KCT):
     dev.set_path("partitioned")
     assert dev.consume(s) == ref.consume(s)
     assert_same_table(dev, ref)
+
+
+# ---- multi-GPU merge building blocks, exercised on one GPU ---------------------------------------------------
+def test_owner_bucketed_export_and_pair_merge_simulated_ranks(KCT):
+    """Four 'ranks' on one device: each counts its shard, exports pairs bucketed by owner
+    (kct_export_by_owner_device), owners fold what they are sent (kct_merge_pairs_device).  The union
+    of the owner tables must equal the single-table oracle, and the native bucketing must agree with
+    the torch implementation the gloo test covers (oxli_amd.distributed.partition_by_owner)."""
+    import ctypes as C
+
+    import torch
+
+    from oxli_amd.distributed import owner_of, partition_by_owner
+    world, k, L, per_rank = 4, 21, 150, 5000
+    genome = oracle.synth_genome(60000)
+    reads = oracle.synth_reads(genome, 0, world * per_rank, L)
+    ref = OracleTable(k)
+    for i in range(reads.shape[0]):
+        ref.consume(reads[i, :L])
+    shards, sent = [], []
+    for r in range(world):
+        t = KCT(k, capacity=100000)
+        t.consume_batch([bytes(x[:L]) for x in reads[r * per_rank:(r + 1) * per_rank]])
+        n = len(t)
+        pairs = torch.empty((n, 2), dtype=torch.int64, device="cuda")
+        counts = np.zeros(world, dtype=np.uint64)
+        got = C.c_uint64()
+        t._check(t._lib.kct_export_by_owner_device(t._h, world, C.c_void_p(pairs.data_ptr()), n, counts.ctypes.data, C.byref(got)))
+        assert got.value == n == int(counts.sum())
+        own = owner_of(pairs[:, 0], world).cpu().numpy()
+        assert np.all(own[1:] >= own[:-1])
+        assert np.array_equal(np.bincount(own, minlength=world).astype(np.uint64), counts)
+        # same multiset per owner as the torch bucketing of a plain dump
+        hk, hc = t.dump_arrays(0)
+        tp, tc = partition_by_owner(torch.from_numpy(hk.view(np.int64).copy()), torch.from_numpy(hc.view(np.int64).copy()), world)
+        assert np.array_equal(tc.numpy().astype(np.uint64), counts)
+        a = pairs.cpu().numpy(); b = tp.numpy()
+        off = 0
+        for p in range(world):
+            c = int(counts[p])
+            assert np.array_equal(a[off:off + c][np.argsort(a[off:off + c, 0].view(np.uint64))], b[off:off + c][np.argsort(b[off:off + c, 0].view(np.uint64))])
+            off += c
+        shards.append(t)
+        sent.append((pairs, counts))
+    keys_all, counts_all = [], []
+    for p in range(world):
+        owner = KCT(k, capacity=100000)
+        for pairs, counts in sent:
+            off = int(counts[:p].sum())
+            part = pairs[off:off + int(counts[p])].contiguous()
+            a_, b_ = C.c_uint64(), C.c_uint64()
+            owner._check(owner._lib.kct_merge_pairs_device(owner._h, C.c_void_p(part.data_ptr()), part.shape[0], C.byref(a_), C.byref(b_)))
+            assert a_.value == int(part[:, 1].sum())
+        dk, dc = owner.dump_arrays(1)
+        keys_all.append(dk); counts_all.append(dc)
+    rk, rc = ref.dump_arrays()
+    assert np.array_equal(np.concatenate(keys_all), rk)   # owner slices are contiguous in hash space
+    assert np.array_equal(np.concatenate(counts_all), rc)
