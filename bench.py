@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- k-mers/sec through consume (BASELINE.json metric) on N MI355X of one node.
 
-A "step" is one whole job over one batch of synthetic reads already resident in HBM:
-clear the device table, count every k-mer of this rank's reads (kct_consume_device), and -- when
-N > 1 -- the owner-partitioned RCCL all-to-all that turns the per-rank tables into the global
-one (oxli_amd.distributed.merge_across_ranks).  Work per GPU is fixed as N grows (weak scaling):
-rank r counts reads [r*R, (r+1)*R) of the same read stream.
+The job: every rank streams batches of synthetic reads (already resident in HBM) into its own
+device table with kct_consume_device -- a "step" is one batch of R reads per GPU -- and, when
+N > 1, ONE final owner-partitioned RCCL all-to-all turns the per-rank tables into the global table
+(oxli_amd.distributed.merge_across_ranks; reference semantics: add(), lib.rs:778-837).  The table
+is empty when the timed region starts, the final merge is INSIDE the timed region, and `value` =
+all k-mers counted by all ranks / that time.  Work per GPU is fixed as N grows (weak scaling):
+step s of rank r counts reads [(s*N + r)*R, (s*N + r + 1)*R) of one read stream, so no read is
+counted twice and every step brings new reads (up to --batches distinct batches per rank are kept
+resident and cycled).
 
 Default workload = BASELINE.json configs[1] ("C2"): R = 1 M reads x 150 bp, k = 21, reads drawn
 from a 5 Mbp synthetic genome (SEED_G 42, SEED_R 1337), device table sized for 5 M distinct keys.
@@ -43,7 +47,9 @@ def parse():
     p.add_argument("--cpu-sample-reads", type=int, default=200_000)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--batches", type=int, default=8, help="distinct read batches resident per GPU (cycled over the steps)")
     p.add_argument("--path", choices=["auto", "direct", "partitioned"], default="auto")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo lets several ranks share one GPU for debugging")
     return p.parse_args()
 
 
@@ -111,9 +117,13 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     def log(msg):
         if rank == 0:
@@ -124,24 +134,28 @@ def main():
     kmers_per_step = R * (L - k + 1)
     stream = torch.cuda.current_stream().cuda_stream
     genome = torch.empty(G, dtype=torch.uint8, device="cuda")
-    reads = torch.empty(R * (L + 1), dtype=torch.uint8, device="cuda")
     assert lib.kct_synth_genome_device(genome.data_ptr(), G, SEED_G, stream) == 0
-    assert lib.kct_synth_reads_device(reads.data_ptr(), genome.data_ptr(), G, rank * R, R, L, SEED_R, stream) == 0
+    nb = max(1, min(args.batches, args.steps))
+    batches = []
+    for b in range(nb):
+        reads = torch.empty(R * (L + 1), dtype=torch.uint8, device="cuda")
+        assert lib.kct_synth_reads_device(reads.data_ptr(), genome.data_ptr(), G, (b * world + rank) * R, R, L, SEED_R, stream) == 0
+        batches.append(reads)
     torch.cuda.synchronize()
 
     table = KmerCountTable(k, capacity=G, device=local)
     table.set_stream(stream)
     table.set_path(args.path)
 
-    def step():
-        table.clear()
-        n = table.consume_device(reads.data_ptr(), reads.numel(), R * L)
-        if world > 1:
-            merge_across_ranks(table)
-        return n
+    def step(s):
+        reads = batches[s % nb]
+        return table.consume_device(reads.data_ptr(), reads.numel(), R * L)
 
-    for _ in range(args.warmup):
-        step()
+    for s in range(args.warmup):
+        step(s)
+    if world > 1 and args.warmup:
+        merge_across_ranks(table)  # warm the collective and the merge kernels too
+    table.clear()
     table.profile(True)
     table.profile_reset()
     torch.cuda.synchronize()
@@ -149,16 +163,20 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     n_total = 0
-    for _ in range(args.steps):
-        n_total += step()
+    for s in range(args.steps):
+        n_total += step(s)
+    t_merge = time.perf_counter()
+    if world > 1:
+        merge_across_ranks(table)
     torch.cuda.synchronize()
+    merge_ms = (time.perf_counter() - t_merge) * 1e3
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = table.profile_read()
     table.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         n_all = global_scalar_sum(n_total, "cuda")
@@ -170,7 +188,7 @@ def main():
     # invariants of the finished job (cheap, outside the timed region)
     distinct = global_scalar_sum(len(table), "cuda") if world > 1 else len(table)
     total_counts = global_scalar_sum(table.sum_counts, "cuda") if world > 1 else table.sum_counts
-    assert ablate or total_counts == world * kmers_per_step, (total_counts, world * kmers_per_step)
+    assert ablate or total_counts == world * kmers_per_step * args.steps, (total_counts, world * kmers_per_step * args.steps)
 
     value = n_all / elapsed
     b_alg = L / (L - k + 1) + 24.0
@@ -198,7 +216,9 @@ def main():
         "config": {"workload": f"C2: {R} x {L} bp synthetic reads per GPU, k={k}, genome {G} bp (seed {SEED_G}/{SEED_R}), "
                                f"device hash table in HBM ({table.capacity} slots x 16 B)",
                    "reads_per_gpu": R, "read_len": L, "k": k, "genome": G, "distinct_kmers": distinct,
-                   "step": "clear table + consume all reads" + (" + RCCL owner all-to-all merge" if world > 1 else "")},
+                   "distinct_batches_per_gpu": nb,
+                   "step": "consume one batch of reads into the rank's table" +
+                           (f"; one final RCCL owner all-to-all merge inside the timed region ({merge_ms:.3f} ms on rank 0)" if world > 1 else "")},
         "roofline": roofline,
     }
 
@@ -211,7 +231,7 @@ def main():
             # the same sample through the GPU must give the oracle's table bit for bit
             ns = sample_reads.shape[0]
             table.clear()
-            n = table.consume_device(reads.data_ptr(), ns * (L + 1), ns * L)
+            n = table.consume_device(batches[0].data_ptr(), ns * (L + 1), ns * L)
             dk, dc = table.dump_arrays(1)
             rk, rc = sample_table.dump_arrays()
             ok = n == ns * (L - k + 1) and np.array_equal(dk, rk) and np.array_equal(dc, rc)

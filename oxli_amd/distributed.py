@@ -50,6 +50,10 @@ def exchange_pairs(pairs, send_counts, zero_count=0, group=None):
     world = dist.get_world_size(group)
     assert world == send_counts.numel()
     dev = pairs.device
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":
+        # debugging aid (several ranks sharing one GPU, no RCCL): stage the collective through host memory
+        out, zero_total = exchange_pairs(pairs.cpu(), send_counts, zero_count, group)
+        return out.to(dev), zero_total
     # 1) how much will I receive from each peer (tiny fixed-layout exchange)
     meta = torch.zeros((world, 2), dtype=torch.int64)
     meta[:, 0] = send_counts
@@ -68,6 +72,8 @@ def exchange_pairs(pairs, send_counts, zero_count=0, group=None):
 
 
 def global_scalar_sum(value: int, device, group=None) -> int:
+    if dist.get_backend(group) == "gloo":
+        device = "cpu"
     t = torch.tensor([value], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return int(t.item())
