@@ -112,6 +112,14 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
 kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes,
                               uint64_t *n_total);
 
+/* The README loop itself (README.md:89-99: `for record in screed.open(file): kct.consume(record.sequence)`)
+ * for a FASTA or FASTQ file, plain or gzip: a host parser builds record-stream chunks in pinned
+ * memory while the previous chunk is uploaded and counted.  skip_bad must be non-zero (the
+ * reference's default); *n_total = sum of the per-record n, *n_records / *n_bases = records and
+ * sequence bytes read (`consumed` grows by *n_bases).  Out-parameters other than n_total may be NULL. */
+kct_status kct_consume_file(kct_table *t, const char *path, int skip_bad, uint64_t *n_total, uint64_t *n_records,
+                            uint64_t *n_bases);
+
 /* ---- table attributes ---------------------------------------------------------------------
  * __len__ lib.rs:665-667; sum_counts lib.rs:536-539; consumed lib.rs:530-533; ksize lib.rs:34 */
 kct_status kct_len(kct_table *t, uint64_t *out);

@@ -5,7 +5,12 @@
 // to the CPU -- without a device every entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <zlib.h>
+
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +24,9 @@
 
 typedef uint64_t u64;     // host-side 64-bit values (matches the ABI's uint64_t)
 typedef kct::u64 du64;    // words that live in device memory (unsigned long long, what HIP atomics take)
+
+extern "C" int kx_sort_pairs_u64(const unsigned long long *keys_in, unsigned long long *keys_out, const unsigned long long *vals_in,
+                                 unsigned long long *vals_out, size_t n, void *tmp, size_t *tmp_bytes, void *stream);  // sort.hip
 
 namespace {
 
@@ -112,7 +120,7 @@ struct kct_table {
 
     du64 *d_counters = nullptr;  // kNumCounters tallies + 8 scratch words (device)
     u64 *h_counters = nullptr;   // pinned mirror
-    DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr;
+    DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort;
     PinnedBuf h_stage;
 
     bool prof_on = false;
@@ -584,7 +592,7 @@ void kct_destroy(kct_table *t) {
     if (t->d_counters) (void)hipFree(t->d_counters);
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     t->d_stream.release(); t->d_spill.release(); t->d_aux.release(); t->d_aux2.release();
-    t->d_scratch.release(); t->d_regions.release(); t->d_irr.release();
+    t->d_scratch.release(); t->d_regions.release(); t->d_irr.release(); t->d_sort.release();
     t->h_stage.release();
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
@@ -904,25 +912,46 @@ kct_status kct_dump(kct_table *t, uint64_t *hashes_out, uint64_t *counts_out, si
     *n_out = n;
     if (cap == 0 || n == 0) return KCT_OK;
     if (!hashes_out || !counts_out) { set_err("null argument"); return KCT_ERR_ARG; }
-    std::vector<std::pair<u64, u64>> pairs(n);
+    std::vector<u64> hk(n), hc(n);
     if (n_dev) {
+        // compact on the device, sort on the device (rocPRIM radix sort, stable), copy out
         KCT_TRY(t->d_aux.reserve(n_dev * 16));
         du64 *dk = (du64 *)t->d_aux.p, *dc = dk + n_dev;
         u64 got = 0;
         KCT_TRY(kct_export_device(t, dk, dc, n_dev, &got));
         if (got != n_dev) { set_err("table scan found %llu keys, expected %llu", (unsigned long long)got, (unsigned long long)n_dev); return KCT_ERR_HIP; }
-        std::vector<u64> hk(n_dev), hc(n_dev);
-        HIP_TRY(hipMemcpy(hk.data(), dk, n_dev * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(hc.data(), dc, n_dev * 8, hipMemcpyDeviceToHost));
-        for (u64 i = 0; i < n_dev; ++i) pairs[i] = {hk[i], hc[i]};
+        if (order == 1 || order == 2) {
+            KCT_TRY(t->d_aux2.reserve(n_dev * 16));
+            du64 *sk = (du64 *)t->d_aux2.p, *sc = sk + n_dev;
+            size_t tmp_bytes = 0;
+            if (kx_sort_pairs_u64(dk, sk, dc, sc, n_dev, nullptr, &tmp_bytes, t->stream) != 0) { set_err("rocprim size query failed"); return KCT_ERR_HIP; }
+            KCT_TRY(t->d_sort.reserve(tmp_bytes + 16));
+            {
+                ProfScope ps(t, "radix_sort_pairs(by hash)");
+                if (kx_sort_pairs_u64(dk, sk, dc, sc, n_dev, t->d_sort.p, &tmp_bytes, t->stream) != 0) { set_err("rocprim radix sort failed"); return KCT_ERR_HIP; }
+            }
+            if (order == 2) {  // (count, hash): stable sort by count of the hash-sorted pairs (lib.rs:353-356)
+                ProfScope ps(t, "radix_sort_pairs(by count)");
+                if (kx_sort_pairs_u64(sc, dc, sk, dk, n_dev, t->d_sort.p, &tmp_bytes, t->stream) != 0) { set_err("rocprim radix sort failed"); return KCT_ERR_HIP; }
+            } else { dk = sk; dc = sc; }
+        }
+        HIP_TRY(hipMemcpyAsync(hk.data(), dk, n_dev * 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(hc.data(), dc, n_dev * 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
     }
-    if (t->zero_present) pairs[n_dev] = {0, t->zero_count};
-    if (order == 1) std::sort(pairs.begin(), pairs.end());
-    else if (order == 2)
-        std::sort(pairs.begin(), pairs.end(), [](const std::pair<u64, u64> &a, const std::pair<u64, u64> &b) {
-            return a.second != b.second ? a.second < b.second : a.first < b.first;  // lib.rs:353-356
-        });
-    for (size_t i = 0; i < std::min<size_t>(cap, n); ++i) { hashes_out[i] = pairs[i].first; counts_out[i] = pairs[i].second; }
+    if (t->zero_present) {  // hash 0 lives host-side: put it where the order wants it
+        size_t at = n_dev;
+        if (order == 1) at = 0;
+        else if (order == 2) {
+            at = 0;
+            while (at < n_dev && hc[at] < t->zero_count) ++at;  // smallest hash among equal counts
+        }
+        hk.insert(hk.begin() + at, 0); hk.pop_back();
+        hc.insert(hc.begin() + at, t->zero_count); hc.pop_back();
+    }
+    const size_t ncopy = std::min<size_t>(cap, n);
+    memcpy(hashes_out, hk.data(), ncopy * 8);
+    memcpy(counts_out, hc.data(), ncopy * 8);
     return KCT_OK;
 }
 
@@ -984,6 +1013,200 @@ kct_status kct_add(kct_table *dst, kct_table *src, uint64_t *total_added, uint64
     if (new_keys) *new_keys = nk;
     return KCT_OK;
 }
+
+}  // extern "C" (reopened below)
+
+// ---- FASTA / FASTQ ingestion: the caller side of the path (README.md:89-99) ---------------------------
+// The reference delegates parsing to screed and calls consume() once per record.  Here a host
+// parser turns the file (plain or gzip) into record-stream chunks in pinned memory while a worker
+// thread uploads and counts the previous chunk, so parsing and device work overlap.  A record longer
+// than a chunk is cut with a (k-1)-base overlap, which keeps every window counted exactly once.
+namespace {
+
+struct FileChunk {
+    PinnedBuf host;
+    DevBuf dev;
+    size_t used = 0;
+};
+
+struct RecordParser {
+    gzFile f = nullptr;
+    std::vector<unsigned char> buf;
+    size_t pos = 0, end = 0;
+    bool eof = false;
+    int fmt = 0;  // '>' FASTA, '@' FASTQ, 0 unknown yet
+    bool fill() {
+        if (eof) return false;
+        int n = gzread(f, buf.data(), (unsigned)buf.size());
+        if (n <= 0) { eof = true; return false; }
+        pos = 0; end = (size_t)n;
+        return true;
+    }
+    int peek() { if (pos >= end && !fill()) return -1; return buf[pos]; }
+    int get() { int c = peek(); if (c >= 0) ++pos; return c; }
+    void skip_line() { int c; while ((c = get()) >= 0 && c != '\n') {} }
+};
+
+}  // namespace
+
+extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_bad, uint64_t *n_total, uint64_t *n_records,
+                                       uint64_t *n_bases) {
+    KCT_TRY(use(t));
+    if (!path || !n_total) { set_err("null argument"); return KCT_ERR_ARG; }
+    if (!skip_bad) { set_err("kct_consume_file supports skip_bad_kmers=True only; use kct_consume_batch for error mode"); return KCT_ERR_ARG; }
+    *n_total = 0;
+    if (n_records) *n_records = 0;
+    if (n_bases) *n_bases = 0;
+    RecordParser ps;
+    ps.f = gzopen(path, "rb");
+    if (!ps.f) { set_err("cannot open %s", path); return KCT_ERR_ARG; }
+    gzbuffer(ps.f, 1 << 20);
+    ps.buf.resize(1 << 22);
+    const size_t k = t->k;
+    size_t chunk_cap = (size_t)64 << 20;  // stream bytes per chunk
+    if (const char *e = getenv("KCT_FILE_CHUNK")) chunk_cap = std::max<size_t>(1024, (size_t)atoll(e));  // tests shrink it to exercise record splitting
+    FileChunk chunks[2];
+    kct_status st = KCT_OK;
+    for (auto &c : chunks) {
+        if (st == KCT_OK) st = c.host.reserve(chunk_cap + 64);
+        if (st == KCT_OK) st = c.dev.reserve(chunk_cap + 64);
+    }
+    // worker: uploads and counts chunk `job` while the parser fills the other one
+    std::mutex mu;
+    std::condition_variable cv;
+    int job = -1;             // chunk index handed to the worker, -1 = none
+    bool done = false, busy = false;
+    kct_status worker_status = KCT_OK;
+    std::string worker_msg;
+    u64 counted = 0;
+    std::thread worker([&] {
+        (void)hipSetDevice(t->device);
+        for (;;) {
+            int j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return job >= 0 || done; });
+                if (job < 0 && done) return;
+                j = job; job = -1; busy = true;
+            }
+            FileChunk &c = chunks[j];
+            kct_status ws = KCT_OK;
+            const size_t padded = (c.used + 15) & ~(size_t)15;
+            memset((char *)c.host.p + c.used, '\n', padded + 16 - c.used);
+            if (hipMemcpyAsync(c.dev.p, c.host.p, padded + 16, hipMemcpyHostToDevice, t->stream) != hipSuccess) { set_err("H2D copy failed"); ws = KCT_ERR_HIP; }
+            u64 n = 0;
+            if (ws == KCT_OK) ws = consume_stream(t, (const unsigned char *)c.dev.p, c.used, &n);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                counted += n;
+                if (ws != KCT_OK && worker_status == KCT_OK) { worker_status = ws; worker_msg = g_err; }
+                busy = false;
+            }
+            cv.notify_all();
+        }
+    });
+    auto submit = [&](int j) {  // hand chunk j to the worker once it is idle
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return job < 0 && !busy; });
+        job = j;
+        lk.unlock();
+        cv.notify_all();
+    };
+    int cur = 0;
+    u64 records = 0, bases = 0;
+    unsigned char *out = (unsigned char *)chunks[cur].host.p;
+    size_t used = 0, rec_len = 0;  // rec_len = bases of the current record already emitted into this chunk run
+    auto flush = [&](bool mid_record) {
+        // keep the last k-1 bases of an unfinished record: they open the next chunk
+        unsigned char tail[256];
+        size_t ntail = 0;
+        if (mid_record) { ntail = std::min(rec_len, k - 1); memcpy(tail, out + used - ntail, ntail); }
+        chunks[cur].used = used;
+        submit(cur);
+        cur ^= 1;
+        // submit() returned once the worker was idle, i.e. the other buffer's chunk is finished: it is free
+        out = (unsigned char *)chunks[cur].host.p;
+        memcpy(out, tail, ntail);
+        used = ntail;
+        rec_len = ntail;
+    };
+    auto emit = [&](const unsigned char *p, size_t n) {  // append sequence bytes of the current record
+        while (n) {
+            if (used + 1 >= chunk_cap) flush(true);
+            const size_t take = std::min(n, chunk_cap - 1 - used);
+            memcpy(out + used, p, take);
+            used += take; rec_len += take; p += take; n -= take; bases += take;
+        }
+    };
+    auto end_record = [&] {
+        if (used + 1 >= chunk_cap) flush(true);
+        out[used++] = '\n';
+        rec_len = 0;
+        ++records;
+    };
+    // copies the rest of the current line (without CR/LF) into the record; returns its length
+    auto emit_line = [&]() -> size_t {
+        size_t total = 0;
+        for (;;) {
+            if (ps.pos >= ps.end && !ps.fill()) break;
+            const unsigned char *b = ps.buf.data() + ps.pos;
+            const size_t avail = ps.end - ps.pos;
+            const unsigned char *nl = (const unsigned char *)memchr(b, '\n', avail);
+            size_t n = nl ? (size_t)(nl - b) : avail;
+            size_t m = n;
+            if (m && b[m - 1] == '\r') --m;
+            emit(b, m); total += m;
+            ps.pos += n + (nl ? 1 : 0);
+            if (nl) break;
+        }
+        return total;
+    };
+    if (st == KCT_OK) {
+        int c;
+        while ((c = ps.peek()) >= 0) {
+            if (c == '\n' || c == '\r' || c == ' ' || c == '\t') { ps.get(); continue; }
+            if (ps.fmt == 0) {
+                if (c != '>' && c != '@') { set_err("%s: neither FASTA nor FASTQ (starts with 0x%02x)", path, c); st = KCT_ERR_ARG; break; }
+                ps.fmt = c;
+            }
+            if (c != ps.fmt) { set_err("%s: malformed record header near record %llu", path, (unsigned long long)records); st = KCT_ERR_ARG; break; }
+            ps.skip_line();  // header
+            size_t seq_len = 0;
+            if (ps.fmt == '>') {
+                while ((c = ps.peek()) >= 0 && c != '>') seq_len += emit_line();
+            } else {
+                while ((c = ps.peek()) >= 0 && c != '+') seq_len += emit_line();
+                ps.skip_line();  // '+' line
+                size_t q = 0;    // quality: as many characters as the sequence had
+                while (q < seq_len && ps.peek() >= 0) {
+                    int d = ps.get();
+                    if (d != '\n' && d != '\r') ++q;
+                }
+                ps.skip_line();
+            }
+            end_record();
+        }
+        if (st == KCT_OK && used) { chunks[cur].used = used; submit(cur); }
+    }
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return job < 0 && !busy; });
+        done = true;
+    }
+    cv.notify_all();
+    worker.join();
+    gzclose(ps.f);
+    for (auto &c : chunks) { c.host.release(); c.dev.release(); }
+    if (st == KCT_OK && worker_status != KCT_OK) { st = worker_status; set_err("%s", worker_msg.c_str()); }
+    if (st != KCT_OK) return st;
+    t->consumed += bases;
+    *n_total = counted;
+    if (n_records) *n_records = records;
+    if (n_bases) *n_bases = bases;
+    return KCT_OK;
+}
+
+extern "C" {
 
 kct_status kct_set_stream(kct_table *t, void *hip_stream) {
     KCT_TRY(use(t));

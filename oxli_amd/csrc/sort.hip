@@ -1,0 +1,14 @@
+// sort.hip -- device radix sort of (hash, count) pairs for dump(sortkeys / sortcounts) (lib.rs:330-381).
+// rocPRIM's radix sort is a plain library primitive; it lives in its own translation unit so that
+// the kernels in kct.hip do not pay its compile time.
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+// Sorts n pairs by key (ascending, stable).  Call with tmp == nullptr to get the temporary size.
+extern "C" __attribute__((visibility("hidden"))) int kx_sort_pairs_u64(const unsigned long long *keys_in, unsigned long long *keys_out,
+                                                                      const unsigned long long *vals_in, unsigned long long *vals_out,
+                                                                      size_t n, void *tmp, size_t *tmp_bytes, void *stream) {
+    return (int)rocprim::radix_sort_pairs(tmp, *tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, (hipStream_t)stream);
+}

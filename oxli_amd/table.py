@@ -13,6 +13,8 @@ from . import _lib as L
 
 __all__ = ["KmerCountTable", "VERSION"]
 
+_COMP = str.maketrans("ACGT", "TGCA")
+
 # The reference reports its crate version (lib.rs:27, Cargo.toml:3); the wire-compatible value
 # for tables written by this engine.
 VERSION = "0.3.0"
@@ -37,10 +39,6 @@ class KmerCountTable:
     def __init__(self, ksize, store_kmers=False, *, capacity=0, device=0):
         if not 0 <= int(ksize) <= 255:
             raise OverflowError("out of range integral type conversion attempted")  # pyo3's u8 extraction
-        if store_kmers:
-            raise NotImplementedError(
-                "store_kmers=True (hash -> k-mer string map, lib.rs:552-573) is outside the accelerated "
-                "consume path of this build")
         self._lib = L.load()
         self._h = C.c_void_p()
         st = self._lib.kct_create(int(ksize), int(capacity), int(device), C.byref(self._h))
@@ -49,7 +47,11 @@ class KmerCountTable:
             raise RuntimeError(f"kct_create failed ({st}): {L.last_error()}")
         self.ksize = int(ksize)
         self.version = VERSION
-        self.store_kmers = False
+        # lib.rs:37-38: optional hash -> canonical k-mer string map.  It is bookkeeping beside the counted
+        # path and stays on the host, exactly like the reference's HashMap<u64, String>; the hashes that
+        # key it still come from the device.
+        self.store_kmers = bool(store_kmers)
+        self._hash_to_kmer = {} if store_kmers else None
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -106,7 +108,50 @@ class KmerCountTable:
         if st == L.KCT_ERR_INVALID_DNA:
             raise RuntimeError(f"invalid DNA character in input k-mer: {kmer}")
         self._check(st)
+        if self.store_kmers:  # lib.rs:155-163
+            self._hash_to_kmer[self.hash_kmer(kmer)] = self.canon(kmer)
         return out.value
+
+    def canon(self, kmer):
+        """lib.rs:107-142: the lexicographically smaller of the upper-cased k-mer and its reverse complement."""
+        if len(_bytes(kmer)) != self.ksize:
+            raise ValueError("kmer size does not match count table ksize")
+        up = kmer.upper() if isinstance(kmer, str) else _bytes(kmer).decode("utf-8", "replace").upper()
+        if not all(c in "ATCG" for c in up):
+            raise ValueError("kmer contains invalid characters")
+        rc = up[::-1].translate(_COMP)
+        return up if up <= rc else rc
+
+    def unhash(self, hashval):
+        """lib.rs:84-97."""
+        if not self.store_kmers:
+            raise ValueError("K-mer storage is not enabled.")
+        try:
+            return self._hash_to_kmer[int(hashval)]
+        except KeyError:
+            raise KeyError(f"Warning: Hash {hashval} not found in table.") from None
+
+    def kmers_and_hashes(self, seq, skip_bad_kmers=True):
+        """lib.rs:683-703 / 853-950: [(canonical k-mer, hash)] for every window of ``seq``.  Hashes come from
+        the device; bad windows are reported on stderr and either skipped or returned as ("", 0)."""
+        import sys
+        b = _bytes(seq)
+        up = b.decode("utf-8", "replace").upper() if not isinstance(seq, str) else seq.upper()
+        if len(b) < self.ksize:
+            return []  # the reference underflows `seq.len() - ksize + 1` here (lib.rs:872) and panics; an empty list is kinder
+        hashes = self.hash_windows(b)
+        out = []
+        k = self.ksize
+        for i, h in enumerate(hashes.tolist()):
+            sub = up[i:i + k]
+            if h:
+                rc = sub[::-1].translate(_COMP)
+                out.append((sub if sub < rc else rc, h))
+            else:
+                print(f"bad k-mer at position {i + 1}: {sub}", file=sys.stderr)
+                if not skip_bad_kmers:
+                    out.append(("", 0))
+        return out
 
     def get(self, kmer):
         """lib.rs:170-182: ValueError on wrong length; 0 when absent."""
@@ -148,6 +193,14 @@ class KmerCountTable:
         window holding a non-ACGT byte raises ``ValueError("bad k-mer encountered at position n")``
         after the k-mers before it were counted, leaving ``consumed`` unchanged."""
         b = _bytes(seq)
+        if self.store_kmers:
+            # lib.rs:552-573: this branch walks KmersAndHashesIter, which always skips bad windows
+            # (force=true) -- so it never raises, whatever skip_bad_kmers says -- and records
+            # hash -> canonical k-mer for every counted window.
+            for kmer, h in self.kmers_and_hashes(b, skip_bad_kmers):
+                if h:
+                    self._hash_to_kmer[h] = kmer
+            skip_bad_kmers = True
         out = C.c_uint64()
         st = self._lib.kct_consume(self._h, b, len(b), 1 if skip_bad_kmers else 0, C.byref(out))
         if st == L.KCT_ERR_BAD_KMER:
@@ -180,6 +233,29 @@ class KmerCountTable:
             err.counted = n.value
             raise err
         self._check(st)
+        return n.value
+
+    def consume_file(self, path, skip_bad_kmers=True):
+        """``for record in screed.open(path): kct.consume(record.sequence)`` (README.md:89-99) for a FASTA
+        or FASTQ file, plain or gzip.  Returns the total number of k-mers counted.  With
+        ``skip_bad_kmers=False`` the records are fed through ``consume_batch`` so the first bad k-mer
+        raises exactly as the per-record loop would."""
+        if not skip_bad_kmers:
+            from .io import read_records
+            total, batch, size = 0, [], 0
+            for _, seq in read_records(path):
+                batch.append(seq)
+                size += len(seq)
+                if size >= (64 << 20):
+                    total += self.consume_batch(batch, skip_bad_kmers=False)
+                    batch, size = [], 0
+            return total + (self.consume_batch(batch, skip_bad_kmers=False) if batch else 0)
+        n, nrec, nb = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        st = self._lib.kct_consume_file(self._h, str(path).encode(), 1, C.byref(n), C.byref(nrec), C.byref(nb))
+        if st == L.KCT_ERR_ARG and "cannot open" in L.last_error():
+            raise OSError(L.last_error())
+        self._check(st)
+        self.last_file_records = nrec.value
         return n.value
 
     def consume_device(self, data_ptr, nbytes, consumed_bytes):
@@ -248,12 +324,192 @@ class KmerCountTable:
         if st == L.KCT_ERR_KSIZE_MISMATCH:
             raise ValueError("KmerCountTables must have the same ksize")
         self._check(st)
+        if self.store_kmers:  # lib.rs:810-828
+            if other.store_kmers:
+                for h, kmer in other._hash_to_kmer.items():
+                    self._hash_to_kmer.setdefault(h, kmer)
+            else:
+                import sys
+                print("Warning: Incoming table does not store k-mers, but target table does. "
+                      "K-mer information for new hashes will be missing.", file=sys.stderr)
         print(f"Added {a.value} k-mer counts to the table")  # lib.rs:833-834
         print(f"Added {b.value} new keys to the table")
         return a.value, b.value
 
     def clear(self):
         self._check(self._lib.kct_clear(self._h))
+        if self._hash_to_kmer is not None:
+            self._hash_to_kmer = {}
+
+    # ---- table-wide reads beside the path: each is one device dump (compaction + radix sort) ----------
+    # followed by numpy on the (hash, count) arrays.  No hash or count is ever produced on the host.
+    def __iter__(self):
+        """lib.rs:658-662: (hash, count) pairs.  The reference's order is HashMap order; here by hash."""
+        keys, counts = self.dump_arrays(1)
+        return iter(zip(keys.tolist(), counts.tolist()))
+
+    @property
+    def min(self):
+        """lib.rs:492-501 (0 for an empty table)."""
+        counts = self.dump_arrays(0)[1]
+        return int(counts.min()) if counts.size else 0
+
+    @property
+    def max(self):
+        """lib.rs:505-514."""
+        counts = self.dump_arrays(0)[1]
+        return int(counts.max()) if counts.size else 0
+
+    def histo(self, zero=True):
+        """lib.rs:464-488: [(frequency, number of k-mers with that count)]."""
+        counts = self.dump_arrays(0)[1]
+        vals, freq = np.unique(counts, return_counts=True)
+        observed = dict(zip(vals.tolist(), freq.tolist()))
+        if zero:
+            return [(f, observed.get(f, 0)) for f in range(0, (int(vals.max()) if vals.size else 0) + 1)]
+        return sorted(observed.items())
+
+    def dump_kmers(self, file=None, sortcounts=False, sortkeys=False):
+        """lib.rs:389-456."""
+        if not self.store_kmers:
+            raise ValueError("K-mer storage is disabled. No hash:kmer map is available.")
+        if sortcounts and sortkeys:
+            raise ValueError("Cannot sort by both counts and kmers at the same time.")
+        keys, counts = self.dump_arrays(0)
+        have = dict(zip(keys.tolist(), counts.tolist()))
+        pairs = [(kmer, have[h]) for h, kmer in self._hash_to_kmer.items() if h in have]
+        if sortkeys:
+            pairs.sort(key=lambda p: p[0])
+        elif sortcounts:
+            pairs.sort(key=lambda p: (p[1], p[0]))
+        if file is not None:
+            with open(file, "w") as f:
+                f.write("".join(f"{k}\t{c}\n" for k, c in pairs))
+            return []
+        return pairs
+
+    # removal rebuilds the device table from the surviving pairs (cold path)
+    def _rebuild(self, keys, counts):
+        consumed = self.consumed
+        h2k = self._hash_to_kmer
+        self.clear()
+        self._hash_to_kmer = h2k
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint64)
+        if keys.size:
+            self._check(self._lib.kct_merge_host(self._h, keys.ctypes.data, counts.ctypes.data, keys.size, None, None))
+        self._check(self._lib.kct_add_consumed(self._h, consumed))
+
+    def drop_hash(self, hashval):
+        """lib.rs:213-224."""
+        keys, counts = self.dump_arrays(0)
+        keep = keys != np.uint64(int(hashval))
+        if not keep.all():
+            self._rebuild(keys[keep], counts[keep])
+
+    def drop(self, kmer):
+        """lib.rs:197-210."""
+        self.drop_hash(self.hash_kmer(kmer))
+
+    def mincut(self, min_count):
+        """lib.rs:227-246: remove k-mers with count < min_count; returns how many were removed."""
+        keys, counts = self.dump_arrays(0)
+        keep = counts >= np.uint64(int(min_count))
+        removed = int((~keep).sum())
+        if removed:
+            self._rebuild(keys[keep], counts[keep])
+        return removed
+
+    def maxcut(self, max_count):
+        """lib.rs:249-267: remove k-mers with count > max_count."""
+        keys, counts = self.dump_arrays(0)
+        keep = counts <= np.uint64(int(max_count))
+        removed = int((~keep).sum())
+        if removed:
+            self._rebuild(keys[keep], counts[keep])
+        return removed
+
+    def _hash_set(self):
+        return set(self.dump_arrays(0)[0].tolist())
+
+    def union(self, other):
+        return self._hash_set() | other._hash_set()  # lib.rs:615-617
+
+    def intersection(self, other):
+        return self._hash_set() & other._hash_set()  # lib.rs:619-624
+
+    def difference(self, other):
+        return self._hash_set() - other._hash_set()  # lib.rs:626-631
+
+    def symmetric_difference(self, other):
+        return self._hash_set() ^ other._hash_set()  # lib.rs:633-638
+
+    __or__, __and__, __sub__, __xor__ = union, intersection, difference, symmetric_difference
+
+    def jaccard(self, other):
+        """lib.rs:708-722 (two empty tables are identical: 1.0)."""
+        a, b = self.dump_arrays(0)[0], other.dump_arrays(0)[0]
+        inter = np.intersect1d(a, b, assume_unique=True).size
+        uni = a.size + b.size - inter
+        return 1.0 if uni == 0 else inter / uni
+
+    def cosine(self, other):
+        """lib.rs:727-765: f64 arithmetic as in the reference (u64 dot product, f64 magnitudes)."""
+        ka, ca = self.dump_arrays(1)
+        kb, cb = other.dump_arrays(1)
+        if ka.size == 0 or kb.size == 0:
+            return 0.0
+        _, ia, ib = np.intersect1d(ka, kb, assume_unique=True, return_indices=True)
+        dot = int(np.sum(ca[ia].astype(object) * cb[ib].astype(object))) if ia.size else 0
+        ma = float(np.sqrt(np.sum(ca.astype(np.float64) ** 2)))
+        mb = float(np.sqrt(np.sum(cb.astype(np.float64) ** 2)))
+        if ma == 0.0 or mb == 0.0:
+            return 0.0
+        return float(dot) / (ma * mb)
+
+    # ---- on-disk format (lib.rs:269-322): serde_json of the struct, gzip level 1 ------------------------
+    def serialize_json(self):
+        keys, counts = self.dump_arrays(1)
+        import json
+        body = ",".join(f'"{h}":{c}' for h, c in zip(keys.tolist(), counts.tolist()))
+        h2k = "null" if self._hash_to_kmer is None else \
+            "{" + ",".join(f'"{h}":{json.dumps(kmer)}' for h, kmer in self._hash_to_kmer.items()) + "}"
+        return ('{"counts":{' + body + '},"ksize":' + str(self.ksize) + ',"version":' + json.dumps(self.version) +
+                ',"consumed":' + str(self.consumed) + ',"store_kmers":' + ("true" if self.store_kmers else "false") +
+                ',"hash_to_kmer":' + h2k + "}")
+
+    def save(self, filepath):
+        import gzip
+        with gzip.open(filepath, "wb", compresslevel=1) as f:  # OSError on a bad path, like File::create
+            f.write(self.serialize_json().encode())
+
+    @staticmethod
+    def load(filepath, *, device=0):
+        """lib.rs:295-322: accepts gzip or plain JSON (niffler sniffs the format); warns on a version mismatch."""
+        import gzip
+        import json
+        import sys
+        with open(filepath, "rb") as f:
+            raw = f.read()
+        if raw[:2] == b"\x1f\x8b":
+            raw = gzip.decompress(raw)
+        try:
+            d = json.loads(raw.decode("utf-8"))
+            ksize, counts = int(d["ksize"]), d["counts"]
+            keys = np.fromiter((int(h) for h in counts.keys()), dtype=np.uint64, count=len(counts))
+            vals = np.fromiter((int(c) for c in counts.values()), dtype=np.uint64, count=len(counts))
+        except Exception as e:  # noqa: BLE001
+            raise RuntimeError(f"Deserialization error: {e}") from None
+        t = KmerCountTable(ksize, store_kmers=bool(d.get("store_kmers", False)), capacity=len(counts), device=device)
+        if keys.size:
+            t._check(t._lib.kct_merge_host(t._h, keys.ctypes.data, vals.ctypes.data, keys.size, None, None))
+        t._check(t._lib.kct_add_consumed(t._h, int(d.get("consumed", 0))))
+        if t.store_kmers and d.get("hash_to_kmer"):
+            t._hash_to_kmer = {int(h): kmer for h, kmer in d["hash_to_kmer"].items()}
+        t.version = d.get("version", VERSION)
+        if t.version != VERSION:
+            print(f"Version mismatch: loaded version is {t.version}, but current version is {VERSION}", file=sys.stderr)
+        return t
 
     def set_path(self, mode):
         """0 = choose per pass, 1 = direct atomic path only, 2 = partitioned path whenever possible."""

@@ -1,0 +1,236 @@
+"""The rest of the KmerCountTable surface (SURVEY.md 8f "next" rows: dump / save / load formats,
+store_kmers, table analytics, set operations, similarity), re-expressing what the reference's tests
+pin (src/python/tests/test_dump.py, test_histo.py, test_remove.py, test_serialization.py,
+test_setops.py, test_metrics.py, test_kmers_and_hashes.py:126-283, test_canonicalization.py,
+test_dunders.py, test_attr.py).  Hashes and counts always come from the device."""
+import gzip
+import json
+import math
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def KCT():
+    from oxli_amd import KmerCountTable
+    return KmerCountTable
+
+
+AAAA, AATT, GGGG = 17832910516274425539, 382727017318141683, 73459868045630124  # test_dump.py:52-54
+
+
+@pytest.fixture
+def small(KCT):
+    t = KCT(ksize=4)
+    t.count("AAAA"); t.count("TTTT"); t.count("AATT"); t.count("GGGG"); t.count("GGGG")
+    return t
+
+
+# ---- dump (test_dump.py) ----------------------------------------------------------------------------------
+def test_dump_file_tsv(small, tmp_path):
+    f = tmp_path / "d.tsv"
+    assert small.dump(file=str(f), sortkeys=True) == []
+    assert f.read_text() == f"{GGGG}\t2\n{AATT}\t1\n{AAAA}\t2\n"       # "{hash}\t{count}\n" (test_dump.py:111-115)
+    assert small.dump(file=str(f), sortcounts=True) == []
+    assert f.read_text() == f"{AATT}\t1\n{GGGG}\t2\n{AAAA}\t2\n"
+    with pytest.raises(ValueError):
+        small.dump(file=str(f), sortcounts=True, sortkeys=True)
+    with pytest.raises(OSError):
+        small.dump(file=str(tmp_path / "no" / "such.tsv"))
+
+
+def test_dump_large_sorted_on_device(KCT):
+    rng = random.Random(1)
+    seq = "".join(rng.choice("ACGT") for _ in range(200000))
+    t = KCT(15)
+    t.consume(seq); t.consume(seq[:50000])
+    keys, counts = t.dump_arrays(1)
+    assert np.all(keys[:-1] < keys[1:])
+    k2, c2 = t.dump_arrays(2)
+    assert np.all((c2[:-1] < c2[1:]) | ((c2[:-1] == c2[1:]) & (k2[:-1] < k2[1:])))
+    order = np.lexsort((keys, counts))
+    assert np.array_equal(k2, keys[order]) and np.array_equal(c2, counts[order])
+    assert sorted(t.dump()) == list(zip(keys.tolist(), counts.tolist()))
+    assert list(t) == list(zip(keys.tolist(), counts.tolist()))
+    assert sorted(t.hashes) == keys.tolist()
+
+
+# ---- histo / min / max (test_histo.py) -----------------------------------------------------------------------
+def test_histo_min_max(KCT):
+    t = KCT(4)
+    assert t.min == 0 and t.max == 0 and t.histo() == [(0, 0)] and t.histo(zero=False) == []
+    t.count("AAAA"); t.count("TTTT"); t.consume("CCCCCC")
+    assert t.min == 2 and t.max == 3
+    assert t.histo(zero=False) == [(2, 1), (3, 1)]
+    assert t.histo(zero=True) == [(0, 0), (1, 0), (2, 1), (3, 1)]
+
+
+# ---- removal (test_remove.py) ----------------------------------------------------------------------------------
+def test_drop_mincut_maxcut(KCT):
+    t = KCT(4)
+    t.count("AAAA"); t.count("TTTT"); t.count("AATT"); t.count("GGGG"); t.count("GGGG"); t.count("GGGG")
+    consumed = t.consumed
+    t.drop("AAAA")
+    assert t.get("AAAA") == 0 and len(t) == 2
+    t.drop("ACGT")                      # absent: no error
+    t.drop_hash(AATT)
+    assert len(t) == 1 and t.get("GGGG") == 3 and t.consumed == consumed
+    t.count("AAAA"); t.count("AATT"); t.count("AATT")
+    assert t.mincut(2) == 1 and sorted(c for _, c in t) == [2, 3]      # removes count < 2
+    assert t.maxcut(2) == 1 and [c for _, c in t] == [2]               # removes count > 2
+    assert t.mincut(0) == 0 and t.maxcut(100) == 0
+
+
+# ---- set operations (test_setops.py) ---------------------------------------------------------------------------
+def test_set_operations(KCT):
+    a, b = KCT(4), KCT(4)
+    for k in ("AAAA", "AATT", "GGGG"):
+        a.count(k)
+    for k in ("AATT", "GGGG", "ATAT"):
+        b.count(k)
+    sa, sb = set(a.hashes), set(b.hashes)
+    assert a.union(b) == sa | sb == (a | b)
+    assert a.intersection(b) == sa & sb == (a & b)
+    assert a.difference(b) == sa - sb == (a - b)
+    assert a.symmetric_difference(b) == sa ^ sb == (a ^ b)
+
+
+# ---- similarity (test_metrics.py) ---------------------------------------------------------------------------------
+def test_jaccard_and_cosine(KCT):
+    a, b, e1, e2 = KCT(4), KCT(4), KCT(4), KCT(4)
+    assert e1.jaccard(e2) == 1.0 and e1.cosine(e2) == 0.0          # empty-table conventions
+    for k, n in (("AAAA", 3), ("AATT", 1), ("GGGG", 2)):
+        for _ in range(n):
+            a.count(k)
+    for k, n in (("AATT", 4), ("GGGG", 1), ("ATAT", 5)):
+        for _ in range(n):
+            b.count(k)
+    assert a.jaccard(b) == 2 / 4 and a.jaccard(a) == 1.0 and a.jaccard(e1) == 0.0
+    dot = 1 * 4 + 2 * 1
+    want = dot / (math.sqrt(9 + 1 + 4) * math.sqrt(16 + 1 + 25))
+    assert math.isclose(a.cosine(b), want, rel_tol=1e-12)          # the reference compares with rel_tol 1e-5
+    assert math.isclose(a.cosine(a), 1.0, rel_tol=1e-12) and a.cosine(e1) == 0.0
+
+
+# ---- save / load (test_serialization.py): wire format = serde_json of the struct, gzip ------------------------
+def test_serialize_save_load(KCT, tmp_path, capfd):
+    from oxli_amd import VERSION
+    t = KCT(4)
+    t.count("AAAA"); t.count("TTTT"); t.consume("GGGGG")
+    d = json.loads(t.serialize_json())
+    assert list(d) == ["counts", "ksize", "version", "consumed", "store_kmers", "hash_to_kmer"]   # struct order (lib.rs:32-39)
+    assert d["ksize"] == 4 and d["version"] == VERSION == t.version and d["consumed"] == 13
+    assert d["counts"] == {str(AAAA): 2, str(GGGG): 2} and d["store_kmers"] is False and d["hash_to_kmer"] is None
+    f = str(tmp_path / "save.json")
+    t.save(f)
+    assert open(f, "rb").read(2) == b"\x1f\x8b"                     # gzip (niffler Format::Gzip)
+    u = KCT.load(f)
+    assert list(u) == list(t) and u.get("TTTT") == 2 and u.consumed == 13 and u.ksize == 4 and len(u) == 2
+    # a file as the reference writes it: compact serde_json, u64 keys as strings, gzip
+    ref_json = '{"counts":{"17832910516274425539":5,"73459868045630124":1},"ksize":4,"version":"0.3.0","consumed":24,"store_kmers":false,"hash_to_kmer":null}'
+    g = str(tmp_path / "ref.json.gz")
+    with gzip.open(g, "wt") as fh:
+        fh.write(ref_json)
+    r = KCT.load(g)
+    assert r.get("AAAA") == 5 and r.get("CCCC") == 1 and r.consumed == 24 and r.sum_counts == 6
+    p = str(tmp_path / "plain.json")                                 # niffler also accepts uncompressed input
+    open(p, "w").write(ref_json.replace("0.3.0", "0.0.1"))
+    capfd.readouterr()
+    r2 = KCT.load(p)
+    assert "Version mismatch: loaded version is 0.0.1, but current version is " + VERSION in capfd.readouterr().err
+    assert r2.version == "0.0.1" and r2.get("AAAA") == 5
+    open(p, "w").write("hello, world")
+    with pytest.raises(RuntimeError, match="Deserialization error:"):
+        KCT.load(p)
+    with pytest.raises(OSError, match="No such file or directory"):
+        t.save(str(tmp_path / "noexist" / "save.json"))
+
+
+# ---- dunders / attributes (test_dunders.py, test_attr.py) ------------------------------------------------------
+def test_dunders_and_attrs(KCT):
+    from oxli_amd import VERSION
+    t = KCT(ksize=16)
+    assert len(t) == 0 and t.version == VERSION == "0.3.0" and t.consumed == 0 and t.sum_counts == 0 and t.hashes == []
+    t["ACGTACGTACGTACGT"] = 5
+    assert t["ACGTACGTACGTACGT"] == 5 and len(t) == 1 and t.consumed == 0
+    t.consume("GCTAGCTAGCTA")                                       # shorter than k: nothing counted, consumed grows
+    assert len(t) == 1 and t.consumed == 12
+    with pytest.raises(ValueError):
+        t["ACGT"]
+    with pytest.raises(OverflowError):
+        KCT(256)
+
+
+# ---- canonical form (test_canonicalization.py) and store_kmers (test_kmers_and_hashes.py:126-283) ----------------
+def test_canon(KCT):
+    t = KCT(4)
+    assert t.canon("TTTT") == "AAAA" and t.canon("acgt") == "ACGT" and t.canon("GGTA") == "GGTA" and t.canon("TACC") == "GGTA"
+    with pytest.raises(ValueError, match="kmer size does not match count table ksize"):
+        t.canon("ACG")
+    with pytest.raises(ValueError, match="kmer contains invalid characters"):
+        t.canon("ACGN")
+
+
+def test_kmers_and_hashes_lists(KCT, kats, capfd):
+    cg = KCT(ksize=4)
+    assert cg.kmers_and_hashes("ATAAACC", False) == [("ATAA", 179996601836427478), ("TAAA", 15286642655859448092),
+                                                     ("AAAC", 9097280691811734508), ("AACC", 6779379503393060785)]
+    assert cg.kmers_and_hashes("GGTTTAT", False) == [("AACC", 6779379503393060785), ("AAAC", 9097280691811734508),
+                                                     ("TAAA", 15286642655859448092), ("ATAA", 179996601836427478)]
+    assert cg.kmers_and_hashes("acgttg", False) == [("ACGT", 2597925387403686983), ("AACG", 7952982457453691616),
+                                                    ("CAAC", 7315150081962684964)]
+    capfd.readouterr()
+    assert cg.kmers_and_hashes("aattxttgg", False) == [("AATT", 382727017318141683), ("", 0), ("", 0), ("", 0), ("", 0),
+                                                       ("CCAA", 1798905482136869687)]
+    assert "bad k-mer at position 2: ATTX" in capfd.readouterr().err
+    assert cg.kmers_and_hashes("aattxttgg", True) == [("AATT", 382727017318141683), ("CCAA", 1798905482136869687)]
+    cg.kmers_and_hashes("acxttg", False)
+    assert "bad k-mer at position 1: ACXT" in capfd.readouterr().err
+
+
+def test_store_kmers(KCT, capfd):
+    cg = KCT(ksize=4, store_kmers=True)
+    assert cg.count("AAAA") == 1 and cg.count("TTTT") == 2
+    assert cg.unhash(cg.hash_kmer("TTTT")) == "AAAA"
+    with pytest.raises(KeyError, match="Warning: Hash 1234567890 not found in table."):
+        cg.unhash(1234567890)
+    with pytest.raises(ValueError, match="K-mer storage is not enabled."):
+        KCT(3).unhash(1)
+    cg = KCT(ksize=4, store_kmers=True)
+    assert cg.consume("ACGTTG") == 3
+    for kmer in ["ACGT", "AACG", "CAAC"]:
+        assert cg.unhash(cg.hash_kmer(kmer)) == kmer
+    cg = KCT(ksize=4, store_kmers=True)
+    assert cg.consume("AAAAACCCC") == 6 and cg.get("AAAA") == 2
+    # bad k-mers never raise on this branch, whatever the flag says (lib.rs:552-573)
+    cg = KCT(ksize=3, store_kmers=True)
+    capfd.readouterr()
+    assert cg.consume("XAAAAAXGGGG", skip_bad_kmers=False) == 5 and len(cg) == 2
+    err = capfd.readouterr().err
+    for msg in ("bad k-mer at position 1: XAA", "bad k-mer at position 5: AAX", "bad k-mer at position 6: AXG", "bad k-mer at position 7: XGG"):
+        assert msg in err
+    assert cg.unhash(cg.hash_kmer("AAA")) == "AAA" and cg.unhash(cg.hash_kmer("GGG")) == "CCC"
+    # dump_kmers and add() with string maps (test_add.py:87-109, test_dump.py)
+    a, b = KCT(5, store_kmers=True), KCT(5, store_kmers=True)
+    a.consume("ATGCA"); b.consume("GGCAT")
+    assert a.add(b) == (1, 1)
+    assert a.dump_kmers(sortkeys=True) == [("ATGCA", 1), ("ATGCC", 1)]
+    assert a.dump_kmers(sortcounts=True) == [("ATGCA", 1), ("ATGCC", 1)]
+    c = KCT(5, store_kmers=False)
+    c.consume("GGCAT")
+    capfd.readouterr()
+    a.add(c)
+    assert "Warning: Incoming table does not store k-mers" in capfd.readouterr().err
+    with pytest.raises(ValueError, match="K-mer storage is disabled"):
+        c.dump_kmers()
+    # the string map survives save / load
+    import os
+    import tempfile
+    f = os.path.join(tempfile.mkdtemp(), "t.json")
+    a.save(f)
+    r = KCT.load(f)
+    assert r.store_kmers and r.unhash(r.hash_kmer("ATGCA")) == "ATGCA" and r.dump_kmers(sortkeys=True) == a.dump_kmers(sortkeys=True)

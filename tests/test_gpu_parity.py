@@ -532,3 +532,64 @@ def test_owner_bucketed_export_and_pair_merge_simulated_ranks(KCT):
     rk, rc = ref.dump_arrays()
     assert np.array_equal(np.concatenate(keys_all), rk)   # owner slices are contiguous in hash space
     assert np.array_equal(np.concatenate(counts_all), rc)
+
+
+# ---- file ingestion (the README loop) ----------------------------------------------------------------------
+def _write_fasta(path, records, width=70, gz=False):
+    import gzip
+    op = gzip.open if gz else open
+    with op(path, "wt") as f:
+        for i, s in enumerate(records):
+            f.write(f">rec{i} some description\n")
+            for j in range(0, len(s), width):
+                f.write(s[j:j + width] + "\n")
+
+
+def test_consume_file_example_fa(KCT, kats):
+    import os
+    fa = os.path.join(os.path.dirname(__file__), "golden", "example.fa")
+    for e in kats["example_fa"]:
+        t = KCT(e["k"])
+        assert t.consume_file(fa) == e["n"]          # README.md:94-99 / doc/api.md:20-25
+        assert t.last_file_records == 1 and t.consumed == 349930
+
+
+def test_consume_file_formats_match_oracle(KCT, tmp_path, monkeypatch):
+    import gzip
+    rng = random.Random(31)
+    recs = [rand_dna(rng, rng.choice([0, 10, 21, 150, 151, 1000, 25000]), "ACGTACGTACGTNacgt") for _ in range(200)]
+    k = 21
+    ref = OracleTable(k)
+    n_ref = sum(ref.consume(r) for r in recs)
+    fa, fagz, fq = tmp_path / "a.fa", tmp_path / "a.fa.gz", tmp_path / "a.fq"
+    _write_fasta(fa, recs)
+    _write_fasta(fagz, recs, width=61, gz=True)
+    with open(fq, "w") as f:
+        for i, s in enumerate(recs):
+            f.write(f"@r{i}\n{s}\n+\n{'I' * len(s)}\n")
+    for path in (fa, fagz, fq):
+        dev = KCT(k)
+        assert dev.consume_file(str(path)) == n_ref, path
+        assert dev.last_file_records == len(recs)
+        assert_same_table(dev, ref)
+    # records longer than a staging chunk are cut with a (k-1)-base overlap: force tiny chunks
+    monkeypatch.setenv("KCT_FILE_CHUNK", "4096")
+    dev = KCT(k)
+    assert dev.consume_file(str(fa)) == n_ref
+    assert_same_table(dev, ref)
+    monkeypatch.delenv("KCT_FILE_CHUNK")
+    # error mode goes through the per-record semantics
+    dev2, ref2 = KCT(k), OracleTable(k)
+    err_ref = None
+    for r in recs:
+        try:
+            ref2.consume(r, skip_bad_kmers=False)
+        except ValueError as e:
+            err_ref = str(e)
+            break
+    with pytest.raises(ValueError) as ei:
+        dev2.consume_file(str(fa), skip_bad_kmers=False)
+    assert str(ei.value) == err_ref
+    assert_same_table(dev2, ref2)
+    with pytest.raises(OSError):
+        KCT(k).consume_file(str(tmp_path / "missing.fa"))
