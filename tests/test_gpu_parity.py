@@ -593,3 +593,41 @@ def test_consume_file_formats_match_oracle(KCT, tmp_path, monkeypatch):
     assert_same_table(dev2, ref2)
     with pytest.raises(OSError):
         KCT(k).consume_file(str(tmp_path / "missing.fa"))
+
+
+def test_multi_chunk_stream_and_large_table_paths(KCT):
+    """Two scale checks that need no oracle run:
+    (1) a 302 MB record stream crosses the 2^28-position launch chunk inside one consume_device call;
+        consuming it whole must equal consuming its two halves (same table, bit for bit);
+    (2) BASELINE config C3's shape (k=31, table too large for the partitioned path) on the direct
+        atomic path: n, sum_counts, len agree with the partitioned path's result on a table that fits."""
+    import torch
+
+    from oxli_amd import _lib
+    lib = _lib.load()
+    G, L, N = 20_000_000, 150, 2_000_000
+    g = torch.empty(G, dtype=torch.uint8, device="cuda")
+    r = torch.empty(N * (L + 1), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.kct_synth_genome_device(g.data_ptr(), G, 7, stream) == 0
+    assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), G, 0, N, L, 99, stream) == 0
+    torch.cuda.synchronize()
+    assert r.numel() > (1 << 28)
+    k = 31
+    whole = KCT(k, capacity=5_000_000)            # 2^23 slots: partitioned path, grows while counting
+    n = whole.consume_device(r.data_ptr(), r.numel(), N * L)
+    assert n == N * (L - k + 1) == whole.sum_counts
+    halves = KCT(k, capacity=5_000_000)
+    half = (N // 2) * (L + 1)
+    n2 = halves.consume_device(r.data_ptr(), half, (N // 2) * L) + halves.consume_device(r.data_ptr() + half, r.numel() - half, (N // 2) * L)
+    assert n2 == n
+    wk, wc = whole.dump_arrays(1)
+    hk, hc = halves.dump_arrays(1)
+    assert np.array_equal(wk, hk) and np.array_equal(wc, hc)
+    big = KCT(k, capacity=40_000_000)             # 2^26 slots = 1 GiB: 8192 blocks -> direct atomic path
+    big.set_path("auto")
+    assert big.capacity == 1 << 26
+    assert big.consume_device(r.data_ptr(), r.numel(), N * L) == n
+    assert len(big) == len(whole) and big.sum_counts == n
+    bk, bc = big.dump_arrays(1)
+    assert np.array_equal(bk, wk) and np.array_equal(bc, wc)
