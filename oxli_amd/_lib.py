@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libkct_hip.so")
+LIB_PATH = os.environ.get("KCT_LIB_PATH") or os.path.join(HERE, "csrc", "libkct_hip.so")  # override: A/B builds of the same ABI
 
 KCT_OK = 0
 KCT_ERR_WRONG_KSIZE = 1

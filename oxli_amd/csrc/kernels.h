@@ -345,6 +345,9 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
                                                                          u64 ntiles, PartitionArgs a) {
     __shared__ __attribute__((aligned(16))) u64 ring[kRingEntries];
     __shared__ u32 fill[1024], flushed[1024];
+    constexpr u32 kListCap = KW == 0 ? 1792 : 2048;  // the bytewise path's raw tile leaves a little less LDS
+    __shared__ u32 flist[kListCap];  // lines ready to leave the ring: block | position << 10
+    __shared__ u32 fcount;
     __shared__ u32 ovf_n;
     // the staged tile: raw bytes for the bytewise path (k > 64), pre-encoded 2-bit words otherwise
     constexpr int kTileBytes = KW == 0 ? kPartTile + kHaloMax + 16 : 16;
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     const u32 D = (u32)(kRingEntries >> a.pbits), dmask = D - 1;
     for (int i = threadIdx.x; i < kRingEntries; i += kPartThreads) ring[i] = 0;
     for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
-    if (threadIdx.x == 0) ovf_n = 0;
+    if (threadIdx.x == 0) { ovf_n = 0; fcount = 0; }
     u64 *my_scratch = a.scratch + (u64)blockIdx.x * P * a.region_cap;
 
     // A hash whose ring slot is still occupied (many lanes hitting one block in the same few steps:
@@ -370,21 +373,41 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         if (i < a.ovf_cap) my_ovf[i] = h;
         else *a.overflow = 1ULL;
     };
-    // one thread moves one 64-byte line of a block's ring to this workgroup's region of that block
-    auto flush_chunk = [&](int b, u32 f) {
-        uint4 *src = reinterpret_cast<uint4 *>(&ring[(u32)b * D + (f & dmask)]);
-        uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        src[0] = z; src[1] = z; src[2] = z; src[3] = z;
-        if (f + kChunk <= a.region_cap) {
-            uint4 *dst = reinterpret_cast<uint4 *>(my_scratch + (u64)b * a.region_cap + f);
-            dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
-        } else {  // region full (badly skewed input): hand the line to the side list
-            const u64 e[8] = {((u64)v0.y << 32) | v0.x, ((u64)v0.w << 32) | v0.z, ((u64)v1.y << 32) | v1.x, ((u64)v1.w << 32) | v1.z,
-                              ((u64)v2.y << 32) | v2.x, ((u64)v2.w << 32) | v2.z, ((u64)v3.y << 32) | v3.x, ((u64)v3.w << 32) | v3.z};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) if (e[i]) overflow_hash(e[i]);
+    // Moving full 64-byte lines out of the ring, in two steps so that the stores coalesce:
+    // (1) every thread looks at its block(s) and lists the lines that are ready, (2) the listed
+    // lines are copied by groups of four adjacent lanes, 16 bytes each -- one whole-line store per
+    // group instead of four partial-line stores from a lone lane, and only as many wave
+    // instructions as there are lines to move.
+    auto flush_lines = [&](bool drain) {
+        __syncthreads();  // appends of this interval are in the ring
+        for (int b = threadIdx.x; b < P; b += kPartThreads) {
+            u32 f = flushed[b];
+            const u32 top = fill[b];
+            while (drain ? (int)(top - f) > 0 : top - f >= kChunk) {
+                const u32 slot = atomicAdd(&fcount, 1u);
+                if (slot >= kListCap) break;  // list full: this line waits for the next flush
+                flist[slot] = (u32)b | (f << 10);
+                f += kChunk;
+            }
+            flushed[b] = f;
         }
+        __syncthreads();
+        const u32 nlines = fcount < kListCap ? fcount : kListCap;
+        for (u32 item = threadIdx.x; item < 4 * nlines; item += kPartThreads) {
+            const u32 e = flist[item >> 2], q = item & 3u, b = e & 1023u, f = e >> 10;
+            uint4 *src = reinterpret_cast<uint4 *>(&ring[b * D + (f & dmask)]) + q;
+            const uint4 v = *src;
+            *src = make_uint4(0, 0, 0, 0);
+            if (f + kChunk <= a.region_cap) {
+                reinterpret_cast<uint4 *>(my_scratch + (u64)b * a.region_cap + f)[q] = v;
+            } else {  // region full (badly skewed input): hand the entries to the overflow region
+                const u64 e0 = ((u64)v.y << 32) | v.x, e1 = ((u64)v.w << 32) | v.z;
+                if (e0) overflow_hash(e0);
+                if (e1) overflow_hash(e1);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) fcount = 0;
     };
 
     // A tile is kPartTile + k - 1 <= 1024 + 16 sixteen-byte chunks: one per thread plus a halo that
@@ -427,32 +450,40 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
             pre_main = load_chunk(next * kPartTile, threadIdx.x);
             if (threadIdx.x < 16) pre_halo = load_chunk(next * kPartTile, kPartThreads + threadIdx.x);
         }
+        // The append is software-pipelined: window j's ring cursor is bumped (ds_add_rtn_u32) and the
+        // block's flush mark is read as soon as its hash exists, but the returned position is only
+        // consumed -- and the hash written into the ring -- after window j+1 has been hashed, so the
+        // LDS round trip hides under ~130 VALU instructions instead of stalling the wave.
+        u64 pend_h = 0;
+        u32 pend_b = 0, pend_pos = 0, pend_mark = 0;
+        auto commit = [&]() {
+            if (pend_h) {
+                if (pend_pos - pend_mark < D) ring[pend_b * D + (pend_pos & dmask)] = pend_h;  // slot's previous tenant is flushed
+                else overflow_hash(pend_h);                                                    // ring full: position stays a 0 hole
+                pend_h = 0;
+            }
+        };
         auto sink = [&](int j, bool good, u64 h) {
+            commit();  // the previous window's append
             if (good && h != 0 && !(a.ablate & 1)) {
-                const u32 b = (u32)((h & a.mask) >> a.block_bits);
-                const u32 pos = atomicAdd(&fill[b], 1u);
-                if (pos - flushed[b] < D) ring[b * D + (pos & dmask)] = h;  // slot's previous tenant is flushed
-                else overflow_hash(h);                                      // ring full: position stays a 0 hole
+                pend_b = ((u32)h & (u32)a.mask) >> a.block_bits;  // block index: the low 32 bits suffice (table <= 2^23 slots here)
+                pend_pos = atomicAdd(&fill[pend_b], 1u);
+                pend_mark = flushed[pend_b];
+                pend_h = h;
             }
             if ((j & 3) == 3 && !(a.ablate & 2)) {  // every fourth step: move every full line out
-                __syncthreads();
-                for (int b = threadIdx.x; b < P; b += kPartThreads) {
-                    u32 f = flushed[b];
-                    const u32 top = fill[b];
-                    while (top - f >= kChunk) { flush_chunk(b, f); f += kChunk; }
-                    flushed[b] = f;
-                }
-                __syncthreads();
+                commit();
+                flush_lines(false);
             }
         };
         if constexpr (KW == 0) walk_windows<0, 0, kPartWPT>(lds, k, sink);
         else walk_windows_encoded<KW, KC>(tcodes, tvalid, k, sink);
+        commit();
     }
-    __syncthreads();
-    for (int b = threadIdx.x; b < P; b += kPartThreads) {  // drain: partial lines go out zero-padded
-        u32 f = flushed[b];
-        const u32 top = fill[b];
-        while ((int)(top - f) > 0) { flush_chunk(b, f); f += kChunk; }
+    flush_lines(true);  // drain: partial lines go out zero-padded
+    flush_lines(true);  // (a second pass covers a full ring when the list is smaller than the ring's 2048 lines)
+    for (int b = threadIdx.x; b < P; b += kPartThreads) {
+        const u32 f = flushed[b];
         a.region_count[(u64)b * gridDim.x + blockIdx.x] = f < a.region_cap ? f : a.region_cap;
     }
     __syncthreads();
