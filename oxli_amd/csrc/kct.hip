@@ -112,6 +112,8 @@ struct kct_table {
     int block_bits = 0;     // log2(slots per probing block) = min(13, log2 cap)
     bool lazy_empty = false;  // kct_clear() was called and the memset has not been issued yet
     int num_cus = 256;
+    int ablate = 0;         // KCT_ABLATE at create time: measurement-only switches that skip work (results invalid)
+    bool debug = false;     // KCT_DEBUG at create time: one stderr line per partitioned pass
     int force_path = 0;     // 0 = choose per pass, 1 = direct atomic kernel only, 2 = partitioned whenever the geometry allows
     u64 n_keys = 0;        // distinct non-zero hashes in `slots`
     u64 consumed = 0;      // lib.rs:36
@@ -388,7 +390,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     pa.mask = t->cap - 1; pa.block_bits = t->block_bits; pa.pbits = pbits;
     pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
     pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
-    pa.ablate = getenv("KCT_ABLATE") ? atoi(getenv("KCT_ABLATE")) : 0;  // measurement only; wrong counts when set
+    pa.ablate = t->ablate;  // measurement only; wrong counts when set
     {
         ProfScope ps(t, "partition_windows_kernel");
         dispatch_k<PartitionLauncher>(k, t->stream, nwg, d_stream, chunk_bytes, k, ntiles, pa);
@@ -415,7 +417,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     HIP_TRY(hipGetLastError());
     u64 c[4], spilled;
     KCT_TRY(read_counters(t, c, &spilled));
-    if (getenv("KCT_DEBUG")) {
+    if (t->debug) {
         std::vector<unsigned int> oc(nwg);
         (void)hipMemcpy(oc.data(), d_ovf_count, nwg * 4, hipMemcpyDeviceToHost);
         u64 tot = 0; unsigned int mx = 0;
@@ -577,6 +579,8 @@ kct_status kct_create(uint8_t ksize, uint64_t capacity_hint, int device, kct_tab
     t->cap = cap;
     set_geometry(t);
     t->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = getenv("KCT_ABLATE")) t->ablate = atoi(e);
+    t->debug = getenv("KCT_DEBUG") != nullptr;
     if (hipStreamSynchronize(t->stream) != hipSuccess) { set_err("stream sync failed"); return fail(KCT_ERR_HIP); }
     *out = t;
     return KCT_OK;

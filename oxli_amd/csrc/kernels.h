@@ -321,9 +321,10 @@ __global__ __launch_bounds__(kBlock) void count_windows_kernel(const unsigned ch
 //        count them with LDS atomics (ds_cmpst_rtn_b64 claim + ds_add_u64), store the block back.
 //
 // HBM traffic per k-mer: 1.15 B bases + 8 B scratch write + 8 B scratch read, plus 32 B per table
-// slot per pass -- all of it coalesced streaming.  Anything irregular (a wavefront full of one
-// repeated k-mer, a ring or region that is full) goes to a small (hash, count) side list that
-// the host folds in afterwards with the direct atomic kernel, so results are identical.
+// slot per pass -- all of it coalesced streaming.  A hash that finds its ring slot or its region
+// full (many lanes hitting one block at once: homopolymers, tandem repeats) goes to a per-workgroup
+// overflow region that merge_overflow_kernel folds in afterwards with the direct atomic insert,
+// so results are identical.
 // =================================================================================================
 
 struct PartitionArgs {
