@@ -122,7 +122,7 @@ struct kct_table {
 
     du64 *d_counters = nullptr;  // kNumCounters tallies + 8 scratch words (device)
     u64 *h_counters = nullptr;   // pinned mirror
-    DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort;
+    DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort, d_scratch2, d_regions2, d_irr2;
     PinnedBuf h_stage;
 
     bool prof_on = false;
@@ -356,12 +356,22 @@ kct_status replay_spill(kct_table *t, u64 spilled, u64 *n_out) {
     return KCT_OK;
 }
 
-// The partitioned path pays 16 B of streaming scratch traffic per k-mer plus 32 B per table
-// slot per pass; the direct path pays one memory-side atomic per k-mer.  It wins once a pass
-// brings at least ~a quarter as many windows as the table has slots.
+// The partitioned path pays 16 B (one level) or 32 B (two levels) of streaming scratch traffic per
+// k-mer plus 32 B per table slot per pass; the direct path pays one memory-side atomic per k-mer.
+// It wins once a pass brings a fair fraction as many windows as the table has slots.
+bool partition_geometry_ok(const kct_table *t) {
+    const u64 nblocks = t->cap >> t->block_bits;
+    return nblocks >= 16 && t->cap <= (1ULL << 32);
+}
+
 bool partition_pays(const kct_table *t, u64 npos) {
     const u64 nblocks = t->cap >> t->block_bits;
-    return nblocks >= 16 && nblocks <= 1024 && npos >= (1ULL << 20) && npos >= t->cap / 4;
+    if (!partition_geometry_ok(t) || npos < (1ULL << 20)) return false;
+    return nblocks <= 1024 ? npos >= t->cap / 4 : npos >= t->cap / 2;
+}
+
+unsigned int region_capacity(double avg) {
+    return (unsigned int)((((u64)(avg * 1.15 + 8.0 * __builtin_sqrt(avg) + 64.0)) + 7) & ~7ULL);
 }
 
 // One pass of the partitioned path over window starts [0, npos) of d_stream.  *handled = false
@@ -369,13 +379,15 @@ bool partition_pays(const kct_table *t, u64 npos) {
 kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled) {
     *handled = false;
     const int k = t->k;
-    const int pbits = log2_u64(t->cap >> t->block_bits);
-    const u64 P = 1ULL << pbits;
+    const int bbits = log2_u64(t->cap >> t->block_bits);      // log2(table blocks)
+    const bool two_level = bbits > 10;
+    const int pbits = two_level ? 10 : bbits;                 // K1 fans out to 2^pbits bins ...
+    const int sub_bits = bbits - pbits;                       // ... each holding 2^sub_bits table blocks
+    const u64 P = 1ULL << pbits, B = 1ULL << bbits;
     const int nwg = t->num_cus;
     const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
     const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
-    const double avg = (double)(tiles_per_wg * kct::kPartTile) / (double)P;
-    const unsigned int region_cap = (unsigned int)((((u64)(avg * 1.15 + 8.0 * __builtin_sqrt(avg) + 64.0)) + 7) & ~7ULL);
+    const unsigned int region_cap = region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P);
     const unsigned int ovf_cap = (unsigned int)std::max<u64>(4096, tiles_per_wg * kct::kPartTile / 8);
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 8));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
@@ -387,7 +399,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     const bool fresh = t->lazy_empty;
 
     kct::PartitionArgs pa;
-    pa.mask = t->cap - 1; pa.block_bits = t->block_bits; pa.pbits = pbits;
+    pa.mask = t->cap - 1; pa.block_bits = t->block_bits + sub_bits; pa.pbits = pbits;
     pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
     pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
     pa.ablate = t->ablate;  // measurement only; wrong counts when set
@@ -398,13 +410,38 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     HIP_TRY(hipGetLastError());
 
     kct::AggregateArgs aa;
-    aa.words = t->slots; aa.block_bits = t->block_bits; aa.pbits = pbits;
-    aa.scratch = (const du64 *)t->d_scratch.p; aa.region_cap = region_cap; aa.region_count = (const unsigned int *)t->d_regions.p;
-    aa.nwg = nwg; aa.fresh = fresh ? 1 : 0; aa.overflow = d_overflow; aa.ablate = pa.ablate;
+    aa.words = t->slots; aa.block_bits = t->block_bits; aa.pbits = bbits;
+    aa.fresh = fresh ? 1 : 0; aa.overflow = d_overflow; aa.ablate = pa.ablate;
     aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
+    unsigned int ovf2_cap = 0, *d_ovf2_count = nullptr;
+    if (!two_level) {
+        aa.scratch = (const du64 *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
+        aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
+    } else {
+        // second level: one workgroup per super-bin spreads its hashes over the super-bin's blocks
+        const unsigned int out_cap = region_capacity((double)npos / (double)B);
+        ovf2_cap = (unsigned int)std::max<u64>(4096, npos / P / 8);
+        KCT_TRY(t->d_scratch2.reserve(B * out_cap * 8));
+        KCT_TRY(t->d_regions2.reserve(B * 4));
+        KCT_TRY(t->d_irr2.reserve(P * ovf2_cap * 8 + P * 4));
+        d_ovf2_count = (unsigned int *)((du64 *)t->d_irr2.p + P * ovf2_cap);
+        kct::RepartitionArgs ra;
+        ra.mask = t->cap - 1; ra.block_bits = t->block_bits; ra.sub_bits = sub_bits;
+        ra.in = (const du64 *)t->d_scratch.p; ra.in_cap = region_cap; ra.in_count = (const unsigned int *)t->d_regions.p;
+        ra.nseg = nwg; ra.nbins = (int)P;
+        ra.out = (du64 *)t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
+        ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow;
+        {
+            ProfScope ps(t, "repartition_kernel");
+            hipLaunchKernelGGL(kct::repartition_kernel, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, ra);
+        }
+        HIP_TRY(hipGetLastError());
+        aa.scratch = (const du64 *)t->d_scratch2.p; aa.seg_stride = 0; aa.block_stride = out_cap;
+        aa.region_count = (const unsigned int *)t->d_regions2.p; aa.nregions = 1;
+    }
     {
         ProfScope ps(t, "aggregate_blocks_kernel");
-        hipLaunchKernelGGL(kct::aggregate_blocks_kernel, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, aa);
+        hipLaunchKernelGGL(kct::aggregate_blocks_kernel, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
     }
     HIP_TRY(hipGetLastError());
     {
@@ -413,6 +450,9 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         ProfScope ps(t, "merge_overflow_kernel");
         hipLaunchKernelGGL(kct::merge_overflow_kernel, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
                            (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, view(t, npos), t->d_counters);
+        if (two_level)
+            hipLaunchKernelGGL(kct::merge_overflow_kernel, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
+                               (const unsigned int *)d_ovf2_count, (int)P, ovf2_cap, (const du64 *)d_overflow, view(t, npos), t->d_counters);
     }
     HIP_TRY(hipGetLastError());
     u64 c[4], spilled;
@@ -420,13 +460,14 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     if (t->debug) {
         std::vector<unsigned int> oc(nwg);
         (void)hipMemcpy(oc.data(), d_ovf_count, nwg * 4, hipMemcpyDeviceToHost);
-        u64 tot = 0; unsigned int mx = 0;
-        for (auto v : oc) { tot += v; mx = std::max(mx, v); }
-        fprintf(stderr, "[kct] partitioned pass: npos=%llu P=%llu region_cap=%u ovf_cap=%u overflow entries total=%llu max/wg=%u counted=%llu merged=%llu spilled=%llu abandon=%llu\n",
-                (unsigned long long)npos, (unsigned long long)P, region_cap, ovf_cap, (unsigned long long)tot, mx, (unsigned long long)c[kct::CTR_COUNTED],
-                (unsigned long long)c[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled, (unsigned long long)t->h_counters[kNumCounters + 6]);
+        u64 tot = 0;
+        for (auto v : oc) tot += v;
+        fprintf(stderr, "[kct] partitioned pass: npos=%llu blocks=%llu levels=%d region_cap=%u overflow(K1)=%llu counted=%llu merged=%llu spilled=%llu abandon=%llu\n",
+                (unsigned long long)npos, (unsigned long long)B, two_level ? 2 : 1, region_cap, (unsigned long long)tot,
+                (unsigned long long)c[kct::CTR_COUNTED], (unsigned long long)c[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled,
+                (unsigned long long)t->h_counters[kNumCounters + 6]);
     }
-    if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // abandoned: K2 and the merge exited early, nothing was touched
+    if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // abandoned: K2 and the merges exited early, nothing was touched
     t->lazy_empty = false;
     *handled = true;
     *n_out += c[kct::CTR_COUNTED] + c[kct::CTR_TOTAL_ADDED];
@@ -449,11 +490,21 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
     while (done <= last_start) {
         KCT_TRY(maybe_grow(t));
         // a chunk owns window starts [done, done + npos); its loads reach k-1 bytes further
-        const u64 npos = std::min<u64>(kChunkPositions, last_start + 1 - done);
+        // Launch chunk.  The partitioned path on a large table re-reads and re-writes every table block
+        // once per pass, so it wants passes of several windows per slot; its scratch + spill lists cost
+        // ~36 B per window start, which bounds the pass by free HBM (this is what 288 GB is for).
+        u64 chunk_limit = kChunkPositions;
+        if (t->force_path != 1 && partition_geometry_ok(t) && (t->cap >> t->block_bits) > 1024) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const u64 by_mem = (u64)(free_b / 2) / 36;
+                chunk_limit = std::max<u64>(kChunkPositions, std::min<u64>(4 * t->cap, by_mem));
+                chunk_limit &= ~(u64)0xFFFF;  // keeps `d_stream + done` 16-byte aligned
+            }
+        }
+        const u64 npos = std::min<u64>(chunk_limit, last_start + 1 - done);
         const u64 chunk_bytes = std::min<u64>(nbytes - done, npos + k - 1);
-        const u64 nblocks = t->cap >> t->block_bits;
-        const bool geometry_ok = nblocks >= 16 && nblocks <= 1024;
-        if (geometry_ok && t->force_path != 1 && (t->force_path == 2 || partition_pays(t, npos))) {
+        if (partition_geometry_ok(t) && t->force_path != 1 && (t->force_path == 2 || partition_pays(t, npos))) {
             bool handled = false;
             KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled));
             if (handled) { done += npos; continue; }
@@ -597,6 +648,7 @@ void kct_destroy(kct_table *t) {
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     t->d_stream.release(); t->d_spill.release(); t->d_aux.release(); t->d_aux2.release();
     t->d_scratch.release(); t->d_regions.release(); t->d_irr.release(); t->d_sort.release();
+    t->d_scratch2.release(); t->d_regions2.release(); t->d_irr2.release();
     t->h_stage.release();
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
     delete t;

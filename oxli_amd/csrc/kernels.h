@@ -327,6 +327,56 @@ __global__ __launch_bounds__(kBlock) void count_windows_kernel(const unsigned ch
 // so results are identical.
 // =================================================================================================
 
+// ---- LDS write-combining ring shared by both partition levels ------------------------------------------
+// Bin b owns ring[b*D .. b*D+D).  An append takes position pos = fill[b]++ and lands in slot pos % D
+// unless the slot's previous tenant (position pos - D) has not left yet, i.e. pos - flushed[b] >= D;
+// such an append goes to the caller's overflow region and its position stays a HOLE in the sequence.
+// Position p of bin b is stored at offset p of the bin's output region (zeros = padding / holes).
+// ring_flush moves 64-byte lines (8 positions) out:
+//   step 1  each bin's thread lists its ready lines.  Lines at or beyond flushed + D were never in the
+//           ring (all holes): they are listed as ZERO lines, because their slots alias the lines in front;
+//   step 2  groups of four adjacent lanes move one listed line, 16 bytes each: one whole-line store per
+//           group, and only as many wave instructions as there are lines.
+// Returns (workgroup-uniformly) whether the list was too short for everything that was ready.
+template <u32 LISTCAP, class Overflow>
+__device__ __forceinline__ bool ring_flush(u64 *ring, u32 *fill, u32 *flushed, u32 *flist, u32 *fcount, int P, u32 D,
+                                           u64 *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash) {
+    const u32 dmask = D - 1;
+    __syncthreads();  // appends of this interval are in the ring; *fcount == 0
+    for (int b = threadIdx.x; b < P; b += kPartThreads) {
+        const u32 f0 = flushed[b], top = fill[b];
+        u32 f = f0;
+        while (drain ? (int)(top - f) > 0 : top - f >= kChunk) {
+            const u32 slot = atomicAdd(fcount, 1u);
+            if (slot >= LISTCAP) break;  // list full: this line waits for the next call
+            flist[slot] = (u32)b | (f << 10) | (f - f0 >= D ? 0x80000000u : 0u);
+            f += kChunk;
+        }
+        flushed[b] = f;
+    }
+    __syncthreads();
+    const u32 listed = *fcount, nlist = listed < LISTCAP ? listed : LISTCAP;
+    for (u32 item = threadIdx.x; item < 4 * nlist; item += kPartThreads) {
+        const u32 e = flist[item >> 2], q = item & 3u, b = e & 1023u, f = (e >> 10) & 0x1FFFFFu;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (!(e >> 31)) {
+            uint4 *src = reinterpret_cast<uint4 *>(&ring[b * D + (f & dmask)]) + q;
+            v = *src;
+            *src = make_uint4(0, 0, 0, 0);
+        }
+        if (f + kChunk <= out_cap) {
+            reinterpret_cast<uint4 *>(out_base + (u64)b * out_cap + f)[q] = v;
+        } else {  // region full (badly skewed input): hand the entries to the overflow region
+            const u64 e0 = ((u64)v.y << 32) | v.x, e1 = ((u64)v.w << 32) | v.z;
+            if (e0) overflow_hash(e0);
+            if (e1) overflow_hash(e1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *fcount = 0;
+    return listed > LISTCAP;
+}
+
 struct PartitionArgs {
     u64 mask;            // table capacity - 1
     int block_bits;      // log2(slots per block)
@@ -347,7 +397,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     __shared__ __attribute__((aligned(16))) u64 ring[kRingEntries];
     __shared__ u32 fill[1024], flushed[1024];
     constexpr u32 kListCap = KW == 0 ? 1792 : 2048;  // the bytewise path's raw tile leaves a little less LDS
-    __shared__ u32 flist[kListCap];  // lines ready to leave the ring: block | position << 10
+    __shared__ u32 flist[kListCap];  // lines ready to leave the ring: block | position << 10 | hole << 31
     __shared__ u32 fcount;
     __shared__ u32 ovf_n;
     // the staged tile: raw bytes for the bytewise path (k > 64), pre-encoded 2-bit words otherwise
@@ -374,41 +424,8 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         if (i < a.ovf_cap) my_ovf[i] = h;
         else *a.overflow = 1ULL;
     };
-    // Moving full 64-byte lines out of the ring, in two steps so that the stores coalesce:
-    // (1) every thread looks at its block(s) and lists the lines that are ready, (2) the listed
-    // lines are copied by groups of four adjacent lanes, 16 bytes each -- one whole-line store per
-    // group instead of four partial-line stores from a lone lane, and only as many wave
-    // instructions as there are lines to move.
     auto flush_lines = [&](bool drain) {
-        __syncthreads();  // appends of this interval are in the ring
-        for (int b = threadIdx.x; b < P; b += kPartThreads) {
-            u32 f = flushed[b];
-            const u32 top = fill[b];
-            while (drain ? (int)(top - f) > 0 : top - f >= kChunk) {
-                const u32 slot = atomicAdd(&fcount, 1u);
-                if (slot >= kListCap) break;  // list full: this line waits for the next flush
-                flist[slot] = (u32)b | (f << 10);
-                f += kChunk;
-            }
-            flushed[b] = f;
-        }
-        __syncthreads();
-        const u32 nlines = fcount < kListCap ? fcount : kListCap;
-        for (u32 item = threadIdx.x; item < 4 * nlines; item += kPartThreads) {
-            const u32 e = flist[item >> 2], q = item & 3u, b = e & 1023u, f = e >> 10;
-            uint4 *src = reinterpret_cast<uint4 *>(&ring[b * D + (f & dmask)]) + q;
-            const uint4 v = *src;
-            *src = make_uint4(0, 0, 0, 0);
-            if (f + kChunk <= a.region_cap) {
-                reinterpret_cast<uint4 *>(my_scratch + (u64)b * a.region_cap + f)[q] = v;
-            } else {  // region full (badly skewed input): hand the entries to the overflow region
-                const u64 e0 = ((u64)v.y << 32) | v.x, e1 = ((u64)v.w << 32) | v.z;
-                if (e0) overflow_hash(e0);
-                if (e1) overflow_hash(e1);
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) fcount = 0;
+        return ring_flush<kListCap>(ring, fill, flushed, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_hash);
     };
 
     // A tile is kPartTile + k - 1 <= 1024 + 16 sixteen-byte chunks: one per thread plus a halo that
@@ -481,8 +498,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         else walk_windows_encoded<KW, KC>(tcodes, tvalid, k, sink);
         commit();
     }
-    flush_lines(true);  // drain: partial lines go out zero-padded
-    flush_lines(true);  // (a second pass covers a full ring when the list is smaller than the ring's 2048 lines)
+    while (flush_lines(true)) {}  // drain: partial lines go out zero-padded; repeat while the list was too short
     for (int b = threadIdx.x; b < P; b += kPartThreads) {
         const u32 f = flushed[b];
         a.region_count[(u64)b * gridDim.x + blockIdx.x] = f < a.region_cap ? f : a.region_cap;
@@ -491,14 +507,106 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     if (threadIdx.x == 0) a.ovf_count[blockIdx.x] = ovf_n < a.ovf_cap ? ovf_n : a.ovf_cap;
 }
 
+// ---- second partition level (tables with more than 1024 blocks) ---------------------------------------
+// K1 can only fan out to 1024 bins (the LDS ring).  For larger tables its bins are SUPER-BINS of
+// 2^sub_bits consecutive table blocks, and this kernel -- one 1024-thread workgroup per super-bin --
+// re-partitions a super-bin's hashes by block with the same LDS write-combining ring.  Exactly one
+// workgroup writes a given block's region, so K2 then reads a single region per block.
+struct RepartitionArgs {
+    u64 mask;            // table capacity - 1
+    int block_bits;      // log2(slots per block)
+    int sub_bits;        // log2(blocks per super-bin); ring depth D = kRingEntries >> sub_bits >= 16
+    const u64 *in;       // K1's regions: region (seg, s) at in + (seg * nbins + s) * in_cap
+    u32 in_cap;
+    const u32 *in_count; // [nbins][nseg]
+    int nseg, nbins;
+    u64 *out;            // region of block b at out + b * out_cap
+    u32 out_cap;         // multiple of kChunk
+    u32 *out_count;      // [blocks]
+    u64 *ovf; u32 ovf_cap; u32 *ovf_count;  // per super-bin overflow regions
+    u64 *overflow;       // abandon flag (shared with K1)
+};
+
+__global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionArgs a) {
+    __shared__ __attribute__((aligned(16))) u64 ring[kRingEntries];
+    __shared__ u32 fill[1024], flushed[1024];
+    __shared__ u32 flist[2048];
+    __shared__ u32 fcount, ovf_n, rounds;
+    const int s = blockIdx.x, P2 = 1 << a.sub_bits;
+    const u32 D = (u32)(kRingEntries >> a.sub_bits), dmask = D - 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < kRingEntries; i += kPartThreads) ring[i] = 0;
+    for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
+    if (threadIdx.x == 0) { fcount = 0; ovf_n = 0; rounds = 0; }
+    if (threadIdx.x == 0 && *a.overflow) rounds = ~0u;  // K1 (or another super-bin) gave up on this pass
+    __syncthreads();
+    if (rounds == ~0u) return;  // read through LDS so that the whole workgroup takes the same branch
+    __syncthreads();
+    u64 *my_out = a.out + ((u64)s << a.sub_bits) * a.out_cap;
+    u64 *my_ovf = a.ovf + (u64)s * a.ovf_cap;
+    auto overflow_hash = [&](u64 h) {
+        const u32 i = atomicAdd(&ovf_n, 1u);
+        if (i < a.ovf_cap) my_ovf[i] = h;
+        else *a.overflow = 1ULL;
+    };
+    auto flush_lines = [&](bool drain) {
+        return ring_flush<2048u>(ring, fill, flushed, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_hash);
+    };
+    // A wave owns the input regions seg = wave, wave+16, ...; work unit = a slab of 8 x 64 entries whose
+    // loads are all issued before the first append.  Every wave runs the same number of rounds so that
+    // the flush barriers line up.
+    constexpr int kLoads = 8;
+    constexpr u32 kSlab = 64 * kLoads;
+    const u32 *counts = a.in_count + (u64)s * a.nseg;
+    u32 my_slabs = 0;
+    for (int seg = wave; seg < a.nseg; seg += kPartThreads / 64) my_slabs += (counts[seg] + kSlab - 1) / kSlab;
+    if (lane == 0) atomicMax(&rounds, my_slabs);
+    __syncthreads();
+    const u32 nrounds = rounds;
+    int seg = wave;
+    u32 off = 0;
+    for (u32 r = 0; r < nrounds; ++r) {
+        u64 v[kLoads];
+#pragma unroll
+        for (int j = 0; j < kLoads; ++j) v[j] = 0;
+        while (seg < a.nseg && off >= counts[seg]) { seg += kPartThreads / 64; off = 0; }  // next non-empty region
+        if (seg < a.nseg) {
+            const u32 cnt = counts[seg];
+            const u64 *src = a.in + ((u64)seg * a.nbins + s) * a.in_cap + off;
+            const u32 left = cnt - off;
+#pragma unroll
+            for (int j = 0; j < kLoads; ++j) { const u32 i = lane + 64 * j; v[j] = i < left ? src[i] : 0ULL; }
+            off += kSlab;
+        }
+#pragma unroll
+        for (int j = 0; j < kLoads; ++j) {
+            const u64 h = v[j];
+            if (h) {
+                const u32 b = (((u32)h & (u32)a.mask) >> a.block_bits) & (u32)(P2 - 1);
+                const u32 pos = atomicAdd(&fill[b], 1u);
+                if (pos - flushed[b] < D) ring[b * D + (pos & dmask)] = h;
+                else overflow_hash(h);
+            }
+            if ((j & 3) == 3) flush_lines(false);
+        }
+    }
+    while (flush_lines(true)) {}
+    for (int b = threadIdx.x; b < P2; b += kPartThreads) {
+        const u32 f = flushed[b];
+        a.out_count[((u64)s << a.sub_bits) + b] = f < a.out_cap ? f : a.out_cap;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.ovf_count[s] = ovf_n < a.ovf_cap ? ovf_n : a.ovf_cap;
+}
+
 struct AggregateArgs {
     u64 *words;          // the table (block-SoA)
     int block_bits;
     int pbits;
-    const u64 *scratch;
-    u32 region_cap;
-    const u32 *region_count;
-    int nwg;             // workgroups K1 ran with (= regions per block)
+    const u64 *scratch;  // region (seg, b) starts at scratch + seg * seg_stride + b * block_stride (u64 words)
+    u64 seg_stride, block_stride;
+    const u32 *region_count;  // [P][nregions] entries in each region
+    int nregions;        // source regions per block: K1's workgroups (one level) or 1 (two levels)
     int fresh;           // table known empty: start every block from zeros instead of loading it
     const u64 *overflow; // K1's abandon flag
     int ablate;          // measurement only: bit 2 = no count add, bit 4 = loads only
@@ -512,7 +620,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
     __shared__ __attribute__((aligned(16))) unsigned char tags[1 << kBlockBitsMax];  // one fingerprint byte per slot, 8 KiB
     __shared__ u64 s_counted, s_new;
     if (*a.overflow) return;  // wave-uniform: K1 gave up, the host reruns the batch on the direct path
-    const int P = 1 << a.pbits, b = blockIdx.x;
+    const int b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
     u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u64 *keys = tab, *cnts = tab + S;
@@ -607,16 +715,16 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
             if (qn > kWaveQueue - 64) drain(31);
         }
     };
-    // One wave per source region.  All of a lane's loads for the region are issued before the
-    // first insert so that ~10 x 512 B are in flight per wave instead of one dependent load.
+    // The block's hashes arrive as `nregions` regions; they are cut into slabs of 64 x kInFlight
+    // entries that the 16 waves take round-robin.  All of a lane's loads for a slab are issued before
+    // the first insert, so ~12 x 512 B are in flight per wave instead of one dependent load.
     constexpr int kInFlight = 12;
-    const u32 *my_counts = a.region_count + (u64)b * a.nwg;
-    for (int seg = wave; seg < a.nwg; seg += kPartThreads / 64) {
-        const u32 cnt = my_counts[seg];
-        const u64 *src = a.scratch + ((u64)seg * P + b) * a.region_cap;
+    constexpr u32 kSlab = 64 * kInFlight;
+    const u32 *my_counts = a.region_count + (u64)b * a.nregions;
+    auto do_slab = [&](const u64 *src, u32 left) {
         u64 v[kInFlight];
 #pragma unroll
-        for (int j = 0; j < kInFlight; ++j) { const u32 i = lane + 64 * j; v[j] = i < cnt ? src[i] : 0ULL; }
+        for (int j = 0; j < kInFlight; ++j) { const u32 i = lane + 64 * j; v[j] = i < left ? src[i] : 0ULL; }
         if (a.ablate & 16) {
 #pragma unroll
             for (int j = 0; j < kInFlight; ++j) counted += (u32)v[j];
@@ -624,7 +732,22 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
 #pragma unroll
             for (int j = 0; j < kInFlight; ++j) fast(v[j]);
         }
-        for (u32 i0 = 64 * kInFlight; i0 < cnt; i0 += 64) { const u32 i = i0 + lane; fast(i < cnt ? src[i] : 0ULL); }
+    };
+    constexpr int kWaves = kPartThreads / 64;
+    if (a.nregions >= kWaves) {  // one level: many short regions, one wave each
+        for (int seg = wave; seg < a.nregions; seg += kWaves) {
+            const u32 cnt = my_counts[seg];
+            const u64 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
+            for (u32 s0 = 0; s0 < cnt; s0 += kSlab) do_slab(region + s0, cnt - s0);
+        }
+    } else {  // two levels: one long region per block, its slabs dealt round-robin to the waves
+        u32 slab_id = 0;
+        for (int seg = 0; seg < a.nregions; ++seg) {
+            const u32 cnt = my_counts[seg];
+            const u64 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
+            for (u32 s0 = 0; s0 < cnt; s0 += kSlab, ++slab_id)
+                if ((slab_id & (kWaves - 1)) == (u32)wave) do_slab(region + s0, cnt - s0);
+        }
     }
     drain(0);
     u64 wc = wave_sum(counted), wn = wave_sum(newkeys);

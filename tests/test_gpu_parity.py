@@ -431,6 +431,40 @@ def test_partitioned_path_matches_oracle(KCT, k):
     assert_same_table(dev, ref)
 
 
+@pytest.mark.parametrize("k", [21, 51])
+def test_two_level_partitioned_path_matches_oracle(KCT, k):
+    """Tables with more than 1024 blocks (> 128 MiB) take two partition levels: K1 into 1024 super-bins,
+    repartition_kernel into the table blocks, then the per-block LDS count."""
+    rng = random.Random(5000 + k)
+    seqs = _mixed_inputs(rng, k)
+    ref = OracleTable(k)
+    n_ref = [ref.consume(s) for s in seqs]
+    dev = KCT(k, capacity=12_000_000)      # 2^25 slots = 4096 blocks: 4 blocks per super-bin
+    assert dev.capacity == 1 << 25
+    dev.set_path("partitioned")
+    assert [dev.consume(s) for s in seqs] == n_ref
+    assert_same_table(dev, ref)
+    dev.clear()
+    assert dev.consume_batch(seqs) == sum(n_ref)   # one pass over everything, starting from a lazily cleared table
+    assert_same_table(dev, ref)
+
+
+def test_partitioned_path_shallow_ring_bursts(KCT):
+    """1024 table blocks leave each block a 16-entry ring.  Repeats send far more than 16 hashes to one
+    block between two flushes: positions beyond the ring must come out as holes, never as a second
+    copy of the lines in front (regression test for an aliasing bug in the compacted flush)."""
+    rng = random.Random(4242)
+    k = 21
+    seqs = [rand_dna(rng, 500) * 400, "ACGT" * 50000, rand_dna(rng, 200000), ("AC" * 40 + rand_dna(rng, 37)) * 2000]
+    ref = OracleTable(k)
+    n_ref = [ref.consume(s) for s in seqs]
+    dev = KCT(k, capacity=5_000_000)       # 2^23 slots = 1024 blocks
+    assert dev.capacity == 1 << 23
+    dev.set_path("partitioned")
+    assert [dev.consume(s) for s in seqs] == n_ref
+    assert_same_table(dev, ref)
+
+
 def test_partitioned_path_updates_a_live_table(KCT):
     """Second and later passes load each table block into LDS instead of starting from zeros; point
     updates made through the atomic path in between must be seen and kept."""
