@@ -487,21 +487,23 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
     if (nbytes < (u64)k) return KCT_OK;
     u64 done = 0;
     const u64 last_start = nbytes - k;  // last window start position
+    // Launch chunk.  The partitioned path on a large table re-reads and re-writes every table block
+    // once per pass, so it wants passes of several windows per slot; its scratch + spill lists cost
+    // ~36 B per window start, which bounds the pass by HBM (this is what 288 GB is for).  Decided
+    // once per call: buffers this table already holds are reused, so they count as available.
+    u64 chunk_limit = kChunkPositions;
+    if (t->force_path != 1 && partition_geometry_ok(t) && (t->cap >> t->block_bits) > 1024) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const u64 held = t->d_scratch.cap + t->d_scratch2.cap + t->d_spill.cap + t->d_irr.cap + t->d_irr2.cap;
+            const u64 by_mem = ((u64)free_b + held) / 2 / 36;
+            chunk_limit = std::max<u64>(kChunkPositions, std::min<u64>(4 * t->cap, by_mem));
+            chunk_limit &= ~(u64)0xFFFF;  // keeps `d_stream + done` 16-byte aligned
+        }
+    }
     while (done <= last_start) {
         KCT_TRY(maybe_grow(t));
         // a chunk owns window starts [done, done + npos); its loads reach k-1 bytes further
-        // Launch chunk.  The partitioned path on a large table re-reads and re-writes every table block
-        // once per pass, so it wants passes of several windows per slot; its scratch + spill lists cost
-        // ~36 B per window start, which bounds the pass by free HBM (this is what 288 GB is for).
-        u64 chunk_limit = kChunkPositions;
-        if (t->force_path != 1 && partition_geometry_ok(t) && (t->cap >> t->block_bits) > 1024) {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                const u64 by_mem = (u64)(free_b / 2) / 36;
-                chunk_limit = std::max<u64>(kChunkPositions, std::min<u64>(4 * t->cap, by_mem));
-                chunk_limit &= ~(u64)0xFFFF;  // keeps `d_stream + done` 16-byte aligned
-            }
-        }
         const u64 npos = std::min<u64>(chunk_limit, last_start + 1 - done);
         const u64 chunk_bytes = std::min<u64>(nbytes - done, npos + k - 1);
         if (partition_geometry_ok(t) && t->force_path != 1 && (t->force_path == 2 || partition_pays(t, npos))) {
