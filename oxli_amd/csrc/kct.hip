@@ -806,15 +806,34 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
     KCT_TRY(t->h_stage.reserve(padded + 16 + off_bytes));
     char *dst = (char *)t->h_stage.p;
     u64 *rec_off = (u64 *)(dst + padded + 16);  // 16-aligned since padded is
-    u64 w = 0;
-    for (size_t r = 0; r < nrec; ++r) {
+    // Pack the records into the record stream: record r lands at (offsets[r] - offsets[0]) + r, one
+    // separator behind it.  Positions are known up front, so large batches are packed by several threads.
+    for (size_t r = 0; r < nrec; ++r)
         if (offsets[r + 1] < offsets[r]) { set_err("offsets must be non-decreasing"); return KCT_ERR_ARG; }
-        const u64 n = offsets[r + 1] - offsets[r];
-        if (!skip_bad) rec_off[r] = w;
-        memcpy(dst + w, bytes + offsets[r], n);
-        w += n;
-        dst[w++] = '\n';
+    const u64 base0 = offsets[0];
+    auto pack_range = [&](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1; ++r) {
+            const u64 n = offsets[r + 1] - offsets[r], w = (offsets[r] - base0) + r;
+            if (!skip_bad) rec_off[r] = w;
+            memcpy(dst + w, bytes + offsets[r], n);
+            dst[w + n] = '\n';
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nthreads = stream_len >= (8u << 20) ? std::min<size_t>({(size_t)8, hw ? hw : 1, nrec}) : 1;
+    if (nthreads <= 1) pack_range(0, nrec);
+    else {
+        std::vector<std::thread> pool;
+        for (size_t i = 0; i < nthreads; ++i) {
+            // split by bytes, not by record count: records may be ragged
+            const u64 lo = base0 + total * i / nthreads, hi = base0 + total * (i + 1) / nthreads;
+            const size_t r0 = (size_t)(std::lower_bound(offsets, offsets + nrec, lo) - offsets);
+            const size_t r1 = i + 1 == nthreads ? nrec : (size_t)(std::lower_bound(offsets, offsets + nrec, hi) - offsets);
+            if (r1 > r0) pool.emplace_back(pack_range, r0, r1);
+        }
+        for (auto &th : pool) th.join();
     }
+    const u64 w = stream_len;
     if (!skip_bad) rec_off[nrec] = w;
     memset(dst + w, '\n', padded + 16 - w);
     KCT_TRY(upload_stream(t, stream_len));
