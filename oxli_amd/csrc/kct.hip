@@ -794,7 +794,8 @@ kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, 
 kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *offsets, size_t nrec, int skip_bad,
                              uint64_t *n_total, uint64_t *bad_record, uint64_t *bad_position) {
     KCT_TRY(use(t));
-    if (!n_total || (nrec && (!bytes || !offsets))) { set_err("null argument"); return KCT_ERR_ARG; }
+    if (!n_total || (nrec && !offsets)) { set_err("null argument"); return KCT_ERR_ARG; }
+    if (nrec && !bytes && offsets[nrec] != offsets[0]) { set_err("null argument"); return KCT_ERR_ARG; }  // all-empty records need no bytes
     *n_total = 0;
     if (bad_record) *bad_record = nrec;
     if (bad_position) *bad_position = 0;

@@ -255,6 +255,8 @@ def test_consume_batch_equals_loop(KCT):
         assert dev2.consume_batch((data, offs)) == n
         assert_same_table(dev2, ref)
     assert KCT(21).consume_batch([]) == 0
+    t = KCT(21)
+    assert t.consume_batch(["", b""]) == 0 and t.consumed == 0 and len(t) == 0   # records with no bytes at all
 
 
 def test_consume_batch_error_mode(KCT):

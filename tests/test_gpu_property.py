@@ -13,7 +13,8 @@ from oracle import OracleTable  # noqa: E402
 # mostly DNA, some lower case, a sprinkling of everything else (N, IUPAC, NUL, newline, high bytes)
 base = st.sampled_from(list(b"ACGT" * 12 + b"acgt" * 2 + b"NnRYxX-*\n\r\t \x00\xff\xc3\xa9"))
 seqs = st.lists(base, min_size=0, max_size=700).map(bytes)
-COMMON = dict(deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+# derandomize: the same examples every run (CI must not flake); explore with `--hypothesis-seed=N` by hand
+COMMON = dict(deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 
 
 @pytest.fixture(scope="module")
