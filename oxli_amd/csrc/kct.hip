@@ -112,6 +112,7 @@ struct kct_table {
     int block_bits = 0;     // log2(slots per probing block) = min(13, log2 cap)
     bool lazy_empty = false;  // kct_clear() was called and the memset has not been issued yet
     int num_cus = 256;
+    bool auto_sized = true; // no capacity hint / reserve yet: bulk ingest ramps its launch size up with the table
     int ablate = 0;         // KCT_ABLATE at create time: measurement-only switches that skip work (results invalid)
     bool debug = false;     // KCT_DEBUG at create time: one stderr line per partitioned pass
     int force_path = 0;     // 0 = choose per pass, 1 = direct atomic kernel only, 2 = partitioned whenever the geometry allows
@@ -487,6 +488,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
     if (nbytes < (u64)k) return KCT_OK;
     u64 done = 0;
     const u64 last_start = nbytes - k;  // last window start position
+    const u64 cap_at_entry = t->cap;
     // Launch chunk.  The partitioned path on a large table re-reads and re-writes every table block
     // once per pass, so it wants passes of several windows per slot; its scratch + spill lists cost
     // ~36 B per window start, which bounds the pass by HBM (this is what 288 GB is for).  Decided
@@ -504,7 +506,11 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
     while (done <= last_start) {
         KCT_TRY(maybe_grow(t));
         // a chunk owns window starts [done, done + npos); its loads reach k-1 bytes further
-        const u64 npos = std::min<u64>(chunk_limit, last_start + 1 - done);
+        // A table that was never sized by its owner starts tiny: feed it launches of at most a few windows
+        // per slot, so that what cannot be placed (and must be replayed after growing) stays small while
+        // the table finds its size; launches grow with it.
+        const u64 ramp = t->auto_sized ? std::max<u64>(1ULL << 20, 4 * t->cap) : ~0ULL;
+        const u64 npos = std::min<u64>({chunk_limit, ramp, last_start + 1 - done});
         const u64 chunk_bytes = std::min<u64>(nbytes - done, npos + k - 1);
         if (partition_geometry_ok(t) && t->force_path != 1 && (t->force_path == 2 || partition_pays(t, npos))) {
             bool handled = false;
@@ -533,6 +539,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         }
         done += npos;
     }
+    if (t->auto_sized && t->cap == cap_at_entry && nbytes >= (1u << 20)) t->auto_sized = false;  // the table has found its size
     return KCT_OK;
 }
 
@@ -626,6 +633,7 @@ kct_status kct_create(uint8_t ksize, uint64_t capacity_hint, int device, kct_tab
     if (hipMalloc((void **)&t->d_counters, (kNumCounters + 8) * sizeof(u64)) != hipSuccess) { set_err("hipMalloc(counters) failed"); return fail(KCT_ERR_NOMEM); }
     if (hipHostMalloc((void **)&t->h_counters, (kNumCounters + 8) * sizeof(u64), hipHostMallocDefault) != hipSuccess) { set_err("hipHostMalloc failed"); return fail(KCT_ERR_NOMEM); }
     u64 cap = capacity_hint ? next_pow2((u64)((double)capacity_hint / kMaxLoad) + 1) : kDefaultSlots;
+    t->auto_sized = capacity_hint == 0;
     cap = std::max(cap, kMinSlots);
     st = alloc_slots(device, cap, t->stream, &t->slots);
     if (st != KCT_OK) return fail(st);
@@ -666,6 +674,7 @@ kct_status kct_clear(kct_table *t) {
 kct_status kct_reserve(kct_table *t, uint64_t distinct) {
     KCT_TRY(use(t));
     u64 want = next_pow2((u64)((double)distinct / kMaxLoad) + 1);
+    t->auto_sized = false;
     if (want > t->cap) return grow_to(t, want);
     return KCT_OK;
 }
