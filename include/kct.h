@@ -23,6 +23,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* Only the entry points below are exported from libkct_hip.so (it is built with -fvisibility=hidden). */
+#if defined(KCT_BUILDING_LIBRARY)
+#define KCT_API __attribute__((visibility("default")))
+#else
+#define KCT_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -42,57 +49,57 @@ typedef enum kct_status {
 } kct_status;
 
 /* Text of the most recent failure on this thread ("" if none). */
-const char *kct_last_error(void);
+KCT_API const char *kct_last_error(void);
 
 /* Number of visible HIP devices (0 on a CPU-only machine; never an error). */
-int kct_device_count(void);
+KCT_API int kct_device_count(void);
 
 /* ---- lifetime ---------------------------------------------------------------------------
  * KmerCountTable::new(ksize, store_kmers=false)                              lib.rs:44-62
  * `capacity_hint` = expected number of distinct k-mers (0 = default); the table grows by
  * itself, the hint only avoids early re-hashes.  `device` = HIP device ordinal. */
-kct_status kct_create(uint8_t ksize, uint64_t capacity_hint, int device, kct_table **out);
-void kct_destroy(kct_table *t);
+KCT_API kct_status kct_create(uint8_t ksize, uint64_t capacity_hint, int device, kct_table **out);
+KCT_API void kct_destroy(kct_table *t);
 
 /* Forget all counts and `consumed`; keeps the allocation. (No reference counterpart: a fresh
  * KmerCountTable.) */
-kct_status kct_clear(kct_table *t);
+KCT_API kct_status kct_clear(kct_table *t);
 
 /* Ensure room for `distinct` keys without further growth. */
-kct_status kct_reserve(kct_table *t, uint64_t distinct);
+KCT_API kct_status kct_reserve(kct_table *t, uint64_t distinct);
 
 /* ---- hashing ----------------------------------------------------------------------------
  * KmerCountTable::hash_kmer(kmer)                                            lib.rs:65-81
  * WRONG_KSIZE if (uint8_t)len != ksize (the reference compares `len as u8`), INVALID_DNA if
  * the first ksize bytes are not all ACGT/acgt. */
-kct_status kct_hash_kmer(kct_table *t, const char *kmer, size_t len, uint64_t *hash_out);
+KCT_API kct_status kct_hash_kmer(kct_table *t, const char *kmer, size_t len, uint64_t *hash_out);
 
 /* sourmash SeqToHashes as consume drives it (lib.rs:576-600): one value per k-window of
  * `seq`, 0 for a window holding a non-ACGT byte.  Writes min(windows, cap) values, returns
  * the window count in *n_windows and the index of the first bad window in *first_bad
  * (== *n_windows if none). */
-kct_status kct_hash_windows(kct_table *t, const char *seq, size_t len, uint64_t *hashes_out, size_t cap,
+KCT_API kct_status kct_hash_windows(kct_table *t, const char *seq, size_t len, uint64_t *hashes_out, size_t cap,
                             uint64_t *n_windows, uint64_t *first_bad);
 
 /* ---- point updates and lookups ------------------------------------------------------------
  * count_hash(hashval) -> new count                                           lib.rs:100-104
  * count(kmer) -> new count; consumed += len                                  lib.rs:145-167
  * get(kmer) / get_hash(hashval) / get_hash_array(hash_keys)                  lib.rs:170-194  */
-kct_status kct_count_hash(kct_table *t, uint64_t hash, uint64_t *count_out);
-kct_status kct_count(kct_table *t, const char *kmer, size_t len, uint64_t *count_out);
-kct_status kct_get(kct_table *t, const char *kmer, size_t len, uint64_t *count_out);
-kct_status kct_get_hash(kct_table *t, uint64_t hash, uint64_t *count_out);
-kct_status kct_get_hash_array(kct_table *t, const uint64_t *hashes, size_t n, uint64_t *counts_out);
+KCT_API kct_status kct_count_hash(kct_table *t, uint64_t hash, uint64_t *count_out);
+KCT_API kct_status kct_count(kct_table *t, const char *kmer, size_t len, uint64_t *count_out);
+KCT_API kct_status kct_get(kct_table *t, const char *kmer, size_t len, uint64_t *count_out);
+KCT_API kct_status kct_get_hash(kct_table *t, uint64_t hash, uint64_t *count_out);
+KCT_API kct_status kct_get_hash_array(kct_table *t, const uint64_t *hashes, size_t n, uint64_t *counts_out);
 
 /* __setitem__(kmer, count) is built from this                                lib.rs:675-681 */
-kct_status kct_set_hash(kct_table *t, uint64_t hash, uint64_t count);
+KCT_API kct_status kct_set_hash(kct_table *t, uint64_t hash, uint64_t count);
 
 /* ---- bulk ingest: the hot path -------------------------------------------------------------
  * consume(seq, skip_bad_kmers=true) -> n                                     lib.rs:545-607
  * *n_out = k-mers counted (valid windows whose hash is not 0).  With skip_bad == 0 and a bad
  * window present: returns KCT_ERR_BAD_KMER, *n_out = k-mers counted before it (they stay
  * counted), `consumed` unchanged -- the message is "bad k-mer encountered at position {n}". */
-kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out);
+KCT_API kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out);
 
 /* The reference is called once per FASTA/FASTQ record (README.md:96-98).  This is the same
  * loop in one call: record r is bytes[offsets[r] .. offsets[r+1]); k-mers never span records.
@@ -102,14 +109,14 @@ kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, 
  * position {n}"), records before it are fully counted, its windows before the bad one are
  * counted, later records are untouched, and `consumed` covers only the records before it.
  * Without an error *bad_record = nrec.  bad_record / bad_position may be NULL. */
-kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *offsets, size_t nrec, int skip_bad,
+KCT_API kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *offsets, size_t nrec, int skip_bad,
                              uint64_t *n_total, uint64_t *bad_record, uint64_t *bad_position);
 
 /* Same, for input already resident in HBM: `d_stream` is a 16-byte-aligned device pointer to
  * `nbytes` bytes in which records are separated by at least one non-ACGT byte (e.g. '\n');
  * skip_bad semantics.  `consumed` grows by `consumed_bytes` (the caller knows the record
  * lengths).  Runs on the table's stream and returns after it completes. */
-kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes,
+KCT_API kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes,
                               uint64_t *n_total);
 
 /* The README loop itself (README.md:89-99: `for record in screed.open(file): kct.consume(record.sequence)`)
@@ -117,35 +124,35 @@ kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes,
  * memory while the previous chunk is uploaded and counted.  skip_bad must be non-zero (the
  * reference's default); *n_total = sum of the per-record n, *n_records / *n_bases = records and
  * sequence bytes read (`consumed` grows by *n_bases).  Out-parameters other than n_total may be NULL. */
-kct_status kct_consume_file(kct_table *t, const char *path, int skip_bad, uint64_t *n_total, uint64_t *n_records,
+KCT_API kct_status kct_consume_file(kct_table *t, const char *path, int skip_bad, uint64_t *n_total, uint64_t *n_records,
                             uint64_t *n_bases);
 
 /* ---- table attributes ---------------------------------------------------------------------
  * __len__ lib.rs:665-667; sum_counts lib.rs:536-539; consumed lib.rs:530-533; ksize lib.rs:34 */
-kct_status kct_len(kct_table *t, uint64_t *out);
-kct_status kct_sum_counts(kct_table *t, uint64_t *out);
-kct_status kct_consumed(kct_table *t, uint64_t *out);
-kct_status kct_add_consumed(kct_table *t, uint64_t delta);
-uint8_t kct_ksize(const kct_table *t);
-kct_status kct_capacity(kct_table *t, uint64_t *slots_out);
+KCT_API kct_status kct_len(kct_table *t, uint64_t *out);
+KCT_API kct_status kct_sum_counts(kct_table *t, uint64_t *out);
+KCT_API kct_status kct_consumed(kct_table *t, uint64_t *out);
+KCT_API kct_status kct_add_consumed(kct_table *t, uint64_t delta);
+KCT_API uint8_t kct_ksize(const kct_table *t);
+KCT_API kct_status kct_capacity(kct_table *t, uint64_t *slots_out);
 
 /* ---- dump / merge ---------------------------------------------------------------------------
  * dump(file=None, sortcounts, sortkeys) -> [(hash, count)]                   lib.rs:330-381
  * order: 0 = unspecified (the reference's HashMap order is unspecified too), 1 = by hash,
  * 2 = by (count, hash).  Writes min(len, cap) pairs; *n_out = len. */
-kct_status kct_dump(kct_table *t, uint64_t *hashes_out, uint64_t *counts_out, size_t cap, int order, uint64_t *n_out);
+KCT_API kct_status kct_dump(kct_table *t, uint64_t *hashes_out, uint64_t *counts_out, size_t cap, int order, uint64_t *n_out);
 
 /* add(other) -> (total_counts_added, new_keys_added); consumed += other.consumed
  *                                                                            lib.rs:778-837 */
-kct_status kct_add(kct_table *dst, kct_table *src, uint64_t *total_added, uint64_t *new_keys);
+KCT_API kct_status kct_add(kct_table *dst, kct_table *src, uint64_t *total_added, uint64_t *new_keys);
 
 /* The two halves of add() for shards that live on different GPUs / ranks: compact the table
  * into caller-owned device arrays, and fold (hash, count) pairs into a table with add()'s
  * tallies.  `d_*` are device pointers on the table's device. */
-kct_status kct_export_device(kct_table *t, void *d_hashes, void *d_counts, size_t cap, uint64_t *n_out);
-kct_status kct_merge_device(kct_table *t, const void *d_hashes, const void *d_counts, size_t n,
+KCT_API kct_status kct_export_device(kct_table *t, void *d_hashes, void *d_counts, size_t cap, uint64_t *n_out);
+KCT_API kct_status kct_merge_device(kct_table *t, const void *d_hashes, const void *d_counts, size_t n,
                             uint64_t *total_added, uint64_t *new_keys);
-kct_status kct_merge_host(kct_table *t, const uint64_t *hashes, const uint64_t *counts, size_t n,
+KCT_API kct_status kct_merge_host(kct_table *t, const uint64_t *hashes, const uint64_t *counts, size_t n,
                           uint64_t *total_added, uint64_t *new_keys);
 
 /* The same two halves shaped for an all-to-all between ranks: the export writes interleaved
@@ -153,28 +160,28 @@ kct_status kct_merge_host(kct_table *t, const uint64_t *hashes, const uint64_t *
  * owner(hash) = floor(hi32(hash) * nparts / 2^32), owner p's pairs contiguous and in rank order;
  * part_counts[p] (host, nparts entries) = pairs of owner p; *n_out = their sum.  nparts <= 256.
  * kct_merge_pairs_device folds n interleaved pairs with add()'s tallies. */
-kct_status kct_export_by_owner_device(kct_table *t, uint32_t nparts, void *d_pairs, size_t cap, uint64_t *part_counts,
+KCT_API kct_status kct_export_by_owner_device(kct_table *t, uint32_t nparts, void *d_pairs, size_t cap, uint64_t *part_counts,
                                       uint64_t *n_out);
-kct_status kct_merge_pairs_device(kct_table *t, const void *d_pairs, size_t n, uint64_t *total_added, uint64_t *new_keys);
+KCT_API kct_status kct_merge_pairs_device(kct_table *t, const void *d_pairs, size_t n, uint64_t *total_added, uint64_t *new_keys);
 
 /* Which device path bulk ingest uses: 0 = chosen per pass (default), 1 = direct path only (one
  * HBM atomic per k-mer), 2 = partitioned path whenever the table geometry allows (radix-partition
  * the hashes by 128-KiB table block, count each block in LDS).  Results are identical; this
  * exists for tests and measurement. */
-kct_status kct_set_path(kct_table *t, int mode);
+KCT_API kct_status kct_set_path(kct_table *t, int mode);
 
 /* ---- streams and in-library kernel timing ----------------------------------------------------
  * The table owns a HIP stream; a caller that has its own (e.g. torch's current stream) can
  * hand it over as a `hipStream_t` cast to void*. */
-kct_status kct_set_stream(kct_table *t, void *hip_stream);
-void *kct_get_stream(kct_table *t);
+KCT_API kct_status kct_set_stream(kct_table *t, void *hip_stream);
+KCT_API void *kct_get_stream(kct_table *t);
 
 /* When enabled, every kernel launch on this table is bracketed by HIP events on the table's
  * stream.  kct_profile_read(i) returns the i-th kernel name seen since the last reset with
  * its launch count and summed device time; KCT_ERR_ARG past the end. */
-kct_status kct_profile_enable(kct_table *t, int on);
-kct_status kct_profile_reset(kct_table *t);
-kct_status kct_profile_read(kct_table *t, int index, char *name_out, size_t name_cap, uint64_t *launches,
+KCT_API kct_status kct_profile_enable(kct_table *t, int on);
+KCT_API kct_status kct_profile_reset(kct_table *t);
+KCT_API kct_status kct_profile_read(kct_table *t, int index, char *name_out, size_t name_cap, uint64_t *launches,
                             double *total_ms);
 
 #ifdef __cplusplus

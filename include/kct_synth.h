@@ -15,15 +15,22 @@
 #define KCT_SYNTH_H
 #include <stddef.h>
 #include <stdint.h>
+/* Only the entry points below are exported from libkct_hip.so (it is built with -fvisibility=hidden). */
+#if defined(KCT_BUILDING_LIBRARY)
+#define KCT_API __attribute__((visibility("default")))
+#else
+#define KCT_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 /* d_genome: device buffer of G bytes.  stream: hipStream_t as void* (NULL = default stream). Returns 0 on success. */
-int kct_synth_genome_device(void *d_genome, uint64_t G, uint64_t seed_g, void *stream);
+KCT_API int kct_synth_genome_device(void *d_genome, uint64_t G, uint64_t seed_g, void *stream);
 
 /* d_reads: device buffer of count * (L + 1) bytes, reads [first, first + count) of the stream. */
-int kct_synth_reads_device(void *d_reads, const void *d_genome, uint64_t G, uint64_t first, uint64_t count, uint32_t L,
+KCT_API int kct_synth_reads_device(void *d_reads, const void *d_genome, uint64_t G, uint64_t first, uint64_t count, uint32_t L,
                            uint64_t seed_r, void *stream);
 
 #ifdef __cplusplus
