@@ -1,0 +1,432 @@
+// kct_consume.hip -- bulk ingest behind the C ABI: the launch policy of the direct and the partitioned
+// (one- and two-level) counting paths, staging of host input, and the entry points that hash windows.
+#include "kct_internal.h"
+#include "partition_kernels.h"
+
+namespace kcth {
+
+template <template <int, int> class Launcher, class... Args>
+void dispatch_k(int k, Args &&...args) {
+    if (k == 21) Launcher<1, 21>::run(args...);
+    else if (k == 31) Launcher<1, 31>::run(args...);
+    else if (k == 51) Launcher<2, 51>::run(args...);
+    else if (k <= 32) Launcher<1, 0>::run(args...);
+    else if (k <= 64) Launcher<2, 0>::run(args...);
+    else Launcher<0, 0>::run(args...);
+}
+
+template <int KW, int KC>
+struct CountLauncher {
+    static void run(hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, int k, kct::TableView tv, du64 *ctr) {
+        hipLaunchKernelGGL((kct::count_windows_kernel<KW, KC>), dim3(grid), dim3(kct::kBlock), 0, s, stream, nbytes, k, tv, ctr);
+    }
+};
+
+template <int KW, int KC>
+struct HashLauncher {
+    static void run(hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, int k, u64 nwin, du64 *out, du64 *fb) {
+        hipLaunchKernelGGL((kct::hash_windows_kernel<KW, KC>), dim3(grid), dim3(kct::kBlock), 0, s, stream, nbytes, k, nwin, out, fb);
+    }
+};
+
+template <int KW, int KC>
+struct PartitionLauncher {
+    static void run(hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, int k, u64 ntiles, kct::PartitionArgs a) {
+        hipLaunchKernelGGL((kct::partition_windows_kernel<KW, KC>), dim3(grid), dim3(kct::kPartThreads), 0, s, stream, nbytes, k, ntiles, a);
+    }
+};
+
+// Replays a spill list (already copied to d_aux2) after growing; adds what it counted to *n_out.
+// The partitioned path pays 16 B (one level) or 32 B (two levels) of streaming scratch traffic per
+// k-mer plus 32 B per table slot per pass; the direct path pays one memory-side atomic per k-mer.
+// It wins once a pass brings a fair fraction as many windows as the table has slots.
+bool partition_geometry_ok(const kct_table *t) {
+    const u64 nblocks = t->cap >> t->block_bits;
+    return nblocks >= 16 && t->cap <= (1ULL << 32);
+}
+
+bool partition_pays(const kct_table *t, u64 npos) {
+    const u64 nblocks = t->cap >> t->block_bits;
+    if (!partition_geometry_ok(t) || npos < (1ULL << 20)) return false;
+    return nblocks <= 1024 ? npos >= t->cap / 4 : npos >= t->cap / 2;
+}
+
+unsigned int region_capacity(double avg) {
+    return (unsigned int)((((u64)(avg * 1.15 + 8.0 * __builtin_sqrt(avg) + 64.0)) + 7) & ~7ULL);
+}
+
+// One pass of the partitioned path over window starts [0, npos) of d_stream.  *handled = false
+// (and nothing counted) if the pass had to be abandoned; the caller then uses the direct path.
+kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled) {
+    *handled = false;
+    const int k = t->k;
+    const int bbits = log2_u64(t->cap >> t->block_bits);      // log2(table blocks)
+    const bool two_level = bbits > 10;
+    const int pbits = two_level ? 10 : bbits;                 // K1 fans out to 2^pbits bins ...
+    const int sub_bits = bbits - pbits;                       // ... each holding 2^sub_bits table blocks
+    const u64 P = 1ULL << pbits, B = 1ULL << bbits;
+    const int nwg = t->num_cus;
+    const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
+    const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
+    const unsigned int region_cap = region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P);
+    const unsigned int ovf_cap = (unsigned int)std::max<u64>(4096, tiles_per_wg * kct::kPartTile / 8);
+    KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 8));
+    KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
+    KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
+    KCT_TRY(t->d_spill.reserve(npos * 16));
+    KCT_TRY(zero_counters(t));
+    du64 *d_overflow = t->d_counters + kNumCounters + 6;
+    unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
+    const bool fresh = t->lazy_empty;
+
+    kct::PartitionArgs pa;
+    pa.mask = t->cap - 1; pa.block_bits = t->block_bits + sub_bits; pa.pbits = pbits;
+    pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
+    pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
+    pa.ablate = t->ablate;  // measurement only; wrong counts when set
+    {
+        ProfScope ps(t, "partition_windows_kernel");
+        dispatch_k<PartitionLauncher>(k, t->stream, nwg, d_stream, chunk_bytes, k, ntiles, pa);
+    }
+    HIP_TRY(hipGetLastError());
+
+    kct::AggregateArgs aa;
+    aa.words = t->slots; aa.block_bits = t->block_bits; aa.pbits = bbits;
+    aa.fresh = fresh ? 1 : 0; aa.overflow = d_overflow; aa.ablate = pa.ablate;
+    aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
+    unsigned int ovf2_cap = 0, *d_ovf2_count = nullptr;
+    if (!two_level) {
+        aa.scratch = (const du64 *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
+        aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
+    } else {
+        // second level: one workgroup per super-bin spreads its hashes over the super-bin's blocks
+        const unsigned int out_cap = region_capacity((double)npos / (double)B);
+        ovf2_cap = (unsigned int)std::max<u64>(4096, npos / P / 8);
+        KCT_TRY(t->d_scratch2.reserve(B * out_cap * 8));
+        KCT_TRY(t->d_regions2.reserve(B * 4));
+        KCT_TRY(t->d_irr2.reserve(P * ovf2_cap * 8 + P * 4));
+        d_ovf2_count = (unsigned int *)((du64 *)t->d_irr2.p + P * ovf2_cap);
+        kct::RepartitionArgs ra;
+        ra.mask = t->cap - 1; ra.block_bits = t->block_bits; ra.sub_bits = sub_bits;
+        ra.in = (const du64 *)t->d_scratch.p; ra.in_cap = region_cap; ra.in_count = (const unsigned int *)t->d_regions.p;
+        ra.nseg = nwg; ra.nbins = (int)P;
+        ra.out = (du64 *)t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
+        ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow;
+        {
+            ProfScope ps(t, "repartition_kernel");
+            hipLaunchKernelGGL(kct::repartition_kernel, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, ra);
+        }
+        HIP_TRY(hipGetLastError());
+        aa.scratch = (const du64 *)t->d_scratch2.p; aa.seg_stride = 0; aa.block_stride = out_cap;
+        aa.region_count = (const unsigned int *)t->d_regions2.p; aa.nregions = 1;
+    }
+    {
+        ProfScope ps(t, "aggregate_blocks_kernel");
+        hipLaunchKernelGGL(kct::aggregate_blocks_kernel, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
+    }
+    HIP_TRY(hipGetLastError());
+    {
+        // fold the overflow regions with the direct atomic path; the kernel reads the region lengths
+        // and the abandon flag from device memory, so no host round trip sits between the launches
+        ProfScope ps(t, "merge_overflow_kernel");
+        hipLaunchKernelGGL(kct::merge_overflow_kernel, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
+                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, view(t, npos), t->d_counters);
+        if (two_level)
+            hipLaunchKernelGGL(kct::merge_overflow_kernel, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
+                               (const unsigned int *)d_ovf2_count, (int)P, ovf2_cap, (const du64 *)d_overflow, view(t, npos), t->d_counters);
+    }
+    HIP_TRY(hipGetLastError());
+    u64 c[4], spilled;
+    KCT_TRY(read_counters(t, c, &spilled));
+    if (t->debug) {
+        std::vector<unsigned int> oc(nwg);
+        (void)hipMemcpy(oc.data(), d_ovf_count, nwg * 4, hipMemcpyDeviceToHost);
+        u64 tot = 0;
+        for (auto v : oc) tot += v;
+        fprintf(stderr, "[kct] partitioned pass: npos=%llu blocks=%llu levels=%d region_cap=%u overflow(K1)=%llu counted=%llu merged=%llu spilled=%llu abandon=%llu\n",
+                (unsigned long long)npos, (unsigned long long)B, two_level ? 2 : 1, region_cap, (unsigned long long)tot,
+                (unsigned long long)c[kct::CTR_COUNTED], (unsigned long long)c[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled,
+                (unsigned long long)t->h_counters[kNumCounters + 6]);
+    }
+    if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // abandoned: K2 and the merges exited early, nothing was touched
+    t->lazy_empty = false;
+    *handled = true;
+    *n_out += c[kct::CTR_COUNTED] + c[kct::CTR_TOTAL_ADDED];
+    t->n_keys += c[kct::CTR_NEWKEYS];
+    if (spilled) {
+        KCT_TRY(t->d_aux2.reserve(spilled * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(replay_spill(t, spilled, n_out));
+    }
+    return KCT_OK;
+}
+
+// Counts every good window of a device-resident record stream.  *n_out = k-mers counted.
+kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 *n_out) {
+    *n_out = 0;
+    const int k = t->k;
+    if (nbytes < (u64)k) return KCT_OK;
+    u64 done = 0;
+    const u64 last_start = nbytes - k;  // last window start position
+    const u64 cap_at_entry = t->cap;
+    // Launch chunk.  The partitioned path on a large table re-reads and re-writes every table block
+    // once per pass, so it wants passes of several windows per slot; its scratch + spill lists cost
+    // ~36 B per window start, which bounds the pass by HBM (this is what 288 GB is for).  Decided
+    // once per call: buffers this table already holds are reused, so they count as available.
+    u64 chunk_limit = kChunkPositions;
+    if (t->force_path != 1 && partition_geometry_ok(t) && (t->cap >> t->block_bits) > 1024) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const u64 held = t->d_scratch.cap + t->d_scratch2.cap + t->d_spill.cap + t->d_irr.cap + t->d_irr2.cap;
+            const u64 by_mem = ((u64)free_b + held) / 2 / 36;
+            chunk_limit = std::max<u64>(kChunkPositions, std::min<u64>(4 * t->cap, by_mem));
+            chunk_limit &= ~(u64)0xFFFF;  // keeps `d_stream + done` 16-byte aligned
+        }
+    }
+    while (done <= last_start) {
+        KCT_TRY(maybe_grow(t));
+        // a chunk owns window starts [done, done + npos); its loads reach k-1 bytes further
+        // A table that was never sized by its owner starts tiny: feed it launches of at most a few windows
+        // per slot, so that what cannot be placed (and must be replayed after growing) stays small while
+        // the table finds its size; launches grow with it.
+        const u64 ramp = t->auto_sized ? std::max<u64>(1ULL << 20, 4 * t->cap) : ~0ULL;
+        const u64 npos = std::min<u64>({chunk_limit, ramp, last_start + 1 - done});
+        const u64 chunk_bytes = std::min<u64>(nbytes - done, npos + k - 1);
+        if (partition_geometry_ok(t) && t->force_path != 1 && (t->force_path == 2 || partition_pays(t, npos))) {
+            bool handled = false;
+            KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled));
+            if (handled) { done += npos; continue; }
+        }
+        KCT_TRY(materialize(t));
+        KCT_TRY(t->d_spill.reserve(npos * 16));
+        KCT_TRY(zero_counters(t));
+        const int grid = (int)((npos + kct::kTile - 1) / kct::kTile);
+        // the kernel derives window ownership from tile positions, so hand it a stream that ends
+        // where this chunk's last window ends
+        {
+            ProfScope ps(t, "count_windows_kernel");
+            dispatch_k<CountLauncher>(k, t->stream, grid, d_stream + done, chunk_bytes, k, view(t, npos), t->d_counters);
+        }
+        HIP_TRY(hipGetLastError());
+        u64 c[4], spilled;
+        KCT_TRY(read_counters(t, c, &spilled));
+        *n_out += c[kct::CTR_COUNTED];
+        t->n_keys += c[kct::CTR_NEWKEYS];
+        if (spilled) {
+            KCT_TRY(t->d_aux2.reserve(spilled * 16));
+            HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+            KCT_TRY(replay_spill(t, spilled, n_out));
+        }
+        done += npos;
+    }
+    if (t->auto_sized && t->cap == cap_at_entry && nbytes >= (1u << 20)) t->auto_sized = false;  // the table has found its size
+    return KCT_OK;
+}
+
+// host bytes -> pinned staging -> device stream buffer (padded with '\n' to a multiple of 16)
+kct_status upload_stream(kct_table *t, size_t nbytes) {
+    const size_t padded = (nbytes + 15) & ~(size_t)15;
+    KCT_TRY(t->d_stream.reserve(padded + 16));
+    HIP_TRY(hipMemcpyAsync(t->d_stream.p, t->h_stage.p, padded, hipMemcpyHostToDevice, t->stream));
+    return KCT_OK;
+}
+
+kct_status stage_single(kct_table *t, const char *seq, size_t len) {
+    const size_t padded = (len + 15) & ~(size_t)15;
+    KCT_TRY(t->h_stage.reserve(padded + 16));
+    memcpy(t->h_stage.p, seq, len);
+    memset((char *)t->h_stage.p + len, '\n', padded + 16 - len);
+    return upload_stream(t, len);
+}
+
+// hashes of all windows of the staged stream [0, nbytes) into d_aux; returns first bad window index
+kct_status hash_stream(kct_table *t, u64 nbytes, u64 nwin, u64 *first_bad) {
+    KCT_TRY(t->d_aux.reserve(nwin * 8));
+    du64 *d_fb = t->d_counters + kNumCounters + 1;  // scratch word 1
+    HIP_TRY(hipMemsetAsync(d_fb, 0xFF, 8, t->stream));
+    const int grid = (int)((nwin + kct::kTile - 1) / kct::kTile);
+    {
+        ProfScope ps(t, "hash_windows_kernel");
+        dispatch_k<HashLauncher>((int)t->k, t->stream, grid, (const unsigned char *)t->d_stream.p, nbytes, (int)t->k, nwin,
+                                 (du64 *)t->d_aux.p, d_fb);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(t->h_counters, d_fb, 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    *first_bad = t->h_counters[0] == ~0ULL ? nwin : t->h_counters[0];
+    return KCT_OK;
+}
+
+}  // namespace kcth
+
+using namespace kcth;
+
+extern "C" {
+
+kct_status kct_hash_windows(kct_table *t, const char *seq, size_t len, uint64_t *hashes_out, size_t cap, uint64_t *n_windows,
+                            uint64_t *first_bad) {
+    KCT_TRY(use(t));
+    if ((!seq && len) || !n_windows || !first_bad) { set_err("null argument"); return KCT_ERR_ARG; }
+    const u64 nwin = len >= t->k ? len - t->k + 1 : 0;
+    *n_windows = nwin;
+    *first_bad = nwin;
+    if (nwin == 0) return KCT_OK;
+    KCT_TRY(stage_single(t, seq, len));
+    KCT_TRY(hash_stream(t, len, nwin, first_bad));
+    const size_t ncopy = std::min<size_t>(cap, nwin);
+    if (ncopy && hashes_out) HIP_TRY(hipMemcpy(hashes_out, t->d_aux.p, ncopy * 8, hipMemcpyDeviceToHost));
+    return KCT_OK;
+}
+
+kct_status kct_hash_kmer(kct_table *t, const char *kmer, size_t len, uint64_t *hash_out) {
+    KCT_TRY(use(t));
+    if (!kmer || !hash_out) { set_err("null argument"); return KCT_ERR_ARG; }
+    if ((uint8_t)len != t->k) { set_err("wrong ksize"); return KCT_ERR_WRONG_KSIZE; }  // lib.rs:66 `len as u8`
+    u64 nwin, fb, h = 0;
+    KCT_TRY(kct_hash_windows(t, kmer, t->k, &h, 1, &nwin, &fb));  // first window only (lib.rs:78 `.next()`)
+    if (fb == 0) { set_err("invalid DNA character in k-mer"); return KCT_ERR_INVALID_DNA; }
+    *hash_out = h;
+    return KCT_OK;
+}
+
+kct_status kct_count(kct_table *t, const char *kmer, size_t len, uint64_t *count_out) {
+    KCT_TRY(use(t));
+    if ((uint8_t)len != t->k) { set_err("kmer size does not match count table ksize"); return KCT_ERR_WRONG_KSIZE; }
+    u64 h;
+    KCT_TRY(kct_hash_kmer(t, kmer, len, &h));
+    u64 c = 0;
+    KCT_TRY(point_add(t, h, &c));
+    t->consumed += len;  // lib.rs:153
+    if (count_out) *count_out = c;
+    return KCT_OK;
+}
+
+kct_status kct_get(kct_table *t, const char *kmer, size_t len, uint64_t *count_out) {
+    KCT_TRY(use(t));
+    if ((uint8_t)len != t->k) { set_err("kmer size does not match count table ksize"); return KCT_ERR_WRONG_KSIZE; }
+    u64 h;
+    KCT_TRY(kct_hash_kmer(t, kmer, len, &h));
+    return kct_get_hash(t, h, count_out);
+}
+
+kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out) {
+    KCT_TRY(use(t));
+    if ((!seq && len) || !n_out) { set_err("null argument"); return KCT_ERR_ARG; }
+    *n_out = 0;
+    const u64 k = t->k;
+    if (len < k) { t->consumed += len; return KCT_OK; }  // zero windows (lib.rs: max_index = 0), consumed still grows
+    KCT_TRY(stage_single(t, seq, len));
+    u64 use_bytes = len;
+    bool bad = false;
+    if (!skip_bad) {
+        const u64 nwin = len - k + 1;
+        u64 fb;
+        KCT_TRY(hash_stream(t, len, nwin, &fb));  // validity of every window, on the device
+        if (fb < nwin) { bad = true; use_bytes = fb + k - 1; }  // windows 0..fb-1 end before byte fb+k-1
+    }
+    KCT_TRY(consume_stream(t, (const unsigned char *)t->d_stream.p, use_bytes, n_out));
+    if (bad) { set_err("bad k-mer encountered at position %llu", (unsigned long long)*n_out); return KCT_ERR_BAD_KMER; }
+    t->consumed += len;
+    return KCT_OK;
+}
+
+kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *offsets, size_t nrec, int skip_bad,
+                             uint64_t *n_total, uint64_t *bad_record, uint64_t *bad_position) {
+    KCT_TRY(use(t));
+    if (!n_total || (nrec && !offsets)) { set_err("null argument"); return KCT_ERR_ARG; }
+    if (nrec && !bytes && offsets[nrec] != offsets[0]) { set_err("null argument"); return KCT_ERR_ARG; }  // all-empty records need no bytes
+    *n_total = 0;
+    if (bad_record) *bad_record = nrec;
+    if (bad_position) *bad_position = 0;
+    if (nrec == 0) return KCT_OK;
+    const u64 total = offsets[nrec] - offsets[0];
+    const u64 stream_len = total + nrec;  // one '\n' after every record
+    const size_t padded = (stream_len + 15) & ~(size_t)15;
+    const size_t off_bytes = skip_bad ? 0 : (nrec + 1) * 8;
+    KCT_TRY(t->h_stage.reserve(padded + 16 + off_bytes));
+    char *dst = (char *)t->h_stage.p;
+    u64 *rec_off = (u64 *)(dst + padded + 16);  // 16-aligned since padded is
+    // Pack the records into the record stream: record r lands at (offsets[r] - offsets[0]) + r, one
+    // separator behind it.  Positions are known up front, so large batches are packed by several threads.
+    for (size_t r = 0; r < nrec; ++r)
+        if (offsets[r + 1] < offsets[r]) { set_err("offsets must be non-decreasing"); return KCT_ERR_ARG; }
+    const u64 base0 = offsets[0];
+    auto pack_range = [&](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1; ++r) {
+            const u64 n = offsets[r + 1] - offsets[r], w = (offsets[r] - base0) + r;
+            if (!skip_bad) rec_off[r] = w;
+            memcpy(dst + w, bytes + offsets[r], n);
+            dst[w + n] = '\n';
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nthreads = stream_len >= (8u << 20) ? std::min<size_t>({(size_t)8, hw ? hw : 1, nrec}) : 1;
+    if (nthreads <= 1) pack_range(0, nrec);
+    else {
+        std::vector<std::thread> pool;
+        for (size_t i = 0; i < nthreads; ++i) {
+            // split by bytes, not by record count: records may be ragged
+            const u64 lo = base0 + total * i / nthreads, hi = base0 + total * (i + 1) / nthreads;
+            const size_t r0 = (size_t)(std::lower_bound(offsets, offsets + nrec, lo) - offsets);
+            const size_t r1 = i + 1 == nthreads ? nrec : (size_t)(std::lower_bound(offsets, offsets + nrec, hi) - offsets);
+            if (r1 > r0) pool.emplace_back(pack_range, r0, r1);
+        }
+        for (auto &th : pool) th.join();
+    }
+    const u64 w = stream_len;
+    if (!skip_bad) rec_off[nrec] = w;
+    memset(dst + w, '\n', padded + 16 - w);
+    KCT_TRY(upload_stream(t, stream_len));
+
+    if (!skip_bad) {
+        KCT_TRY(t->d_aux.reserve(off_bytes));
+        HIP_TRY(hipMemcpyAsync(t->d_aux.p, rec_off, off_bytes, hipMemcpyHostToDevice, t->stream));
+        du64 *d_q = t->d_counters + kNumCounters + 1;
+        HIP_TRY(hipMemsetAsync(d_q, 0xFF, 8, t->stream));
+        const u64 nthreads = (stream_len + 15) / 16;
+        {
+            ProfScope ps(t, "first_bad_byte_kernel");
+            hipLaunchKernelGGL(kct::first_bad_byte_kernel, dim3((unsigned)((nthreads + kct::kBlock - 1) / kct::kBlock)), dim3(kct::kBlock), 0,
+                               t->stream, (const unsigned char *)t->d_stream.p, stream_len, (int)t->k, (const du64 *)t->d_aux.p, (u64)nrec, d_q);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(t->h_counters, d_q, 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        const u64 q = t->h_counters[0];
+        if (q != ~0ULL) {
+            // Record r holds q.  The per-record loop the reference runs would count records
+            // [0, r) whole, then the windows of r before its first bad one, then raise.
+            const size_t r = (size_t)(std::upper_bound(rec_off, rec_off + nrec + 1, q) - rec_off) - 1;
+            const u64 in_rec = q - rec_off[r];
+            const u64 fbw = in_rec + 1 >= t->k ? in_rec + 1 - t->k : 0;  // index of r's first bad window
+            u64 n_before = 0, n_prefix = 0;
+            KCT_TRY(consume_stream(t, (const unsigned char *)t->d_stream.p, rec_off[r], &n_before));
+            const u64 prefix = fbw + t->k - 1;  // bytes of r that its windows 0..fbw-1 cover
+            if (fbw > 0) {
+                KCT_TRY(t->d_aux2.reserve(((prefix + 15) & ~(u64)15) + 16));
+                HIP_TRY(hipMemcpyAsync(t->d_aux2.p, (const char *)t->d_stream.p + rec_off[r], prefix, hipMemcpyDeviceToDevice, t->stream));
+                KCT_TRY(consume_stream(t, (const unsigned char *)t->d_aux2.p, prefix, &n_prefix));
+            }
+            t->consumed += offsets[r] - offsets[0];  // r raised before lib.rs:604
+            *n_total = n_before + n_prefix;
+            if (bad_record) *bad_record = r;
+            if (bad_position) *bad_position = n_prefix;
+            set_err("bad k-mer encountered at position %llu (record %llu)", (unsigned long long)n_prefix, (unsigned long long)r);
+            return KCT_ERR_BAD_KMER;
+        }
+    }
+    KCT_TRY(consume_stream(t, (const unsigned char *)t->d_stream.p, stream_len, n_total));
+    t->consumed += total;
+    return KCT_OK;
+}
+
+kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes, uint64_t *n_total) {
+    KCT_TRY(use(t));
+    if (!n_total || (!d_stream && nbytes)) { set_err("null argument"); return KCT_ERR_ARG; }
+    if (((uintptr_t)d_stream & 15) != 0) { set_err("d_stream must be 16-byte aligned"); return KCT_ERR_ARG; }
+    KCT_TRY(consume_stream(t, (const unsigned char *)d_stream, nbytes, n_total));
+    t->consumed += consumed_bytes;
+    return KCT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,584 @@
+// kct_core.hip -- the device-resident table behind the C ABI (include/kct.h): lifetime, growth and re-hash,
+// point updates and lookups, dump / export / merge, stream and kernel-timing plumbing.
+// Bulk ingest lives in kct_consume.hip, file parsing in kct_ingest.hip.
+#include "kct_internal.h"
+#include "table_kernels.h"
+
+extern "C" int kx_sort_pairs_u64(const unsigned long long *keys_in, unsigned long long *keys_out, const unsigned long long *vals_in,
+                                 unsigned long long *vals_out, size_t n, void *tmp, size_t *tmp_bytes, void *stream);  // sort.hip
+
+namespace kcth {
+
+thread_local char g_err[512] = "";
+
+void set_err(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+void prof_collect(kct_table *t) {
+    if (t->prof_pending.empty()) return;
+    (void)hipStreamSynchronize(t->stream);
+    for (auto &p : t->prof_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) t->prof[p.entry].ms += ms;
+        t->event_pool.push_back(p.a);
+        t->event_pool.push_back(p.b);
+    }
+    t->prof_pending.clear();
+}
+
+kct_status use(kct_table *t) {
+    if (!t) { set_err("null table handle"); return KCT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(t->device));
+    return KCT_OK;
+}
+
+kct::TableGeom geom(const kct_table *t) {
+    kct::TableGeom g;
+    g.mask = t->cap - 1;
+    g.block_bits = t->block_bits;
+    return g;
+}
+
+kct::TableView view(kct_table *t, u64 spill_cap) {
+    kct::TableView v;
+    v.words = t->slots;
+    v.g = geom(t);
+    v.spill = (du64 *)t->d_spill.p;
+    v.spill_cap = spill_cap;
+    v.spill_n = t->d_counters + kNumCounters;  // scratch word 0
+    return v;
+}
+
+int log2_u64(u64 v) { int b = 0; while ((1ULL << b) < v) ++b; return b; }
+
+void set_geometry(kct_table *t) { t->block_bits = std::min(kct::kBlockBitsMax, log2_u64(t->cap)); }  // cap >= kMinSlots = 1024 > one group
+
+// kct_clear() defers its memset: the partitioned path rewrites every block from zeros anyway.
+// Anything else that touches `slots` calls this first.
+kct_status materialize(kct_table *t) {
+    if (t->lazy_empty) {
+        HIP_TRY(hipMemsetAsync(t->slots, 0, t->cap * 16, t->stream));
+        t->lazy_empty = false;
+    }
+    return KCT_OK;
+}
+
+kct_status zero_counters(kct_table *t) {
+    HIP_TRY(hipMemsetAsync(t->d_counters, 0, (kNumCounters + 8) * sizeof(u64), t->stream));
+    return KCT_OK;
+}
+
+// copies the tallies back and folds the shards; waits for the stream
+kct_status read_counters(kct_table *t, u64 out[4], u64 *spill_n) {
+    HIP_TRY(hipMemcpyAsync(t->h_counters, t->d_counters, (kNumCounters + 8) * sizeof(u64), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    for (int c = 0; c < 4; ++c) out[c] = 0;
+    for (int s = 0; s < kct::kCounterShards; ++s)
+        for (int c = 0; c < 4; ++c) out[c] += t->h_counters[s * kct::kCounterStride + c];
+    *spill_n = t->h_counters[kNumCounters];
+    return KCT_OK;
+}
+
+kct_status alloc_slots(int, u64 cap, hipStream_t stream, du64 **out) {
+    du64 *p = nullptr;
+    HIP_TRY(hipMalloc((void **)&p, cap * 16));
+    hipError_t e = hipMemsetAsync(p, 0, cap * 16, stream);
+    if (e != hipSuccess) { (void)hipFree(p); set_err("hipMemsetAsync: %s", hipGetErrorString(e)); return KCT_ERR_HIP; }
+    *out = p;
+    return KCT_OK;
+}
+
+int merge_grid(u64 n) { return (int)std::min<u64>((n + kct::kBlock - 1) / kct::kBlock, 256 * 8); }
+
+// Folds n (hash, count) pairs into the table, growing and replaying the spill list until every
+// pair is placed.  tallies[] accumulates CTR_* sums.  `stride` 1 = separate arrays, 2 = slot array.
+kct_status grow_to(kct_table *t, u64 new_cap);
+
+kct_status merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n, int stride, u64 tallies[4]) {
+    KCT_TRY(materialize(t));
+    while (n > 0) {
+        KCT_TRY(t->d_spill.reserve(n * 16));
+        KCT_TRY(zero_counters(t));
+        {
+            ProfScope ps(t, "merge_pairs_kernel");
+            hipLaunchKernelGGL(kct::merge_pairs_kernel, dim3(merge_grid(n)), dim3(kct::kBlock), 0, t->stream, d_keys, d_counts, n,
+                               (const du64 *)nullptr, (const du64 *)nullptr, stride, view(t, n), t->d_counters);
+        }
+        HIP_TRY(hipGetLastError());
+        u64 c[4], spilled;
+        KCT_TRY(read_counters(t, c, &spilled));
+        for (int i = 0; i < 4; ++i) tallies[i] += c[i];
+        t->n_keys += c[kct::CTR_NEWKEYS];
+        if (spilled == 0) break;
+        // the table is too full for these keys: move the spill list aside, grow, replay it
+        KCT_TRY(t->d_aux2.reserve(spilled * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(grow_to(t, next_pow2((u64)((double)(t->n_keys + spilled) / kMaxLoad) + 1)));
+        d_keys = (const du64 *)t->d_aux2.p;
+        d_counts = d_keys + 1;
+        stride = 2;
+        n = spilled;
+    }
+    return KCT_OK;
+}
+
+// Re-hash into a table of new_cap slots (no-op if not larger).
+kct_status grow_to(kct_table *t, u64 new_cap) {
+    new_cap = std::max(next_pow2(new_cap), kMinSlots);
+    if (new_cap <= t->cap) new_cap = t->cap * 2;
+    du64 *old = t->slots;
+    const u64 old_cap = t->cap, old_keys = t->n_keys;
+    const kct::TableGeom old_g = geom(t);
+    du64 *fresh = nullptr;
+    KCT_TRY(alloc_slots(t->device, new_cap, t->stream, &fresh));
+    t->slots = fresh;
+    t->cap = new_cap;
+    set_geometry(t);
+    t->n_keys = 0;
+    if (t->lazy_empty) t->lazy_empty = false;  // the old array was never cleaned, but it holds no keys: drop it
+    if (old && old_keys > 0) {
+        // re-insert every occupied slot; the new table is at most ~half full so nothing spills
+        KCT_TRY(t->d_spill.reserve(16));
+        KCT_TRY(zero_counters(t));
+        {
+            ProfScope ps(t, "rehash_kernel");
+            hipLaunchKernelGGL(kct::rehash_kernel, dim3(merge_grid(old_cap)), dim3(kct::kBlock), 0, t->stream, (const du64 *)old, old_g,
+                               view(t, 0), t->d_counters);
+        }
+        HIP_TRY(hipGetLastError());
+        u64 c[4], spilled;
+        KCT_TRY(read_counters(t, c, &spilled));
+        t->n_keys = c[kct::CTR_NEWKEYS];
+        if (spilled != 0 || t->n_keys != old_keys) {
+            set_err("re-hash lost keys: %llu of %llu placed, %llu spilled", (unsigned long long)t->n_keys,
+                    (unsigned long long)old_keys, (unsigned long long)spilled);
+            return KCT_ERR_HIP;
+        }
+    } else {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+    }
+    if (old) HIP_TRY(hipFree(old));
+    return KCT_OK;
+}
+
+kct_status maybe_grow(kct_table *t) {
+    if ((double)t->n_keys > kMaxLoad * (double)t->cap) {
+        u64 target = t->cap;
+        while ((double)t->n_keys > 0.25 * (double)target) target <<= 1;
+        return grow_to(t, target);
+    }
+    return KCT_OK;
+}
+
+kct_status replay_spill(kct_table *t, u64 spilled, u64 *n_out) {
+    KCT_TRY(grow_to(t, next_pow2((u64)((double)(t->n_keys + spilled) / kMaxLoad) + 1)));
+    u64 tl[4] = {0, 0, 0, 0};
+    KCT_TRY(merge_pairs(t, (const du64 *)t->d_aux2.p, (const du64 *)t->d_aux2.p + 1, spilled, 2, tl));
+    *n_out += tl[kct::CTR_TOTAL_ADDED];
+    return KCT_OK;
+}
+
+kct_status point_add(kct_table *t, u64 h, u64 *count_out) {
+    if (h == 0) {  // 0 is the device EMPTY sentinel: kept host-side (count_hash(0) is legal, lib.rs:100)
+        t->zero_present = true;
+        *count_out = ++t->zero_count;
+        return KCT_OK;
+    }
+    KCT_TRY(maybe_grow(t));
+    KCT_TRY(t->h_stage.reserve(64));
+    KCT_TRY(t->d_aux.reserve(64));
+    u64 *hp = (u64 *)t->h_stage.p;
+    hp[0] = h; hp[1] = 1;
+    HIP_TRY(hipMemcpyAsync(t->d_aux.p, hp, 16, hipMemcpyHostToDevice, t->stream));
+    u64 tl[4] = {0, 0, 0, 0};
+    KCT_TRY(merge_pairs(t, (const du64 *)t->d_aux.p, (const du64 *)t->d_aux.p + 1, 1, 1, tl));
+    return kct_get_hash(t, h, count_out);
+}
+
+}  // namespace kcth
+
+using namespace kcth;
+
+// ================================ C ABI =====================================================
+
+extern "C" {
+
+const char *kct_last_error(void) { return g_err; }
+
+int kct_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+kct_status kct_create(uint8_t ksize, uint64_t capacity_hint, int device, kct_table **out) {
+    if (!out) { set_err("out is null"); return KCT_ERR_ARG; }
+    *out = nullptr;
+    if (ksize == 0) { set_err("ksize must be >= 1"); return KCT_ERR_ARG; }
+    int ndev = kct_device_count();
+    if (ndev <= 0) { set_err("no HIP device visible: the k-mer engine has no CPU fallback"); return KCT_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) { set_err("device %d out of range (0..%d)", device, ndev - 1); return KCT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return KCT_ERR_NO_DEVICE;
+    }
+    kct_table *t = new (std::nothrow) kct_table();
+    if (!t) return KCT_ERR_NOMEM;
+    t->device = device;
+    t->k = ksize;
+    kct_status st = KCT_OK;
+    auto fail = [&](kct_status s) { kct_destroy(t); return s; };
+    if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return fail(KCT_ERR_HIP); }
+    t->own_stream = true;
+    if (hipMalloc((void **)&t->d_counters, (kNumCounters + 8) * sizeof(u64)) != hipSuccess) { set_err("hipMalloc(counters) failed"); return fail(KCT_ERR_NOMEM); }
+    if (hipHostMalloc((void **)&t->h_counters, (kNumCounters + 8) * sizeof(u64), hipHostMallocDefault) != hipSuccess) { set_err("hipHostMalloc failed"); return fail(KCT_ERR_NOMEM); }
+    u64 cap = capacity_hint ? next_pow2((u64)((double)capacity_hint / kMaxLoad) + 1) : kDefaultSlots;
+    t->auto_sized = capacity_hint == 0;
+    cap = std::max(cap, kMinSlots);
+    st = alloc_slots(device, cap, t->stream, &t->slots);
+    if (st != KCT_OK) return fail(st);
+    t->cap = cap;
+    set_geometry(t);
+    t->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = getenv("KCT_ABLATE")) t->ablate = atoi(e);
+    t->debug = getenv("KCT_DEBUG") != nullptr;
+    if (hipStreamSynchronize(t->stream) != hipSuccess) { set_err("stream sync failed"); return fail(KCT_ERR_HIP); }
+    *out = t;
+    return KCT_OK;
+}
+
+void kct_destroy(kct_table *t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    for (auto &p : t->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : t->event_pool) (void)hipEventDestroy(e);
+    if (t->slots) (void)hipFree(t->slots);
+    if (t->d_counters) (void)hipFree(t->d_counters);
+    if (t->h_counters) (void)hipHostFree(t->h_counters);
+    t->d_stream.release(); t->d_spill.release(); t->d_aux.release(); t->d_aux2.release();
+    t->d_scratch.release(); t->d_regions.release(); t->d_irr.release(); t->d_sort.release();
+    t->d_scratch2.release(); t->d_regions2.release(); t->d_irr2.release();
+    t->h_stage.release();
+    if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+}
+
+kct_status kct_clear(kct_table *t) {
+    KCT_TRY(use(t));
+    t->lazy_empty = true;  // the memset is issued by materialize() only if something needs it
+    t->n_keys = 0; t->consumed = 0; t->zero_present = false; t->zero_count = 0;
+    return KCT_OK;
+}
+
+kct_status kct_reserve(kct_table *t, uint64_t distinct) {
+    KCT_TRY(use(t));
+    u64 want = next_pow2((u64)((double)distinct / kMaxLoad) + 1);
+    t->auto_sized = false;
+    if (want > t->cap) return grow_to(t, want);
+    return KCT_OK;
+}
+
+kct_status kct_count_hash(kct_table *t, uint64_t hash, uint64_t *count_out) {
+    KCT_TRY(use(t));
+    u64 c = 0;
+    KCT_TRY(point_add(t, hash, &c));
+    if (count_out) *count_out = c;
+    return KCT_OK;
+}
+
+kct_status kct_get_hash_array(kct_table *t, const uint64_t *hashes, size_t n, uint64_t *counts_out) {
+    KCT_TRY(use(t));
+    if (n == 0) return KCT_OK;
+    if (!hashes || !counts_out) { set_err("null argument"); return KCT_ERR_ARG; }
+    KCT_TRY(materialize(t));
+    KCT_TRY(t->d_aux.reserve(n * 16));
+    du64 *d_in = (du64 *)t->d_aux.p, *d_out = d_in + n;
+    HIP_TRY(hipMemcpyAsync(d_in, hashes, n * 8, hipMemcpyHostToDevice, t->stream));
+    {
+        ProfScope ps(t, "get_hashes_kernel");
+        hipLaunchKernelGGL(kct::get_hashes_kernel, dim3((unsigned)((n + kct::kBlock - 1) / kct::kBlock)), dim3(kct::kBlock), 0, t->stream,
+                           (const du64 *)t->slots, geom(t), (const du64 *)d_in, (u64)n, d_out);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(counts_out, d_out, n * 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    for (size_t i = 0; i < n; ++i)
+        if (hashes[i] == 0) counts_out[i] = t->zero_present ? t->zero_count : 0;
+    return KCT_OK;
+}
+
+kct_status kct_get_hash(kct_table *t, uint64_t hash, uint64_t *count_out) {
+    if (!count_out) { set_err("null argument"); return KCT_ERR_ARG; }
+    if (hash == 0) { KCT_TRY(use(t)); *count_out = t->zero_present ? t->zero_count : 0; return KCT_OK; }  // host-side key
+    return kct_get_hash_array(t, &hash, 1, count_out);
+}
+
+kct_status kct_set_hash(kct_table *t, uint64_t hash, uint64_t count) {
+    KCT_TRY(use(t));
+    if (hash == 0) { t->zero_present = true; t->zero_count = count; return KCT_OK; }
+    // make sure the key exists (adding 0 creates it without changing its count), then overwrite
+    KCT_TRY(maybe_grow(t));
+    KCT_TRY(t->h_stage.reserve(64));
+    KCT_TRY(t->d_aux.reserve(64));
+    u64 *hp = (u64 *)t->h_stage.p;
+    hp[0] = hash; hp[1] = 0;
+    HIP_TRY(hipMemcpyAsync(t->d_aux.p, hp, 16, hipMemcpyHostToDevice, t->stream));
+    u64 tl[4] = {0, 0, 0, 0};
+    KCT_TRY(merge_pairs(t, (const du64 *)t->d_aux.p, (const du64 *)t->d_aux.p + 1, 1, 1, tl));
+    du64 *d_found = t->d_counters + kNumCounters + 2;
+    hipLaunchKernelGGL(kct::set_hash_kernel, dim3(1), dim3(1), 0, t->stream, t->slots, geom(t), (u64)hash, (u64)count, d_found);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return KCT_OK;
+}
+
+kct_status kct_len(kct_table *t, uint64_t *out) {
+    KCT_TRY(use(t));
+    *out = t->n_keys + (t->zero_present ? 1 : 0);
+    return KCT_OK;
+}
+
+kct_status kct_sum_counts(kct_table *t, uint64_t *out) {
+    KCT_TRY(use(t));
+    KCT_TRY(materialize(t));
+    du64 *d_sum = t->d_counters + kNumCounters + 3;
+    HIP_TRY(hipMemsetAsync(d_sum, 0, 8, t->stream));
+    {
+        ProfScope ps(t, "sum_counts_kernel");
+        hipLaunchKernelGGL(kct::sum_counts_kernel, dim3(merge_grid(t->cap)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->slots, geom(t), d_sum);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(t->h_counters, d_sum, 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    *out = t->h_counters[0] + (t->zero_present ? t->zero_count : 0);
+    return KCT_OK;
+}
+
+kct_status kct_consumed(kct_table *t, uint64_t *out) { KCT_TRY(use(t)); *out = t->consumed; return KCT_OK; }
+kct_status kct_add_consumed(kct_table *t, uint64_t delta) { KCT_TRY(use(t)); t->consumed += delta; return KCT_OK; }
+uint8_t kct_ksize(const kct_table *t) { return t ? t->k : 0; }
+kct_status kct_capacity(kct_table *t, uint64_t *slots_out) { KCT_TRY(use(t)); *slots_out = t->cap; return KCT_OK; }
+
+kct_status kct_export_device(kct_table *t, void *d_hashes, void *d_counts, size_t cap, uint64_t *n_out) {
+    KCT_TRY(use(t));
+    if (!n_out || (cap && (!d_hashes || !d_counts))) { set_err("null argument"); return KCT_ERR_ARG; }
+    KCT_TRY(materialize(t));
+    du64 *d_n = t->d_counters + kNumCounters + 4;
+    HIP_TRY(hipMemsetAsync(d_n, 0, 8, t->stream));
+    {
+        ProfScope ps(t, "compact_kernel");
+        hipLaunchKernelGGL(kct::compact_kernel, dim3(merge_grid(t->cap)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->slots, geom(t), (du64 *)d_hashes,
+                           (du64 *)d_counts, (u64)cap, d_n);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(t->h_counters, d_n, 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    *n_out = t->h_counters[0];
+    return KCT_OK;
+}
+
+kct_status kct_export_by_owner_device(kct_table *t, uint32_t nparts, void *d_pairs, size_t cap, uint64_t *part_counts, uint64_t *n_out) {
+    KCT_TRY(use(t));
+    if (!n_out || !part_counts || (cap && !d_pairs)) { set_err("null argument"); return KCT_ERR_ARG; }
+    if (nparts == 0 || nparts > (uint32_t)kct::kMaxParts) { set_err("nparts must be 1..%d", kct::kMaxParts); return KCT_ERR_ARG; }
+    KCT_TRY(materialize(t));
+    KCT_TRY(t->d_aux.reserve((size_t)nparts * 16));
+    du64 *d_counts = (du64 *)t->d_aux.p, *d_cursor = d_counts + nparts;
+    HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nparts * 8, t->stream));
+    {
+        ProfScope ps(t, "count_owners_kernel");
+        hipLaunchKernelGGL(kct::count_owners_kernel, dim3(merge_grid(t->cap)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->slots, geom(t),
+                           (unsigned int)nparts, d_counts);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(t->h_counters, d_counts, (size_t)nparts * 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    u64 total = 0;
+    std::vector<u64> base(nparts);
+    for (uint32_t p = 0; p < nparts; ++p) { part_counts[p] = t->h_counters[p]; base[p] = total; total += part_counts[p]; }
+    *n_out = total;
+    if (total == 0 || cap == 0) return KCT_OK;
+    for (uint32_t p = 0; p < nparts; ++p) t->h_counters[p] = base[p];
+    HIP_TRY(hipMemcpyAsync(d_cursor, t->h_counters, (size_t)nparts * 8, hipMemcpyHostToDevice, t->stream));
+    {
+        ProfScope ps(t, "scatter_owners_kernel");
+        const unsigned grid = (unsigned)std::min<u64>((t->cap + 16 * kct::kBlock - 1) / (16 * kct::kBlock), 2048);
+        hipLaunchKernelGGL(kct::scatter_owners_kernel, dim3(grid), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->slots, geom(t),
+                           (unsigned int)nparts, d_cursor, (du64 *)d_pairs, (u64)cap);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return KCT_OK;
+}
+
+kct_status kct_merge_pairs_device(kct_table *t, const void *d_pairs, size_t n, uint64_t *total_added, uint64_t *new_keys) {
+    KCT_TRY(use(t));
+    u64 tl[4] = {0, 0, 0, 0};
+    if (n) {
+        if (!d_pairs) { set_err("null argument"); return KCT_ERR_ARG; }
+        if ((double)(t->n_keys + n) > kMaxLoad * (double)t->cap) KCT_TRY(grow_to(t, next_pow2((u64)((double)(t->n_keys + n) / kMaxLoad) + 1)));
+        KCT_TRY(merge_pairs(t, (const du64 *)d_pairs, (const du64 *)d_pairs + 1, n, 2, tl));
+    }
+    if (total_added) *total_added = tl[kct::CTR_TOTAL_ADDED];
+    if (new_keys) *new_keys = tl[kct::CTR_NEW_BY_ZERO];
+    return KCT_OK;
+}
+
+kct_status kct_dump(kct_table *t, uint64_t *hashes_out, uint64_t *counts_out, size_t cap, int order, uint64_t *n_out) {
+    KCT_TRY(use(t));
+    if (!n_out) { set_err("null argument"); return KCT_ERR_ARG; }
+    const u64 n_dev = t->n_keys;
+    const u64 n = n_dev + (t->zero_present ? 1 : 0);
+    *n_out = n;
+    if (cap == 0 || n == 0) return KCT_OK;
+    if (!hashes_out || !counts_out) { set_err("null argument"); return KCT_ERR_ARG; }
+    std::vector<u64> hk(n), hc(n);
+    if (n_dev) {
+        // compact on the device, sort on the device (rocPRIM radix sort, stable), copy out
+        KCT_TRY(t->d_aux.reserve(n_dev * 16));
+        du64 *dk = (du64 *)t->d_aux.p, *dc = dk + n_dev;
+        u64 got = 0;
+        KCT_TRY(kct_export_device(t, dk, dc, n_dev, &got));
+        if (got != n_dev) { set_err("table scan found %llu keys, expected %llu", (unsigned long long)got, (unsigned long long)n_dev); return KCT_ERR_HIP; }
+        if (order == 1 || order == 2) {
+            KCT_TRY(t->d_aux2.reserve(n_dev * 16));
+            du64 *sk = (du64 *)t->d_aux2.p, *sc = sk + n_dev;
+            size_t tmp_bytes = 0;
+            if (kx_sort_pairs_u64(dk, sk, dc, sc, n_dev, nullptr, &tmp_bytes, t->stream) != 0) { set_err("rocprim size query failed"); return KCT_ERR_HIP; }
+            KCT_TRY(t->d_sort.reserve(tmp_bytes + 16));
+            {
+                ProfScope ps(t, "radix_sort_pairs(by hash)");
+                if (kx_sort_pairs_u64(dk, sk, dc, sc, n_dev, t->d_sort.p, &tmp_bytes, t->stream) != 0) { set_err("rocprim radix sort failed"); return KCT_ERR_HIP; }
+            }
+            if (order == 2) {  // (count, hash): stable sort by count of the hash-sorted pairs (lib.rs:353-356)
+                ProfScope ps(t, "radix_sort_pairs(by count)");
+                if (kx_sort_pairs_u64(sc, dc, sk, dk, n_dev, t->d_sort.p, &tmp_bytes, t->stream) != 0) { set_err("rocprim radix sort failed"); return KCT_ERR_HIP; }
+            } else { dk = sk; dc = sc; }
+        }
+        HIP_TRY(hipMemcpyAsync(hk.data(), dk, n_dev * 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(hc.data(), dc, n_dev * 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+    }
+    if (t->zero_present) {  // hash 0 lives host-side: put it where the order wants it
+        size_t at = n_dev;
+        if (order == 1) at = 0;
+        else if (order == 2) {
+            at = 0;
+            while (at < n_dev && hc[at] < t->zero_count) ++at;  // smallest hash among equal counts
+        }
+        hk.insert(hk.begin() + at, 0); hk.pop_back();
+        hc.insert(hc.begin() + at, t->zero_count); hc.pop_back();
+    }
+    const size_t ncopy = std::min<size_t>(cap, n);
+    memcpy(hashes_out, hk.data(), ncopy * 8);
+    memcpy(counts_out, hc.data(), ncopy * 8);
+    return KCT_OK;
+}
+
+kct_status kct_merge_device(kct_table *t, const void *d_hashes, const void *d_counts, size_t n, uint64_t *total_added,
+                            uint64_t *new_keys) {
+    KCT_TRY(use(t));
+    u64 tl[4] = {0, 0, 0, 0};
+    if (n) {
+        if (!d_hashes || !d_counts) { set_err("null argument"); return KCT_ERR_ARG; }
+        // make room up front: at most n new keys
+        if ((double)(t->n_keys + n) > kMaxLoad * (double)t->cap) KCT_TRY(grow_to(t, next_pow2((u64)((double)(t->n_keys + n) / kMaxLoad) + 1)));
+        KCT_TRY(merge_pairs(t, (const du64 *)d_hashes, (const du64 *)d_counts, n, 1, tl));
+    }
+    if (total_added) *total_added = tl[kct::CTR_TOTAL_ADDED];
+    if (new_keys) *new_keys = tl[kct::CTR_NEW_BY_ZERO];
+    return KCT_OK;
+}
+
+kct_status kct_merge_host(kct_table *t, const uint64_t *hashes, const uint64_t *counts, size_t n, uint64_t *total_added,
+                          uint64_t *new_keys) {
+    KCT_TRY(use(t));
+    if (total_added) *total_added = 0;
+    if (new_keys) *new_keys = 0;
+    if (n == 0) return KCT_OK;
+    if (!hashes || !counts) { set_err("null argument"); return KCT_ERR_ARG; }
+    // key 0 cannot live on the device: fold it host-side
+    u64 zero_total = 0, zero_new = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (hashes[i] == 0) {
+            if (!t->zero_present || t->zero_count == 0) zero_new = 1;
+            t->zero_present = true;
+            t->zero_count += counts[i];
+            zero_total += counts[i];
+        }
+    KCT_TRY(t->d_aux.reserve(n * 16));
+    du64 *dk = (du64 *)t->d_aux.p, *dc = dk + n;
+    HIP_TRY(hipMemcpyAsync(dk, hashes, n * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(dc, counts, n * 8, hipMemcpyHostToDevice, t->stream));
+    u64 ta = 0, nk = 0;
+    KCT_TRY(kct_merge_device(t, dk, dc, n, &ta, &nk));
+    if (total_added) *total_added = ta + zero_total;
+    if (new_keys) *new_keys = nk + zero_new;
+    return KCT_OK;
+}
+
+kct_status kct_add(kct_table *dst, kct_table *src, uint64_t *total_added, uint64_t *new_keys) {
+    if (!dst || !src) { set_err("null table handle"); return KCT_ERR_ARG; }
+    if (dst->k != src->k) { set_err("KmerCountTables must have the same ksize"); return KCT_ERR_KSIZE_MISMATCH; }
+    // snapshot src (lib.rs:791-795), then fold it into dst (lib.rs:798-806)
+    u64 n = 0;
+    KCT_TRY(kct_len(src, &n));
+    std::vector<u64> hk(n ? n : 1), hc(n ? n : 1);
+    u64 got = 0;
+    KCT_TRY(kct_dump(src, hk.data(), hc.data(), n, 0, &got));
+    u64 ta = 0, nk = 0;
+    KCT_TRY(kct_merge_host(dst, hk.data(), hc.data(), n, &ta, &nk));
+    dst->consumed += src->consumed;  // lib.rs:808
+    if (total_added) *total_added = ta;
+    if (new_keys) *new_keys = nk;
+    return KCT_OK;
+}
+
+kct_status kct_set_stream(kct_table *t, void *hip_stream) {
+    KCT_TRY(use(t));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    prof_collect(t);
+    if (t->own_stream) { HIP_TRY(hipStreamDestroy(t->stream)); t->own_stream = false; }
+    t->stream = (hipStream_t)hip_stream;
+    return KCT_OK;
+}
+
+void *kct_get_stream(kct_table *t) { return t ? (void *)t->stream : nullptr; }
+
+kct_status kct_set_path(kct_table *t, int mode) {
+    KCT_TRY(use(t));
+    if (mode < 0 || mode > 2) { set_err("mode must be 0, 1 or 2"); return KCT_ERR_ARG; }
+    t->force_path = mode;
+    return KCT_OK;
+}
+
+kct_status kct_profile_enable(kct_table *t, int on) { KCT_TRY(use(t)); t->prof_on = on != 0; return KCT_OK; }
+
+kct_status kct_profile_reset(kct_table *t) {
+    KCT_TRY(use(t));
+    prof_collect(t);
+    t->prof.clear();
+    return KCT_OK;
+}
+
+kct_status kct_profile_read(kct_table *t, int index, char *name_out, size_t name_cap, uint64_t *launches, double *total_ms) {
+    KCT_TRY(use(t));
+    prof_collect(t);
+    if (index < 0 || (size_t)index >= t->prof.size()) return KCT_ERR_ARG;
+    const ProfEntry &e = t->prof[index];
+    if (name_out && name_cap) { strncpy(name_out, e.name.c_str(), name_cap - 1); name_out[name_cap - 1] = 0; }
+    if (launches) *launches = e.launches;
+    if (total_ms) *total_ms = e.ms;
+    return KCT_OK;
+}
+
+}  // extern "C"
+

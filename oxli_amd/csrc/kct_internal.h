@@ -1,0 +1,169 @@
+// kct_internal.h -- host-side internals shared by the translation units of libkct_hip.so.
+// Nothing here is exported (the library is built with -fvisibility=hidden); the C ABI is include/kct.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/kct.h"
+#include "device_common.h"
+
+typedef uint64_t u64;     // host-side 64-bit values (matches the ABI's uint64_t)
+typedef kct::u64 du64;    // words that live in device memory (unsigned long long, what HIP atomics take)
+
+namespace kcth {
+
+extern thread_local char g_err[512];
+void set_err(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? KCT_ERR_NOMEM : KCT_ERR_HIP;                 \
+        }                                                                                   \
+    } while (0)
+
+#define KCT_TRY(expr)                 \
+    do {                              \
+        kct_status s_ = (expr);       \
+        if (s_ != KCT_OK) return s_;  \
+    } while (0)
+
+constexpr u64 kDefaultSlots = 1ULL << 16;
+constexpr u64 kMinSlots = 1ULL << 10;
+constexpr double kMaxLoad = 0.65;                // grow between launches once load exceeds this
+constexpr u64 kChunkPositions = 1ULL << 28;      // stream bytes per launch (bounds the spill list)
+constexpr int kNumCounters = kct::kCounterShards * kct::kCounterStride;
+
+inline u64 next_pow2(u64 v) {
+    u64 p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+struct DevBuf {  // grow-only device buffer
+    void *p = nullptr;
+    size_t cap = 0;
+    kct_status reserve(size_t n) {
+        if (n <= cap) return KCT_OK;
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr; cap = 0;
+        size_t want = std::max(n, (size_t)4096);
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return KCT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct PinnedBuf {  // grow-only pinned host buffer
+    void *p = nullptr;
+    size_t cap = 0;
+    kct_status reserve(size_t n) {
+        if (n <= cap) return KCT_OK;
+        if (p) HIP_TRY(hipHostFree(p));
+        p = nullptr; cap = 0;
+        size_t want = std::max(n, (size_t)4096);
+        HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return KCT_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct ProfEntry { std::string name; u64 launches = 0; double ms = 0; };
+struct ProfPending { int entry; hipEvent_t a, b; };
+
+}  // namespace kcth
+
+struct kct_table {
+    int device = 0;
+    uint8_t k = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    du64 *slots = nullptr;  // 2 * cap words (device)
+    u64 cap = 0;
+    int block_bits = 0;     // log2(slots per probing block) = min(13, log2 cap)
+    bool lazy_empty = false;  // kct_clear() was called and the memset has not been issued yet
+    int num_cus = 256;
+    bool auto_sized = true; // no capacity hint / reserve yet: bulk ingest ramps its launch size up with the table
+    int ablate = 0;         // KCT_ABLATE at create time: measurement-only switches that skip work (results invalid)
+    bool debug = false;     // KCT_DEBUG at create time: one stderr line per partitioned pass
+    int force_path = 0;     // 0 = choose per pass, 1 = direct atomic kernel only, 2 = partitioned whenever the geometry allows
+    u64 n_keys = 0;        // distinct non-zero hashes in `slots`
+    u64 consumed = 0;      // lib.rs:36
+    bool zero_present = false;  // key 0 lives host-side (0 is the EMPTY sentinel on the device)
+    u64 zero_count = 0;
+
+    du64 *d_counters = nullptr;  // kNumCounters tallies + 8 scratch words (device)
+    u64 *h_counters = nullptr;   // pinned mirror
+    kcth::DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort, d_scratch2, d_regions2, d_irr2;
+    kcth::PinnedBuf h_stage;
+
+    bool prof_on = false;
+    std::vector<kcth::ProfEntry> prof;
+    std::vector<kcth::ProfPending> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace kcth {
+
+struct ProfScope {
+    kct_table *t;
+    int idx = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(kct_table *t_, const char *name) : t(t_) {
+        if (!t->prof_on) return;
+        for (size_t i = 0; i < t->prof.size(); ++i)
+            if (t->prof[i].name == name) idx = (int)i;
+        if (idx < 0) { t->prof.push_back(ProfEntry{name}); idx = (int)t->prof.size() - 1; }
+        a = take(); b = take();
+        if (a && b) (void)hipEventRecord(a, t->stream);
+    }
+    ~ProfScope() {
+        if (idx < 0 || !a || !b) return;
+        (void)hipEventRecord(b, t->stream);
+        t->prof[idx].launches++;
+        t->prof_pending.push_back(ProfPending{idx, a, b});
+    }
+    hipEvent_t take() {
+        if (!t->event_pool.empty()) { hipEvent_t e = t->event_pool.back(); t->event_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+
+void prof_collect(kct_table *t);
+kct_status use(kct_table *t);
+kct::TableGeom geom(const kct_table *t);
+kct::TableView view(kct_table *t, u64 spill_cap);
+int log2_u64(u64 v);
+void set_geometry(kct_table *t);
+kct_status materialize(kct_table *t);
+kct_status zero_counters(kct_table *t);
+kct_status read_counters(kct_table *t, u64 out[4], u64 *spill_n);
+int merge_grid(u64 n);
+kct_status grow_to(kct_table *t, u64 new_cap);
+kct_status maybe_grow(kct_table *t);
+kct_status merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n, int stride, u64 tallies[4]);
+kct_status replay_spill(kct_table *t, u64 spilled, u64 *n_out);
+kct_status point_add(kct_table *t, u64 h, u64 *count_out);
+// kct_consume.hip
+kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 *n_out);
+
+}  // namespace kcth

@@ -1,313 +1,14 @@
-// kernels.h -- gfx950 kernels of the consume path.
-//
-// Input layout ("record stream"): the bytes of all records of a batch back to back, each record
-// followed by at least one byte that is not A/C/G/T (the host packer writes '\n').  A k-window
-// is good iff its k bytes are all ACGT (either case), so windows that would span two records
-// are bad by construction and no offsets are needed on the device.
-//
-// Decomposition: one 256-thread workgroup owns a tile of kTile consecutive window START
-// positions.  It stages kTile + k - 1 bytes in LDS with 16-byte coalesced global loads, then
-// every thread walks kWPT consecutive windows with a rolling 2-bit forward word and a rolling
-// reverse-complement word (k - 1 warm-up steps).  Long reads need nothing special: a 10 kbp or
-// 350 kbp record is simply many tiles.
+// partition_kernels.h -- the partitioned counting path: K1 partition_windows_kernel, K1b
+// repartition_kernel, K2 aggregate_blocks_kernel and merge_overflow_kernel.
 #pragma once
-#include "kmer_device.h"
-#include "table_device.h"
+#include "window_kernels.h"
 
 namespace kct {
-
-constexpr int kBlock = 256;
-constexpr int kWPT = 32;                  // windows per thread (direct kernels)
-constexpr int kTile = kBlock * kWPT;      // window start positions per workgroup (8192)
-constexpr int kHaloMax = 256;             // k - 1 <= 254
-constexpr int kPartThreads = 1024;        // partitioned path: one 16-wave workgroup per CU
-constexpr int kPartWPT = 16;
-constexpr int kPartTile = kPartThreads * kPartWPT;  // 16384 window starts per tile
-constexpr int kRingEntries = 16384;       // LDS write-combining ring: 128 KiB of u64, split over the bins
-constexpr int kChunk = 8;                 // entries per flush = one 64-byte line
-constexpr int kWaveQueue = 160;           // K2: deferred entries per wave
-constexpr int kCounterShards = 64;        // per-launch tallies are spread over this many 128-B lines
-constexpr int kCounterStride = 16;        // u64 words per shard (128 B)
-enum { CTR_COUNTED = 0, CTR_NEWKEYS = 1, CTR_TOTAL_ADDED = 2, CTR_NEW_BY_ZERO = 3 };
-
-// 64-bit value of lane `src` (wave-uniform index) broadcast through SGPRs: two v_readlane_b32,
-// no LDS round trip (what __shfl would cost).
-__device__ __forceinline__ u64 read_lane64(u64 v, int src) {
-    const u32 lo = __builtin_amdgcn_readlane((u32)v, src), hi = __builtin_amdgcn_readlane((u32)(v >> 32), src);
-    return ((u64)hi << 32) | lo;
-}
-
-__device__ __forceinline__ u64 wave_sum(u64 v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    return v;  // valid in lane 0
-}
-
-// Stage stream[tile_base, tile_base + TILE + k - 1) into LDS; bytes past `nbytes` read as 0.
-template <int BLOCK, int TILE>
-__device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ stream, u64 nbytes, u64 tile_base, int k,
-                                           unsigned char *lds) {
-    const int nchunks = (TILE + k - 1 + 15) >> 4;
-    for (int c = threadIdx.x; c < nchunks; c += BLOCK) {
-        const u64 off = tile_base + 16ULL * (u64)c;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (off + 16 <= nbytes) {
-            v = *reinterpret_cast<const uint4 *>(stream + off);
-        } else if (off < nbytes) {
-            unsigned char tmp[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) tmp[i] = (off + i < nbytes) ? stream[off + i] : (unsigned char)0;
-            v = *reinterpret_cast<uint4 *>(tmp);
-        }
-        *reinterpret_cast<uint4 *>(lds + 16 * c) = v;
-    }
-    __syncthreads();
-}
-
-// Walks this thread's WPT windows of the staged tile and calls sink(j, good, hash) for each,
-// j = 0..WPT-1 (window start = tile_base + threadIdx.x * WPT + j).  KC > 0 fixes k at compile
-// time; KW = 64-bit words of the packed k-mer (k <= 32 * KW).  Every thread of the workgroup
-// makes the same WPT calls, so a sink may use wave collectives and workgroup barriers.
-template <int KW, int KC, int WPT, class Sink>
-__device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, int k_rt, Sink &&sink) {
-    const int k = KC > 0 ? KC : k_rt;
-    const unsigned char *p = lds + threadIdx.x * WPT;
-    Packed<KW> fw, rc;
-#pragma unroll
-    for (int i = 0; i < KW; ++i) { fw.w[i] = 0; rc.w[i] = 0; }
-    int run = 0;  // length of the run of valid bases ending at the current byte
-    for (int j = 0; j < k - 1; ++j) {
-        u32 code = base_code(p[j]);
-        bool ok = code < 4;
-        push_fw(fw, code & 3u);
-        push_rc(rc, 3u - (code & 3u), k);
-        run = ok ? run + 1 : 0;
-    }
-#pragma unroll 4
-    for (int j = 0; j < WPT; ++j) {
-        u32 code = base_code(p[k - 1 + j]);
-        bool ok = code < 4;
-        push_fw(fw, code & 3u);
-        mask_k(fw, k);
-        push_rc(rc, 3u - (code & 3u), k);
-        run = ok ? run + 1 : 0;
-        const bool good = run >= k;
-        u64 h = 0;
-        if (good) {
-            Packed<KW> c = less_eq(fw, rc) ? fw : rc;
-            left_align(c, k);
-            h = hash_packed(c, k);
-        }
-        sink(j, good, h);
-    }
-}
-
-// Same contract as walk_windows_packed, over a PRE-ENCODED tile (kmer_device.h encode16):
-// codes[c] / valid[c] describe bases 16c .. 16c+15 of the tile.  The first window is assembled
-// directly from the packed words (no k-1 warm-up steps); the WPT-1 following bases come out of two
-// shift registers.  WPT must be 16 (one code word per thread).
-template <int KW, int KC, class Sink>
-__device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const unsigned short *valid, int k_rt, Sink &&sink) {
-    constexpr int WPT = 16, NW = 2 * KW + 1;  // code words covering bases 0 .. 15 + k
-    const int k = KC > 0 ? KC : k_rt;
-    u32 w[NW];
-    u64 vbits = 0;  // validity of the first 64 bases, base n in bit 63 - n (KW = 1 needs 47, KW = 2 needs 79)
-    u32 vtail = 0;  // ... bases 64..79 in bits 15..0 (KW = 2 only)
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        w[i] = codes[threadIdx.x + i];
-        const u64 v = valid[threadIdx.x + i];
-        if (i < 4) vbits |= v << (48 - 16 * i);
-        else vtail = (u32)v;
-    }
-    // ---- window 0: bases 0 .. k-1
-    Packed<KW> fw;
-#pragma unroll
-    for (int i = 0; i < KW; ++i) fw.w[i] = ((u64)w[2 * i] << 32) | w[2 * i + 1];
-    {   // shift right so that base k-1 sits in the low 2 bits
-        const int s = 64 * KW - 2 * k, ws = s >> 6, bs = s & 63;
-        Packed<KW> o;
-#pragma unroll
-        for (int i = 0; i < KW; ++i) {
-            u64 lo = 0, hi = 0;
-#pragma unroll
-            for (int j = 0; j < KW; ++j) {
-                if (j == i - ws) lo = fw.w[j];
-                if (j == i - ws - 1) hi = fw.w[j];
-            }
-            o.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
-        }
-        fw = o;
-    }
-    Packed<KW> rc = revcomp_packed(fw, k);
-    // run = valid bases in a row ending at base k-1
-    int run;
-    {
-        u64 inv_hi = ~vbits;                 // invalid bases among 0..63
-        if (k < 64) inv_hi &= ~0ULL << (64 - k);  // keep bases 0..k-1 only
-        // the last invalid base before k: its distance to base k-1
-        run = inv_hi ? (int)__builtin_ctzll(inv_hi) - (64 - k) : k;
-        if (k > 64) run = k;  // unreachable for KW <= 2 (k <= 64)
-    }
-    // ---- streams of the WPT-1 bases k .. k+WPT-2 (and their validity), next one in the top bits
-    u32 cs, vs;
-    {
-        const int idx = k >> 4, sh = 2 * (k & 15);
-        u32 a = 0, b = 0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) { if (i == idx) a = w[i]; if (i == idx + 1) b = w[i]; }
-        cs = sh ? ((a << sh) | (b >> (32 - sh))) : a;
-        // validity of base n: n < 64 -> vbits bit 63-n, else vtail bit 79-n
-        const u64 v_lo = k < 64 ? (vbits << k) : 0ULL;                       // base k at bit 63
-        const u64 v_hi = k < 64 ? ((u64)vtail << 48) >> (64 - k) : (u64)vtail << 48;  // bases 64.. follow
-        vs = (u32)((v_lo | (k ? v_hi : 0ULL)) >> 32);
-    }
-#pragma unroll 4
-    for (int j = 0; j < WPT; ++j) {
-        const bool good = run >= k;
-        u64 h = 0;
-        if (good) {
-            Packed<KW> c = less_eq(fw, rc) ? fw : rc;
-            left_align(c, k);
-            h = hash_packed(c, k);
-        }
-        sink(j, good, h);
-        if (j + 1 < WPT) {
-            const u32 code = cs >> 30;
-            cs <<= 2;
-            const bool ok = (int)vs < 0;
-            vs <<= 1;
-            push_fw(fw, code);
-            mask_k(fw, k);
-            push_rc(rc, 3u - code, k);
-            run = ok ? run + 1 : 0;
-        }
-    }
-}
-
-// Any k (used for k > 64): validity by run length, canonical choice and hashing bytewise.
-template <int WPT, class Sink>
-__device__ __forceinline__ void walk_windows_bytes(const unsigned char *lds, int k, Sink &&sink) {
-    const unsigned char *p = lds + threadIdx.x * WPT;
-    int run = 0;
-    for (int j = 0; j < k - 1; ++j) run = base_code(p[j]) < 4 ? run + 1 : 0;
-    for (int j = 0; j < WPT; ++j) {
-        run = base_code(p[k - 1 + j]) < 4 ? run + 1 : 0;
-        const bool good = run >= k;
-        u64 h = good ? hash_bytes_canonical(p + j, k) : 0;
-        sink(j, good, h);
-    }
-}
-
-template <int KW, int KC, int WPT, class Sink>
-__device__ __forceinline__ void walk_windows(const unsigned char *lds, int k, Sink &&sink) {
-    if constexpr (KW == 0) walk_windows_bytes<WPT>(lds, k, sink);
-    else walk_windows_packed<KW, KC, WPT>(lds, k, sink);
-}
-
-// ---- hash-only kernel: SeqToHashes as consume drives it (lib.rs:576-600) ------------------------
-// out[p] = hash of the window starting at p (0 if bad), p in [0, nwindows);
-// *first_bad = min index of a bad window (left untouched if none).
-template <int KW, int KC>
-__global__ __launch_bounds__(kBlock) void hash_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
-                                                              u64 nwindows, u64 *__restrict__ out, u64 *first_bad) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kTile + kHaloMax + 16];
-    const u64 tile_base = (u64)blockIdx.x * kTile;
-    stage_tile<kBlock, kTile>(stream, nbytes, tile_base, k, lds);
-    const u64 p0 = tile_base + (u64)threadIdx.x * kWPT;
-    u64 my_bad = ~0ULL;
-    walk_windows<KW, KC, kWPT>(lds, k, [&](int j, bool good, u64 h) {
-        const u64 p = p0 + j;
-        if (p < nwindows) {
-            out[p] = good ? h : 0;
-            if (!good && my_bad == ~0ULL) my_bad = p;
-        }
-    });
-    if (my_bad != ~0ULL) atomicMin(first_bad, my_bad);
-}
-
-// ---- validity-only kernel for skip_bad_kmers == False over a multi-record stream -------------------
-// Finds the smallest stream position q of an invalid byte that lies INSIDE a record of length
-// >= k (separators and records too short to have a window do not raise, lib.rs:593-596 only
-// fires for a window that exists).  rec_off[r] = stream offset of record r, rec_off[nrec] = end;
-// record r spans [rec_off[r], rec_off[r+1] - 1) and is followed by its separator byte.
-__global__ __launch_bounds__(kBlock) void first_bad_byte_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
-                                                                const u64 *__restrict__ rec_off, u64 nrec, u64 *first_bad_q) {
-    const u64 base = ((u64)blockIdx.x * kBlock + threadIdx.x) * 16ULL;
-    if (base >= nbytes) return;
-    unsigned char b[16];
-    if (base + 16 <= nbytes) *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(stream + base);
-    else
-        for (int i = 0; i < 16; ++i) b[i] = base + i < nbytes ? stream[base + i] : (unsigned char)'A';
-    u64 best = ~0ULL;
-    for (int i = 0; i < 16; ++i) {
-        if (base_code(b[i]) < 4) continue;
-        const u64 q = base + i;
-        // record holding q: largest r with rec_off[r] <= q
-        u64 lo = 0, hi = nrec;  // invariant rec_off[lo] <= q < rec_off[hi]
-        while (hi - lo > 1) {
-            u64 mid = (lo + hi) >> 1;
-            if (rec_off[mid] <= q) lo = mid; else hi = mid;
-        }
-        const u64 start = rec_off[lo], end = rec_off[lo + 1] - 1;  // end = separator position
-        if (q < end && end - start >= (u64)k) { best = q; break; }
-    }
-    if (best != ~0ULL) atomicMin(first_bad_q, best);
-}
-
-// ---- the hot kernel: windows -> canonical hash -> scatter-increment -------------------------------
-// consume's loop body (lib.rs:586-600) for every window of the stream at once.
-template <int KW, int KC>
-__global__ __launch_bounds__(kBlock) void count_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
-                                                               TableView table, u64 *counters) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kTile + kHaloMax + 16];
-    __shared__ u64 s_counted, s_new;
-    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
-    const u64 tile_base = (u64)blockIdx.x * kTile;
-    stage_tile<kBlock, kTile>(stream, nbytes, tile_base, k, lds);
-    const int lane = threadIdx.x & 63;
-    int counted = 0;  // signed: a leader whose folded add spills takes back the folded lanes' tallies
-    int newkeys = 0;
-    walk_windows<KW, KC, kWPT>(lds, k, [&](int, bool good, u64 h) {
-        bool active = good && h != 0;  // lib.rs:589: a hash of 0 is skipped and not tallied
-        u64 c = 1;
-        int tally = 0;
-        // Wavefront combining: lanes whose hash equals the first active lane's hash fold into
-        // one add.  Tandem repeats and homopolymers put the same k-mer in every lane at once
-        // (lanes are kWPT windows apart), which would otherwise serialise on one HBM atomic.
-        const u64 act = __ballot(active);
-        if (act) {
-            const int leader = __ffsll((long long)act) - 1;
-            const u64 hl = read_lane64(h, leader);
-            const u64 same = __ballot(active && h == hl);
-            if (same != (1ULL << leader)) {
-                if (lane == leader) c = (u64)__popcll(same);
-                else if ((same >> lane) & 1ULL) { active = false; tally = 1; }
-            }
-        }
-        if (active) {
-            const AddResult r = table_add<false>(table, h, c);
-            // spilled entries are tallied when the host replays them: a leader whose folded
-            // add spilled also takes back the folded lanes' tallies (the replay adds c)
-            tally = r.spilled ? 1 - (int)c : 1;
-            newkeys += r.claimed ? 1 : 0;
-        }
-        counted += tally;
-    });
-    u64 wc = wave_sum((u64)(long long)counted), wn = wave_sum((u64)newkeys);
-    if (lane == 0) { atomicAdd(&s_counted, wc); atomicAdd(&s_new, wn); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
-        if (s_counted) atomicAdd(shard + CTR_COUNTED, s_counted);
-        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
-    }
-}
 
 // =================================================================================================
 // Partitioned path: the same consume loop, without one HBM atomic per k-mer.
 //
-// The direct kernel above is bound by the memory-side atomic rate (~2.3e10 64-byte atomic
+// The direct kernel (window_kernels.h) is bound by the memory-side atomic rate (~2.3e10 64-byte atomic
 // requests/s measured on MI355X, profiles/r01a_*), not by HBM bandwidth.  Because probing is
 // confined to 128-KiB table blocks (table_device.h), a block can be owned by ONE workgroup:
 //
@@ -761,42 +462,6 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
     }
 }
 
-// ---- (hash, count) pairs -> table: add()'s inner loop (lib.rs:798-806), spill replay, re-hash --------
-// pairs are read as keys[i * key_stride], counts[i * count_stride] so that the same kernel folds
-// separate arrays (stride 1) and an old slot array (stride 2, keys = slots, counts = slots + 1).
-// n_dev (if not null) holds the pair count in device memory, clamped to n; a non-zero *abort
-// (if not null) turns the launch into a no-op.
-__global__ __launch_bounds__(kBlock) void merge_pairs_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ counts,
-                                                             u64 n, const u64 *n_dev, const u64 *abort, int stride, TableView table,
-                                                             u64 *counters) {
-    __shared__ u64 s_tot, s_new, s_zero;
-    if (abort && *abort) return;
-    if (n_dev) { const u64 nd = *n_dev; n = nd < n ? nd : n; }
-    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; s_zero = 0; }
-    __syncthreads();
-    u64 tot = 0, nk = 0, nz = 0;
-    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
-        const u64 h = keys[i * stride];
-        if (h == 0) continue;
-        const u64 c = counts[i * stride];
-        const AddResult r = table_add<true>(table, h, c);
-        if (!r.spilled) {
-            tot += c;
-            nk += r.claimed;
-            nz += (r.old == 0);  // lib.rs:801-803: a key counts as new when its current count is 0
-        }
-    }
-    tot = wave_sum(tot); nk = wave_sum(nk); nz = wave_sum(nz);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); atomicAdd(&s_zero, nz); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
-        if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
-        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
-        if (s_zero) atomicAdd(shard + CTR_NEW_BY_ZERO, s_zero);
-    }
-}
-
 // ---- overflow regions of the partitioned path -> table ---------------------------------------------
 // regions[r] holds counts[r] hashes (each standing for one k-mer).  Neighbouring entries are often
 // equal (that is why they overflowed), so every wave first folds equal hashes: the lowest active
@@ -840,127 +505,6 @@ __global__ __launch_bounds__(kBlock) void merge_overflow_kernel(const u64 *__res
         if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
         if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
     }
-}
-
-// ---- re-hash: every occupied slot of an old table -> the new table (growth) ------------------------
-__global__ __launch_bounds__(kBlock) void rehash_kernel(const u64 *__restrict__ old_words, TableGeom old_g, TableView table,
-                                                        u64 *counters) {
-    __shared__ u64 s_new;
-    if (threadIdx.x == 0) s_new = 0;
-    __syncthreads();
-    const u64 cap = old_g.mask + 1, S = block_slots(old_g);
-    u64 nk = 0;
-    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock) {
-        const u64 kw = key_word(old_g, s);
-        const u64 h = old_words[kw];
-        if (h == 0) continue;
-        const AddResult r = table_add<false>(table, h, old_words[kw + S]);
-        nk += (r.claimed && !r.spilled) ? 1 : 0;
-    }
-    nk = wave_sum(nk);
-    if ((threadIdx.x & 63) == 0 && nk) atomicAdd(&s_new, nk);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_new) atomicAdd(counters + (blockIdx.x % kCounterShards) * kCounterStride + CTR_NEWKEYS, s_new);
-}
-
-// ---- lookups / point update ---------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void get_hashes_kernel(const u64 *__restrict__ words, TableGeom g,
-                                                            const u64 *__restrict__ hashes, u64 n, u64 *__restrict__ out) {
-    const u64 i = (u64)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const u64 w = hashes[i] ? table_find(words, g, hashes[i]) : ~0ULL;
-    out[i] = w == ~0ULL ? 0 : words[w + block_slots(g)];
-}
-
-// set the count of an existing key (returns 1 in *found) -- __setitem__ (lib.rs:675-681)
-__global__ void set_hash_kernel(u64 *words, TableGeom g, u64 h, u64 value, u64 *found) {
-    const u64 w = table_find(words, g, h);
-    *found = w != ~0ULL;
-    if (w != ~0ULL) words[w + block_slots(g)] = value;
-}
-
-// ---- whole-table scans ---------------------------------------------------------------------------
-// compaction for dump / export: out_n must be zero on entry
-__global__ __launch_bounds__(kBlock) void compact_kernel(const u64 *__restrict__ words, TableGeom g, u64 *__restrict__ out_keys,
-                                                         u64 *__restrict__ out_counts, u64 out_cap, u64 *out_n) {
-    const u64 cap = g.mask + 1, S = block_slots(g);
-    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock) {
-        const u64 kw = key_word(g, s);
-        const u64 key = words[kw];
-        if (key != 0) {
-            const u64 i = atomicAdd(out_n, 1ULL);  // hipcc folds this into one add per wave
-            if (i < out_cap) { out_keys[i] = key; out_counts[i] = words[kw + S]; }
-        }
-    }
-}
-
-// ---- export bucketed by owner rank (multi-GPU merge) -------------------------------------------------
-// owner(h) = floor(hi32(h) * nparts / 2^32): a contiguous slice of hash space per rank.
-__device__ __forceinline__ u32 owner_of(u64 h, u32 nparts) { return (u32)(((h >> 32) * (u64)nparts) >> 32); }
-
-constexpr int kMaxParts = 256;
-
-// pass 1: how many occupied slots belong to each owner
-__global__ __launch_bounds__(kBlock) void count_owners_kernel(const u64 *__restrict__ words, TableGeom g, u32 nparts, u64 *part_counts) {
-    __shared__ u32 hist[kMaxParts];
-    for (u32 i = threadIdx.x; i < nparts; i += kBlock) hist[i] = 0;
-    __syncthreads();
-    const u64 cap = g.mask + 1;
-    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock) {
-        const u64 key = words[key_word(g, s)];
-        if (key != 0) atomicAdd(&hist[owner_of(key, nparts)], 1u);
-    }
-    __syncthreads();
-    for (u32 i = threadIdx.x; i < nparts; i += kBlock) if (hist[i]) atomicAdd(part_counts + i, (u64)hist[i]);
-}
-
-// pass 2: write interleaved {hash, count} pairs, owner p's pairs contiguous from part_base[p].
-// Each workgroup reserves one range per owner per chunk of slots, so the global cursors see
-// (chunks x nparts) atomics instead of one per key.
-__global__ __launch_bounds__(kBlock) void scatter_owners_kernel(const u64 *__restrict__ words, TableGeom g, u32 nparts,
-                                                                u64 *part_cursor /* starts at part_base */, u64 *__restrict__ out_pairs,
-                                                                u64 out_cap) {
-    __shared__ u32 hist[kMaxParts];
-    __shared__ u64 base[kMaxParts];
-    const u64 cap = g.mask + 1, S = block_slots(g);
-    constexpr u64 kChunkSlots = 16 * kBlock;
-    for (u64 c0 = (u64)blockIdx.x * kChunkSlots; c0 < cap; c0 += (u64)gridDim.x * kChunkSlots) {
-        for (u32 i = threadIdx.x; i < nparts; i += kBlock) hist[i] = 0;
-        __syncthreads();
-        u64 keys[16], cnts[16];
-        u32 rank[16], own[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const u64 s = c0 + (u64)j * kBlock + threadIdx.x;
-            keys[j] = 0;
-            if (s < cap) {
-                const u64 kw = key_word(g, s);
-                keys[j] = words[kw];
-                if (keys[j]) { cnts[j] = words[kw + S]; own[j] = owner_of(keys[j], nparts); rank[j] = atomicAdd(&hist[own[j]], 1u); }
-            }
-        }
-        __syncthreads();
-        for (u32 i = threadIdx.x; i < nparts; i += kBlock) base[i] = hist[i] ? atomicAdd(part_cursor + i, (u64)hist[i]) : 0;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (keys[j]) {
-                const u64 pos = base[own[j]] + rank[j];
-                if (pos < out_cap) { out_pairs[2 * pos] = keys[j]; out_pairs[2 * pos + 1] = cnts[j]; }
-            }
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void sum_counts_kernel(const u64 *__restrict__ words, TableGeom g, u64 *out) {
-    const u64 cap = g.mask + 1, S = block_slots(g);
-    u64 acc = 0;
-    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock) {
-        const u64 kw = key_word(g, s);
-        if (words[kw] != 0) acc += words[kw + S];
-    }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
 }  // namespace kct

@@ -1,6 +1,6 @@
 // sort.hip -- device radix sort of (hash, count) pairs for dump(sortkeys / sortcounts) (lib.rs:330-381).
 // rocPRIM's radix sort is a plain library primitive; it lives in its own translation unit so that
-// the kernels in kct.hip do not pay its compile time.
+// the other sources do not pay its compile time.
 #include <cstring>
 
 #include <hip/hip_runtime.h>

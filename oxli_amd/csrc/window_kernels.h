@@ -1,0 +1,281 @@
+// window_kernels.h -- tile staging, window walkers, and the kernels that hash every window of a record
+// stream: hash-only, validity-only, and the direct (one HBM atomic per k-mer) counting kernel.
+//
+// Input layout ("record stream"): the bytes of all records of a batch back to back, each record
+// followed by at least one byte that is not A/C/G/T (the host packer writes '\n').  A k-window
+// is good iff its k bytes are all ACGT (either case), so windows that would span two records
+// are bad by construction and no offsets are needed on the device.
+//
+// Decomposition: one 256-thread workgroup owns a tile of kTile consecutive window START
+// positions.  It stages kTile + k - 1 bytes in LDS with 16-byte coalesced global loads, then
+// every thread walks kWPT consecutive windows with a rolling 2-bit forward word and a rolling
+// reverse-complement word (k - 1 warm-up steps).  Long reads need nothing special: a 10 kbp or
+// 350 kbp record is simply many tiles.
+#pragma once
+#include "device_common.h"
+
+namespace kct {
+
+
+// Stage stream[tile_base, tile_base + TILE + k - 1) into LDS; bytes past `nbytes` read as 0.
+template <int BLOCK, int TILE>
+__device__ __forceinline__ void stage_tile(const unsigned char *__restrict__ stream, u64 nbytes, u64 tile_base, int k,
+                                           unsigned char *lds) {
+    const int nchunks = (TILE + k - 1 + 15) >> 4;
+    for (int c = threadIdx.x; c < nchunks; c += BLOCK) {
+        const u64 off = tile_base + 16ULL * (u64)c;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (off + 16 <= nbytes) {
+            v = *reinterpret_cast<const uint4 *>(stream + off);
+        } else if (off < nbytes) {
+            unsigned char tmp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tmp[i] = (off + i < nbytes) ? stream[off + i] : (unsigned char)0;
+            v = *reinterpret_cast<uint4 *>(tmp);
+        }
+        *reinterpret_cast<uint4 *>(lds + 16 * c) = v;
+    }
+    __syncthreads();
+}
+
+// Walks this thread's WPT windows of the staged tile and calls sink(j, good, hash) for each,
+// j = 0..WPT-1 (window start = tile_base + threadIdx.x * WPT + j).  KC > 0 fixes k at compile
+// time; KW = 64-bit words of the packed k-mer (k <= 32 * KW).  Every thread of the workgroup
+// makes the same WPT calls, so a sink may use wave collectives and workgroup barriers.
+template <int KW, int KC, int WPT, class Sink>
+__device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, int k_rt, Sink &&sink) {
+    const int k = KC > 0 ? KC : k_rt;
+    const unsigned char *p = lds + threadIdx.x * WPT;
+    Packed<KW> fw, rc;
+#pragma unroll
+    for (int i = 0; i < KW; ++i) { fw.w[i] = 0; rc.w[i] = 0; }
+    int run = 0;  // length of the run of valid bases ending at the current byte
+    for (int j = 0; j < k - 1; ++j) {
+        u32 code = base_code(p[j]);
+        bool ok = code < 4;
+        push_fw(fw, code & 3u);
+        push_rc(rc, 3u - (code & 3u), k);
+        run = ok ? run + 1 : 0;
+    }
+#pragma unroll 4
+    for (int j = 0; j < WPT; ++j) {
+        u32 code = base_code(p[k - 1 + j]);
+        bool ok = code < 4;
+        push_fw(fw, code & 3u);
+        mask_k(fw, k);
+        push_rc(rc, 3u - (code & 3u), k);
+        run = ok ? run + 1 : 0;
+        const bool good = run >= k;
+        u64 h = 0;
+        if (good) {
+            Packed<KW> c = less_eq(fw, rc) ? fw : rc;
+            left_align(c, k);
+            h = hash_packed(c, k);
+        }
+        sink(j, good, h);
+    }
+}
+
+// Same contract as walk_windows_packed, over a PRE-ENCODED tile (kmer_device.h encode16):
+// codes[c] / valid[c] describe bases 16c .. 16c+15 of the tile.  The first window is assembled
+// directly from the packed words (no k-1 warm-up steps); the WPT-1 following bases come out of two
+// shift registers.  WPT must be 16 (one code word per thread).
+template <int KW, int KC, class Sink>
+__device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const unsigned short *valid, int k_rt, Sink &&sink) {
+    constexpr int WPT = 16, NW = 2 * KW + 1;  // code words covering bases 0 .. 15 + k
+    const int k = KC > 0 ? KC : k_rt;
+    u32 w[NW];
+    u64 vbits = 0;  // validity of the first 64 bases, base n in bit 63 - n (KW = 1 needs 47, KW = 2 needs 79)
+    u32 vtail = 0;  // ... bases 64..79 in bits 15..0 (KW = 2 only)
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        w[i] = codes[threadIdx.x + i];
+        const u64 v = valid[threadIdx.x + i];
+        if (i < 4) vbits |= v << (48 - 16 * i);
+        else vtail = (u32)v;
+    }
+    // ---- window 0: bases 0 .. k-1
+    Packed<KW> fw;
+#pragma unroll
+    for (int i = 0; i < KW; ++i) fw.w[i] = ((u64)w[2 * i] << 32) | w[2 * i + 1];
+    {   // shift right so that base k-1 sits in the low 2 bits
+        const int s = 64 * KW - 2 * k, ws = s >> 6, bs = s & 63;
+        Packed<KW> o;
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+            u64 lo = 0, hi = 0;
+#pragma unroll
+            for (int j = 0; j < KW; ++j) {
+                if (j == i - ws) lo = fw.w[j];
+                if (j == i - ws - 1) hi = fw.w[j];
+            }
+            o.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+        }
+        fw = o;
+    }
+    Packed<KW> rc = revcomp_packed(fw, k);
+    // run = valid bases in a row ending at base k-1
+    int run;
+    {
+        u64 inv_hi = ~vbits;                 // invalid bases among 0..63
+        if (k < 64) inv_hi &= ~0ULL << (64 - k);  // keep bases 0..k-1 only
+        // the last invalid base before k: its distance to base k-1
+        run = inv_hi ? (int)__builtin_ctzll(inv_hi) - (64 - k) : k;
+        if (k > 64) run = k;  // unreachable for KW <= 2 (k <= 64)
+    }
+    // ---- streams of the WPT-1 bases k .. k+WPT-2 (and their validity), next one in the top bits
+    u32 cs, vs;
+    {
+        const int idx = k >> 4, sh = 2 * (k & 15);
+        u32 a = 0, b = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { if (i == idx) a = w[i]; if (i == idx + 1) b = w[i]; }
+        cs = sh ? ((a << sh) | (b >> (32 - sh))) : a;
+        // validity of base n: n < 64 -> vbits bit 63-n, else vtail bit 79-n
+        const u64 v_lo = k < 64 ? (vbits << k) : 0ULL;                       // base k at bit 63
+        const u64 v_hi = k < 64 ? ((u64)vtail << 48) >> (64 - k) : (u64)vtail << 48;  // bases 64.. follow
+        vs = (u32)((v_lo | (k ? v_hi : 0ULL)) >> 32);
+    }
+#pragma unroll 4
+    for (int j = 0; j < WPT; ++j) {
+        const bool good = run >= k;
+        u64 h = 0;
+        if (good) {
+            Packed<KW> c = less_eq(fw, rc) ? fw : rc;
+            left_align(c, k);
+            h = hash_packed(c, k);
+        }
+        sink(j, good, h);
+        if (j + 1 < WPT) {
+            const u32 code = cs >> 30;
+            cs <<= 2;
+            const bool ok = (int)vs < 0;
+            vs <<= 1;
+            push_fw(fw, code);
+            mask_k(fw, k);
+            push_rc(rc, 3u - code, k);
+            run = ok ? run + 1 : 0;
+        }
+    }
+}
+
+// Any k (used for k > 64): validity by run length, canonical choice and hashing bytewise.
+template <int WPT, class Sink>
+__device__ __forceinline__ void walk_windows_bytes(const unsigned char *lds, int k, Sink &&sink) {
+    const unsigned char *p = lds + threadIdx.x * WPT;
+    int run = 0;
+    for (int j = 0; j < k - 1; ++j) run = base_code(p[j]) < 4 ? run + 1 : 0;
+    for (int j = 0; j < WPT; ++j) {
+        run = base_code(p[k - 1 + j]) < 4 ? run + 1 : 0;
+        const bool good = run >= k;
+        u64 h = good ? hash_bytes_canonical(p + j, k) : 0;
+        sink(j, good, h);
+    }
+}
+
+template <int KW, int KC, int WPT, class Sink>
+__device__ __forceinline__ void walk_windows(const unsigned char *lds, int k, Sink &&sink) {
+    if constexpr (KW == 0) walk_windows_bytes<WPT>(lds, k, sink);
+    else walk_windows_packed<KW, KC, WPT>(lds, k, sink);
+}
+
+// ---- hash-only kernel: SeqToHashes as consume drives it (lib.rs:576-600) ------------------------
+// out[p] = hash of the window starting at p (0 if bad), p in [0, nwindows);
+// *first_bad = min index of a bad window (left untouched if none).
+template <int KW, int KC>
+__global__ __launch_bounds__(kBlock) void hash_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
+                                                              u64 nwindows, u64 *__restrict__ out, u64 *first_bad) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kTile + kHaloMax + 16];
+    const u64 tile_base = (u64)blockIdx.x * kTile;
+    stage_tile<kBlock, kTile>(stream, nbytes, tile_base, k, lds);
+    const u64 p0 = tile_base + (u64)threadIdx.x * kWPT;
+    u64 my_bad = ~0ULL;
+    walk_windows<KW, KC, kWPT>(lds, k, [&](int j, bool good, u64 h) {
+        const u64 p = p0 + j;
+        if (p < nwindows) {
+            out[p] = good ? h : 0;
+            if (!good && my_bad == ~0ULL) my_bad = p;
+        }
+    });
+    if (my_bad != ~0ULL) atomicMin(first_bad, my_bad);
+}
+
+// ---- validity-only kernel for skip_bad_kmers == False over a multi-record stream -------------------
+// Finds the smallest stream position q of an invalid byte that lies INSIDE a record of length
+// >= k (separators and records too short to have a window do not raise, lib.rs:593-596 only
+// fires for a window that exists).  rec_off[r] = stream offset of record r, rec_off[nrec] = end;
+// record r spans [rec_off[r], rec_off[r+1] - 1) and is followed by its separator byte.
+__global__ __launch_bounds__(kBlock) void first_bad_byte_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
+                                                                const u64 *__restrict__ rec_off, u64 nrec, u64 *first_bad_q) {
+    const u64 base = ((u64)blockIdx.x * kBlock + threadIdx.x) * 16ULL;
+    if (base >= nbytes) return;
+    unsigned char b[16];
+    if (base + 16 <= nbytes) *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(stream + base);
+    else
+        for (int i = 0; i < 16; ++i) b[i] = base + i < nbytes ? stream[base + i] : (unsigned char)'A';
+    u64 best = ~0ULL;
+    for (int i = 0; i < 16; ++i) {
+        if (base_code(b[i]) < 4) continue;
+        const u64 q = base + i;
+        // record holding q: largest r with rec_off[r] <= q
+        u64 lo = 0, hi = nrec;  // invariant rec_off[lo] <= q < rec_off[hi]
+        while (hi - lo > 1) {
+            u64 mid = (lo + hi) >> 1;
+            if (rec_off[mid] <= q) lo = mid; else hi = mid;
+        }
+        const u64 start = rec_off[lo], end = rec_off[lo + 1] - 1;  // end = separator position
+        if (q < end && end - start >= (u64)k) { best = q; break; }
+    }
+    if (best != ~0ULL) atomicMin(first_bad_q, best);
+}
+
+// ---- the hot kernel: windows -> canonical hash -> scatter-increment -------------------------------
+// consume's loop body (lib.rs:586-600) for every window of the stream at once.
+template <int KW, int KC>
+__global__ __launch_bounds__(kBlock) void count_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
+                                                               TableView table, u64 *counters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kTile + kHaloMax + 16];
+    __shared__ u64 s_counted, s_new;
+    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
+    const u64 tile_base = (u64)blockIdx.x * kTile;
+    stage_tile<kBlock, kTile>(stream, nbytes, tile_base, k, lds);
+    const int lane = threadIdx.x & 63;
+    int counted = 0;  // signed: a leader whose folded add spills takes back the folded lanes' tallies
+    int newkeys = 0;
+    walk_windows<KW, KC, kWPT>(lds, k, [&](int, bool good, u64 h) {
+        bool active = good && h != 0;  // lib.rs:589: a hash of 0 is skipped and not tallied
+        u64 c = 1;
+        int tally = 0;
+        // Wavefront combining: lanes whose hash equals the first active lane's hash fold into
+        // one add.  Tandem repeats and homopolymers put the same k-mer in every lane at once
+        // (lanes are kWPT windows apart), which would otherwise serialise on one HBM atomic.
+        const u64 act = __ballot(active);
+        if (act) {
+            const int leader = __ffsll((long long)act) - 1;
+            const u64 hl = read_lane64(h, leader);
+            const u64 same = __ballot(active && h == hl);
+            if (same != (1ULL << leader)) {
+                if (lane == leader) c = (u64)__popcll(same);
+                else if ((same >> lane) & 1ULL) { active = false; tally = 1; }
+            }
+        }
+        if (active) {
+            const AddResult r = table_add<false>(table, h, c);
+            // spilled entries are tallied when the host replays them: a leader whose folded
+            // add spilled also takes back the folded lanes' tallies (the replay adds c)
+            tally = r.spilled ? 1 - (int)c : 1;
+            newkeys += r.claimed ? 1 : 0;
+        }
+        counted += tally;
+    });
+    u64 wc = wave_sum((u64)(long long)counted), wn = wave_sum((u64)newkeys);
+    if (lane == 0) { atomicAdd(&s_counted, wc); atomicAdd(&s_new, wn); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_counted) atomicAdd(shard + CTR_COUNTED, s_counted);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+    }
+}
+
+}  // namespace kct
