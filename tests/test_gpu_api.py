@@ -234,3 +234,30 @@ def test_store_kmers(KCT, capfd):
     a.save(f)
     r = KCT.load(f)
     assert r.store_kmers and r.unhash(r.hash_kmer("ATGCA")) == "ATGCA" and r.dump_kmers(sortkeys=True) == a.dump_kmers(sortkeys=True)
+
+
+# ---- the boundary from plain C (what a foreign-language binding sees) ---------------------------------------
+def test_c_program_through_the_abi(tmp_path):
+    import os
+    import subprocess
+
+    import oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_abi_example"
+    libdir = os.path.join(root, "oxli_amd", "csrc")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi_example.c"),
+                    "-L", libdir, "-lkct_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    rng = random.Random(99)
+    seq = "".join(rng.choice("ACGTACGTN") for _ in range(5000))
+    k = 4
+    out = subprocess.run([str(exe), str(k), seq], check=True, capture_output=True, text=True).stdout.splitlines()
+    ref = oracle.OracleTable(k)
+    n = ref.consume(seq)
+    ref2 = oracle.OracleTable(k)
+    ref2.consume(seq)
+    added, fresh = ref.add(ref2)
+    keys, counts = ref.dump_arrays()
+    assert out[0] == f"n {n} {n}" and out[1] == f"added {added} new {fresh}"
+    assert out[2] == f"len {len(ref)}" and out[3] == f"sum {ref.sum_counts}" and out[4] == f"consumed {ref.consumed}"
+    assert out[5:5 + keys.size] == [f"{h} {c}" for h, c in zip(keys.tolist(), counts.tolist())]
+    assert out[-1] == "error_mode status 3 position 1"      # KCT_ERR_BAD_KMER after one good 4-mer (ACGT | CGTN is bad)
