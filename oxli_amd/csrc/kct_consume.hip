@@ -36,7 +36,6 @@ struct PartitionLauncher {
     }
 };
 
-// Replays a spill list (already copied to d_aux2) after growing; adds what it counted to *n_out.
 // The partitioned path pays 16 B (one level) or 32 B (two levels) of streaming scratch traffic per
 // k-mer plus 32 B per table slot per pass; the direct path pays one memory-side atomic per k-mer.
 // It wins once a pass brings a fair fraction as many windows as the table has slots.

@@ -174,6 +174,7 @@ kct_status maybe_grow(kct_table *t) {
     return KCT_OK;
 }
 
+// Replays a spill list (already copied to d_aux2) after growing; adds what it counted to *n_out.
 kct_status replay_spill(kct_table *t, u64 spilled, u64 *n_out) {
     KCT_TRY(grow_to(t, next_pow2((u64)((double)(t->n_keys + spilled) / kMaxLoad) + 1)));
     u64 tl[4] = {0, 0, 0, 0};
