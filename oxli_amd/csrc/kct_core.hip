@@ -92,6 +92,14 @@ kct_status alloc_slots(int, u64 cap, hipStream_t stream, du64 **out) {
     return KCT_OK;
 }
 
+// A spill list counts OCCURRENCES of the keys that found no room, not distinct keys, so sizing the new table
+// for all of them can overshoot by the coverage of the data.  Grow by at most 4x per step; what still does
+// not fit spills again and the caller's loop grows once more.
+u64 spill_growth_target(const kct_table *t, u64 spilled) {
+    const u64 want = next_pow2((u64)((double)(t->n_keys + spilled) / kMaxLoad) + 1);
+    return std::max<u64>(2 * t->cap, std::min<u64>(want, 4 * t->cap));
+}
+
 int merge_grid(u64 n) { return (int)std::min<u64>((n + kct::kBlock - 1) / kct::kBlock, 256 * 8); }
 
 // Folds n (hash, count) pairs into the table, growing and replaying the spill list until every
@@ -117,7 +125,7 @@ kct_status merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u
         // the table is too full for these keys: move the spill list aside, grow, replay it
         KCT_TRY(t->d_aux2.reserve(spilled * 16));
         HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
-        KCT_TRY(grow_to(t, next_pow2((u64)((double)(t->n_keys + spilled) / kMaxLoad) + 1)));
+        KCT_TRY(grow_to(t, spill_growth_target(t, spilled)));
         d_keys = (const du64 *)t->d_aux2.p;
         d_counts = d_keys + 1;
         stride = 2;
@@ -176,7 +184,7 @@ kct_status maybe_grow(kct_table *t) {
 
 // Replays a spill list (already copied to d_aux2) after growing; adds what it counted to *n_out.
 kct_status replay_spill(kct_table *t, u64 spilled, u64 *n_out) {
-    KCT_TRY(grow_to(t, next_pow2((u64)((double)(t->n_keys + spilled) / kMaxLoad) + 1)));
+    KCT_TRY(grow_to(t, spill_growth_target(t, spilled)));
     u64 tl[4] = {0, 0, 0, 0};
     KCT_TRY(merge_pairs(t, (const du64 *)t->d_aux2.p, (const du64 *)t->d_aux2.p + 1, spilled, 2, tl));
     *n_out += tl[kct::CTR_TOTAL_ADDED];
