@@ -164,6 +164,16 @@ KCT_API kct_status kct_export_by_owner_device(kct_table *t, uint32_t nparts, voi
                                       uint64_t *n_out);
 KCT_API kct_status kct_merge_pairs_device(kct_table *t, const void *d_pairs, size_t n, uint64_t *total_added, uint64_t *new_keys);
 
+/* Deferred mode (off by default).  The reference is called once per record; one device pass per 150 bp
+ * read is launch-bound (~80 us).  With deferred mode on, kct_consume(skip_bad != 0) only appends the record
+ * to a pinned host buffer and returns; buffered records are counted in ONE device pass when the buffer
+ * (64 MiB) fills or when any other call needs the table (get, len, dump, add, ...), so every read still
+ * observes every earlier write.  *n_out then comes from a host-side scan for valid windows (the same
+ * all-ACGT rule the device applies); it differs from the reference's n only if a window's true hash is 0
+ * (probability 2^-64 per window).  Hashing and counting still happen on the device only.  Error mode
+ * (skip_bad == 0) is never deferred. */
+KCT_API kct_status kct_set_deferred(kct_table *t, int on);
+
 /* Which device path bulk ingest uses: 0 = chosen per pass (default), 1 = direct path only (one
  * HBM atomic per k-mer), 2 = partitioned path whenever the table geometry allows (radix-partition
  * the hashes by 128-KiB table block, count each block in LDS).  Results are identical; this

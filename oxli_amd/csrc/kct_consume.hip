@@ -238,6 +238,35 @@ kct_status stage_single(kct_table *t, const char *seq, size_t len) {
     return upload_stream(t, len);
 }
 
+// ---- deferred mode -------------------------------------------------------------------------------------------
+constexpr size_t kPendingBytes = (size_t)64 << 20;
+
+// Valid k-windows of one record: the host-side twin of the device's window rule (all k bytes in ACGTacgt).
+// Used only for the number deferred consume() returns; the counting itself happens on the device at flush.
+u64 host_valid_windows(const unsigned char *s, size_t len, size_t k) {
+    static const struct Lut { bool ok[256]; Lut() { for (bool &b : ok) b = false; for (unsigned char c : {'A','C','G','T','a','c','g','t'}) ok[c] = true; } } lut;
+    u64 n = 0;
+    size_t run = 0;
+    for (size_t i = 0; i < len; ++i) {
+        run = lut.ok[s[i]] ? run + 1 : 0;
+        n += run >= k;
+    }
+    return n;
+}
+
+kct_status flush_pending(kct_table *t) {
+    const size_t used = t->pending_used;
+    if (!used) return KCT_OK;
+    t->pending_used = 0;  // consume_stream -> ... -> use() must not re-enter
+    t->pending_records = 0;
+    const size_t padded = (used + 15) & ~(size_t)15;
+    memset((char *)t->h_pending.p + used, '\n', padded + 16 - used);
+    KCT_TRY(t->d_stream.reserve(padded + 16));
+    HIP_TRY(hipMemcpyAsync(t->d_stream.p, t->h_pending.p, padded + 16, hipMemcpyHostToDevice, t->stream));
+    u64 n = 0;
+    return consume_stream(t, (const unsigned char *)t->d_stream.p, used, &n);
+}
+
 // hashes of all windows of the staged stream [0, nbytes) into d_aux; returns first bad window index
 kct_status hash_stream(kct_table *t, u64 nbytes, u64 nwin, u64 *first_bad) {
     KCT_TRY(t->d_aux.reserve(nwin * 8));
@@ -309,6 +338,24 @@ kct_status kct_get(kct_table *t, const char *kmer, size_t len, uint64_t *count_o
 }
 
 kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out) {
+    if (t && t->deferred && skip_bad && len + 64 < kPendingBytes / 2) {
+        // deferred mode: buffer the record, answer from the host-side validity scan, count later
+        KCT_TRY(use_device(t));
+        if ((!seq && len) || !n_out) { set_err("null argument"); return KCT_ERR_ARG; }
+        *n_out = 0;
+        if (len >= t->k) {
+            KCT_TRY(t->h_pending.reserve(kPendingBytes + 64));
+            if (t->pending_used + len + 1 > kPendingBytes) KCT_TRY(flush_pending(t));
+            char *dst = (char *)t->h_pending.p + t->pending_used;
+            memcpy(dst, seq, len);
+            dst[len] = '\n';
+            t->pending_used += len + 1;
+            t->pending_records += 1;
+            *n_out = host_valid_windows((const unsigned char *)seq, len, t->k);
+        }
+        t->consumed += len;
+        return KCT_OK;
+    }
     KCT_TRY(use(t));
     if ((!seq && len) || !n_out) { set_err("null argument"); return KCT_ERR_ARG; }
     *n_out = 0;

@@ -30,9 +30,15 @@ void prof_collect(kct_table *t) {
     t->prof_pending.clear();
 }
 
-kct_status use(kct_table *t) {
+kct_status use_device(kct_table *t) {
     if (!t) { set_err("null table handle"); return KCT_ERR_ARG; }
     HIP_TRY(hipSetDevice(t->device));
+    return KCT_OK;
+}
+
+kct_status use(kct_table *t) {
+    KCT_TRY(use_device(t));
+    if (t->pending_used) KCT_TRY(flush_pending(t));  // reads must observe every earlier consume()
     return KCT_OK;
 }
 
@@ -275,13 +281,14 @@ void kct_destroy(kct_table *t) {
     t->d_stream.release(); t->d_spill.release(); t->d_aux.release(); t->d_aux2.release();
     t->d_scratch.release(); t->d_regions.release(); t->d_irr.release(); t->d_sort.release();
     t->d_scratch2.release(); t->d_regions2.release(); t->d_irr2.release();
-    t->h_stage.release();
+    t->h_stage.release(); t->h_pending.release();
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
 }
 
 kct_status kct_clear(kct_table *t) {
-    KCT_TRY(use(t));
+    KCT_TRY(use_device(t));
+    t->pending_used = 0; t->pending_records = 0;  // buffered records are forgotten with everything else
     t->lazy_empty = true;  // the memset is issued by materialize() only if something needs it
     t->n_keys = 0; t->consumed = 0; t->zero_present = false; t->zero_count = 0;
     return KCT_OK;
@@ -371,8 +378,8 @@ kct_status kct_sum_counts(kct_table *t, uint64_t *out) {
     return KCT_OK;
 }
 
-kct_status kct_consumed(kct_table *t, uint64_t *out) { KCT_TRY(use(t)); *out = t->consumed; return KCT_OK; }
-kct_status kct_add_consumed(kct_table *t, uint64_t delta) { KCT_TRY(use(t)); t->consumed += delta; return KCT_OK; }
+kct_status kct_consumed(kct_table *t, uint64_t *out) { KCT_TRY(use_device(t)); *out = t->consumed; return KCT_OK; }
+kct_status kct_add_consumed(kct_table *t, uint64_t delta) { KCT_TRY(use_device(t)); t->consumed += delta; return KCT_OK; }
 uint8_t kct_ksize(const kct_table *t) { return t ? t->k : 0; }
 kct_status kct_capacity(kct_table *t, uint64_t *slots_out) { KCT_TRY(use(t)); *slots_out = t->cap; return KCT_OK; }
 
@@ -561,6 +568,12 @@ kct_status kct_set_stream(kct_table *t, void *hip_stream) {
 }
 
 void *kct_get_stream(kct_table *t) { return t ? (void *)t->stream : nullptr; }
+
+kct_status kct_set_deferred(kct_table *t, int on) {
+    KCT_TRY(use(t));  // flushes what is buffered
+    t->deferred = on != 0;
+    return KCT_OK;
+}
 
 kct_status kct_set_path(kct_table *t, int mode) {
     KCT_TRY(use(t));

@@ -100,6 +100,13 @@ struct kct_table {
     int block_bits = 0;     // log2(slots per probing block) = min(13, log2 cap)
     bool lazy_empty = false;  // kct_clear() was called and the memset has not been issued yet
     int num_cus = 256;
+    // Opt-in deferred mode (kct_set_deferred): per-record consume() calls only append to a pinned host buffer
+    // and return; the buffered records are counted in one device pass when the buffer fills or anything reads
+    // the table.  The k-mer count returned to the caller comes from a host-side validity scan.
+    bool deferred = false;
+    kcth::PinnedBuf h_pending;
+    size_t pending_used = 0;
+    u64 pending_records = 0;
     bool auto_sized = true; // no capacity hint / reserve yet: bulk ingest ramps its launch size up with the table
     int ablate = 0;         // KCT_ABLATE at create time: measurement-only switches that skip work (results invalid)
     bool debug = false;     // KCT_DEBUG at create time: one stderr line per partitioned pass
@@ -149,7 +156,9 @@ struct ProfScope {
 };
 
 void prof_collect(kct_table *t);
-kct_status use(kct_table *t);
+kct_status use(kct_table *t);         // select the device AND count whatever deferred mode has buffered
+kct_status use_device(kct_table *t);  // select the device only
+kct_status flush_pending(kct_table *t);
 kct::TableGeom geom(const kct_table *t);
 kct::TableView view(kct_table *t, u64 spill_cap);
 int log2_u64(u64 v);

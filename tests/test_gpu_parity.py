@@ -667,3 +667,62 @@ def test_multi_chunk_stream_and_large_table_paths(KCT):
     assert len(big) == len(whole) and big.sum_counts == n
     bk, bc = big.dump_arrays(1)
     assert np.array_equal(bk, wk) and np.array_equal(bc, wc)
+
+
+# ---- deferred mode: per-record consume() buffered on the host, counted in one device pass ------------
+@pytest.mark.parametrize("k", [4, 21, 33, 70])
+def test_deferred_consume_matches_oracle(KCT, k):
+    rng = random.Random(900 + k)
+    dev, ref = KCT(k, deferred=True), OracleTable(k)
+    plain = KCT(k)
+    for i in range(400):
+        kind = rng.random()
+        if kind < 0.1:
+            s = rand_dna(rng, rng.randrange(0, k))                      # shorter than k
+        elif kind < 0.4:
+            s = rand_dna(rng, rng.randrange(k, 4 * k + 40), "ACGTNacgtn-")  # bad bytes, lower case
+        else:
+            s = rand_dna(rng, rng.randrange(k, 300))
+        n = dev.consume(s, skip_bad_kmers=True)
+        assert n == ref.consume(s, skip_bad_kmers=True) == plain.consume(s, skip_bad_kmers=True), (i, s)
+        if i % 97 == 0:  # a read in the middle must see everything consumed so far
+            probe = rand_dna(rng, k)
+            assert dev.get(probe) == ref.get(probe)
+            assert len(dev) == len(ref)
+    assert_same_table(dev, ref)
+
+
+def test_deferred_error_mode_and_clear(KCT):
+    k = 9
+    dev, ref = KCT(k, deferred=True), OracleTable(k)
+    dev.consume("ACGTACGTACGTTTGA"); ref.consume("ACGTACGTACGTTTGA")
+    with pytest.raises(ValueError) as e_dev:
+        dev.consume("ACGTACGTACNTACGTACGT", skip_bad_kmers=False)
+    with pytest.raises(ValueError) as e_ref:
+        ref.consume("ACGTACGTACNTACGTACGT", skip_bad_kmers=False)
+    assert str(e_dev.value) == str(e_ref.value)
+    assert_same_table(dev, ref)      # the windows before the bad one were counted, like the reference
+    dev.consume("GGGGGGGGGGGGG")     # buffered ...
+    dev.clear()                      # ... and forgotten
+    assert len(dev) == 0 and dev.sum_counts == 0
+    dev.consume("GGGGGGGGGGGGG")
+    dev.set_deferred(False)          # switching off counts what is buffered
+    assert dev.get("GGGGGGGGG") == 5
+    other = KCT(k, deferred=True)
+    other.consume("GGGGGGGGGGGGG")
+    dev.add(other)                   # src's buffered records are part of src
+    assert dev.get("GGGGGGGGG") == 10
+
+
+def test_deferred_buffer_rollover(KCT):
+    # more than the 64 MiB pending buffer: flushes happen mid-stream, totals stay exact
+    k = 31
+    rng = np.random.default_rng(5)
+    read = "".join("ACGT"[i] for i in rng.integers(0, 4, 1 << 20))
+    dev = KCT(k, deferred=True)
+    total = 0
+    for i in range(70):
+        total += dev.consume(read[i:] if i else read)
+    per = [len(read) - i - k + 1 for i in range(70)]
+    assert total == sum(per) == dev.sum_counts
+    assert dev.get(read[100:100 + k]) >= 70

@@ -24,5 +24,10 @@ bench("count(kmer)", lambda i: t.count(kmer), 1000)
 bench("get(kmer)", lambda i: t.get(kmer), 1000)
 bench("get_hash", lambda i: t.get_hash(h), 1000)
 bench("count_hash", lambda i: t.count_hash(h), 1000)
+td = KmerCountTable(21, deferred=True)
+def deferred_pass(i):
+    td.consume(reads[i % len(reads)])
+bench("consume(150bp read), deferred", deferred_pass, 200000)
+t0 = time.perf_counter(); len(td); out["deferred flush (200000 reads)"] = {"us_total": (time.perf_counter() - t0) * 1e6}
 t0 = time.perf_counter(); n = t.consume_batch(reads); out["consume_batch(2000 reads)"] = {"us_total": (time.perf_counter() - t0) * 1e6}
 print(json.dumps(out, indent=1))
