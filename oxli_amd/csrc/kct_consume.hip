@@ -405,24 +405,51 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
             dst[w + n] = '\n';
         }
     };
+    KCT_TRY(t->d_stream.reserve(padded + 16));
     const unsigned hw = std::thread::hardware_concurrency();
     const size_t nthreads = stream_len >= (8u << 20) ? std::min<size_t>({(size_t)8, hw ? hw : 1, nrec}) : 1;
-    if (nthreads <= 1) pack_range(0, nrec);
-    else {
+    if (nthreads <= 1) {
+        pack_range(0, nrec);
+        if (!skip_bad) rec_off[nrec] = stream_len;
+        memset(dst + stream_len, '\n', padded + 16 - stream_len);
+        HIP_TRY(hipMemcpyAsync(t->d_stream.p, dst, padded, hipMemcpyHostToDevice, t->stream));
+    } else {
+        // The stream is cut into slices of records (by bytes: records may be ragged) that the packers take in
+        // order, round-robin; this thread uploads slice s as soon as it is packed, so the H2D copy runs under
+        // the packing of the slices behind it instead of after all of it.
+        const size_t nslices = std::min<size_t>(nrec, 4 * nthreads);
+        std::vector<size_t> cut(nslices + 1);
+        for (size_t i = 0; i <= nslices; ++i) {
+            const u64 lo = base0 + total * i / nslices;
+            cut[i] = i == nslices ? nrec : (size_t)(std::lower_bound(offsets, offsets + nrec, lo) - offsets);
+        }
+        cut[0] = 0;
+        std::vector<std::atomic<int>> ready(nslices);
+        for (auto &r : ready) r.store(0, std::memory_order_relaxed);
         std::vector<std::thread> pool;
-        for (size_t i = 0; i < nthreads; ++i) {
-            // split by bytes, not by record count: records may be ragged
-            const u64 lo = base0 + total * i / nthreads, hi = base0 + total * (i + 1) / nthreads;
-            const size_t r0 = (size_t)(std::lower_bound(offsets, offsets + nrec, lo) - offsets);
-            const size_t r1 = i + 1 == nthreads ? nrec : (size_t)(std::lower_bound(offsets, offsets + nrec, hi) - offsets);
-            if (r1 > r0) pool.emplace_back(pack_range, r0, r1);
+        for (size_t i = 0; i < nthreads; ++i)
+            pool.emplace_back([&, i]() {
+                for (size_t sl = i; sl < nslices; sl += nthreads) {
+                    if (cut[sl + 1] > cut[sl]) pack_range(cut[sl], cut[sl + 1]);
+                    ready[sl].store(1, std::memory_order_release);
+                }
+            });
+        hipError_t copy_err = hipSuccess;
+        for (size_t sl = 0; sl < nslices; ++sl) {
+            while (!ready[sl].load(std::memory_order_acquire)) std::this_thread::yield();
+            const u64 b0 = cut[sl] < nrec ? (offsets[cut[sl]] - base0) + cut[sl] : stream_len;
+            u64 b1 = cut[sl + 1] < nrec ? (offsets[cut[sl + 1]] - base0) + cut[sl + 1] : stream_len;
+            if (sl + 1 == nslices) {  // the tail slice carries the padding
+                if (!skip_bad) rec_off[nrec] = stream_len;
+                memset(dst + stream_len, '\n', padded + 16 - stream_len);
+                b1 = padded;
+            }
+            if (b1 > b0 && copy_err == hipSuccess)
+                copy_err = hipMemcpyAsync((char *)t->d_stream.p + b0, dst + b0, b1 - b0, hipMemcpyHostToDevice, t->stream);
         }
         for (auto &th : pool) th.join();
+        HIP_TRY(copy_err);
     }
-    const u64 w = stream_len;
-    if (!skip_bad) rec_off[nrec] = w;
-    memset(dst + w, '\n', padded + 16 - w);
-    KCT_TRY(upload_stream(t, stream_len));
 
     if (!skip_bad) {
         KCT_TRY(t->d_aux.reserve(off_bytes));

@@ -30,6 +30,18 @@ void prof_collect(kct_table *t) {
     t->prof_pending.clear();
 }
 
+void parallel_memcpy(void *dst, const void *src, size_t nbytes) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nthreads = nbytes >= ((size_t)8 << 20) ? std::min<size_t>(8, hw ? hw : 1) : 1;
+    if (nthreads <= 1) { if (nbytes) memcpy(dst, src, nbytes); return; }
+    std::vector<std::thread> pool;
+    for (size_t i = 0; i < nthreads; ++i) {
+        const size_t lo = (nbytes * i / nthreads) & ~(size_t)4095, hi = i + 1 == nthreads ? nbytes : (nbytes * (i + 1) / nthreads) & ~(size_t)4095;
+        if (hi > lo) pool.emplace_back([=]() { memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+    }
+    for (auto &th : pool) th.join();
+}
+
 kct_status use_device(kct_table *t) {
     if (!t) { set_err("null table handle"); return KCT_ERR_ARG; }
     HIP_TRY(hipSetDevice(t->device));
@@ -456,7 +468,10 @@ kct_status kct_dump(kct_table *t, uint64_t *hashes_out, uint64_t *counts_out, si
     *n_out = n;
     if (cap == 0 || n == 0) return KCT_OK;
     if (!hashes_out || !counts_out) { set_err("null argument"); return KCT_ERR_ARG; }
-    std::vector<u64> hk(n), hc(n);
+    // device -> pinned staging (full-rate D2H) -> the caller's arrays (several threads: the destination is
+    // usually freshly allocated, so the copy is page-fault bound)
+    KCT_TRY(t->h_stage.reserve(n_dev * 16 + 16));
+    const u64 *hk = (const u64 *)t->h_stage.p, *hc = hk + n_dev;
     if (n_dev) {
         // compact on the device, sort on the device (rocPRIM radix sort, stable), copy out
         KCT_TRY(t->d_aux.reserve(n_dev * 16));
@@ -479,23 +494,24 @@ kct_status kct_dump(kct_table *t, uint64_t *hashes_out, uint64_t *counts_out, si
                 if (kx_sort_pairs_u64(sc, dc, sk, dk, n_dev, t->d_sort.p, &tmp_bytes, t->stream) != 0) { set_err("rocprim radix sort failed"); return KCT_ERR_HIP; }
             } else { dk = sk; dc = sc; }
         }
-        HIP_TRY(hipMemcpyAsync(hk.data(), dk, n_dev * 8, hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipMemcpyAsync(hc.data(), dc, n_dev * 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync((void *)hk, dk, n_dev * 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync((void *)hc, dc, n_dev * 8, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
     }
-    if (t->zero_present) {  // hash 0 lives host-side: put it where the order wants it
-        size_t at = n_dev;
-        if (order == 1) at = 0;
-        else if (order == 2) {
-            at = 0;
-            while (at < n_dev && hc[at] < t->zero_count) ++at;  // smallest hash among equal counts
-        }
-        hk.insert(hk.begin() + at, 0); hk.pop_back();
-        hc.insert(hc.begin() + at, t->zero_count); hc.pop_back();
-    }
+    // hash 0 lives host-side: `at` is where the order wants it (n_dev = at the end / not present)
+    size_t at = n_dev;
+    if (t->zero_present && order == 1) at = 0;
+    if (t->zero_present && order == 2) at = (size_t)(std::lower_bound(hc, hc + n_dev, t->zero_count) - hc);  // smallest hash among equal counts
+    // output element i comes from staging element i (i < at), the zero key (i == at), staging element i - 1 (i > at)
     const size_t ncopy = std::min<size_t>(cap, n);
-    memcpy(hashes_out, hk.data(), ncopy * 8);
-    memcpy(counts_out, hc.data(), ncopy * 8);
+    const size_t head = std::min(ncopy, at);
+    parallel_memcpy(hashes_out, hk, head * 8);
+    parallel_memcpy(counts_out, hc, head * 8);
+    if (t->zero_present && at < ncopy) { hashes_out[at] = 0; counts_out[at] = t->zero_count; }
+    if (ncopy > at + 1) {
+        parallel_memcpy(hashes_out + at + 1, hk + at, (ncopy - at - 1) * 8);
+        parallel_memcpy(counts_out + at + 1, hc + at, (ncopy - at - 1) * 8);
+    }
     return KCT_OK;
 }
 

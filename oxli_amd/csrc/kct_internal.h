@@ -5,6 +5,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -157,6 +158,7 @@ struct ProfScope {
 
 void prof_collect(kct_table *t);
 kct_status use(kct_table *t);         // select the device AND count whatever deferred mode has buffered
+void parallel_memcpy(void *dst, const void *src, size_t nbytes);  // several threads above 8 MiB
 kct_status use_device(kct_table *t);  // select the device only
 kct_status flush_pending(kct_table *t);
 kct::TableGeom geom(const kct_table *t);

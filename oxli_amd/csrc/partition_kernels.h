@@ -107,6 +107,8 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     __shared__ __attribute__((aligned(16))) unsigned char lds[kTileBytes];
     __shared__ u32 tcodes[kTileWords];
     __shared__ unsigned short tvalid[kTileWords];
+    __shared__ u32 ascii4[KW == 0 ? 1 : 256];  // four packed bases -> four ASCII bytes
+    if constexpr (KW != 0) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
     const int P = 1 << a.pbits;
     const u32 D = (u32)(kRingEntries >> a.pbits), dmask = D - 1;
     for (int i = threadIdx.x; i < kRingEntries; i += kPartThreads) ring[i] = 0;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
             }
         };
         if constexpr (KW == 0) walk_windows<0, 0, kPartWPT>(lds, k, sink);
-        else walk_windows_encoded<KW, KC>(tcodes, tvalid, k, sink);
+        else walk_windows_encoded<KW, KC, true>(tcodes, tvalid, k, sink, ascii4);
         commit();
     }
     while (flush_lines(true)) {}  // drain: partial lines go out zero-padded; repeat while the list was too short
@@ -310,7 +312,7 @@ struct AggregateArgs {
     int nregions;        // source regions per block: K1's workgroups (one level) or 1 (two levels)
     int fresh;           // table known empty: start every block from zeros instead of loading it
     const u64 *overflow; // K1's abandon flag
-    int ablate;          // measurement only: bit 2 = no count add, bit 4 = loads only
+    int ablate;          // measurement only: bit 2 (4) = no count add, bit 4 (16) = loads only, bit 6 (64) = no streaming at all
     u64 *spill; u64 spill_cap; u64 *spill_n;
     u64 *counters;
 };
@@ -435,7 +437,8 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
         }
     };
     constexpr int kWaves = kPartThreads / 64;
-    if (a.nregions >= kWaves) {  // one level: many short regions, one wave each
+    if (a.ablate & 64) {
+    } else if (a.nregions >= kWaves) {  // one level: many short regions, one wave each
         for (int seg = wave; seg < a.nregions; seg += kWaves) {
             const u32 cnt = my_counts[seg];
             const u64 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;

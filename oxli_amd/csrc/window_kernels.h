@@ -80,8 +80,10 @@ __device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, in
 // codes[c] / valid[c] describe bases 16c .. 16c+15 of the tile.  The first window is assembled
 // directly from the packed words (no k-1 warm-up steps); the WPT-1 following bases come out of two
 // shift registers.  WPT must be 16 (one code word per thread).
-template <int KW, int KC, class Sink>
-__device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const unsigned short *valid, int k_rt, Sink &&sink) {
+// `lut` (LDS, kmer_device.h fill_ascii4_lut) switches the ASCII re-expansion to table look-ups.
+template <int KW, int KC, bool LUT = false, class Sink>
+__device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const unsigned short *valid, int k_rt, Sink &&sink,
+                                                     const u32 *lut = nullptr) {
     constexpr int WPT = 16, NW = 2 * KW + 1;  // code words covering bases 0 .. 15 + k
     const int k = KC > 0 ? KC : k_rt;
     u32 w[NW];
@@ -143,7 +145,7 @@ __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const uns
         if (good) {
             Packed<KW> c = less_eq(fw, rc) ? fw : rc;
             left_align(c, k);
-            h = hash_packed(c, k);
+            h = hash_packed<KW, LUT>(c, k, lut);
         }
         sink(j, good, h);
         if (j + 1 < WPT) {
