@@ -294,6 +294,7 @@ void kct_destroy(kct_table *t) {
     t->d_scratch.release(); t->d_regions.release(); t->d_irr.release(); t->d_sort.release();
     t->d_scratch2.release(); t->d_regions2.release(); t->d_irr2.release();
     t->h_stage.release(); t->h_pending.release();
+    for (auto &b : t->h_file) b.release();
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
 }

@@ -1,27 +1,112 @@
 // kct_ingest.hip -- FASTA / FASTQ file ingestion (kct_consume_file): the caller side of the path.
 #include "kct_internal.h"
 
+#include <deque>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 using namespace kcth;
 
 // ---- FASTA / FASTQ ingestion: the caller side of the path (README.md:89-99) ---------------------------
-// The reference delegates parsing to screed and calls consume() once per record.  Here a host
-// parser turns the file (plain or gzip) into record-stream chunks in pinned memory while a worker
-// thread uploads and counts the previous chunk, so parsing and device work overlap.  A record longer
-// than a chunk is cut with a (k-1)-base overlap, which keeps every window counted exactly once.
+// The reference delegates parsing to screed and calls consume() once per record.  Here host parsers
+// turn the file into record-stream chunks in pinned memory while ONE worker thread uploads and counts
+// the finished chunks (the table is not thread-safe), so parsing and device work overlap.
+//   * plain files are mapped and cut into segments that several parser threads take in turn; a thread
+//     starts at the first record start at or after its segment's first byte and stops at the first record
+//     start at or after the segment's end, so every record is parsed by exactly one thread.  Records are
+//     independent, so the chunks can be counted in any order;
+//   * gzip files are inflated and parsed by the calling thread (inflate is the bottleneck).
+// A record longer than a chunk is cut with a (k-1)-base overlap, which keeps every window counted
+// exactly once.
 namespace {
 
 struct FileChunk {
-    PinnedBuf host;
-    DevBuf dev;
+    PinnedBuf *host = nullptr;
     size_t used = 0;
+    bool in_flight = false;
 };
 
-struct RecordParser {
+// Hands finished chunks to the worker thread and waits for buffers to come back.
+struct ChunkQueue {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<FileChunk *> q;
+    bool done = false;
+    kct_status status = KCT_OK;  // first failure of the worker (or of a parser): everyone stops
+    std::string msg;
+    u64 counted = 0;
+
+    void submit(FileChunk *c) {
+        { std::lock_guard<std::mutex> lk(mu); c->in_flight = true; q.push_back(c); }
+        cv.notify_all();
+    }
+    void wait_free(FileChunk *c) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !c->in_flight; });
+    }
+    bool failed() { std::lock_guard<std::mutex> lk(mu); return status != KCT_OK; }
+    void fail(kct_status st, const char *m) {
+        { std::lock_guard<std::mutex> lk(mu); if (status == KCT_OK) { status = st; msg = m; } }
+        cv.notify_all();
+    }
+};
+
+// Appends records to a pair of chunk buffers; a full buffer goes to the queue.
+struct ChunkWriter {
+    ChunkQueue *queue;
+    FileChunk chunk[2];
+    int cur = 0;
+    size_t cap, k;
+    unsigned char *out;
+    size_t used = 0, rec_len = 0;  // rec_len = bases of the current record already in this chunk
+    u64 records = 0, bases = 0;
+
+    ChunkWriter(ChunkQueue *q, PinnedBuf *a, PinnedBuf *b, size_t chunk_cap, size_t ksize) : queue(q), cap(chunk_cap), k(ksize) {
+        chunk[0].host = a; chunk[1].host = b;
+        out = (unsigned char *)a->p;
+    }
+    void flush(bool mid_record) {
+        unsigned char tail[256];  // the last k-1 bases of an unfinished record open the next chunk
+        size_t ntail = 0;
+        if (mid_record) { ntail = std::min(rec_len, k - 1); memcpy(tail, out + used - ntail, ntail); }
+        chunk[cur].used = used;
+        queue->submit(&chunk[cur]);
+        cur ^= 1;
+        queue->wait_free(&chunk[cur]);
+        out = (unsigned char *)chunk[cur].host->p;
+        memcpy(out, tail, ntail);
+        used = ntail;
+        rec_len = ntail;
+    }
+    void emit(const unsigned char *p, size_t n) {  // sequence bytes of the current record
+        while (n) {
+            if (used + 1 >= cap) flush(true);
+            const size_t take = std::min(n, cap - 1 - used);
+            memcpy(out + used, p, take);
+            used += take; rec_len += take; p += take; n -= take; bases += take;
+        }
+    }
+    void end_record() {
+        if (used + 1 >= cap) flush(true);
+        out[used++] = '\n';
+        rec_len = 0;
+        ++records;
+    }
+    void finish() {
+        if (used) { chunk[cur].used = used; queue->submit(&chunk[cur]); used = 0; }
+        queue->wait_free(&chunk[0]);
+        queue->wait_free(&chunk[1]);
+    }
+};
+
+// Byte sources: a gzip (or plain) stream read through zlib, or a mapped file.
+struct GzSource {
     gzFile f = nullptr;
     std::vector<unsigned char> buf;
     size_t pos = 0, end = 0;
     bool eof = false;
-    int fmt = 0;  // '>' FASTA, '@' FASTQ, 0 unknown yet
     bool fill() {
         if (eof) return false;
         int n = gzread(f, buf.data(), (unsigned)buf.size());
@@ -30,8 +115,106 @@ struct RecordParser {
         return true;
     }
     int peek() { if (pos >= end && !fill()) return -1; return buf[pos]; }
-    int get() { int c = peek(); if (c >= 0) ++pos; return c; }
-    void skip_line() { int c; while ((c = get()) >= 0 && c != '\n') {} }
+    bool span(const unsigned char *&b, size_t &avail) { if (pos >= end && !fill()) return false; b = buf.data() + pos; avail = end - pos; return true; }
+    void advance(size_t n) { pos += n; }
+    size_t offset() const { return 0; }  // unused: one parser, no segment end
+};
+
+struct MemSource {
+    const unsigned char *base, *p, *end;
+    int peek() { return p < end ? *p : -1; }
+    bool span(const unsigned char *&b, size_t &avail) { if (p >= end) return false; b = p; avail = (size_t)(end - p); return true; }
+    void advance(size_t n) { p += n; }
+    size_t offset() const { return (size_t)(p - base); }
+};
+
+template <class Src>
+void skip_line(Src &s) {
+    const unsigned char *b; size_t avail;
+    while (s.span(b, avail)) {
+        const unsigned char *nl = (const unsigned char *)memchr(b, '\n', avail);
+        s.advance(nl ? (size_t)(nl - b) + 1 : avail);
+        if (nl) return;
+    }
+}
+
+// copies the rest of the current line (without CR/LF) into the record; returns its length
+template <class Src>
+size_t emit_line(Src &s, ChunkWriter &w) {
+    size_t total = 0;
+    const unsigned char *b; size_t avail;
+    while (s.span(b, avail)) {
+        const unsigned char *nl = (const unsigned char *)memchr(b, '\n', avail);
+        const size_t n = nl ? (size_t)(nl - b) : avail;
+        size_t m = n;
+        if (m && b[m - 1] == '\r') --m;
+        w.emit(b, m); total += m;
+        s.advance(n + (nl ? 1 : 0));
+        if (nl) break;
+    }
+    return total;
+}
+
+// Parses records until the source ends or (segmented sources) a record would start at or after `stop`.
+// `fmt` is '>' or '@'.  Returns false (with set_err) on a malformed file.
+template <class Src>
+bool parse_records(Src &s, ChunkWriter &w, int fmt, size_t stop, ChunkQueue &queue, const char *path) {
+    int c;
+    u64 seen = 0;
+    while ((c = s.peek()) >= 0) {
+        if (c == '\n' || c == '\r' || c == ' ' || c == '\t') { s.advance(1); continue; }
+        if (s.offset() >= stop) break;
+        if (c != fmt) { set_err("%s: malformed record header near record %llu", path, (unsigned long long)w.records); return false; }
+        skip_line(s);  // header
+        size_t seq_len = 0;
+        if (fmt == '>') {
+            while ((c = s.peek()) >= 0 && c != '>') seq_len += emit_line(s, w);
+        } else {
+            while ((c = s.peek()) >= 0 && c != '+') seq_len += emit_line(s, w);
+            skip_line(s);  // '+' line
+            size_t q = 0;  // quality: as many characters as the sequence had
+            const unsigned char *b; size_t avail;
+            while (q < seq_len && s.span(b, avail)) {
+                size_t i = 0;
+                for (; i < avail && q < seq_len; ++i) q += (b[i] != '\n' && b[i] != '\r');
+                s.advance(i);
+            }
+            skip_line(s);
+        }
+        w.end_record();
+        if ((++seen & 1023) == 0 && queue.failed()) return true;  // the worker failed: stop early, its error is reported
+    }
+    return true;
+}
+
+// First record start at or after `from` in a mapped file (file size if there is none).
+size_t find_record_start(const unsigned char *base, size_t size, size_t from, int fmt) {
+    if (from == 0) return 0;
+    if (from >= size) return size;
+    // line starts at or after `from`: one after every '\n' at or after from - 1
+    const unsigned char *p = base + from - 1, *end = base + size;
+    auto line_end = [&](const unsigned char *q) { const unsigned char *nl = (const unsigned char *)memchr(q, '\n', (size_t)(end - q)); return nl ? nl : end; };
+    while (p < end) {
+        const unsigned char *nl = (const unsigned char *)memchr(p, '\n', (size_t)(end - p));
+        if (!nl || nl + 1 >= end) return size;
+        const unsigned char *ls = nl + 1;
+        if (*ls == (unsigned char)fmt) {
+            if (fmt == '>') return (size_t)(ls - base);
+            // FASTQ: '@' may also open a quality line.  A header is followed by a sequence line and a '+' line;
+            // a quality line is followed by the next header and ITS sequence line, which never starts with '+'.
+            const unsigned char *l1 = line_end(ls);                       // end of the candidate header
+            const unsigned char *l2 = l1 < end ? line_end(l1 + 1) : end;  // end of the sequence line
+            if (l2 < end && l2 + 1 < end && l2[1] == '+') return (size_t)(ls - base);
+        }
+        p = ls;
+    }
+    return size;
+}
+
+struct Mapping {
+    const unsigned char *p = nullptr;
+    size_t size = 0;
+    ~Mapping() { if (p) munmap((void *)p, size); }
 };
 
 }  // namespace
@@ -44,152 +227,124 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
     *n_total = 0;
     if (n_records) *n_records = 0;
     if (n_bases) *n_bases = 0;
-    RecordParser ps;
-    ps.f = gzopen(path, "rb");
-    if (!ps.f) { set_err("cannot open %s", path); return KCT_ERR_ARG; }
-    gzbuffer(ps.f, 1 << 20);
-    ps.buf.resize(1 << 22);
-    const size_t k = t->k;
-    size_t chunk_cap = (size_t)64 << 20;  // stream bytes per chunk
-    if (const char *e = getenv("KCT_FILE_CHUNK")) chunk_cap = std::max<size_t>(1024, (size_t)atoll(e));  // tests shrink it to exercise record splitting
-    FileChunk chunks[2];
-    kct_status st = KCT_OK;
-    for (auto &c : chunks) {
-        if (st == KCT_OK) st = c.host.reserve(chunk_cap + 64);
-        if (st == KCT_OK) st = c.dev.reserve(chunk_cap + 64);
+
+    // plain or gzip?  Plain files of some size are mapped and parsed by several threads.
+    Mapping map;
+    bool gz = false;
+    {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) { set_err("cannot open %s", path); return KCT_ERR_ARG; }
+        struct stat sb;
+        unsigned char magic[2] = {0, 0};
+        const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+        if (regular && sb.st_size >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) gz = true;
+        if (regular && !gz && sb.st_size > 0) {
+            void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                map.p = (const unsigned char *)m; map.size = (size_t)sb.st_size;
+                (void)madvise(m, map.size, MADV_SEQUENTIAL);
+            }
+        }
+        close(fd);
     }
-    // worker: uploads and counts chunk `job` while the parser fills the other one
-    std::mutex mu;
-    std::condition_variable cv;
-    int job = -1;             // chunk index handed to the worker, -1 = none
-    bool done = false, busy = false;
-    kct_status worker_status = KCT_OK;
-    std::string worker_msg;
-    u64 counted = 0;
-    std::thread worker([&] {
+    const size_t k = t->k;
+    size_t chunk_cap = (size_t)16 << 20;  // stream bytes per chunk
+    if (const char *e = getenv("KCT_FILE_CHUNK")) chunk_cap = std::max<size_t>(1024, (size_t)atoll(e));  // tests shrink it to exercise record splitting
+    size_t segment = (size_t)8 << 20;     // file bytes a parser thread takes at a time
+    if (const char *e = getenv("KCT_FILE_SEGMENT")) segment = std::max<size_t>(64, (size_t)atoll(e));
+    const unsigned hw = std::thread::hardware_concurrency();
+    size_t nparsers = 1;
+    if (map.p) nparsers = std::max<size_t>(1, std::min<size_t>({(size_t)8, hw ? hw : 1, (map.size + segment - 1) / segment}));
+    if (const char *e = getenv("KCT_FILE_THREADS")) nparsers = map.p ? std::max<size_t>(1, std::min<size_t>(64, (size_t)atoll(e))) : 1;
+
+    // chunk buffers stay with the table: pinning memory costs more than parsing a small file
+    if (t->h_file.size() < 2 * nparsers) t->h_file.resize(2 * nparsers);
+    for (size_t i = 0; i < 2 * nparsers; ++i) KCT_TRY(t->h_file[i].reserve(chunk_cap + 64));
+    KCT_TRY(t->d_stream.reserve(chunk_cap + 64));
+
+    ChunkQueue queue;
+    std::thread worker([&] {  // uploads and counts finished chunks, one at a time
         (void)hipSetDevice(t->device);
         for (;;) {
-            int j;
+            FileChunk *c;
             {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return job >= 0 || done; });
-                if (job < 0 && done) return;
-                j = job; job = -1; busy = true;
+                std::unique_lock<std::mutex> lk(queue.mu);
+                queue.cv.wait(lk, [&] { return !queue.q.empty() || queue.done; });
+                if (queue.q.empty()) return;
+                c = queue.q.front(); queue.q.pop_front();
             }
-            FileChunk &c = chunks[j];
             kct_status ws = KCT_OK;
-            const size_t padded = (c.used + 15) & ~(size_t)15;
-            memset((char *)c.host.p + c.used, '\n', padded + 16 - c.used);
-            if (hipMemcpyAsync(c.dev.p, c.host.p, padded + 16, hipMemcpyHostToDevice, t->stream) != hipSuccess) { set_err("H2D copy failed"); ws = KCT_ERR_HIP; }
             u64 n = 0;
-            if (ws == KCT_OK) ws = consume_stream(t, (const unsigned char *)c.dev.p, c.used, &n);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                counted += n;
-                if (ws != KCT_OK && worker_status == KCT_OK) { worker_status = ws; worker_msg = g_err; }
-                busy = false;
+            if (!queue.failed()) {
+                const size_t padded = (c->used + 15) & ~(size_t)15;
+                memset((char *)c->host->p + c->used, '\n', padded + 16 - c->used);
+                if (hipMemcpyAsync(t->d_stream.p, c->host->p, padded + 16, hipMemcpyHostToDevice, t->stream) != hipSuccess) { set_err("H2D copy failed"); ws = KCT_ERR_HIP; }
+                if (ws == KCT_OK) ws = consume_stream(t, (const unsigned char *)t->d_stream.p, c->used, &n);
             }
-            cv.notify_all();
+            if (ws != KCT_OK) queue.fail(ws, g_err);
+            { std::lock_guard<std::mutex> lk(queue.mu); queue.counted += n; c->in_flight = false; }
+            queue.cv.notify_all();
         }
     });
-    auto submit = [&](int j) {  // hand chunk j to the worker once it is idle
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return job < 0 && !busy; });
-        job = j;
-        lk.unlock();
-        cv.notify_all();
-    };
-    int cur = 0;
+
     u64 records = 0, bases = 0;
-    unsigned char *out = (unsigned char *)chunks[cur].host.p;
-    size_t used = 0, rec_len = 0;  // rec_len = bases of the current record already emitted into this chunk run
-    auto flush = [&](bool mid_record) {
-        // keep the last k-1 bases of an unfinished record: they open the next chunk
-        unsigned char tail[256];
-        size_t ntail = 0;
-        if (mid_record) { ntail = std::min(rec_len, k - 1); memcpy(tail, out + used - ntail, ntail); }
-        chunks[cur].used = used;
-        submit(cur);
-        cur ^= 1;
-        // submit() returned once the worker was idle, i.e. the other buffer's chunk is finished: it is free
-        out = (unsigned char *)chunks[cur].host.p;
-        memcpy(out, tail, ntail);
-        used = ntail;
-        rec_len = ntail;
-    };
-    auto emit = [&](const unsigned char *p, size_t n) {  // append sequence bytes of the current record
-        while (n) {
-            if (used + 1 >= chunk_cap) flush(true);
-            const size_t take = std::min(n, chunk_cap - 1 - used);
-            memcpy(out + used, p, take);
-            used += take; rec_len += take; p += take; n -= take; bases += take;
-        }
-    };
-    auto end_record = [&] {
-        if (used + 1 >= chunk_cap) flush(true);
-        out[used++] = '\n';
-        rec_len = 0;
-        ++records;
-    };
-    // copies the rest of the current line (without CR/LF) into the record; returns its length
-    auto emit_line = [&]() -> size_t {
-        size_t total = 0;
-        for (;;) {
-            if (ps.pos >= ps.end && !ps.fill()) break;
-            const unsigned char *b = ps.buf.data() + ps.pos;
-            const size_t avail = ps.end - ps.pos;
-            const unsigned char *nl = (const unsigned char *)memchr(b, '\n', avail);
-            size_t n = nl ? (size_t)(nl - b) : avail;
-            size_t m = n;
-            if (m && b[m - 1] == '\r') --m;
-            emit(b, m); total += m;
-            ps.pos += n + (nl ? 1 : 0);
-            if (nl) break;
-        }
-        return total;
-    };
-    if (st == KCT_OK) {
-        int c;
-        while ((c = ps.peek()) >= 0) {
-            if (c == '\n' || c == '\r' || c == ' ' || c == '\t') { ps.get(); continue; }
-            if (ps.fmt == 0) {
-                if (c != '>' && c != '@') { set_err("%s: neither FASTA nor FASTQ (starts with 0x%02x)", path, c); st = KCT_ERR_ARG; break; }
-                ps.fmt = c;
-            }
-            if (c != ps.fmt) { set_err("%s: malformed record header near record %llu", path, (unsigned long long)records); st = KCT_ERR_ARG; break; }
-            ps.skip_line();  // header
-            size_t seq_len = 0;
-            if (ps.fmt == '>') {
-                while ((c = ps.peek()) >= 0 && c != '>') seq_len += emit_line();
-            } else {
-                while ((c = ps.peek()) >= 0 && c != '+') seq_len += emit_line();
-                ps.skip_line();  // '+' line
-                size_t q = 0;    // quality: as many characters as the sequence had
-                while (q < seq_len && ps.peek() >= 0) {
-                    int d = ps.get();
-                    if (d != '\n' && d != '\r') ++q;
+    kct_status st = KCT_OK;
+    if (map.p) {
+        size_t first = 0;
+        while (first < map.size && (map.p[first] == '\n' || map.p[first] == '\r' || map.p[first] == ' ' || map.p[first] == '\t')) ++first;
+        const int fmt = first < map.size ? map.p[first] : '>';
+        if (first < map.size && fmt != '>' && fmt != '@') { set_err("%s: neither FASTA nor FASTQ (starts with 0x%02x)", path, fmt); st = KCT_ERR_ARG; }
+        if (st == KCT_OK && first < map.size) {
+            const size_t nseg = (map.size + segment - 1) / segment;
+            std::atomic<size_t> next_seg{0};
+            std::mutex tally_mu;
+            auto parser = [&](size_t id) {
+                ChunkWriter w(&queue, &t->h_file[2 * id], &t->h_file[2 * id + 1], chunk_cap, k);
+                for (;;) {
+                    const size_t sg = next_seg.fetch_add(1);
+                    if (sg >= nseg || queue.failed()) break;
+                    const size_t lo = find_record_start(map.p, map.size, sg * segment, fmt);
+                    const size_t hi = sg + 1 == nseg ? map.size : find_record_start(map.p, map.size, (sg + 1) * segment, fmt);
+                    if (lo >= hi) continue;  // no record starts in this segment
+                    MemSource src{map.p, map.p + lo, map.p + map.size};
+                    if (!parse_records(src, w, fmt, hi, queue, path)) { queue.fail(KCT_ERR_ARG, g_err); break; }
                 }
-                ps.skip_line();
-            }
-            end_record();
+                w.finish();
+                std::lock_guard<std::mutex> lk(tally_mu);
+                records += w.records; bases += w.bases;
+            };
+            std::vector<std::thread> pool;
+            for (size_t i = 1; i < nparsers; ++i) pool.emplace_back(parser, i);
+            parser(0);
+            for (auto &th : pool) th.join();
         }
-        if (st == KCT_OK && used) { chunks[cur].used = used; submit(cur); }
+    } else {
+        GzSource src;
+        src.f = gzopen(path, "rb");
+        if (!src.f) { set_err("cannot open %s", path); st = KCT_ERR_ARG; }
+        else {
+            gzbuffer(src.f, 1 << 20);
+            src.buf.resize(1 << 22);
+            int c;
+            while ((c = src.peek()) >= 0 && (c == '\n' || c == '\r' || c == ' ' || c == '\t')) src.advance(1);
+            if (c >= 0 && c != '>' && c != '@') { set_err("%s: neither FASTA nor FASTQ (starts with 0x%02x)", path, c); st = KCT_ERR_ARG; }
+            if (st == KCT_OK && c >= 0) {
+                ChunkWriter w(&queue, &t->h_file[0], &t->h_file[1], chunk_cap, k);
+                if (!parse_records(src, w, c, ~(size_t)0, queue, path)) st = KCT_ERR_ARG;
+                w.finish();
+                records = w.records; bases = w.bases;
+            }
+            gzclose(src.f);
+        }
     }
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return job < 0 && !busy; });
-        done = true;
-    }
-    cv.notify_all();
+    { std::lock_guard<std::mutex> lk(queue.mu); queue.done = true; }
+    queue.cv.notify_all();
     worker.join();
-    gzclose(ps.f);
-    for (auto &c : chunks) { c.host.release(); c.dev.release(); }
-    if (st == KCT_OK && worker_status != KCT_OK) { st = worker_status; set_err("%s", worker_msg.c_str()); }
+    if (st == KCT_OK && queue.status != KCT_OK) { st = queue.status; set_err("%s", queue.msg.c_str()); }
     if (st != KCT_OK) return st;
     t->consumed += bases;
-    *n_total = counted;
+    *n_total = queue.counted;
     if (n_records) *n_records = records;
     if (n_bases) *n_bases = bases;
     return KCT_OK;
 }
-

@@ -121,6 +121,7 @@ struct kct_table {
     u64 *h_counters = nullptr;   // pinned mirror
     kcth::DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort, d_scratch2, d_regions2, d_irr2;
     kcth::PinnedBuf h_stage;
+    std::vector<kcth::PinnedBuf> h_file;  // kct_consume_file's chunk buffers (two per parser thread), kept between calls
 
     bool prof_on = false;
     std::vector<kcth::ProfEntry> prof;

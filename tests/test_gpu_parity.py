@@ -631,6 +631,43 @@ def test_consume_file_formats_match_oracle(KCT, tmp_path, monkeypatch):
         KCT(k).consume_file(str(tmp_path / "missing.fa"))
 
 
+def test_consume_file_parallel_parsers_match_oracle(KCT, tmp_path, monkeypatch):
+    """Plain files are mapped and cut into segments that several parser threads take in turn: every record must be
+    parsed exactly once wherever the cuts fall (tiny segments put cuts inside headers, sequences, quality lines)."""
+    rng = random.Random(77)
+    recs = [rand_dna(rng, rng.choice([0, 1, 20, 21, 22, 150, 700, 5000]), "ACGTACGTACGTNacgt") for _ in range(400)]
+    k = 21
+    ref = OracleTable(k)
+    n_ref = sum(ref.consume(r) for r in recs)
+    fa, facr, fq = tmp_path / "p.fa", tmp_path / "p_crlf.fa", tmp_path / "p.fq"
+    _write_fasta(fa, recs, width=60)
+    with open(facr, "wb") as f:                                    # CRLF line ends, blank lines, '>' inside headers
+        f.write(b"\r\n\r\n")
+        for i, s in enumerate(recs):
+            f.write(b">r%d >not a record > really\r\n" % i)
+            for j in range(0, len(s), 33):
+                f.write(s[j:j + 33].encode() + b"\r\n")
+            if i % 7 == 0:
+                f.write(b"\r\n")
+    with open(fq, "w") as f:                                       # quality lines that start with '@' and '+'
+        for i, s in enumerate(recs):
+            q = "".join(rng.choice("@+I#>") for _ in s)
+            f.write(f"@r{i} @x\n{s}\n+r{i}\n{q}\n")
+    for seg, threads in (("64", "5"), ("1000", "3"), ("40000", "8")):
+        monkeypatch.setenv("KCT_FILE_SEGMENT", seg)
+        monkeypatch.setenv("KCT_FILE_THREADS", threads)
+        monkeypatch.setenv("KCT_FILE_CHUNK", "30000")
+        for path in (fa, facr, fq):
+            dev = KCT(k)
+            assert dev.consume_file(str(path)) == n_ref, (path, seg)
+            assert dev.last_file_records == len(recs), (path, seg)
+            assert_same_table(dev, ref)
+    bad = tmp_path / "bad.fa"
+    bad.write_text("ACGT\n>r\nACGT\n")
+    with pytest.raises(RuntimeError, match="neither FASTA nor FASTQ"):
+        KCT(k).consume_file(str(bad))
+
+
 def test_multi_chunk_stream_and_large_table_paths(KCT):
     """Two scale checks that need no oracle run:
     (1) a 302 MB record stream crosses the 2^28-position launch chunk inside one consume_device call;
