@@ -164,6 +164,33 @@ KCT_API kct_status kct_export_by_owner_device(kct_table *t, uint32_t nparts, voi
                                       uint64_t *n_out);
 KCT_API kct_status kct_merge_pairs_device(kct_table *t, const void *d_pairs, size_t n, uint64_t *total_added, uint64_t *new_keys);
 
+/* ---- table analytics on the resident table (reference: lib.rs:197-267, 464-514, 610-655, 708-765) ------------
+ * Scans, reductions and table-against-table lookups run on the device; nothing is dumped to the host first. */
+
+/* min() / max() (lib.rs:492-514; both 0 for an empty table) and the sum of squared counts as f64, the
+ * magnitude term of cosine() (lib.rs:747-760).  Any output pointer may be NULL. */
+KCT_API kct_status kct_count_stats(kct_table *t, uint64_t *min_out, uint64_t *max_out, double *sum_squares_out);
+
+/* histo(zero=False) (lib.rs:464-488): the distinct count values in ascending order and how many keys have
+ * each.  *n_out = number of distinct values; at most `cap` are written. */
+KCT_API kct_status kct_histogram(kct_table *t, uint64_t *values_out, uint64_t *freq_out, size_t cap, uint64_t *n_out);
+
+/* mincut / maxcut (lib.rs:227-267): keep only keys with min_count <= count <= max_count; *removed_out = keys
+ * removed.  The survivors are re-inserted on the device (the probe layout has no tombstones). */
+KCT_API kct_status kct_retain_counts(kct_table *t, uint64_t min_count, uint64_t max_count, uint64_t *removed_out);
+
+/* drop_hash (lib.rs:213-224): remove one key if present; *removed_out = 0 or 1. */
+KCT_API kct_status kct_remove_hash(kct_table *t, uint64_t hash, uint64_t *removed_out);
+
+/* |keys(a) & keys(b)| and the dot product sum(count_a * count_b) over the common keys (u64, wrapping) --
+ * jaccard() and cosine() (lib.rs:708-765) are arithmetic on these and the tables' sizes.  Both tables must
+ * live on the same device. */
+KCT_API kct_status kct_compare(kct_table *a, kct_table *b, uint64_t *common_out, uint64_t *dot_out);
+
+/* union (op 0), intersection (1), difference a - b (2), symmetric difference (3) of the two key sets
+ * (lib.rs:610-655), in no particular order.  *n_out = size of the result; at most `cap` hashes are written. */
+KCT_API kct_status kct_set_op(kct_table *a, kct_table *b, int op, uint64_t *hashes_out, size_t cap, uint64_t *n_out);
+
 /* Deferred mode (off by default).  The reference is called once per record; one device pass per 150 bp
  * read is launch-bound (~80 us).  With deferred mode on, kct_consume(skip_bad != 0) only appends the record
  * to a pinned host buffer and returns; buffered records are counted in ONE device pass when the buffer

@@ -56,6 +56,12 @@ SIGNATURES = {
     "kct_export_by_owner_device": (ci, [vp, C.c_uint32, vp, sz, vp, u64p]),
     "kct_merge_pairs_device": (ci, [vp, vp, sz, u64p, u64p]),
     "kct_set_deferred": (ci, [vp, ci]),
+    "kct_count_stats": (ci, [vp, u64p, u64p, C.POINTER(C.c_double)]),
+    "kct_histogram": (ci, [vp, vp, vp, sz, u64p]),
+    "kct_retain_counts": (ci, [vp, u64, u64, u64p]),
+    "kct_remove_hash": (ci, [vp, u64, u64p]),
+    "kct_compare": (ci, [vp, vp, u64p, u64p]),
+    "kct_set_op": (ci, [vp, vp, ci, vp, sz, u64p]),
     "kct_set_path": (ci, [vp, ci]),
     "kct_set_stream": (ci, [vp, vp]),
     "kct_get_stream": (vp, [vp]),

@@ -7,6 +7,8 @@ them on the host.
 """
 import ctypes as C
 
+import math
+
 import numpy as np
 
 from . import _lib as L
@@ -343,32 +345,40 @@ class KmerCountTable:
         if self._hash_to_kmer is not None:
             self._hash_to_kmer = {}
 
-    # ---- table-wide reads beside the path: each is one device dump (compaction + radix sort) ----------
-    # followed by numpy on the (hash, count) arrays.  No hash or count is ever produced on the host.
+    # ---- table analytics: scans, reductions and table-against-table lookups on the resident table ---------
+    # (kct_analytics.hip).  No hash or count is ever produced on the host.
     def __iter__(self):
         """lib.rs:658-662: (hash, count) pairs.  The reference's order is HashMap order; here by hash."""
         keys, counts = self.dump_arrays(1)
         return iter(zip(keys.tolist(), counts.tolist()))
 
+    def _count_stats(self):
+        lo, hi, sq = C.c_uint64(), C.c_uint64(), C.c_double()
+        self._check(self._lib.kct_count_stats(self._h, C.byref(lo), C.byref(hi), C.byref(sq)))
+        return lo.value, hi.value, sq.value
+
     @property
     def min(self):
         """lib.rs:492-501 (0 for an empty table)."""
-        counts = self.dump_arrays(0)[1]
-        return int(counts.min()) if counts.size else 0
+        return self._count_stats()[0]
 
     @property
     def max(self):
         """lib.rs:505-514."""
-        counts = self.dump_arrays(0)[1]
-        return int(counts.max()) if counts.size else 0
+        return self._count_stats()[1]
 
     def histo(self, zero=True):
         """lib.rs:464-488: [(frequency, number of k-mers with that count)]."""
-        counts = self.dump_arrays(0)[1]
-        vals, freq = np.unique(counts, return_counts=True)
-        observed = dict(zip(vals.tolist(), freq.tolist()))
+        cap = 1 << 16
+        while True:
+            vals, freq, n = np.empty(cap, dtype=np.uint64), np.empty(cap, dtype=np.uint64), C.c_uint64()
+            self._check(self._lib.kct_histogram(self._h, vals.ctypes.data, freq.ctypes.data, cap, C.byref(n)))
+            if n.value <= cap:
+                break
+            cap = n.value
+        observed = dict(zip(vals[: n.value].tolist(), freq[: n.value].tolist()))
         if zero:
-            return [(f, observed.get(f, 0)) for f in range(0, (int(vals.max()) if vals.size else 0) + 1)]
+            return [(f, observed.get(f, 0)) for f in range(0, (max(observed) if observed else 0) + 1)]
         return sorted(observed.items())
 
     def dump_kmers(self, file=None, sortcounts=False, sortkeys=False):
@@ -390,24 +400,10 @@ class KmerCountTable:
             return []
         return pairs
 
-    # removal rebuilds the device table from the surviving pairs (cold path)
-    def _rebuild(self, keys, counts):
-        consumed = self.consumed
-        h2k = self._hash_to_kmer
-        self.clear()
-        self._hash_to_kmer = h2k
-        keys = np.ascontiguousarray(keys, dtype=np.uint64)
-        counts = np.ascontiguousarray(counts, dtype=np.uint64)
-        if keys.size:
-            self._check(self._lib.kct_merge_host(self._h, keys.ctypes.data, counts.ctypes.data, keys.size, None, None))
-        self._check(self._lib.kct_add_consumed(self._h, consumed))
-
+    # removal happens on the device: the survivors are compacted and re-inserted (kct_retain_counts / kct_remove_hash)
     def drop_hash(self, hashval):
         """lib.rs:213-224."""
-        keys, counts = self.dump_arrays(0)
-        keep = keys != np.uint64(int(hashval))
-        if not keep.all():
-            self._rebuild(keys[keep], counts[keep])
+        self._check(self._lib.kct_remove_hash(self._h, int(hashval), None))
 
     def drop(self, kmer):
         """lib.rs:197-210."""
@@ -415,61 +411,59 @@ class KmerCountTable:
 
     def mincut(self, min_count):
         """lib.rs:227-246: remove k-mers with count < min_count; returns how many were removed."""
-        keys, counts = self.dump_arrays(0)
-        keep = counts >= np.uint64(int(min_count))
-        removed = int((~keep).sum())
-        if removed:
-            self._rebuild(keys[keep], counts[keep])
-        return removed
+        removed = C.c_uint64()
+        self._check(self._lib.kct_retain_counts(self._h, int(min_count), 2 ** 64 - 1, C.byref(removed)))
+        return removed.value
 
     def maxcut(self, max_count):
         """lib.rs:249-267: remove k-mers with count > max_count."""
-        keys, counts = self.dump_arrays(0)
-        keep = counts <= np.uint64(int(max_count))
-        removed = int((~keep).sum())
-        if removed:
-            self._rebuild(keys[keep], counts[keep])
-        return removed
+        removed = C.c_uint64()
+        self._check(self._lib.kct_retain_counts(self._h, 0, int(max_count), C.byref(removed)))
+        return removed.value
 
-    def _hash_set(self):
-        return set(self.dump_arrays(0)[0].tolist())
+    def _set_op(self, other, op):
+        if not isinstance(other, KmerCountTable):
+            raise TypeError("argument 'other': expected KmerCountTable")
+        cap = len(self) if op in (1, 2) else len(self) + len(other)
+        out, n = np.empty(max(cap, 1), dtype=np.uint64), C.c_uint64()
+        self._check(self._lib.kct_set_op(self._h, other._h, op, out.ctypes.data, cap, C.byref(n)))
+        return set(out[: n.value].tolist())
 
     def union(self, other):
-        return self._hash_set() | other._hash_set()  # lib.rs:615-617
+        return self._set_op(other, 0)  # lib.rs:615-617
 
     def intersection(self, other):
-        return self._hash_set() & other._hash_set()  # lib.rs:619-624
+        return self._set_op(other, 1)  # lib.rs:619-624
 
     def difference(self, other):
-        return self._hash_set() - other._hash_set()  # lib.rs:626-631
+        return self._set_op(other, 2)  # lib.rs:626-631
 
     def symmetric_difference(self, other):
-        return self._hash_set() ^ other._hash_set()  # lib.rs:633-638
+        return self._set_op(other, 3)  # lib.rs:633-638
 
     __or__, __and__, __sub__, __xor__ = union, intersection, difference, symmetric_difference
 
+    def _compare(self, other):
+        common, dot = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.kct_compare(self._h, other._h, C.byref(common), C.byref(dot)))
+        return common.value, dot.value
+
     def jaccard(self, other):
         """lib.rs:708-722 (two empty tables are identical: 1.0)."""
-        a, b = self.dump_arrays(0)[0], other.dump_arrays(0)[0]
-        inter = np.intersect1d(a, b, assume_unique=True).size
-        uni = a.size + b.size - inter
+        inter = self._compare(other)[0]
+        uni = len(self) + len(other) - inter
         return 1.0 if uni == 0 else inter / uni
 
     def cosine(self, other):
-        """lib.rs:727-765: f64 arithmetic as in the reference (u64 dot product, f64 magnitudes)."""
-        ka, ca = self.dump_arrays(1)
-        kb, cb = other.dump_arrays(1)
-        if ka.size == 0 or kb.size == 0:
+        """lib.rs:727-765: u64 dot product over the common keys, f64 magnitudes."""
+        if len(self) == 0 or len(other) == 0:
             return 0.0
-        _, ia, ib = np.intersect1d(ka, kb, assume_unique=True, return_indices=True)
-        dot = int(np.sum(ca[ia].astype(object) * cb[ib].astype(object))) if ia.size else 0
-        ma = float(np.sqrt(np.sum(ca.astype(np.float64) ** 2)))
-        mb = float(np.sqrt(np.sum(cb.astype(np.float64) ** 2)))
+        dot = self._compare(other)[1]
+        ma, mb = math.sqrt(self._count_stats()[2]), math.sqrt(other._count_stats()[2])
         if ma == 0.0 or mb == 0.0:
             return 0.0
         return float(dot) / (ma * mb)
 
-    # ---- on-disk format (lib.rs:269-322): serde_json of the struct, gzip level 1 ------------------------
     def serialize_json(self):
         keys, counts = self.dump_arrays(1)
         import json

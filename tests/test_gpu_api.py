@@ -261,3 +261,82 @@ def test_c_program_through_the_abi(tmp_path):
     assert out[2] == f"len {len(ref)}" and out[3] == f"sum {ref.sum_counts}" and out[4] == f"consumed {ref.consumed}"
     assert out[5:5 + keys.size] == [f"{h} {c}" for h, c in zip(keys.tolist(), counts.tolist())]
     assert out[-1] == "error_mode status 3 position 1"      # KCT_ERR_BAD_KMER after one good 4-mer (ACGT | CGTN is bad)
+
+
+# ---- analytics on the device (kct_analytics.hip) against plain dict arithmetic --------------------------
+def _random_table(KCT, rng, n, kspace, with_zero, k=21):
+    t, d = KCT(k), {}
+    hashes = rng.integers(1, kspace, size=n, dtype=np.uint64)
+    for h in hashes.tolist():
+        d[h] = d.get(h, 0) + 1
+    keys = np.fromiter(d.keys(), dtype=np.uint64)
+    vals = np.fromiter(d.values(), dtype=np.uint64) * rng.integers(1, 50, size=keys.size, dtype=np.uint64)
+    d = dict(zip(keys.tolist(), vals.tolist()))
+    t._check(t._lib.kct_merge_host(t._h, keys.ctypes.data, vals.ctypes.data, keys.size, None, None))
+    if with_zero:
+        for _ in range(3):
+            t.count_hash(0)              # key 0 lives beside the device table
+        d[0] = 3
+    return t, d
+
+
+def test_device_analytics_match_dict_arithmetic(KCT):
+    rng = np.random.default_rng(11)
+    for with_zero_a, with_zero_b in ((False, False), (True, False), (True, True)):
+        a, da = _random_table(KCT, rng, 30000, 40000, with_zero_a)
+        b, db = _random_table(KCT, rng, 20000, 40000, with_zero_b)
+        assert len(a) == len(da) and len(b) == len(db)
+        assert (a.min, a.max) == (min(da.values()), max(da.values()))
+        hist = {}
+        for c in da.values():
+            hist[c] = hist.get(c, 0) + 1
+        assert a.histo(zero=False) == sorted(hist.items())
+        assert a.histo(zero=True) == [(f, hist.get(f, 0)) for f in range(max(hist) + 1)]
+        sa, sb = set(da), set(db)
+        assert a.union(b) == sa | sb and a.intersection(b) == sa & sb
+        assert a.difference(b) == sa - sb and b.difference(a) == sb - sa and a.symmetric_difference(b) == sa ^ sb
+        assert a.jaccard(b) == len(sa & sb) / len(sa | sb)
+        dot = sum(da[h] * db[h] for h in sa & sb)
+        want = dot / (math.sqrt(sum(v * v for v in da.values())) * math.sqrt(sum(v * v for v in db.values())))
+        assert math.isclose(a.cosine(b), want, rel_tol=1e-12)
+        assert math.isclose(a.cosine(a), 1.0, rel_tol=1e-12)
+        # cuts and drops rebuild the table on the device
+        cut = 20
+        assert a.mincut(cut) == sum(1 for v in da.values() if v < cut)
+        da = {h: v for h, v in da.items() if v >= cut}
+        assert a.maxcut(60) == sum(1 for v in da.values() if v > 60)
+        da = {h: v for h, v in da.items() if v <= 60}
+        victim = next(iter(da))
+        a.drop_hash(victim); da.pop(victim)
+        a.drop_hash(12345678901234567)   # absent: nothing happens
+        if 0 in da:
+            a.drop_hash(0); da.pop(0)
+        keys, counts = a.dump_arrays(1)
+        assert dict(zip(keys.tolist(), counts.tolist())) == da
+        assert len(a) == len(da) and a.sum_counts == sum(da.values())
+        assert a.get_hash(victim) == 0
+        a.count_hash(victim)             # the rebuilt table keeps working
+        assert a.get_hash(victim) == 1
+
+
+def test_device_analytics_edge_cases(KCT):
+    e1, e2 = KCT(5), KCT(5)
+    assert (e1.min, e1.max, e1.histo(), e1.histo(zero=False)) == (0, 0, [(0, 0)], [])
+    assert e1.union(e2) == set() and e1.jaccard(e2) == 1.0 and e1.cosine(e2) == 0.0
+    assert e1.mincut(5) == 0 and e1.maxcut(0) == 0
+    e1.drop_hash(7)
+    t = KCT(4)
+    t.consume("AAAATTTTGGGG")
+    assert t.jaccard(e1) == 0.0 and t.intersection(e1) == set() and t.union(e1) == set(t.hashes)
+    assert t.difference(e1) == set(t.hashes) and e1.difference(t) == set()
+    t["AAAA"] = 0                        # a key whose count is 0 is still a key (lib.rs:675-681)
+    assert t.min == 0 and (0, 1) in t.histo(zero=False)
+    assert t.mincut(1) == 1 and t.get("AAAA") == 0 and t.hash_kmer("AAAA") not in set(t.hashes)
+    only_zero = KCT(4)
+    only_zero.count_hash(0); only_zero.count_hash(0)
+    assert (only_zero.min, only_zero.max, only_zero.histo(zero=False)) == (2, 2, [(2, 1)])
+    assert only_zero.union(t) == {0} | set(t.hashes) and only_zero.maxcut(1) == 1 and len(only_zero) == 0
+    cleared = KCT(4)
+    cleared.consume("ACGTACGTAC"); cleared.clear()   # lazily cleared table: stale slots must not be scanned
+    assert cleared.max == 0 and cleared.histo(zero=False) == [] and t.intersection(cleared) == set() and cleared.union(t) == set(t.hashes)
+    assert t.jaccard(cleared) == 0.0 and cleared.mincut(100) == 0
