@@ -201,6 +201,11 @@ KCT_API kct_status kct_set_op(kct_table *a, kct_table *b, int op, uint64_t *hash
  * (skip_bad == 0) is never deferred. */
 KCT_API kct_status kct_set_deferred(kct_table *t, int on);
 
+/* Flush point (SURVEY.md 8b "kct_sync"): counts whatever deferred mode has buffered and waits for the table's
+ * stream.  Every other call already returns with its device work finished, so this matters only in deferred
+ * mode or after work the caller queued on the table's stream itself. */
+KCT_API kct_status kct_sync(kct_table *t);
+
 /* Which device path bulk ingest uses: 0 = chosen per pass (default), 1 = direct path only (one
  * HBM atomic per k-mer), 2 = partitioned path whenever the table geometry allows (radix-partition
  * the hashes by 128-KiB table block, count each block in LDS).  Results are identical; this

@@ -55,6 +55,7 @@ SIGNATURES = {
     "kct_merge_host": (ci, [vp, vp, vp, sz, u64p, u64p]),
     "kct_export_by_owner_device": (ci, [vp, C.c_uint32, vp, sz, vp, u64p]),
     "kct_merge_pairs_device": (ci, [vp, vp, sz, u64p, u64p]),
+    "kct_sync": (ci, [vp]),
     "kct_set_deferred": (ci, [vp, ci]),
     "kct_count_stats": (ci, [vp, u64p, u64p, C.POINTER(C.c_double)]),
     "kct_histogram": (ci, [vp, vp, vp, sz, u64p]),

@@ -586,6 +586,12 @@ kct_status kct_set_stream(kct_table *t, void *hip_stream) {
 
 void *kct_get_stream(kct_table *t) { return t ? (void *)t->stream : nullptr; }
 
+kct_status kct_sync(kct_table *t) {
+    KCT_TRY(use(t));  // flushes what deferred mode has buffered
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return KCT_OK;
+}
+
 kct_status kct_set_deferred(kct_table *t, int on) {
     KCT_TRY(use(t));  // flushes what is buffered
     t->deferred = on != 0;

@@ -507,6 +507,10 @@ class KmerCountTable:
             print(f"Version mismatch: loaded version is {t.version}, but current version is {VERSION}", file=sys.stderr)
         return t
 
+    def sync(self):
+        """Counts whatever deferred mode has buffered and waits for the table's stream (``kct_sync``)."""
+        self._check(self._lib.kct_sync(self._h))
+
     def set_deferred(self, on=True):
         """Per-record ``consume()`` calls are buffered on the host and counted in one device pass when the buffer
         fills or the table is read (see ``kct_set_deferred`` in include/kct.h).  Off by default."""

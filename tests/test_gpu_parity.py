@@ -743,7 +743,8 @@ def test_deferred_error_mode_and_clear(KCT):
     dev.clear()                      # ... and forgotten
     assert len(dev) == 0 and dev.sum_counts == 0
     dev.consume("GGGGGGGGGGGGG")
-    dev.set_deferred(False)          # switching off counts what is buffered
+    dev.sync()                       # kct_sync: an explicit flush point
+    dev.set_deferred(False)          # switching off also counts what is buffered
     assert dev.get("GGGGGGGGG") == 5
     other = KCT(k, deferred=True)
     other.consume("GGGGGGGGGGGGG")
