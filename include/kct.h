@@ -201,6 +201,17 @@ KCT_API kct_status kct_set_op(kct_table *a, kct_table *b, int op, uint64_t *hash
  * (skip_bad == 0) is never deferred. */
 KCT_API kct_status kct_set_deferred(kct_table *t, int on);
 
+/* save / load in the reference's wire format (lib.rs:269-322): serde_json of the struct, gzip level 1.
+ * kct_save writes {"counts":{"<hash>":count,...}} followed by `tail_json`, the remaining members as text
+ * starting with a comma -- e.g. ,"ksize":21,"version":"0.3.0","consumed":0,"store_kmers":false,"hash_to_kmer":null}
+ * (they belong to the caller's struct).  The pairs are written in hash order, as one gzip member.
+ * kct_load reads gzip or plain JSON, creates a table of the file's ksize on `device` holding its counts, and
+ * keeps every member other than counts as one JSON object that kct_load_rest_json() returns (valid until the
+ * calling thread loads again).  Malformed input: KCT_ERR_ARG with "Deserialization error: ..." . */
+KCT_API kct_status kct_save(kct_table *t, const char *path, const char *tail_json);
+KCT_API kct_status kct_load(const char *path, int device, kct_table **out);
+KCT_API const char *kct_load_rest_json(void);
+
 /* Flush point (SURVEY.md 8b "kct_sync"): counts whatever deferred mode has buffered and waits for the table's
  * stream.  Every other call already returns with its device work finished, so this matters only in deferred
  * mode or after work the caller queued on the table's stream itself. */

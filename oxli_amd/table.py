@@ -464,44 +464,57 @@ class KmerCountTable:
             return 0.0
         return float(dot) / (ma * mb)
 
-    def serialize_json(self):
-        keys, counts = self.dump_arrays(1)
+    def _tail_json(self):
+        """The members of the reference's struct other than counts, as serde_json writes them (lib.rs:32-39)."""
         import json
-        body = ",".join(f'"{h}":{c}' for h, c in zip(keys.tolist(), counts.tolist()))
         h2k = "null" if self._hash_to_kmer is None else \
             "{" + ",".join(f'"{h}":{json.dumps(kmer)}' for h, kmer in self._hash_to_kmer.items()) + "}"
-        return ('{"counts":{' + body + '},"ksize":' + str(self.ksize) + ',"version":' + json.dumps(self.version) +
+        return (',"ksize":' + str(self.ksize) + ',"version":' + json.dumps(self.version) +
                 ',"consumed":' + str(self.consumed) + ',"store_kmers":' + ("true" if self.store_kmers else "false") +
                 ',"hash_to_kmer":' + h2k + "}")
 
+    def serialize_json(self):
+        """lib.rs:269-272: the serde_json image of the struct (counts in hash order)."""
+        keys, counts = self.dump_arrays(1)
+        body = ",".join(f'"{h}":{c}' for h, c in zip(keys.tolist(), counts.tolist()))
+        return '{"counts":{' + body + "}" + self._tail_json()
+
     def save(self, filepath):
-        import gzip
-        with gzip.open(filepath, "wb", compresslevel=1) as f:  # OSError on a bad path, like File::create
-            f.write(self.serialize_json().encode())
+        """lib.rs:274-292: gzip level 1 of ``serialize_json()``; text and deflate are produced natively by
+        several threads (``kct_save``).  OSError on a bad path, like ``File::create``."""
+        st = self._lib.kct_save(self._h, str(filepath).encode(), self._tail_json().encode())
+        if st == L.KCT_ERR_ARG and ("cannot create" in L.last_error() or "writing" in L.last_error()):
+            raise OSError(L.last_error())
+        self._check(st)
 
     @staticmethod
     def load(filepath, *, device=0):
-        """lib.rs:295-322: accepts gzip or plain JSON (niffler sniffs the format); warns on a version mismatch."""
-        import gzip
+        """lib.rs:295-322: accepts gzip or plain JSON (niffler sniffs the format); warns on a version mismatch.
+        The counts are parsed and merged natively (``kct_load``); the scalar members come back as JSON text."""
         import json
+        import os
         import sys
-        with open(filepath, "rb") as f:
-            raw = f.read()
-        if raw[:2] == b"\x1f\x8b":
-            raw = gzip.decompress(raw)
+        lib = L.load()
+        if not os.path.exists(filepath):
+            raise OSError(f"cannot open {filepath}")
+        h = C.c_void_p()
+        st = lib.kct_load(str(filepath).encode(), int(device), C.byref(h))
+        if st != L.KCT_OK:
+            msg = L.last_error()
+            raise RuntimeError(msg if msg.startswith("Deserialization error") else f"Deserialization error: {msg}")
+        rest = lib.kct_load_rest_json()
+        t = KmerCountTable.__new__(KmerCountTable)
+        t._lib, t._h = lib, h
         try:
-            d = json.loads(raw.decode("utf-8"))
-            ksize, counts = int(d["ksize"]), d["counts"]
-            keys = np.fromiter((int(h) for h in counts.keys()), dtype=np.uint64, count=len(counts))
-            vals = np.fromiter((int(c) for c in counts.values()), dtype=np.uint64, count=len(counts))
+            d = json.loads(rest.decode("utf-8"))
         except Exception as e:  # noqa: BLE001
             raise RuntimeError(f"Deserialization error: {e}") from None
-        t = KmerCountTable(ksize, store_kmers=bool(d.get("store_kmers", False)), capacity=len(counts), device=device)
-        if keys.size:
-            t._check(t._lib.kct_merge_host(t._h, keys.ctypes.data, vals.ctypes.data, keys.size, None, None))
-        t._check(t._lib.kct_add_consumed(t._h, int(d.get("consumed", 0))))
+        t.ksize = int(d["ksize"])
+        t.store_kmers = bool(d.get("store_kmers", False))
+        t._hash_to_kmer = {} if t.store_kmers else None
+        t._check(lib.kct_add_consumed(h, int(d.get("consumed", 0))))
         if t.store_kmers and d.get("hash_to_kmer"):
-            t._hash_to_kmer = {int(h): kmer for h, kmer in d["hash_to_kmer"].items()}
+            t._hash_to_kmer = {int(k): kmer for k, kmer in d["hash_to_kmer"].items()}
         t.version = d.get("version", VERSION)
         if t.version != VERSION:
             print(f"Version mismatch: loaded version is {t.version}, but current version is {VERSION}", file=sys.stderr)

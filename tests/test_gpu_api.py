@@ -340,3 +340,36 @@ def test_device_analytics_edge_cases(KCT):
     cleared.consume("ACGTACGTAC"); cleared.clear()   # lazily cleared table: stale slots must not be scanned
     assert cleared.max == 0 and cleared.histo(zero=False) == [] and t.intersection(cleared) == set() and cleared.union(t) == set(t.hashes)
     assert t.jaccard(cleared) == 0.0 and cleared.mincut(100) == 0
+
+
+def test_native_save_load_many_pieces(KCT, tmp_path):
+    """kct_save writes the counts as many independently deflated pieces inside ONE gzip member: any gzip reader
+    (here Python's) must see exactly serialize_json(), and kct_load must bring every pair back."""
+    rng = np.random.default_rng(3)
+    t, d = _random_table(KCT, rng, 300000, 1 << 62, True)     # ~300k pairs: five 65536-pair pieces; key 0 included
+    t.consume("ACGTACGTACGTACGTACGTACGTACGT")                  # consumed > 0
+    f = str(tmp_path / "big.json.gz")
+    t.save(f)
+    text = gzip.open(f, "rb").read().decode()
+    assert text == t.serialize_json()
+    parsed = json.loads(text)
+    assert len(parsed["counts"]) == len(t) and parsed["counts"]["0"] == 3
+    u = KCT.load(f)
+    ku, cu = u.dump_arrays(1)
+    kt, ct = t.dump_arrays(1)
+    assert np.array_equal(ku, kt) and np.array_equal(cu, ct) and u.consumed == t.consumed and u.ksize == t.ksize
+    # members in another order, whitespace, an unknown member: a JSON reader accepts them
+    p = str(tmp_path / "odd.json")
+    open(p, "w").write('{ "ksize": 5, "extra": {"a": [1, "}"]}, "counts": { "7": 2 , "9":1 }, "consumed": 4, '
+                       '"version": "0.3.0", "store_kmers": true, "hash_to_kmer": {"7": "AAAAC"} }')
+    o = KCT.load(p)
+    assert (o.ksize, len(o), o.get_hash(7), o.get_hash(9), o.consumed, o.store_kmers) == (5, 2, 2, 1, 4, True)
+    assert o.unhash(7) == "AAAAC"
+    e = KCT(9)
+    g = str(tmp_path / "empty.json.gz")
+    e.save(g)
+    assert json.loads(gzip.open(g, "rb").read())["counts"] == {} and len(KCT.load(g)) == 0
+    for bad in ('{"counts":{"x":1},"ksize":4}', '{"counts":{"1":-1},"ksize":4}', '{"counts":{},"ksize":400}', '{"counts":{}}', '{"counts":{"1":1}'):
+        open(p, "w").write(bad)
+        with pytest.raises(RuntimeError, match="Deserialization error"):
+            KCT.load(p)
