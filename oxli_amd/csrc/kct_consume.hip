@@ -36,6 +36,23 @@ struct PartitionLauncher {
     }
 };
 
+// K1 is instruction-issue bound, and a compile-time k is worth ~15 % there (constant shifts and masks, the
+// MurmurHash3 block/tail structure unrolled, only the needed table look-ups): every k up to 64 gets its own
+// instantiation.  (The direct kernels are bound by the atomic rate, so they keep the three popular k only.)
+template <int K>
+struct PartitionByK {
+    static void run(int k, hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, u64 ntiles, const kct::PartitionArgs &a) {
+        if (k == K) PartitionLauncher<(K <= 32 ? 1 : 2), K>::run(s, grid, stream, nbytes, k, ntiles, a);
+        else PartitionByK<K - 1>::run(k, s, grid, stream, nbytes, ntiles, a);
+    }
+};
+template <>
+struct PartitionByK<0> {
+    static void run(int k, hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, u64 ntiles, const kct::PartitionArgs &a) {
+        PartitionLauncher<0, 0>::run(s, grid, stream, nbytes, k, ntiles, a);  // k > 64: the bytewise path
+    }
+};
+
 // The partitioned path pays 16 B (one level) or 32 B (two levels) of streaming scratch traffic per
 // k-mer plus 32 B per table slot per pass; the direct path pays one memory-side atomic per k-mer.
 // It wins once a pass brings a fair fraction as many windows as the table has slots.
@@ -85,7 +102,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     pa.ablate = t->ablate;  // measurement only; wrong counts when set
     {
         ProfScope ps(t, "partition_windows_kernel");
-        dispatch_k<PartitionLauncher>(k, t->stream, nwg, d_stream, chunk_bytes, k, ntiles, pa);
+        PartitionByK<64>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
     }
     HIP_TRY(hipGetLastError());
 

@@ -433,6 +433,21 @@ def test_partitioned_path_matches_oracle(KCT, k):
     assert_same_table(dev, ref)
 
 
+def test_partitioned_path_every_k_up_to_64(KCT):
+    """The partition kernel is instantiated once per k <= 64 (compile-time shifts, masks and MurmurHash3 block / tail
+    structure): every instantiation against the oracle, on input with bad bytes, lower case and short records."""
+    rng = random.Random(64)
+    recs = [rand_dna(rng, n, "ACGTACGTACGTACGTNacgt") for n in (0, 1, 31, 32, 33, 63, 64, 65, 100, 150, 151, 1000)] * 6
+    recs += [rand_dna(rng, 20000), "AC" * 5000]
+    for k in range(1, 65):
+        ref = OracleTable(k)
+        n_ref = sum(ref.consume(r) for r in recs)
+        dev = KCT(k, capacity=200000)
+        dev.set_path("partitioned")
+        assert dev.consume_batch(recs) == n_ref, k
+        assert_same_table(dev, ref)
+
+
 @pytest.mark.parametrize("k", [21, 51])
 def test_two_level_partitioned_path_matches_oracle(KCT, k):
     """Tables with more than 1024 blocks (> 128 MiB) take two partition levels: K1 into 1024 super-bins,
