@@ -43,6 +43,7 @@ template <u32 LISTCAP, class Overflow>
 __device__ __forceinline__ bool ring_flush(u64 *ring, u32 *fill, u32 *flushed, u32 *flist, u32 *fcount, int P, u32 D,
                                            u64 *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash) {
     const u32 dmask = D - 1;
+    const int dshift = __builtin_ctz(D);  // D is a power of two: shifts instead of quarter-rate multiplies
     __syncthreads();  // appends of this interval are in the ring; *fcount == 0
     for (int b = threadIdx.x; b < P; b += kPartThreads) {
         const u32 f0 = flushed[b], top = fill[b];
@@ -61,7 +62,7 @@ __device__ __forceinline__ bool ring_flush(u64 *ring, u32 *fill, u32 *flushed, u
         const u32 e = flist[item >> 2], q = item & 3u, b = e & 1023u, f = (e >> 10) & 0x1FFFFFu;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (!(e >> 31)) {
-            uint4 *src = reinterpret_cast<uint4 *>(&ring[b * D + (f & dmask)]) + q;
+            uint4 *src = reinterpret_cast<uint4 *>(&ring[(b << dshift) + (f & dmask)]) + q;
             v = *src;
             *src = make_uint4(0, 0, 0, 0);
         }
@@ -111,6 +112,8 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     if constexpr (KW != 0) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
     const int P = 1 << a.pbits;
     const u32 D = (u32)(kRingEntries >> a.pbits), dmask = D - 1;
+    const int dshift = 14 - a.pbits;  // log2 D
+    static_assert(kRingEntries == 1 << 14, "dshift assumes a 16384-entry ring");
     for (int i = threadIdx.x; i < kRingEntries; i += kPartThreads) ring[i] = 0;
     for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
     if (threadIdx.x == 0) { ovf_n = 0; fcount = 0; }
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         u32 pend_b = 0, pend_pos = 0, pend_mark = 0;
         auto commit = [&]() {
             if (pend_h) {
-                if (pend_pos - pend_mark < D) ring[pend_b * D + (pend_pos & dmask)] = pend_h;  // slot's previous tenant is flushed
+                if (pend_pos - pend_mark < D) ring[(pend_b << dshift) + (pend_pos & dmask)] = pend_h;  // slot's previous tenant is flushed
                 else overflow_hash(pend_h);                                                    // ring full: position stays a 0 hole
                 pend_h = 0;
             }
@@ -237,6 +240,7 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     __shared__ u32 fcount, ovf_n, rounds;
     const int s = blockIdx.x, P2 = 1 << a.sub_bits;
     const u32 D = (u32)(kRingEntries >> a.sub_bits), dmask = D - 1;
+    const int dshift = 14 - a.sub_bits;  // log2 D
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < kRingEntries; i += kPartThreads) ring[i] = 0;
     for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
             if (h) {
                 const u32 b = (((u32)h & (u32)a.mask) >> a.block_bits) & (u32)(P2 - 1);
                 const u32 pos = atomicAdd(&fill[b], 1u);
-                if (pos - flushed[b] < D) ring[b * D + (pos & dmask)] = h;
+                if (pos - flushed[b] < D) ring[(b << dshift) + (pos & dmask)] = h;
                 else overflow_hash(h);
             }
             if ((j & 3) == 3) flush_lines(false);
