@@ -58,7 +58,7 @@ struct PartitionByK<0> {
 // It wins once a pass brings a fair fraction as many windows as the table has slots.
 bool partition_geometry_ok(const kct_table *t) {
     const u64 nblocks = t->cap >> t->block_bits;
-    return nblocks >= 16 && t->cap <= (1ULL << 32);
+    return nblocks >= 16 && t->cap <= (1ULL << 33);  // two levels of 1024 bins x 8192 slots: 128 GiB of table
 }
 
 bool partition_pays(const kct_table *t, u64 npos) {

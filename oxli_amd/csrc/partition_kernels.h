@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         auto sink = [&](int j, bool good, u64 h) {
             commit();  // the previous window's append
             if (good && h != 0 && !(a.ablate & 1)) {
-                pend_b = ((u32)h & (u32)a.mask) >> a.block_bits;  // block index: the low 32 bits suffice (table <= 2^23 slots here)
+                pend_b = (u32)(h >> a.block_bits) & (u32)(P - 1);  // bin = the pbits hash bits above the block (or super-bin) offset
                 pend_pos = atomicAdd(&fill[pend_b], 1u);
                 pend_mark = flushed[pend_b];
                 pend_h = h;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
         for (int j = 0; j < kLoads; ++j) {
             const u64 h = v[j];
             if (h) {
-                const u32 b = (((u32)h & (u32)a.mask) >> a.block_bits) & (u32)(P2 - 1);
+                const u32 b = (u32)(h >> a.block_bits) & (u32)(P2 - 1);
                 const u32 pos = atomicAdd(&fill[b], 1u);
                 if (pos - flushed[b] < D) ring[(b << dshift) + (pos & dmask)] = h;
                 else overflow_hash(h);

@@ -721,6 +721,41 @@ def test_multi_chunk_stream_and_large_table_paths(KCT):
     assert np.array_equal(bk, wk) and np.array_equal(bc, wc)
 
 
+def test_partitioned_path_on_a_128_GiB_table(KCT):
+    """2^33 slots = 128 GiB of table on one GPU (288 GB of HBM): 2^20 blocks, both partition levels at their
+    full fan-out of 1024.  Same reads into a small table must give the same (hash, count) set."""
+    import torch
+
+    from oxli_amd import _lib
+    free, _total = torch.cuda.mem_get_info()
+    if free < 200 * (1 << 30):
+        pytest.skip("needs 200 GiB of free HBM")
+    lib = _lib.load()
+    G, L, N, k = 3_000_000, 150, 2_000_000, 31
+    g = torch.empty(G, dtype=torch.uint8, device="cuda")
+    r = torch.empty(N * (L + 1), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.kct_synth_genome_device(g.data_ptr(), G, 17, stream) == 0
+    assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), G, 0, N, L, 23, stream) == 0
+    torch.cuda.synchronize()
+    small = KCT(k, capacity=G)
+    n = small.consume_device(r.data_ptr(), r.numel(), N * L)
+    assert n == N * (L - k + 1)
+    sk, sc = small.dump_arrays(1)
+    del small
+    big = KCT(k, capacity=5_000_000_000)          # 5e9 / 0.65 -> 2^33 slots
+    assert big.capacity == 1 << 33
+    big.set_path("partitioned")
+    big.profile(True)
+    assert big.consume_device(r.data_ptr(), r.numel(), N * L) == n
+    prof = big.profile_read()
+    assert "repartition_kernel" in prof and "count_windows_kernel" not in prof, prof   # really the two-level path
+    assert len(big) == sk.size and big.sum_counts == n
+    bk, bc = big.dump_arrays(1)
+    assert np.array_equal(bk, sk) and np.array_equal(bc, sc)
+    assert big.get_hash(int(sk[12345])) == int(sc[12345])
+
+
 # ---- deferred mode: per-record consume() buffered on the host, counted in one device pass ------------
 @pytest.mark.parametrize("k", [4, 21, 33, 70])
 def test_deferred_consume_matches_oracle(KCT, k):
