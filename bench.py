@@ -48,7 +48,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--batches", type=int, default=8, help="distinct read batches resident per GPU (cycled over the steps)")
-    p.add_argument("--path", choices=["auto", "direct", "partitioned"], default="auto")
+    p.add_argument("--path", choices=["auto", "direct", "partitioned", "dedupe"], default="auto")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo lets several ranks share one GPU for debugging")
     return p.parse_args()
 

@@ -219,8 +219,10 @@ KCT_API kct_status kct_sync(kct_table *t);
 
 /* Which device path bulk ingest uses: 0 = chosen per pass (default), 1 = direct path only (one
  * HBM atomic per k-mer), 2 = partitioned path whenever the table geometry allows (radix-partition
- * the hashes by 128-KiB table block, count each block in LDS).  Results are identical; this
- * exists for tests and measurement. */
+ * the hashes by 128-KiB table block, count each block in LDS), 3 = dedupe-first whenever k <= 32 and the
+ * pass is large enough (count packed k-mers in LDS first, hash each DISTINCT k-mer of the pass once and add
+ * its count to the table).  Mode 0 picks dedupe-first when what the table already holds says that a pass
+ * repeats few k-mers many times.  Results are identical; this exists for tests and measurement. */
 KCT_API kct_status kct_set_path(kct_table *t, int mode);
 
 /* ---- streams and in-library kernel timing ----------------------------------------------------

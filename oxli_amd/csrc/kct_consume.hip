@@ -46,6 +46,18 @@ struct PartitionByK {
         else PartitionByK<K - 1>::run(k, s, grid, stream, nbytes, ntiles, a);
     }
 };
+// the dedupe-first variant (k <= 32): emits mix64(packed canonical k-mer + 1) instead of hashes
+template <int K>
+struct PartitionRawByK {
+    static void run(int k, hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, u64 ntiles, const kct::PartitionArgs &a) {
+        if (k == K) hipLaunchKernelGGL((kct::partition_windows_kernel<1, K, true>), dim3(grid), dim3(kct::kPartThreads), 0, s, stream, nbytes, k, ntiles, a);
+        else PartitionRawByK<K - 1>::run(k, s, grid, stream, nbytes, ntiles, a);
+    }
+};
+template <>
+struct PartitionRawByK<0> {
+    static void run(int, hipStream_t, int, const unsigned char *, u64, u64, const kct::PartitionArgs &) {}
+};
 template <>
 struct PartitionByK<0> {
     static void run(int k, hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, u64 ntiles, const kct::PartitionArgs &a) {
@@ -69,6 +81,100 @@ bool partition_pays(const kct_table *t, u64 npos) {
 
 unsigned int region_capacity(double avg) {
     return (unsigned int)((((u64)(avg * 1.15 + 8.0 * __builtin_sqrt(avg) + 64.0)) + 7) & ~7ULL);
+}
+
+// Dedupe-first pass (k <= 32): K1 partitions mix64(packed k-mer) values into 1024 scratch blocks, K2 counts each block in
+// LDS and then hashes every DISTINCT k-mer once and adds its count to the real table with the direct atomic insert.
+// MurmurHash3 (~55 % of K1's instructions) and the table update are paid per distinct k-mer of the pass instead of per
+// occurrence, so it pays when the pass holds each k-mer many times (deep coverage of a small genome) and the distinct
+// k-mers fit the scratch blocks (1024 x 8192 slots).  Chosen by dedupe_pays(); results are identical either way.
+constexpr int kDedupeBins = 10;  // log2(scratch blocks)
+
+bool dedupe_pays(const kct_table *t, u64 npos) {
+    if (t->k > 32 || t->dedupe_off || npos < (1ULL << 22)) return false;
+    if (t->force_path == 3) return true;
+    if (t->force_path != 0) return false;
+    // what the table has seen so far is the best guess at what the pass holds: few distinct k-mers, each many times
+    const u64 room = (u64)((1ULL << (kDedupeBins + kct::kBlockBitsMax)) * 0.6);
+    return t->n_keys > 0 && t->n_keys * 4 <= npos && t->n_keys <= room;
+}
+
+kct_status consume_deduped(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled) {
+    *handled = false;
+    const int k = t->k;
+    const int pbits = kDedupeBins;
+    const u64 P = 1ULL << pbits;
+    const int nwg = t->num_cus;
+    const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
+    const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
+    const unsigned int region_cap = region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P);
+    const unsigned int ovf_cap = (unsigned int)std::max<u64>(4096, tiles_per_wg * kct::kPartTile / 8);
+    KCT_TRY(materialize(t));  // the real table takes atomic inserts
+    KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 8));
+    KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
+    KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
+    KCT_TRY(t->d_spill.reserve(npos * 16));
+    KCT_TRY(zero_counters(t));
+    du64 *d_overflow = t->d_counters + kNumCounters + 6;
+    du64 *d_stats = t->d_counters + kNumCounters + 2;  // [0] distinct, [1] blocked
+    unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
+
+    kct::PartitionArgs pa;
+    pa.mask = (1ULL << (pbits + kct::kBlockBitsMax)) - 1; pa.block_bits = kct::kBlockBitsMax; pa.pbits = pbits;
+    pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
+    pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
+    pa.ablate = t->ablate;
+    {
+        ProfScope ps(t, "partition_windows_kernel<raw>");
+        PartitionRawByK<32>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
+    }
+    HIP_TRY(hipGetLastError());
+
+    kct::AggregateArgs aa;
+    aa.words = nullptr; aa.block_bits = kct::kBlockBitsMax; aa.pbits = pbits;
+    aa.scratch = (const du64 *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
+    aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
+    aa.fresh = 1; aa.overflow = d_overflow; aa.ablate = pa.ablate;
+    aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
+    aa.main = view(t, npos); aa.k = k; aa.dedupe_stats = d_stats;
+    KCT_TRY(t->d_aux.reserve(npos * 8));
+    aa.blocked_list = (du64 *)t->d_aux.p; aa.blocked_cap = npos;
+    {
+        ProfScope ps(t, "aggregate_blocks_kernel<dedupe>");
+        hipLaunchKernelGGL(kct::aggregate_blocks_kernel<true>, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, aa);
+    }
+    HIP_TRY(hipGetLastError());
+    {
+        ProfScope ps(t, "merge_overflow_kernel");
+        hipLaunchKernelGGL(kct::merge_overflow_kernel<true>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
+                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, view(t, npos), t->d_counters, k);
+        // entries that found their scratch block full (normally none): one list, cut into 65536-entry pieces
+        constexpr unsigned int kPiece = 1u << 16;
+        hipLaunchKernelGGL(kct::merge_overflow_kernel<true>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_aux.p,
+                           (const unsigned int *)nullptr, (int)((npos + kPiece - 1) / kPiece), kPiece, (const du64 *)d_overflow, view(t, npos),
+                           t->d_counters, k, (const du64 *)(d_stats + 1));
+    }
+    HIP_TRY(hipGetLastError());
+    u64 c[4], spilled;
+    KCT_TRY(read_counters(t, c, &spilled));
+    const u64 distinct = t->h_counters[kNumCounters + 2], blocked = t->h_counters[kNumCounters + 3];
+    if (t->debug)
+        fprintf(stderr, "[kct] dedupe pass: npos=%llu region_cap=%u distinct=%llu blocked=%llu counted=%llu merged=%llu new=%llu spilled=%llu abandon=%llu\n",
+                (unsigned long long)npos, region_cap, (unsigned long long)distinct, (unsigned long long)blocked,
+                (unsigned long long)c[kct::CTR_COUNTED], (unsigned long long)c[kct::CTR_TOTAL_ADDED], (unsigned long long)c[kct::CTR_NEWKEYS],
+                (unsigned long long)spilled, (unsigned long long)t->h_counters[kNumCounters + 6]);
+    if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // abandoned before anything was touched
+    *handled = true;
+    *n_out += c[kct::CTR_COUNTED] + c[kct::CTR_TOTAL_ADDED];
+    t->n_keys += c[kct::CTR_NEWKEYS];
+    // too many distinct k-mers for the scratch blocks, or too few repeats to be worth it: back to hashing every window
+    if (t->force_path != 3 && (blocked * 50 > npos || distinct * 3 > npos)) t->dedupe_off = true;
+    if (spilled) {
+        KCT_TRY(t->d_aux2.reserve(spilled * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(replay_spill(t, spilled, n_out));
+    }
+    return KCT_OK;
 }
 
 // One pass of the partitioned path over window starts [0, npos) of d_stream.  *handled = false
@@ -138,17 +244,17 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     }
     {
         ProfScope ps(t, "aggregate_blocks_kernel");
-        hipLaunchKernelGGL(kct::aggregate_blocks_kernel, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
+        hipLaunchKernelGGL(kct::aggregate_blocks_kernel<false>, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
     }
     HIP_TRY(hipGetLastError());
     {
         // fold the overflow regions with the direct atomic path; the kernel reads the region lengths
         // and the abandon flag from device memory, so no host round trip sits between the launches
         ProfScope ps(t, "merge_overflow_kernel");
-        hipLaunchKernelGGL(kct::merge_overflow_kernel, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
+        hipLaunchKernelGGL(kct::merge_overflow_kernel<false>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
                            (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, view(t, npos), t->d_counters);
         if (two_level)
-            hipLaunchKernelGGL(kct::merge_overflow_kernel, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
+            hipLaunchKernelGGL(kct::merge_overflow_kernel<false>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
                                (const unsigned int *)d_ovf2_count, (int)P, ovf2_cap, (const du64 *)d_overflow, view(t, npos), t->d_counters);
     }
     HIP_TRY(hipGetLastError());
@@ -208,6 +314,11 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         const u64 ramp = t->auto_sized ? std::max<u64>(1ULL << 20, 4 * t->cap) : ~0ULL;
         const u64 npos = std::min<u64>({chunk_limit, ramp, last_start + 1 - done});
         const u64 chunk_bytes = std::min<u64>(nbytes - done, npos + k - 1);
+        if (dedupe_pays(t, npos)) {
+            bool handled = false;
+            KCT_TRY(consume_deduped(t, d_stream + done, chunk_bytes, npos, n_out, &handled));
+            if (handled) { done += npos; continue; }
+        }
         if (partition_geometry_ok(t) && t->force_path != 1 && (t->force_path == 2 || partition_pays(t, npos))) {
             bool handled = false;
             KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled));

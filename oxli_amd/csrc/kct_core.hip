@@ -600,8 +600,10 @@ kct_status kct_set_deferred(kct_table *t, int on) {
 
 kct_status kct_set_path(kct_table *t, int mode) {
     KCT_TRY(use(t));
-    if (mode < 0 || mode > 2) { set_err("mode must be 0, 1 or 2"); return KCT_ERR_ARG; }
+    if (mode < 0 || mode > 3) { set_err("mode must be 0, 1, 2 or 3"); return KCT_ERR_ARG; }
+    if (mode == 3 && t->k > 32) { set_err("the dedupe-first path needs k <= 32"); return KCT_ERR_ARG; }
     t->force_path = mode;
+    t->dedupe_off = false;
     return KCT_OK;
 }
 

@@ -111,7 +111,8 @@ struct kct_table {
     bool auto_sized = true; // no capacity hint / reserve yet: bulk ingest ramps its launch size up with the table
     int ablate = 0;         // KCT_ABLATE at create time: measurement-only switches that skip work (results invalid)
     bool debug = false;     // KCT_DEBUG at create time: one stderr line per partitioned pass
-    int force_path = 0;     // 0 = choose per pass, 1 = direct atomic kernel only, 2 = partitioned whenever the geometry allows
+    int force_path = 0;     // 0 = choose per pass, 1 = direct atomic kernel only, 2 = partitioned whenever the geometry allows, 3 = dedupe-first
+    bool dedupe_off = false;  // a dedupe-first pass found too many distinct k-mers: this table goes back to hashing every window
     u64 n_keys = 0;        // distinct non-zero hashes in `slots`
     u64 consumed = 0;      // lib.rs:36
     bool zero_present = false;  // key 0 lives host-side (0 is the EMPTY sentinel on the device)

@@ -93,7 +93,7 @@ struct PartitionArgs {
     int ablate;          // measurement only: bit 0 = skip the ring append, bit 1 = skip the flush phases
 };
 
-template <int KW, int KC>
+template <int KW, int KC, bool RAW = false>
 __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
                                                                          u64 ntiles, PartitionArgs a) {
     __shared__ __attribute__((aligned(16))) u64 ring[kRingEntries];
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
             }
         };
         if constexpr (KW == 0) walk_windows<0, 0, kPartWPT>(lds, k, sink);
-        else walk_windows_encoded<KW, KC, true>(tcodes, tvalid, k, sink, ascii4);
+        else walk_windows_encoded<KW, KC, true, RAW>(tcodes, tvalid, k, sink, ascii4);
         commit();
     }
     while (flush_lines(true)) {}  // drain: partial lines go out zero-padded; repeat while the list was too short
@@ -319,24 +319,45 @@ struct AggregateArgs {
     int ablate;          // measurement only: bit 2 (4) = no count add, bit 4 (16) = loads only, bit 6 (64) = no streaming at all
     u64 *spill; u64 spill_cap; u64 *spill_n;
     u64 *counters;
+    // dedupe-first variant only: the blocks are a scratch table that lives in LDS alone; what it counted goes to `main`
+    TableView main;
+    int k;
+    u64 *dedupe_stats;   // [0] += distinct keys of the pass, [1] += entries that found their scratch block full ...
+    u64 *blocked_list;   // ... and were appended here (capacity blocked_cap) for merge_overflow_kernel<true>
+    u64 blocked_cap;
 };
 
+// mix64 value of a packed canonical k-mer (dedupe-first path) -> its MurmurHash3 value
+__device__ __forceinline__ u64 hash_of_mixed(u64 m, int k, const u32 *lut) {
+    Packed<1> p;
+    p.w[0] = unmix64(m) - 1ULL;
+    left_align(p, k);
+    return hash_packed<1, true>(p, k, lut);
+}
+
+// DEDUPE (dedupe-first path, k <= 32): the entries are mix64 values of packed canonical k-mers instead of hashes.
+// The block is a scratch table that exists in LDS only -- it starts empty and is never stored; once the block's
+// entries are counted, every distinct k-mer is hashed ONCE and its count added to the real table with the direct
+// atomic insert.  MurmurHash3 and the HBM atomics are paid per distinct k-mer of the pass, not per occurrence.
+template <bool DEDUPE = false>
 __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(AggregateArgs a) {
     __shared__ __attribute__((aligned(16))) u64 tab[2 << kBlockBitsMax];  // S keys then S counts = 128 KiB
     __shared__ u64 wq[(kPartThreads / 64) * kWaveQueue];                  // per-wave queues of deferred entries, 20 KiB
     __shared__ __attribute__((aligned(16))) unsigned char tags[1 << kBlockBitsMax];  // one fingerprint byte per slot, 8 KiB
     __shared__ u64 s_counted, s_new;
+    __shared__ u32 ascii4[DEDUPE ? 256 : 1];
     if (*a.overflow) return;  // wave-uniform: K1 gave up, the host reruns the batch on the direct path
+    if constexpr (DEDUPE) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
     const int b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
-    u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
+    u64 *gblock = DEDUPE ? nullptr : a.words + ((u64)b << (a.block_bits + 1));
     u64 *keys = tab, *cnts = tab + S;
     if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
     // fingerprint of a key: a hash byte that neither the slot index (low bits) nor the multi-GPU
     // owner (top bits) uses; 0 is reserved for "empty slot"
     auto tag_of = [](u64 h) -> u32 { const u32 t = (u32)(h >> 32) & 0xFFu; return t ? t : 1u; };
-    if (a.fresh) {
+    if (DEDUPE || a.fresh) {
         for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
         for (u32 i = threadIdx.x; i < S / 16; i += kPartThreads) reinterpret_cast<uint4 *>(tags)[i] = make_uint4(0, 0, 0, 0);
     } else {
@@ -347,6 +368,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32 counted = 0, newkeys = 0;
+    u64 to_main = 0;  // DEDUPE: counts added to the real table by this thread
     // General insert.  One probe round = the 8 keys of a group = one 64-byte LDS line
     // (4 x ds_read_b128), examined in slot order so a new key lands in the first empty slot of
     // its sequence -- the same arrangement the direct path builds.
@@ -364,7 +386,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
                 u64 ks = keys[g + sel];
                 if (ks == 0) {
                     ks = atomicCAS(&keys[g + sel], 0ULL, h);
-                    if (ks == 0) { ++newkeys; ks = h; tags[g + sel] = (unsigned char)tag_of(h); }
+                    if (ks == 0) { if (!DEDUPE) ++newkeys; ks = h; tags[g + sel] = (unsigned char)tag_of(h); }  // (a scratch slot is not a table key)
                 }
                 if (ks == h) {
                     if (!(a.ablate & 4)) atomicAdd(&cnts[g + sel], 1ULL);
@@ -377,7 +399,12 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
             g = (g + kGroup) & smask;
         }
         if (placed) ++counted;
-        else {  // block full: grow-and-replay list, tallied when replayed
+        else if constexpr (DEDUPE) {
+            // scratch block full (more distinct k-mers than it holds): set the entry aside -- hashing it here would put
+            // MurmurHash3 and the table insert into every unrolled copy of this loop (119 KB of code, I-cache thrash)
+            const u64 si = atomicAdd(a.dedupe_stats + 1, 1ULL);
+            if (si < a.blocked_cap) a.blocked_list[si] = h;
+        } else {  // block full: grow-and-replay list, tallied when replayed
             u64 si = atomicAdd(a.spill_n, 1ULL);
             if (si < a.spill_cap) { a.spill[2 * si] = h; a.spill[2 * si + 1] = 1; }
         }
@@ -458,10 +485,28 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
         }
     }
     drain(0);
-    u64 wc = wave_sum(counted), wn = wave_sum(newkeys);
+    if constexpr (DEDUPE) {
+        __syncthreads();  // every entry of the block is counted
+        u64 distinct = 0;
+        for (u32 i = threadIdx.x; i < S; i += kPartThreads) {
+            const u64 m = keys[i];
+            if (m == 0) continue;
+            ++distinct;
+            const u64 h = hash_of_mixed(m, a.k, ascii4), c = cnts[i];
+            if (h == 0) continue;  // lib.rs:589: hash 0 is skipped
+            if (a.ablate & 128) { to_main += c; continue; }  // measurement only: hash, but leave the table alone
+            const AddResult r = table_add<false>(a.main, h, c);
+            if (!r.spilled) { to_main += c; newkeys += r.claimed; }  // a spilled pair is tallied when it is replayed
+        }
+        distinct = wave_sum(distinct);
+        if (lane == 0 && distinct) atomicAdd(a.dedupe_stats, distinct);
+        counted = 0;  // what counts is what reached the real table
+    }
+    u64 wc = wave_sum(DEDUPE ? to_main : (u64)counted), wn = wave_sum(newkeys);
     if (lane == 0) { atomicAdd(&s_counted, wc); atomicAdd(&s_new, wn); }
     __syncthreads();
-    for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
+    if constexpr (!DEDUPE)
+        for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
     if (threadIdx.x == 0) {
         u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
         if (s_counted) atomicAdd(shard + CTR_COUNTED, s_counted);
@@ -473,17 +518,24 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
 // regions[r] holds counts[r] hashes (each standing for one k-mer).  Neighbouring entries are often
 // equal (that is why they overflowed), so every wave first folds equal hashes: the lowest active
 // lane is the leader, all lanes holding the leader's hash retire into one add, repeat.
+// DEDUPE: the entries are mix64 values of packed k-mers (dedupe-first path); each group leader hashes its k-mer first.
+template <bool DEDUPE = false>
 __global__ __launch_bounds__(kBlock) void merge_overflow_kernel(const u64 *__restrict__ regions, const u32 *__restrict__ counts,
                                                                 int nregions, u32 region_cap, const u64 *abort, TableView table,
-                                                                u64 *counters) {
+                                                                u64 *counters, int k = 0, const u64 *total = nullptr) {
     __shared__ u64 s_tot, s_new;
+    __shared__ u32 ascii4[DEDUPE ? 256 : 1];
     if (abort && *abort) return;
+    if constexpr (DEDUPE) fill_ascii4_lut(ascii4, threadIdx.x, kBlock);
     if (threadIdx.x == 0) { s_tot = 0; s_new = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u64 tot = 0, nk = 0;
     for (int r = blockIdx.x; r < nregions; r += gridDim.x) {  // one workgroup per region
-        const u32 cnt = counts[r];
+        // region sizes: counts[r], or (counts == nullptr) one list of *total entries cut into region_cap pieces
+        u32 cnt;
+        if (counts) cnt = counts[r];
+        else { const u64 tot_n = *total, lo = (u64)r * region_cap; cnt = tot_n > lo ? (u32)(tot_n - lo < region_cap ? tot_n - lo : region_cap) : 0u; }
         const u64 *src = regions + (u64)r * region_cap;
         for (u32 base = 64u * wave; base < cnt; base += kBlock) {
             const u32 i = base + lane;
@@ -499,8 +551,11 @@ __global__ __launch_bounds__(kBlock) void merge_overflow_kernel(const u64 *__res
                 if ((same >> lane) & 1ULL) pending = false;
             }
             if (is_leader) {
-                const AddResult res = table_add<false>(table, h, c);
-                if (!res.spilled) { tot += c; nk += res.claimed; }
+                const u64 hh = DEDUPE ? hash_of_mixed(h, k, ascii4) : h;
+                if (hh != 0) {
+                    const AddResult res = table_add<false>(table, hh, c);
+                    if (!res.spilled) { tot += c; nk += res.claimed; }
+                }
             }
         }
     }

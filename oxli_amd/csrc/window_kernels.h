@@ -81,7 +81,9 @@ __device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, in
 // directly from the packed words (no k-1 warm-up steps); the WPT-1 following bases come out of two
 // shift registers.  WPT must be 16 (one code word per thread).
 // `lut` (LDS, kmer_device.h fill_ascii4_lut) switches the ASCII re-expansion to table look-ups.
-template <int KW, int KC, bool LUT = false, class Sink>
+// RAW (k <= 32 only): the sink receives mix64(packed canonical k-mer + 1) instead of the MurmurHash3 value --
+// the dedupe-first path counts k-mers first and hashes each distinct one once (partition_kernels.h).
+template <int KW, int KC, bool LUT = false, bool RAW = false, class Sink>
 __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const unsigned short *valid, int k_rt, Sink &&sink,
                                                      const u32 *lut = nullptr) {
     constexpr int WPT = 16, NW = 2 * KW + 1;  // code words covering bases 0 .. 15 + k
@@ -144,8 +146,13 @@ __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const uns
         u64 h = 0;
         if (good) {
             Packed<KW> c = less_eq(fw, rc) ? fw : rc;
-            left_align(c, k);
-            h = hash_packed<KW, LUT>(c, k, lut);
+            if constexpr (RAW) {
+                static_assert(!RAW || KW == 1, "the dedupe-first path carries one 64-bit word per k-mer");
+                h = mix64(c.w[0] + 1ULL);
+            } else {
+                left_align(c, k);
+                h = hash_packed<KW, LUT>(c, k, lut);
+            }
         }
         sink(j, good, h);
         if (j + 1 < WPT) {

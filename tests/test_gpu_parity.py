@@ -448,6 +448,79 @@ def test_partitioned_path_every_k_up_to_64(KCT):
         assert_same_table(dev, ref)
 
 
+@pytest.mark.parametrize("k", [1, 5, 16, 21, 31, 32])
+def test_dedupe_first_path_matches_oracle(KCT, k):
+    """Dedupe-first path (k <= 32): packed k-mers are counted in LDS scratch blocks, each distinct one is hashed once.
+    Deep coverage of a small genome (its home ground), bad bytes, lower case, homopolymers, short records."""
+    rng = random.Random(7000 + k)
+    genome = rand_dna(rng, 40000)
+    recs = []
+    for i in range(32000):
+        a = rng.randrange(0, len(genome) - 150)
+        r = genome[a:a + 150]
+        if i % 2:
+            r = r[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        if i % 97 == 0:
+            r = r[:70] + "N" + r[71:]
+        if i % 89 == 0:
+            r = r.lower()
+        recs.append(r)
+    recs += ["A" * 3000, "T" * 3000, "ACGT" * 700, "", "ACG", rand_dna(rng, 5000, "ACGTN")]
+    ref = OracleTable(k)
+    n_ref = sum(ref.consume(r) for r in recs)
+    dev = KCT(k, capacity=200000)
+    dev.set_path("dedupe")
+    dev.profile(True)
+    assert dev.consume_batch(recs) == n_ref
+    assert "aggregate_blocks_kernel<dedupe>" in dev.profile_read()       # really that path
+    assert_same_table(dev, ref)
+    # a second pass into the live table (every key exists already), through the automatic choice this time
+    auto = KCT(k, capacity=200000)
+    assert auto.consume_batch(recs) == n_ref                             # first pass: nothing known yet, standard paths
+    auto.profile(True)
+    assert auto.consume_batch(recs) == n_ref
+    assert "aggregate_blocks_kernel<dedupe>" in auto.profile_read()   # few keys, many k-mers: dedupe-first was chosen
+    for r in recs:
+        ref.consume(r)
+    assert_same_table(auto, ref)
+
+
+def test_dedupe_first_path_with_too_many_distinct_kmers(KCT):
+    """All-distinct input overflows the scratch blocks: the overflow goes straight to the table (still exact), and the
+    table stops choosing the dedupe-first path."""
+    import torch
+
+    from oxli_amd import _lib
+    lib = _lib.load()
+    G, L, N, k = 60_000_000, 150, 300_000, 27          # 3.7e7 k-mers, nearly all distinct: > 8.4e6 scratch slots
+    g = torch.empty(G, dtype=torch.uint8, device="cuda")
+    r = torch.empty(N * (L + 1), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.kct_synth_genome_device(g.data_ptr(), G, 5, stream) == 0
+    assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), G, 0, N, L, 6, stream) == 0
+    torch.cuda.synchronize()
+    std = KCT(k, capacity=40_000_000)
+    std.set_path("partitioned")
+    n = std.consume_device(r.data_ptr(), r.numel(), N * L)
+    sk, sc = std.dump_arrays(1)
+    ded = KCT(k, capacity=40_000_000)
+    ded.set_path("dedupe")
+    assert ded.consume_device(r.data_ptr(), r.numel(), N * L) == n
+    dk, dc = ded.dump_arrays(1)
+    assert np.array_equal(dk, sk) and np.array_equal(dc, sc)
+    # automatic choice: after a pass like that the table gives up on dedupe-first
+    auto = KCT(k, capacity=40_000_000)
+    n0 = (N // 8) // 16 * 16                                               # (a 16-byte aligned cut of the stream)
+    lo = n0 * (L + 1)
+    auto.consume_device(r.data_ptr(), lo, n0 * L)                          # few keys yet -> the next pass tries dedupe-first
+    auto.profile(True)
+    auto.consume_device(r.data_ptr() + lo, r.numel() - lo, (N - n0) * L)
+    assert "aggregate_blocks_kernel<dedupe>" in auto.profile_read()
+    auto.consume_device(r.data_ptr(), r.numel(), N * L)
+    ak, ac = auto.dump_arrays(1)
+    assert np.array_equal(ak, sk) and np.array_equal(ac, 2 * sc)
+
+
 @pytest.mark.parametrize("k", [21, 51])
 def test_two_level_partitioned_path_matches_oracle(KCT, k):
     """Tables with more than 1024 blocks (> 128 MiB) take two partition levels: K1 into 1024 super-bins,
