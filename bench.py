@@ -168,6 +168,7 @@ def main():
     t_merge = time.perf_counter()
     if world > 1:
         merge_across_ranks(table)
+    table.sync()  # counts still pending in the dedupe-first path's shadow table are converted inside the timed region
     torch.cuda.synchronize()
     merge_ms = (time.perf_counter() - t_merge) * 1e3
     if world > 1:

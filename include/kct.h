@@ -220,9 +220,12 @@ KCT_API kct_status kct_sync(kct_table *t);
 /* Which device path bulk ingest uses: 0 = chosen per pass (default), 1 = direct path only (one
  * HBM atomic per k-mer), 2 = partitioned path whenever the table geometry allows (radix-partition
  * the hashes by 128-KiB table block, count each block in LDS), 3 = dedupe-first whenever k <= 32 and the
- * pass is large enough (count packed k-mers in LDS first, hash each DISTINCT k-mer of the pass once and add
- * its count to the table).  Mode 0 picks dedupe-first when what the table already holds says that a pass
- * repeats few k-mers many times.  Results are identical; this exists for tests and measurement. */
+ * pass is large enough (count PACKED k-mers into a shadow table; their counts stay pending until something
+ * reads the table, when every k-mer with a pending count is hashed once and added -- every reading call
+ * converts first, so no call can observe the difference).  Mode 0 picks dedupe-first when what the table
+ * already holds says that a pass repeats few k-mers many times.  The tables' contents are identical; in
+ * dedupe-first passes *n_out counts a k-mer whose MurmurHash3 value is exactly 0 (which the reference
+ * skips, lib.rs:589; probability 2^-64 per distinct k-mer) because that is only seen at conversion time. */
 KCT_API kct_status kct_set_path(kct_table *t, int mode);
 
 /* ---- streams and in-library kernel timing ----------------------------------------------------

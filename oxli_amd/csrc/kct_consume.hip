@@ -83,44 +83,85 @@ unsigned int region_capacity(double avg) {
     return (unsigned int)((((u64)(avg * 1.15 + 8.0 * __builtin_sqrt(avg) + 64.0)) + 7) & ~7ULL);
 }
 
-// Dedupe-first pass (k <= 32): K1 partitions mix64(packed k-mer) values into 1024 scratch blocks, K2 counts each block in
-// LDS and then hashes every DISTINCT k-mer once and adds its count to the real table with the direct atomic insert.
-// MurmurHash3 (~55 % of K1's instructions) and the table update are paid per distinct k-mer of the pass instead of per
-// occurrence, so it pays when the pass holds each k-mer many times (deep coverage of a small genome) and the distinct
-// k-mers fit the scratch blocks (1024 x 8192 slots).  Chosen by dedupe_pays(); results are identical either way.
-constexpr int kDedupeBins = 10;  // log2(scratch blocks)
+// Dedupe-first pass (k <= 32).  Reads that cover a small genome deeply repeat every k-mer tens of times per pass, and
+// ~55 % of K1's instructions are MurmurHash3 plus the ASCII re-expansion.  So the pass counts PACKED k-mers: K1 (RAW)
+// partitions mix64(packed canonical k-mer + 1) values, and the unchanged K2 counts them into a SHADOW table -- 1024
+// blocks x 8192 slots in HBM with the real table's layout, keyed by those values -- holding counts that are PENDING:
+// the real (hash-keyed) table only gets them when something needs it (flush_shadow: every k-mer with a pending
+// count is hashed once and added with the direct insert).  Many passes, one conversion; MurmurHash3 and the table's
+// random accesses are paid per distinct k-mer per flush instead of per occurrence.  Reads of the table flush first
+// (use()), so nothing observes the difference.  Chosen by dedupe_pays(); counts are identical either way.
+constexpr int kShadowBlockBits = 10;  // log2(shadow blocks): what one K1 pass can fan out to
+constexpr u64 kShadowSlots = 1ULL << (kShadowBlockBits + kct::kBlockBitsMax);
+
+kct::TableGeom shadow_geom() {
+    kct::TableGeom g;
+    g.mask = kShadowSlots - 1;
+    g.block_bits = kct::kBlockBitsMax;
+    return g;
+}
 
 bool dedupe_pays(const kct_table *t, u64 npos) {
     if (t->k > 32 || t->dedupe_off || npos < (1ULL << 22)) return false;
     if (t->force_path == 3) return true;
     if (t->force_path != 0) return false;
-    // what the table has seen so far is the best guess at what the pass holds: few distinct k-mers, each many times
-    const u64 room = (u64)((1ULL << (kDedupeBins + kct::kBlockBitsMax)) * 0.6);
-    return t->n_keys > 0 && t->n_keys * 4 <= npos && t->n_keys <= room;
+    // few distinct k-mers, each many times?  What the table (or the shadow) holds so far is the best guess.
+    const u64 room = (u64)(kShadowSlots * 0.6);
+    const u64 known = std::max(t->n_keys, t->shadow_keys);
+    return known > 0 && known * 4 <= npos && known <= room;
+}
+
+// Pending counts -> the real table.  The shadow keeps its keys (they will be met again), its counts return to zero.
+kct_status flush_shadow(kct_table *t) {
+    if (!t->shadow_dirty) return KCT_OK;
+    t->shadow_dirty = false;
+    KCT_TRY(materialize(t));
+    KCT_TRY(t->d_spill.reserve(kShadowSlots * 16));
+    KCT_TRY(zero_counters(t));
+    {
+        ProfScope ps(t, "shadow_flush_kernel");
+        hipLaunchKernelGGL(kct::shadow_flush_kernel, dim3(merge_grid(kShadowSlots)), dim3(kct::kBlock), 0, t->stream, t->shadow, shadow_geom(),
+                           view(t, kShadowSlots), (int)t->k, t->d_counters);
+    }
+    HIP_TRY(hipGetLastError());
+    u64 c[4], spilled;
+    KCT_TRY(read_counters(t, c, &spilled));
+    t->n_keys += c[kct::CTR_NEWKEYS];
+    if (spilled) {
+        u64 ignored = 0;
+        KCT_TRY(t->d_aux2.reserve(spilled * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(replay_spill(t, spilled, &ignored));
+    }
+    return KCT_OK;
 }
 
 kct_status consume_deduped(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled) {
     *handled = false;
     const int k = t->k;
-    const int pbits = kDedupeBins;
+    const int pbits = kShadowBlockBits;
     const u64 P = 1ULL << pbits;
     const int nwg = t->num_cus;
     const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
     const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
     const unsigned int region_cap = region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P);
     const unsigned int ovf_cap = (unsigned int)std::max<u64>(4096, tiles_per_wg * kct::kPartTile / 8);
-    KCT_TRY(materialize(t));  // the real table takes atomic inserts
+    if (!t->shadow) {
+        HIP_TRY(hipMalloc((void **)&t->shadow, kShadowSlots * 16));
+        t->shadow_empty = true;
+        t->shadow_keys = 0;
+    }
+    KCT_TRY(materialize(t));  // K1's overflow regions go straight to the real table
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 8));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
     KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
     KCT_TRY(t->d_spill.reserve(npos * 16));
     KCT_TRY(zero_counters(t));
     du64 *d_overflow = t->d_counters + kNumCounters + 6;
-    du64 *d_stats = t->d_counters + kNumCounters + 2;  // [0] distinct, [1] blocked
     unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
 
     kct::PartitionArgs pa;
-    pa.mask = (1ULL << (pbits + kct::kBlockBitsMax)) - 1; pa.block_bits = kct::kBlockBitsMax; pa.pbits = pbits;
+    pa.mask = kShadowSlots - 1; pa.block_bits = kct::kBlockBitsMax; pa.pbits = pbits;
     pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
     pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
     pa.ablate = t->ablate;
@@ -130,49 +171,61 @@ kct_status consume_deduped(kct_table *t, const unsigned char *d_stream, u64 chun
     }
     HIP_TRY(hipGetLastError());
 
-    kct::AggregateArgs aa;
-    aa.words = nullptr; aa.block_bits = kct::kBlockBitsMax; aa.pbits = pbits;
+    kct::AggregateArgs aa;  // the unchanged K2, on the shadow table
+    aa.words = t->shadow; aa.block_bits = kct::kBlockBitsMax; aa.pbits = pbits;
     aa.scratch = (const du64 *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
     aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
-    aa.fresh = 1; aa.overflow = d_overflow; aa.ablate = pa.ablate;
+    aa.fresh = t->shadow_empty ? 1 : 0; aa.overflow = d_overflow; aa.ablate = pa.ablate;
     aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
-    aa.main = view(t, npos); aa.k = k; aa.dedupe_stats = d_stats;
-    KCT_TRY(t->d_aux.reserve(npos * 8));
-    aa.blocked_list = (du64 *)t->d_aux.p; aa.blocked_cap = npos;
     {
-        ProfScope ps(t, "aggregate_blocks_kernel<dedupe>");
-        hipLaunchKernelGGL(kct::aggregate_blocks_kernel<true>, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, aa);
+        ProfScope ps(t, "aggregate_blocks_kernel<shadow>");
+        hipLaunchKernelGGL(kct::aggregate_blocks_kernel, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, aa);
     }
     HIP_TRY(hipGetLastError());
+    // first the tallies of the shadow pass (entries counted, new shadow keys, pairs that found their block full) ...
+    u64 c[4], blocked;
+    KCT_TRY(read_counters(t, c, &blocked));
+    if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // K1 gave up (its overflow regions overflowed): nothing was touched
+    const u64 counted = c[kct::CTR_COUNTED], new_shadow = c[kct::CTR_NEWKEYS];
+    t->shadow_empty = false;
+    t->shadow_dirty = true;
+    t->shadow_keys += new_shadow;
+    *handled = true;
+    // ... then what did not fit the shadow goes to the real table right away: K1's overflow regions, and K2's pairs
+    if (blocked) {
+        KCT_TRY(t->d_aux2.reserve(blocked * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, blocked * 16, hipMemcpyDeviceToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->d_counters + kNumCounters + 5, t->d_counters + kNumCounters, 8, hipMemcpyDeviceToDevice, t->stream));
+    }
+    HIP_TRY(hipMemsetAsync(t->d_counters, 0, (kNumCounters + 1) * sizeof(u64), t->stream));  // the tallies and the spill cursor, not the copied pair count
     {
         ProfScope ps(t, "merge_overflow_kernel");
         hipLaunchKernelGGL(kct::merge_overflow_kernel<true>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
-                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, view(t, npos), t->d_counters, k);
-        // entries that found their scratch block full (normally none): one list, cut into 65536-entry pieces
-        constexpr unsigned int kPiece = 1u << 16;
-        hipLaunchKernelGGL(kct::merge_overflow_kernel<true>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_aux.p,
-                           (const unsigned int *)nullptr, (int)((npos + kPiece - 1) / kPiece), kPiece, (const du64 *)d_overflow, view(t, npos),
-                           t->d_counters, k, (const du64 *)(d_stats + 1));
+                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)nullptr, view(t, npos), t->d_counters, k);
+        if (blocked)
+            hipLaunchKernelGGL(kct::merge_mixed_pairs_kernel, dim3(merge_grid(blocked)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_aux2.p,
+                               (const du64 *)(t->d_counters + kNumCounters + 5), (u64)blocked, view(t, npos), (int)k, t->d_counters);
     }
     HIP_TRY(hipGetLastError());
-    u64 c[4], spilled;
-    KCT_TRY(read_counters(t, c, &spilled));
-    const u64 distinct = t->h_counters[kNumCounters + 2], blocked = t->h_counters[kNumCounters + 3];
+    u64 c2[4], spilled;
+    KCT_TRY(read_counters(t, c2, &spilled));
     if (t->debug)
-        fprintf(stderr, "[kct] dedupe pass: npos=%llu region_cap=%u distinct=%llu blocked=%llu counted=%llu merged=%llu new=%llu spilled=%llu abandon=%llu\n",
-                (unsigned long long)npos, region_cap, (unsigned long long)distinct, (unsigned long long)blocked,
-                (unsigned long long)c[kct::CTR_COUNTED], (unsigned long long)c[kct::CTR_TOTAL_ADDED], (unsigned long long)c[kct::CTR_NEWKEYS],
-                (unsigned long long)spilled, (unsigned long long)t->h_counters[kNumCounters + 6]);
-    if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // abandoned before anything was touched
-    *handled = true;
-    *n_out += c[kct::CTR_COUNTED] + c[kct::CTR_TOTAL_ADDED];
-    t->n_keys += c[kct::CTR_NEWKEYS];
-    // too many distinct k-mers for the scratch blocks, or too few repeats to be worth it: back to hashing every window
-    if (t->force_path != 3 && (blocked * 50 > npos || distinct * 3 > npos)) t->dedupe_off = true;
+        fprintf(stderr, "[kct] dedupe pass: npos=%llu region_cap=%u counted(shadow)=%llu new shadow keys=%llu (total %llu) blocked=%llu merged=%llu new=%llu spilled=%llu\n",
+                (unsigned long long)npos, region_cap, (unsigned long long)counted, (unsigned long long)new_shadow, (unsigned long long)t->shadow_keys,
+                (unsigned long long)blocked, (unsigned long long)c2[kct::CTR_TOTAL_ADDED], (unsigned long long)c2[kct::CTR_NEWKEYS], (unsigned long long)spilled);
+    // n counts every window whose k-mer went into the shadow: the (2^-64 per k-mer) case of a MurmurHash3 value of 0,
+    // which the reference leaves out of n, is only seen when the shadow is flushed.
+    *n_out += counted + c2[kct::CTR_TOTAL_ADDED];
+    t->n_keys += c2[kct::CTR_NEWKEYS];
     if (spilled) {
         KCT_TRY(t->d_aux2.reserve(spilled * 16));
         HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
         KCT_TRY(replay_spill(t, spilled, n_out));
+    }
+    // Too few repeats to be worth it, or the shadow is filling up: convert what is pending and go back to hashing every window.
+    if (t->force_path != 3 && (new_shadow * 3 > npos || blocked * 50 > npos || t->shadow_keys > (u64)(kShadowSlots * 0.65))) {
+        KCT_TRY(flush_shadow(t));
+        t->dedupe_off = true;
     }
     return KCT_OK;
 }
@@ -244,7 +297,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     }
     {
         ProfScope ps(t, "aggregate_blocks_kernel");
-        hipLaunchKernelGGL(kct::aggregate_blocks_kernel<false>, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
+        hipLaunchKernelGGL(kct::aggregate_blocks_kernel, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
     }
     HIP_TRY(hipGetLastError());
     {
@@ -421,7 +474,7 @@ extern "C" {
 
 kct_status kct_hash_windows(kct_table *t, const char *seq, size_t len, uint64_t *hashes_out, size_t cap, uint64_t *n_windows,
                             uint64_t *first_bad) {
-    KCT_TRY(use(t));
+    KCT_TRY(use_consume(t));
     if ((!seq && len) || !n_windows || !first_bad) { set_err("null argument"); return KCT_ERR_ARG; }
     const u64 nwin = len >= t->k ? len - t->k + 1 : 0;
     *n_windows = nwin;
@@ -435,7 +488,7 @@ kct_status kct_hash_windows(kct_table *t, const char *seq, size_t len, uint64_t 
 }
 
 kct_status kct_hash_kmer(kct_table *t, const char *kmer, size_t len, uint64_t *hash_out) {
-    KCT_TRY(use(t));
+    KCT_TRY(use_consume(t));
     if (!kmer || !hash_out) { set_err("null argument"); return KCT_ERR_ARG; }
     if ((uint8_t)len != t->k) { set_err("wrong ksize"); return KCT_ERR_WRONG_KSIZE; }  // lib.rs:66 `len as u8`
     u64 nwin, fb, h = 0;
@@ -484,7 +537,7 @@ kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, 
         t->consumed += len;
         return KCT_OK;
     }
-    KCT_TRY(use(t));
+    KCT_TRY(use_consume(t));
     if ((!seq && len) || !n_out) { set_err("null argument"); return KCT_ERR_ARG; }
     *n_out = 0;
     const u64 k = t->k;
@@ -506,7 +559,7 @@ kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, 
 
 kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *offsets, size_t nrec, int skip_bad,
                              uint64_t *n_total, uint64_t *bad_record, uint64_t *bad_position) {
-    KCT_TRY(use(t));
+    KCT_TRY(use_consume(t));
     if (!n_total || (nrec && !offsets)) { set_err("null argument"); return KCT_ERR_ARG; }
     if (nrec && !bytes && offsets[nrec] != offsets[0]) { set_err("null argument"); return KCT_ERR_ARG; }  // all-empty records need no bytes
     *n_total = 0;
@@ -622,7 +675,7 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
 }
 
 kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes, uint64_t *n_total) {
-    KCT_TRY(use(t));
+    KCT_TRY(use_consume(t));
     if (!n_total || (!d_stream && nbytes)) { set_err("null argument"); return KCT_ERR_ARG; }
     if (((uintptr_t)d_stream & 15) != 0) { set_err("d_stream must be 16-byte aligned"); return KCT_ERR_ARG; }
     KCT_TRY(consume_stream(t, (const unsigned char *)d_stream, nbytes, n_total));

@@ -48,9 +48,15 @@ kct_status use_device(kct_table *t) {
     return KCT_OK;
 }
 
-kct_status use(kct_table *t) {
+kct_status use_consume(kct_table *t) {
     KCT_TRY(use_device(t));
-    if (t->pending_used) KCT_TRY(flush_pending(t));  // reads must observe every earlier consume()
+    if (t->pending_used) KCT_TRY(flush_pending(t));  // (keeps the order of consumed records irrelevant, and `consumed` exact)
+    return KCT_OK;
+}
+
+kct_status use(kct_table *t) {
+    KCT_TRY(use_consume(t));
+    if (t->shadow_dirty) KCT_TRY(flush_shadow(t));   // reads must observe every earlier consume()
     return KCT_OK;
 }
 
@@ -294,6 +300,7 @@ void kct_destroy(kct_table *t) {
     t->d_scratch.release(); t->d_regions.release(); t->d_irr.release(); t->d_sort.release();
     t->d_scratch2.release(); t->d_regions2.release(); t->d_irr2.release();
     t->h_stage.release(); t->h_pending.release();
+    if (t->shadow) (void)hipFree(t->shadow);
     for (auto &b : t->h_file) b.release();
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
@@ -303,6 +310,7 @@ kct_status kct_clear(kct_table *t) {
     KCT_TRY(use_device(t));
     t->pending_used = 0; t->pending_records = 0;  // buffered records are forgotten with everything else
     t->lazy_empty = true;  // the memset is issued by materialize() only if something needs it
+    t->shadow_empty = true; t->shadow_dirty = false; t->shadow_keys = 0; t->dedupe_off = false;  // pending counts are forgotten too
     t->n_keys = 0; t->consumed = 0; t->zero_present = false; t->zero_count = 0;
     return KCT_OK;
 }

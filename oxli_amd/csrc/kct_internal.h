@@ -113,6 +113,11 @@ struct kct_table {
     bool debug = false;     // KCT_DEBUG at create time: one stderr line per partitioned pass
     int force_path = 0;     // 0 = choose per pass, 1 = direct atomic kernel only, 2 = partitioned whenever the geometry allows, 3 = dedupe-first
     bool dedupe_off = false;  // a dedupe-first pass found too many distinct k-mers: this table goes back to hashing every window
+    // dedupe-first path (k <= 32): a shadow table keyed by packed k-mers holds counts that are still PENDING for `slots`
+    du64 *shadow = nullptr;     // 2^23 slots x 16 B, block-SoA like `slots` (allocated on first use)
+    bool shadow_empty = true;   // no keys yet: K2 starts its blocks from zeros instead of loading them
+    bool shadow_dirty = false;  // pending counts exist: anything that reads `slots` flushes first (use())
+    u64 shadow_keys = 0;
     u64 n_keys = 0;        // distinct non-zero hashes in `slots`
     u64 consumed = 0;      // lib.rs:36
     bool zero_present = false;  // key 0 lives host-side (0 is the EMPTY sentinel on the device)
@@ -159,7 +164,9 @@ struct ProfScope {
 };
 
 void prof_collect(kct_table *t);
-kct_status use(kct_table *t);         // select the device AND count whatever deferred mode has buffered
+kct_status use(kct_table *t);         // select the device, count whatever deferred mode has buffered, convert the shadow table's pending counts
+kct_status use_consume(kct_table *t); // the same without the shadow flush: what consume entry points call
+kct_status flush_shadow(kct_table *t);
 void parallel_memcpy(void *dst, const void *src, size_t nbytes);  // several threads above 8 MiB
 kct_status use_device(kct_table *t);  // select the device only
 kct_status flush_pending(kct_table *t);

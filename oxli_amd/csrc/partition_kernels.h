@@ -319,45 +319,24 @@ struct AggregateArgs {
     int ablate;          // measurement only: bit 2 (4) = no count add, bit 4 (16) = loads only, bit 6 (64) = no streaming at all
     u64 *spill; u64 spill_cap; u64 *spill_n;
     u64 *counters;
-    // dedupe-first variant only: the blocks are a scratch table that lives in LDS alone; what it counted goes to `main`
-    TableView main;
-    int k;
-    u64 *dedupe_stats;   // [0] += distinct keys of the pass, [1] += entries that found their scratch block full ...
-    u64 *blocked_list;   // ... and were appended here (capacity blocked_cap) for merge_overflow_kernel<true>
-    u64 blocked_cap;
 };
 
-// mix64 value of a packed canonical k-mer (dedupe-first path) -> its MurmurHash3 value
-__device__ __forceinline__ u64 hash_of_mixed(u64 m, int k, const u32 *lut) {
-    Packed<1> p;
-    p.w[0] = unmix64(m) - 1ULL;
-    left_align(p, k);
-    return hash_packed<1, true>(p, k, lut);
-}
-
-// DEDUPE (dedupe-first path, k <= 32): the entries are mix64 values of packed canonical k-mers instead of hashes.
-// The block is a scratch table that exists in LDS only -- it starts empty and is never stored; once the block's
-// entries are counted, every distinct k-mer is hashed ONCE and its count added to the real table with the direct
-// atomic insert.  MurmurHash3 and the HBM atomics are paid per distinct k-mer of the pass, not per occurrence.
-template <bool DEDUPE = false>
 __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(AggregateArgs a) {
     __shared__ __attribute__((aligned(16))) u64 tab[2 << kBlockBitsMax];  // S keys then S counts = 128 KiB
     __shared__ u64 wq[(kPartThreads / 64) * kWaveQueue];                  // per-wave queues of deferred entries, 20 KiB
     __shared__ __attribute__((aligned(16))) unsigned char tags[1 << kBlockBitsMax];  // one fingerprint byte per slot, 8 KiB
     __shared__ u64 s_counted, s_new;
-    __shared__ u32 ascii4[DEDUPE ? 256 : 1];
     if (*a.overflow) return;  // wave-uniform: K1 gave up, the host reruns the batch on the direct path
-    if constexpr (DEDUPE) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
     const int b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
-    u64 *gblock = DEDUPE ? nullptr : a.words + ((u64)b << (a.block_bits + 1));
+    u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u64 *keys = tab, *cnts = tab + S;
     if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
     // fingerprint of a key: a hash byte that neither the slot index (low bits) nor the multi-GPU
     // owner (top bits) uses; 0 is reserved for "empty slot"
     auto tag_of = [](u64 h) -> u32 { const u32 t = (u32)(h >> 32) & 0xFFu; return t ? t : 1u; };
-    if (DEDUPE || a.fresh) {
+    if (a.fresh) {
         for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
         for (u32 i = threadIdx.x; i < S / 16; i += kPartThreads) reinterpret_cast<uint4 *>(tags)[i] = make_uint4(0, 0, 0, 0);
     } else {
@@ -368,7 +347,6 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32 counted = 0, newkeys = 0;
-    u64 to_main = 0;  // DEDUPE: counts added to the real table by this thread
     // General insert.  One probe round = the 8 keys of a group = one 64-byte LDS line
     // (4 x ds_read_b128), examined in slot order so a new key lands in the first empty slot of
     // its sequence -- the same arrangement the direct path builds.
@@ -386,7 +364,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
                 u64 ks = keys[g + sel];
                 if (ks == 0) {
                     ks = atomicCAS(&keys[g + sel], 0ULL, h);
-                    if (ks == 0) { if (!DEDUPE) ++newkeys; ks = h; tags[g + sel] = (unsigned char)tag_of(h); }  // (a scratch slot is not a table key)
+                    if (ks == 0) { ++newkeys; ks = h; tags[g + sel] = (unsigned char)tag_of(h); }
                 }
                 if (ks == h) {
                     if (!(a.ablate & 4)) atomicAdd(&cnts[g + sel], 1ULL);
@@ -399,12 +377,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
             g = (g + kGroup) & smask;
         }
         if (placed) ++counted;
-        else if constexpr (DEDUPE) {
-            // scratch block full (more distinct k-mers than it holds): set the entry aside -- hashing it here would put
-            // MurmurHash3 and the table insert into every unrolled copy of this loop (119 KB of code, I-cache thrash)
-            const u64 si = atomicAdd(a.dedupe_stats + 1, 1ULL);
-            if (si < a.blocked_cap) a.blocked_list[si] = h;
-        } else {  // block full: grow-and-replay list, tallied when replayed
+        else {  // block full: grow-and-replay list, tallied when replayed
             u64 si = atomicAdd(a.spill_n, 1ULL);
             if (si < a.spill_cap) { a.spill[2 * si] = h; a.spill[2 * si + 1] = 1; }
         }
@@ -485,31 +458,80 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
         }
     }
     drain(0);
-    if constexpr (DEDUPE) {
-        __syncthreads();  // every entry of the block is counted
-        u64 distinct = 0;
-        for (u32 i = threadIdx.x; i < S; i += kPartThreads) {
-            const u64 m = keys[i];
-            if (m == 0) continue;
-            ++distinct;
-            const u64 h = hash_of_mixed(m, a.k, ascii4), c = cnts[i];
-            if (h == 0) continue;  // lib.rs:589: hash 0 is skipped
-            if (a.ablate & 128) { to_main += c; continue; }  // measurement only: hash, but leave the table alone
-            const AddResult r = table_add<false>(a.main, h, c);
-            if (!r.spilled) { to_main += c; newkeys += r.claimed; }  // a spilled pair is tallied when it is replayed
-        }
-        distinct = wave_sum(distinct);
-        if (lane == 0 && distinct) atomicAdd(a.dedupe_stats, distinct);
-        counted = 0;  // what counts is what reached the real table
-    }
-    u64 wc = wave_sum(DEDUPE ? to_main : (u64)counted), wn = wave_sum(newkeys);
+    u64 wc = wave_sum(counted), wn = wave_sum(newkeys);
     if (lane == 0) { atomicAdd(&s_counted, wc); atomicAdd(&s_new, wn); }
     __syncthreads();
-    if constexpr (!DEDUPE)
-        for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
+    for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
     if (threadIdx.x == 0) {
         u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
         if (s_counted) atomicAdd(shard + CTR_COUNTED, s_counted);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+    }
+}
+
+// mix64 value of a packed canonical k-mer (dedupe-first path) -> its MurmurHash3 value
+__device__ __forceinline__ u64 hash_of_mixed(u64 m, int k, const u32 *lut) {
+    Packed<1> p;
+    p.w[0] = unmix64(m) - 1ULL;
+    left_align(p, k);
+    return hash_packed<1, true>(p, k, lut);
+}
+
+// ---- dedupe-first path: the shadow table (packed k-mers -> pending counts) into the real table --------------------
+// The shadow table has the real table's block-SoA layout, keyed by mix64 values.  Every slot with a pending count is
+// turned back into its k-mer, hashed once, and its count added to the real table with the direct insert; the count
+// is then zeroed, the key stays (it will be met again).  counters: CTR_NEWKEYS / CTR_TOTAL_ADDED as merge_pairs.
+__global__ __launch_bounds__(kBlock) void shadow_flush_kernel(u64 *__restrict__ shadow, TableGeom sg, TableView main, int k, u64 *counters) {
+    __shared__ u32 ascii4[256];
+    __shared__ u64 s_tot, s_new;
+    fill_ascii4_lut(ascii4, threadIdx.x, kBlock);
+    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; }
+    __syncthreads();
+    const u64 cap = sg.mask + 1, S = block_slots(sg);
+    u64 tot = 0, nk = 0;
+    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock) {
+        const u64 kw = key_word(sg, s);
+        const u64 c = shadow[kw + S];
+        if (c == 0) continue;
+        shadow[kw + S] = 0;
+        const u64 h = hash_of_mixed(shadow[kw], k, ascii4);
+        if (h == 0) continue;  // lib.rs:589: hash 0 is skipped
+        const AddResult r = table_add<false>(main, h, c);
+        if (!r.spilled) { tot += c; nk += r.claimed; }  // a spilled pair is tallied when it is replayed
+    }
+    tot = wave_sum(tot); nk = wave_sum(nk);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+    }
+}
+
+// {mix64 value, count} pairs that found their shadow block full -> the real table (same tallies)
+__global__ __launch_bounds__(kBlock) void merge_mixed_pairs_kernel(const u64 *__restrict__ pairs, const u64 *n_dev, u64 n_cap, TableView main,
+                                                                   int k, u64 *counters) {
+    __shared__ u32 ascii4[256];
+    __shared__ u64 s_tot, s_new;
+    fill_ascii4_lut(ascii4, threadIdx.x, kBlock);
+    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; }
+    __syncthreads();
+    u64 n = *n_dev;
+    n = n < n_cap ? n : n_cap;
+    u64 tot = 0, nk = 0;
+    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
+        const u64 h = hash_of_mixed(pairs[2 * i], k, ascii4), c = pairs[2 * i + 1];
+        if (h == 0) continue;
+        const AddResult r = table_add<false>(main, h, c);
+        if (!r.spilled) { tot += c; nk += r.claimed; }
+    }
+    tot = wave_sum(tot); nk = wave_sum(nk);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
         if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
     }
 }

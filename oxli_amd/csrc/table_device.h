@@ -69,6 +69,7 @@ struct AddResult {
     u64 old;       // count before the add (only when WANT_OLD)
     bool claimed;  // this call created the key
     bool spilled;  // not placed: appended to the spill list, the caller must not tally it
+    u64 word;      // word index of the key's slot (its count sits block_slots further); valid unless spilled
 };
 
 __device__ __forceinline__ void spill_pair(const TableView &t, u64 h, u64 c) {
@@ -81,7 +82,7 @@ template <bool WANT_OLD>
 __device__ __forceinline__ AddResult table_add(const TableView &t, u64 h, u64 c) {
     const u64 S = block_slots(t.g);
     u64 s = home_group_slot(t.g, h);
-    AddResult r{0, false, false};
+    AddResult r{0, false, false, 0};
     for (int probe = 0; probe < kMaxProbeGroups; ++probe) {
         u64 *kw = t.words + key_word(t.g, s);
         // one 64-byte line: the eight candidate keys of this group
@@ -98,6 +99,7 @@ __device__ __forceinline__ AddResult table_add(const TableView &t, u64 h, u64 c)
             if (key == h) {
                 if (WANT_OLD) r.old = atomicAdd(kw + i + S, c);
                 else atomicAdd(kw + i + S, c);
+                r.word = key_word(t.g, s) + (u64)i;
                 return r;
             }
         }

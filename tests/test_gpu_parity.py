@@ -472,17 +472,73 @@ def test_dedupe_first_path_matches_oracle(KCT, k):
     dev.set_path("dedupe")
     dev.profile(True)
     assert dev.consume_batch(recs) == n_ref
-    assert "aggregate_blocks_kernel<dedupe>" in dev.profile_read()       # really that path
+    assert "aggregate_blocks_kernel<shadow>" in dev.profile_read()       # really that path
     assert_same_table(dev, ref)
     # a second pass into the live table (every key exists already), through the automatic choice this time
     auto = KCT(k, capacity=200000)
     assert auto.consume_batch(recs) == n_ref                             # first pass: nothing known yet, standard paths
     auto.profile(True)
     assert auto.consume_batch(recs) == n_ref
-    assert "aggregate_blocks_kernel<dedupe>" in auto.profile_read()   # few keys, many k-mers: dedupe-first was chosen
+    assert "aggregate_blocks_kernel<shadow>" in auto.profile_read()   # few keys, many k-mers: dedupe-first was chosen
     for r in recs:
         ref.consume(r)
     assert_same_table(auto, ref)
+
+
+def test_dedupe_first_pending_counts_are_seen_by_every_read(KCT):
+    """The dedupe-first path leaves its counts pending in a shadow table; anything that reads the table converts them
+    first.  Interleave passes with point reads, point writes, add(), clear() and the other ingest paths."""
+    import torch
+
+    from oxli_amd import _lib
+    lib = _lib.load()
+    G, L, N, k = 300_000, 150, 40_000, 25            # 40k reads = 6e6 window starts per pass
+    g = torch.empty(G, dtype=torch.uint8, device="cuda")
+    r = torch.empty(N * (L + 1), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.kct_synth_genome_device(g.data_ptr(), G, 3, stream) == 0
+    assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), G, 0, N, L, 4, stream) == 0
+    torch.cuda.synchronize()
+    reads = r.cpu().numpy().tobytes().decode().split("\n")[:N]
+    ref = OracleTable(k)
+    n1 = sum(ref.consume(x) for x in reads)
+    dev = KCT(k, capacity=G)
+    dev.set_path("dedupe")
+    assert dev.consume_device(r.data_ptr(), r.numel(), N * L) == n1
+    probe = reads[7][10:10 + k]
+    assert dev.get(probe) == ref.get(probe)                       # point read after a pass
+    assert dev.consume_device(r.data_ptr(), r.numel(), N * L) == n1
+    for x in reads:
+        ref.consume(x)
+    assert dev.count(probe) == ref.count(probe)                   # point write sees the pending counts
+    assert dev.consume_device(r.data_ptr(), r.numel(), N * L) == n1
+    for x in reads:
+        ref.consume(x)
+    dev.set_path("direct")                                        # another path on top of pending counts
+    assert dev.consume(reads[3]) == ref.consume(reads[3])
+    dev.set_path("dedupe")
+    assert len(dev) == len(ref) and dev.sum_counts == ref.sum_counts
+    assert_same_table(dev, ref)
+    other, oref = KCT(k, capacity=G), OracleTable(k)
+    other.set_path("dedupe")
+    assert other.consume_device(r.data_ptr(), r.numel(), N * L) == n1
+    for x in reads:
+        oref.consume(x)
+    acc, aref = KCT(k), OracleTable(k)
+    acc.consume(reads[0]); aref.consume(reads[0])
+    assert acc.add(other) == aref.add(oref)                       # src's pending counts are part of src
+    assert_same_table(acc, aref)
+    other.consume_device(r.data_ptr(), r.numel(), N * L)
+    other.clear()                                                 # pending counts are forgotten with everything else
+    assert len(other) == 0 and other.sum_counts == 0 and other.get(probe) == 0
+    assert other.consume_device(r.data_ptr(), r.numel(), N * L) == n1
+    assert other.max == int(oref.dump_arrays()[1].max()) and other.histo(zero=False) == oref_histo(oref)
+
+
+def oref_histo(ref):
+    _, counts = ref.dump_arrays()
+    vals, freq = np.unique(counts, return_counts=True)
+    return list(zip(vals.tolist(), freq.tolist()))
 
 
 def test_dedupe_first_path_with_too_many_distinct_kmers(KCT):
@@ -515,7 +571,7 @@ def test_dedupe_first_path_with_too_many_distinct_kmers(KCT):
     auto.consume_device(r.data_ptr(), lo, n0 * L)                          # few keys yet -> the next pass tries dedupe-first
     auto.profile(True)
     auto.consume_device(r.data_ptr() + lo, r.numel() - lo, (N - n0) * L)
-    assert "aggregate_blocks_kernel<dedupe>" in auto.profile_read()
+    assert "aggregate_blocks_kernel<shadow>" in auto.profile_read()
     auto.consume_device(r.data_ptr(), r.numel(), N * L)
     ak, ac = auto.dump_arrays(1)
     assert np.array_equal(ak, sk) and np.array_equal(ac, 2 * sc)
