@@ -58,7 +58,7 @@ def pmc_traffic(kernel):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(kernel.replace("<shadow>", ""), {}).get("hbm_bytes_per_launch")  # (K2 on the shadow table is K2)
     except (OSError, ValueError):
         return None
 

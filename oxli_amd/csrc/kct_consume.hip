@@ -108,7 +108,8 @@ bool dedupe_pays(const kct_table *t, u64 npos) {
     // few distinct k-mers, each many times?  What the table (or the shadow) holds so far is the best guess.
     const u64 room = (u64)(kShadowSlots * 0.6);
     const u64 known = std::max(t->n_keys, t->shadow_keys);
-    return known > 0 && known * 4 <= npos && known <= room;
+    if (known == 0) return t->dedupe_hint;  // nothing counted yet (new or cleared table): go by how the last pass went
+    return known * 4 <= npos && known <= room;
 }
 
 // Pending counts -> the real table.  The shadow keeps its keys (they will be met again), its counts return to zero.
@@ -226,7 +227,8 @@ kct_status consume_deduped(kct_table *t, const unsigned char *d_stream, u64 chun
     if (t->force_path != 3 && (new_shadow * 3 > npos || blocked * 50 > npos || t->shadow_keys > (u64)(kShadowSlots * 0.65))) {
         KCT_TRY(flush_shadow(t));
         t->dedupe_off = true;
-    }
+        t->dedupe_hint = false;
+    } else t->dedupe_hint = true;
     return KCT_OK;
 }
 

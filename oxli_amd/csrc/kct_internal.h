@@ -118,6 +118,7 @@ struct kct_table {
     bool shadow_empty = true;   // no keys yet: K2 starts its blocks from zeros instead of loading them
     bool shadow_dirty = false;  // pending counts exist: anything that reads `slots` flushes first (use())
     u64 shadow_keys = 0;
+    bool dedupe_hint = false;   // the last dedupe-first pass paid off: a cleared table starts with that path again
     u64 n_keys = 0;        // distinct non-zero hashes in `slots`
     u64 consumed = 0;      // lib.rs:36
     bool zero_present = false;  // key 0 lives host-side (0 is the EMPTY sentinel on the device)
