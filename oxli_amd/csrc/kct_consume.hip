@@ -1,6 +1,8 @@
 // kct_consume.hip -- bulk ingest behind the C ABI: the launch policy of the direct and the partitioned
 // (one- and two-level) counting paths, staging of host input, and the entry points that hash windows.
 #include "kct_internal.h"
+
+#include <type_traits>
 #include "partition_kernels.h"
 
 namespace kcth {
@@ -91,25 +93,40 @@ unsigned int region_capacity(double avg) {
 // count is hashed once and added with the direct insert).  Many passes, one conversion; MurmurHash3 and the table's
 // random accesses are paid per distinct k-mer per flush instead of per occurrence.  Reads of the table flush first
 // (use()), so nothing observes the difference.  Chosen by dedupe_pays(); counts are identical either way.
-constexpr int kShadowBlockBits = 10;  // log2(shadow blocks): what one K1 pass can fan out to
-constexpr u64 kShadowSlots = 1ULL << (kShadowBlockBits + kct::kBlockBitsMax);
-
-kct::TableGeom shadow_geom() {
+kct::TableGeom shadow_geom(const kct_table *t) {
     kct::TableGeom g;
-    g.mask = kShadowSlots - 1;
-    g.block_bits = kct::kBlockBitsMax;
+    g.mask = t->shadow_cap - 1;
+    g.block_bits = t->shadow_block_bits;
     return g;
 }
 
 bool dedupe_pays(const kct_table *t, u64 npos) {
-    if (t->k > 32 || t->dedupe_off || npos < (1ULL << 22)) return false;
+    if (t->k > 32 || t->dedupe_off || npos < (1ULL << 22) || !partition_geometry_ok(t)) return false;
     if (t->force_path == 3) return true;
-    if (t->force_path != 0) return false;
+    if (t->force_path != 0 || !partition_pays(t, npos)) return false;  // the shadow mirrors the table's geometry
     // few distinct k-mers, each many times?  What the table (or the shadow) holds so far is the best guess.
-    const u64 room = (u64)(kShadowSlots * 0.6);
     const u64 known = std::max(t->n_keys, t->shadow_keys);
     if (known == 0) return t->dedupe_hint;  // nothing counted yet (new or cleared table): go by how the last pass went
-    return known * 4 <= npos && known <= room;
+    // A flush costs ~0.11 ns per pending k-mer (one random table access each), a dedupe-first pass saves ~3-4 ps per
+    // window (no MurmurHash3 in K1): converting pays once ~32 windows have been counted per distinct k-mer since the
+    // table was last read.  The caller's run so far is the evidence that reads are that rare.
+    return known * 32 <= t->windows_since_read + npos;
+}
+
+// The shadow mirrors the real table's capacity (the same k-mers live in both).  (Re)allocated empty when that changes.
+kct_status ensure_shadow(kct_table *t, bool *ok) {
+    *ok = true;
+    if (t->shadow && t->shadow_cap == t->cap) return KCT_OK;
+    KCT_TRY(flush_shadow(t));
+    if (t->shadow) { (void)hipFree(t->shadow); t->shadow = nullptr; t->shadow_cap = 0; }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 3.0 * (double)t->cap * 16.0) { *ok = false; return KCT_OK; }  // not with HBM this tight
+    if (hipMalloc((void **)&t->shadow, t->cap * 16) != hipSuccess) { (void)hipGetLastError(); t->shadow = nullptr; *ok = false; return KCT_OK; }
+    t->shadow_cap = t->cap;
+    t->shadow_block_bits = t->block_bits;
+    t->shadow_empty = true;
+    t->shadow_keys = 0;
+    return KCT_OK;
 }
 
 // Pending counts -> the real table.  The shadow keeps its keys (they will be met again), its counts return to zero.
@@ -117,12 +134,12 @@ kct_status flush_shadow(kct_table *t) {
     if (!t->shadow_dirty) return KCT_OK;
     t->shadow_dirty = false;
     KCT_TRY(materialize(t));
-    KCT_TRY(t->d_spill.reserve(kShadowSlots * 16));
+    KCT_TRY(t->d_spill.reserve(t->shadow_cap * 16));
     KCT_TRY(zero_counters(t));
     {
         ProfScope ps(t, "shadow_flush_kernel");
-        hipLaunchKernelGGL(kct::shadow_flush_kernel, dim3(merge_grid(kShadowSlots)), dim3(kct::kBlock), 0, t->stream, t->shadow, shadow_geom(),
-                           view(t, kShadowSlots), (int)t->k, t->d_counters);
+        hipLaunchKernelGGL(kct::shadow_flush_kernel, dim3(merge_grid(t->shadow_cap)), dim3(kct::kBlock), 0, t->stream, t->shadow, shadow_geom(t),
+                           view(t, t->shadow_cap), (int)t->k, t->d_counters);
     }
     HIP_TRY(hipGetLastError());
     u64 c[4], spilled;
@@ -137,112 +154,34 @@ kct_status flush_shadow(kct_table *t) {
     return KCT_OK;
 }
 
-kct_status consume_deduped(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled) {
-    *handled = false;
-    const int k = t->k;
-    const int pbits = kShadowBlockBits;
-    const u64 P = 1ULL << pbits;
-    const int nwg = t->num_cus;
-    const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
-    const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
-    const unsigned int region_cap = region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P);
-    const unsigned int ovf_cap = (unsigned int)std::max<u64>(4096, tiles_per_wg * kct::kPartTile / 8);
-    if (!t->shadow) {
-        HIP_TRY(hipMalloc((void **)&t->shadow, kShadowSlots * 16));
-        t->shadow_empty = true;
-        t->shadow_keys = 0;
-    }
-    KCT_TRY(materialize(t));  // K1's overflow regions go straight to the real table
-    KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 8));
-    KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
-    KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
-    KCT_TRY(t->d_spill.reserve(npos * 16));
-    KCT_TRY(zero_counters(t));
-    du64 *d_overflow = t->d_counters + kNumCounters + 6;
-    unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
-
-    kct::PartitionArgs pa;
-    pa.mask = kShadowSlots - 1; pa.block_bits = kct::kBlockBitsMax; pa.pbits = pbits;
-    pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
-    pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
-    pa.ablate = t->ablate;
-    {
-        ProfScope ps(t, "partition_windows_kernel<raw>");
-        PartitionRawByK<32>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
-    }
-    HIP_TRY(hipGetLastError());
-
-    kct::AggregateArgs aa;  // the unchanged K2, on the shadow table
-    aa.words = t->shadow; aa.block_bits = kct::kBlockBitsMax; aa.pbits = pbits;
-    aa.scratch = (const du64 *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
-    aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
-    aa.fresh = t->shadow_empty ? 1 : 0; aa.overflow = d_overflow; aa.ablate = pa.ablate;
-    aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
-    {
-        ProfScope ps(t, "aggregate_blocks_kernel<shadow>");
-        hipLaunchKernelGGL(kct::aggregate_blocks_kernel, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, aa);
-    }
-    HIP_TRY(hipGetLastError());
-    // first the tallies of the shadow pass (entries counted, new shadow keys, pairs that found their block full) ...
-    u64 c[4], blocked;
-    KCT_TRY(read_counters(t, c, &blocked));
-    if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // K1 gave up (its overflow regions overflowed): nothing was touched
-    const u64 counted = c[kct::CTR_COUNTED], new_shadow = c[kct::CTR_NEWKEYS];
-    t->shadow_empty = false;
-    t->shadow_dirty = true;
-    t->shadow_keys += new_shadow;
-    *handled = true;
-    // ... then what did not fit the shadow goes to the real table right away: K1's overflow regions, and K2's pairs
-    if (blocked) {
-        KCT_TRY(t->d_aux2.reserve(blocked * 16));
-        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, blocked * 16, hipMemcpyDeviceToDevice, t->stream));
-        HIP_TRY(hipMemcpyAsync(t->d_counters + kNumCounters + 5, t->d_counters + kNumCounters, 8, hipMemcpyDeviceToDevice, t->stream));
-    }
-    HIP_TRY(hipMemsetAsync(t->d_counters, 0, (kNumCounters + 1) * sizeof(u64), t->stream));  // the tallies and the spill cursor, not the copied pair count
-    {
-        ProfScope ps(t, "merge_overflow_kernel");
-        hipLaunchKernelGGL(kct::merge_overflow_kernel<true>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
-                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)nullptr, view(t, npos), t->d_counters, k);
-        if (blocked)
-            hipLaunchKernelGGL(kct::merge_mixed_pairs_kernel, dim3(merge_grid(blocked)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_aux2.p,
-                               (const du64 *)(t->d_counters + kNumCounters + 5), (u64)blocked, view(t, npos), (int)k, t->d_counters);
-    }
-    HIP_TRY(hipGetLastError());
-    u64 c2[4], spilled;
-    KCT_TRY(read_counters(t, c2, &spilled));
-    if (t->debug)
-        fprintf(stderr, "[kct] dedupe pass: npos=%llu region_cap=%u counted(shadow)=%llu new shadow keys=%llu (total %llu) blocked=%llu merged=%llu new=%llu spilled=%llu\n",
-                (unsigned long long)npos, region_cap, (unsigned long long)counted, (unsigned long long)new_shadow, (unsigned long long)t->shadow_keys,
-                (unsigned long long)blocked, (unsigned long long)c2[kct::CTR_TOTAL_ADDED], (unsigned long long)c2[kct::CTR_NEWKEYS], (unsigned long long)spilled);
-    // n counts every window whose k-mer went into the shadow: the (2^-64 per k-mer) case of a MurmurHash3 value of 0,
-    // which the reference leaves out of n, is only seen when the shadow is flushed.
-    *n_out += counted + c2[kct::CTR_TOTAL_ADDED];
-    t->n_keys += c2[kct::CTR_NEWKEYS];
-    if (spilled) {
-        KCT_TRY(t->d_aux2.reserve(spilled * 16));
-        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
-        KCT_TRY(replay_spill(t, spilled, n_out));
-    }
-    // Too few repeats to be worth it, or the shadow is filling up: convert what is pending and go back to hashing every window.
-    if (t->force_path != 3 && (new_shadow * 3 > npos || blocked * 50 > npos || t->shadow_keys > (u64)(kShadowSlots * 0.65))) {
-        KCT_TRY(flush_shadow(t));
-        t->dedupe_off = true;
-        t->dedupe_hint = false;
-    } else t->dedupe_hint = true;
-    return KCT_OK;
-}
-
 // One pass of the partitioned path over window starts [0, npos) of d_stream.  *handled = false
 // (and nothing counted) if the pass had to be abandoned; the caller then uses the direct path.
-kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled) {
+// raw = false: K1 hashes, K2 counts into the real table.
+// raw = true (dedupe-first, k <= 32): K1 emits mix64(packed k-mer) values, K2 counts them into the shadow table
+//        (same geometry); what does not fit (overflow regions, pairs that found their block full) is hashed and goes
+//        to the real table at once.
+kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled, bool raw) {
     *handled = false;
     const int k = t->k;
+    if (raw) {
+        bool ok = true;
+        KCT_TRY(ensure_shadow(t, &ok));
+        if (!ok) { t->dedupe_off = true; return KCT_OK; }
+        KCT_TRY(materialize(t));  // what does not fit the shadow goes straight to the real table
+    }
+    du64 *words = raw ? t->shadow : t->slots;
     const int bbits = log2_u64(t->cap >> t->block_bits);      // log2(table blocks)
     const bool two_level = bbits > 10;
-    const int pbits = two_level ? 10 : bbits;                 // K1 fans out to 2^pbits bins ...
+    // K1 fans out to 2^pbits bins, each holding 2^sub_bits table blocks that K1b separates.  K1b wants >= 64 bins per
+    // super-bin: with 16 its lanes fight over a handful of LDS cursors (2.5x slower per k-mer), so small tables give K1
+    // FEWER bins, and W workgroups share a super-bin so that K1b still fills the chip.
+    int pbits = bbits;
+    if (two_level) pbits = bbits <= 14 ? bbits - 6 : std::min(10, bbits - 7);
+    if (const char *e = getenv("KCT_PBITS")) if (two_level) pbits = std::max(bbits - 10, std::min(10, atoi(e)));  // measurement only
     const int sub_bits = bbits - pbits;                       // ... each holding 2^sub_bits table blocks
     const u64 P = 1ULL << pbits, B = 1ULL << bbits;
     const int nwg = t->num_cus;
+    const u64 W = two_level ? std::max<u64>(1, (u64)nwg / P) : 1;  // K1b workgroups per super-bin
     const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
     const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
     const unsigned int region_cap = region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P);
@@ -254,7 +193,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     KCT_TRY(zero_counters(t));
     du64 *d_overflow = t->d_counters + kNumCounters + 6;
     unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
-    const bool fresh = t->lazy_empty;
+    const bool fresh = raw ? t->shadow_empty : t->lazy_empty;
 
     kct::PartitionArgs pa;
     pa.mask = t->cap - 1; pa.block_bits = t->block_bits + sub_bits; pa.pbits = pbits;
@@ -262,13 +201,14 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
     pa.ablate = t->ablate;  // measurement only; wrong counts when set
     {
-        ProfScope ps(t, "partition_windows_kernel");
-        PartitionByK<64>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
+        ProfScope ps(t, raw ? "partition_windows_kernel<raw>" : "partition_windows_kernel");
+        if (raw) PartitionRawByK<32>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
+        else PartitionByK<64>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
     }
     HIP_TRY(hipGetLastError());
 
     kct::AggregateArgs aa;
-    aa.words = t->slots; aa.block_bits = t->block_bits; aa.pbits = bbits;
+    aa.words = words; aa.block_bits = t->block_bits; aa.pbits = bbits;
     aa.fresh = fresh ? 1 : 0; aa.overflow = d_overflow; aa.ablate = pa.ablate;
     aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
     unsigned int ovf2_cap = 0, *d_ovf2_count = nullptr;
@@ -277,42 +217,46 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
     } else {
         // second level: one workgroup per super-bin spreads its hashes over the super-bin's blocks
-        const unsigned int out_cap = region_capacity((double)npos / (double)B);
-        ovf2_cap = (unsigned int)std::max<u64>(4096, npos / P / 8);
-        KCT_TRY(t->d_scratch2.reserve(B * out_cap * 8));
-        KCT_TRY(t->d_regions2.reserve(B * 4));
-        KCT_TRY(t->d_irr2.reserve(P * ovf2_cap * 8 + P * 4));
-        d_ovf2_count = (unsigned int *)((du64 *)t->d_irr2.p + P * ovf2_cap);
+        const unsigned int out_cap = region_capacity((double)npos / (double)B / (double)W);
+        ovf2_cap = (unsigned int)std::max<u64>(4096, npos / P / W / 8);
+        KCT_TRY(t->d_scratch2.reserve(B * W * out_cap * 8));
+        KCT_TRY(t->d_regions2.reserve(B * W * 4));
+        KCT_TRY(t->d_irr2.reserve(P * W * ovf2_cap * 8 + P * W * 4));
+        d_ovf2_count = (unsigned int *)((du64 *)t->d_irr2.p + P * W * ovf2_cap);
         kct::RepartitionArgs ra;
         ra.mask = t->cap - 1; ra.block_bits = t->block_bits; ra.sub_bits = sub_bits;
         ra.in = (const du64 *)t->d_scratch.p; ra.in_cap = region_cap; ra.in_count = (const unsigned int *)t->d_regions.p;
-        ra.nseg = nwg; ra.nbins = (int)P;
+        ra.nseg = nwg; ra.nbins = (int)P; ra.writers = (int)W;
         ra.out = (du64 *)t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
         ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow;
         {
             ProfScope ps(t, "repartition_kernel");
-            hipLaunchKernelGGL(kct::repartition_kernel, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, ra);
+            hipLaunchKernelGGL(kct::repartition_kernel, dim3((unsigned)(P * W)), dim3(kct::kPartThreads), 0, t->stream, ra);
         }
         HIP_TRY(hipGetLastError());
-        aa.scratch = (const du64 *)t->d_scratch2.p; aa.seg_stride = 0; aa.block_stride = out_cap;
-        aa.region_count = (const unsigned int *)t->d_regions2.p; aa.nregions = 1;
+        aa.scratch = (const du64 *)t->d_scratch2.p; aa.seg_stride = out_cap; aa.block_stride = W * out_cap;
+        aa.region_count = (const unsigned int *)t->d_regions2.p; aa.nregions = (int)W;
     }
     {
-        ProfScope ps(t, "aggregate_blocks_kernel");
+        ProfScope ps(t, raw ? "aggregate_blocks_kernel<shadow>" : "aggregate_blocks_kernel");
         hipLaunchKernelGGL(kct::aggregate_blocks_kernel, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
     }
     HIP_TRY(hipGetLastError());
-    {
+    auto merge_overflows = [&](auto dedupe_tag, const du64 *abort) {
         // fold the overflow regions with the direct atomic path; the kernel reads the region lengths
-        // and the abandon flag from device memory, so no host round trip sits between the launches
+        // (and the abandon flag) from device memory, so no host round trip sits between the launches
+        constexpr bool D = decltype(dedupe_tag)::value;
         ProfScope ps(t, "merge_overflow_kernel");
-        hipLaunchKernelGGL(kct::merge_overflow_kernel<false>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
-                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, view(t, npos), t->d_counters);
+        hipLaunchKernelGGL(kct::merge_overflow_kernel<D>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
+                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, abort, view(t, npos), t->d_counters, k);
         if (two_level)
-            hipLaunchKernelGGL(kct::merge_overflow_kernel<false>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
-                               (const unsigned int *)d_ovf2_count, (int)P, ovf2_cap, (const du64 *)d_overflow, view(t, npos), t->d_counters);
+            hipLaunchKernelGGL(kct::merge_overflow_kernel<D>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
+                               (const unsigned int *)d_ovf2_count, (int)(P * W), ovf2_cap, abort, view(t, npos), t->d_counters, k);
+    };
+    if (!raw) {
+        merge_overflows(std::false_type{}, (const du64 *)d_overflow);
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
     u64 c[4], spilled;
     KCT_TRY(read_counters(t, c, &spilled));
     if (t->debug) {
@@ -320,20 +264,63 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         (void)hipMemcpy(oc.data(), d_ovf_count, nwg * 4, hipMemcpyDeviceToHost);
         u64 tot = 0;
         for (auto v : oc) tot += v;
-        fprintf(stderr, "[kct] partitioned pass: npos=%llu blocks=%llu levels=%d region_cap=%u overflow(K1)=%llu counted=%llu merged=%llu spilled=%llu abandon=%llu\n",
-                (unsigned long long)npos, (unsigned long long)B, two_level ? 2 : 1, region_cap, (unsigned long long)tot,
-                (unsigned long long)c[kct::CTR_COUNTED], (unsigned long long)c[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled,
-                (unsigned long long)t->h_counters[kNumCounters + 6]);
+        fprintf(stderr, "[kct] partitioned pass%s: npos=%llu blocks=%llu levels=%d region_cap=%u overflow(K1)=%llu counted=%llu merged=%llu new=%llu spilled=%llu abandon=%llu\n",
+                raw ? " (shadow)" : "", (unsigned long long)npos, (unsigned long long)B, two_level ? 2 : 1, region_cap, (unsigned long long)tot,
+                (unsigned long long)c[kct::CTR_COUNTED], (unsigned long long)c[kct::CTR_TOTAL_ADDED], (unsigned long long)c[kct::CTR_NEWKEYS],
+                (unsigned long long)spilled, (unsigned long long)t->h_counters[kNumCounters + 6]);
     }
     if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // abandoned: K2 and the merges exited early, nothing was touched
-    t->lazy_empty = false;
     *handled = true;
-    *n_out += c[kct::CTR_COUNTED] + c[kct::CTR_TOTAL_ADDED];
-    t->n_keys += c[kct::CTR_NEWKEYS];
-    if (spilled) {
-        KCT_TRY(t->d_aux2.reserve(spilled * 16));
-        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
-        KCT_TRY(replay_spill(t, spilled, n_out));
+    if (!raw) {
+        t->lazy_empty = false;
+        *n_out += c[kct::CTR_COUNTED] + c[kct::CTR_TOTAL_ADDED];
+        t->n_keys += c[kct::CTR_NEWKEYS];
+        if (spilled) {
+            KCT_TRY(t->d_aux2.reserve(spilled * 16));
+            HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+            KCT_TRY(replay_spill(t, spilled, n_out));
+        }
+        return KCT_OK;
+    }
+    // ---- shadow pass: c = entries counted into the shadow / new shadow keys; `spilled` = pairs that found their block full
+    const u64 counted = c[kct::CTR_COUNTED], new_shadow = c[kct::CTR_NEWKEYS], blocked = spilled;
+    t->shadow_empty = false;
+    t->shadow_dirty = true;
+    t->shadow_keys += new_shadow;
+    if (blocked) {
+        KCT_TRY(t->d_aux2.reserve(blocked * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, blocked * 16, hipMemcpyDeviceToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->d_counters + kNumCounters + 5, t->d_counters + kNumCounters, 8, hipMemcpyDeviceToDevice, t->stream));
+    }
+    HIP_TRY(hipMemsetAsync(t->d_counters, 0, (kNumCounters + 1) * sizeof(u64), t->stream));  // the tallies and the spill cursor, not the copied pair count
+    merge_overflows(std::true_type{}, (const du64 *)nullptr);
+    if (blocked) {
+        ProfScope ps(t, "merge_mixed_pairs_kernel");
+        hipLaunchKernelGGL(kct::merge_mixed_pairs_kernel, dim3(merge_grid(blocked)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_aux2.p,
+                           (const du64 *)(t->d_counters + kNumCounters + 5), (u64)blocked, view(t, npos), (int)k, t->d_counters);
+    }
+    HIP_TRY(hipGetLastError());
+    u64 c2[4], spilled2;
+    KCT_TRY(read_counters(t, c2, &spilled2));
+    // n counts every window whose k-mer went into the shadow: the (2^-64 per k-mer) case of a MurmurHash3 value of 0,
+    // which the reference leaves out of n, is only seen when the shadow is flushed.
+    *n_out += counted + c2[kct::CTR_TOTAL_ADDED];
+    t->n_keys += c2[kct::CTR_NEWKEYS];
+    if (spilled2) {
+        KCT_TRY(t->d_aux2.reserve(spilled2 * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled2 * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(replay_spill(t, spilled2, n_out));
+    }
+    // Too few repeats to be worth it, or the shadow is filling up: convert what is pending and go back to hashing every window.
+    if (t->force_path != 3 && (new_shadow * 3 > npos || blocked * 50 > npos)) {
+        KCT_TRY(flush_shadow(t));
+        t->dedupe_off = true;
+        t->dedupe_hint = false;
+    } else t->dedupe_hint = true;
+    // the shadow holds as many keys as the table would: grow both (the table's growth re-creates the shadow, flushed)
+    if ((double)t->shadow_keys > kMaxLoad * (double)t->shadow_cap) {
+        KCT_TRY(flush_shadow(t));
+        KCT_TRY(grow_to(t, t->cap * 2));
     }
     return KCT_OK;
 }
@@ -371,13 +358,13 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         const u64 chunk_bytes = std::min<u64>(nbytes - done, npos + k - 1);
         if (dedupe_pays(t, npos)) {
             bool handled = false;
-            KCT_TRY(consume_deduped(t, d_stream + done, chunk_bytes, npos, n_out, &handled));
-            if (handled) { done += npos; continue; }
+            KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true));
+            if (handled) { done += npos; t->windows_since_read += npos; continue; }
         }
         if (partition_geometry_ok(t) && t->force_path != 1 && (t->force_path == 2 || partition_pays(t, npos))) {
             bool handled = false;
-            KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled));
-            if (handled) { done += npos; continue; }
+            KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, false));
+            if (handled) { done += npos; t->windows_since_read += npos; continue; }
         }
         KCT_TRY(materialize(t));
         KCT_TRY(t->d_spill.reserve(npos * 16));
@@ -400,6 +387,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
             KCT_TRY(replay_spill(t, spilled, n_out));
         }
         done += npos;
+        t->windows_since_read += npos;
     }
     if (t->auto_sized && t->cap == cap_at_entry && nbytes >= (1u << 20)) t->auto_sized = false;  // the table has found its size
     return KCT_OK;

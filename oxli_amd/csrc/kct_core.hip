@@ -57,6 +57,7 @@ kct_status use_consume(kct_table *t) {
 kct_status use(kct_table *t) {
     KCT_TRY(use_consume(t));
     if (t->shadow_dirty) KCT_TRY(flush_shadow(t));   // reads must observe every earlier consume()
+    t->windows_since_read = 0;
     return KCT_OK;
 }
 

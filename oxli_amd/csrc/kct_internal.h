@@ -114,10 +114,13 @@ struct kct_table {
     int force_path = 0;     // 0 = choose per pass, 1 = direct atomic kernel only, 2 = partitioned whenever the geometry allows, 3 = dedupe-first
     bool dedupe_off = false;  // a dedupe-first pass found too many distinct k-mers: this table goes back to hashing every window
     // dedupe-first path (k <= 32): a shadow table keyed by packed k-mers holds counts that are still PENDING for `slots`
-    du64 *shadow = nullptr;     // 2^23 slots x 16 B, block-SoA like `slots` (allocated on first use)
+    du64 *shadow = nullptr;     // as many slots as `slots`, same block-SoA layout (allocated on first use, re-created when the table grows)
+    u64 shadow_cap = 0;
+    int shadow_block_bits = 0;
     bool shadow_empty = true;   // no keys yet: K2 starts its blocks from zeros instead of loading them
     bool shadow_dirty = false;  // pending counts exist: anything that reads `slots` flushes first (use())
     u64 shadow_keys = 0;
+    u64 windows_since_read = 0; // window starts consumed since anything last read the table (use()): how long the caller's runs are
     bool dedupe_hint = false;   // the last dedupe-first pass paid off: a cleared table starts with that path again
     u64 n_keys = 0;        // distinct non-zero hashes in `slots`
     u64 consumed = 0;      // lib.rs:36

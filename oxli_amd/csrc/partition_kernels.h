@@ -41,8 +41,9 @@ namespace kct {
 // Returns (workgroup-uniformly) whether the list was too short for everything that was ready.
 template <u32 LISTCAP, class Overflow>
 __device__ __forceinline__ bool ring_flush(u64 *ring, u32 *fill, u32 *flushed, u32 *flist, u32 *fcount, int P, u32 D,
-                                           u64 *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash) {
+                                           u64 *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash, u64 bin_stride = 0) {
     const u32 dmask = D - 1;
+    if (bin_stride == 0) bin_stride = out_cap;  // distance between the regions of consecutive bins
     const int dshift = __builtin_ctz(D);  // D is a power of two: shifts instead of quarter-rate multiplies
     __syncthreads();  // appends of this interval are in the ring; *fcount == 0
     for (int b = threadIdx.x; b < P; b += kPartThreads) {
@@ -67,7 +68,7 @@ __device__ __forceinline__ bool ring_flush(u64 *ring, u32 *fill, u32 *flushed, u
             *src = make_uint4(0, 0, 0, 0);
         }
         if (f + kChunk <= out_cap) {
-            reinterpret_cast<uint4 *>(out_base + (u64)b * out_cap + f)[q] = v;
+            reinterpret_cast<uint4 *>(out_base + (u64)b * bin_stride + f)[q] = v;
         } else {  // region full (badly skewed input): hand the entries to the overflow region
             const u64 e0 = ((u64)v.y << 32) | v.x, e1 = ((u64)v.w << 32) | v.z;
             if (e0) overflow_hash(e0);
@@ -226,10 +227,12 @@ struct RepartitionArgs {
     u32 in_cap;
     const u32 *in_count; // [nbins][nseg]
     int nseg, nbins;
-    u64 *out;            // region of block b at out + b * out_cap
+    int writers;         // workgroups per super-bin (W): each takes every W-th group of 16 input regions, so that
+                         // W x nbins workgroups fill the chip even when there are few super-bins
+    u64 *out;            // region of (block b, writer w) at out + (b * W + w) * out_cap
     u32 out_cap;         // multiple of kChunk
-    u32 *out_count;      // [blocks]
-    u64 *ovf; u32 ovf_cap; u32 *ovf_count;  // per super-bin overflow regions
+    u32 *out_count;      // [blocks][W]
+    u64 *ovf; u32 ovf_cap; u32 *ovf_count;  // per workgroup overflow regions
     u64 *overflow;       // abandon flag (shared with K1)
 };
 
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     __shared__ u32 fill[1024], flushed[1024];
     __shared__ u32 flist[2048];
     __shared__ u32 fcount, ovf_n, rounds;
-    const int s = blockIdx.x, P2 = 1 << a.sub_bits;
+    const int W = a.writers, s = blockIdx.x / W, w = blockIdx.x % W, P2 = 1 << a.sub_bits;
     const u32 D = (u32)(kRingEntries >> a.sub_bits), dmask = D - 1;
     const int dshift = 14 - a.sub_bits;  // log2 D
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -249,34 +252,36 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     __syncthreads();
     if (rounds == ~0u) return;  // read through LDS so that the whole workgroup takes the same branch
     __syncthreads();
-    u64 *my_out = a.out + ((u64)s << a.sub_bits) * a.out_cap;
-    u64 *my_ovf = a.ovf + (u64)s * a.ovf_cap;
+    u64 *my_out = a.out + (((u64)s << a.sub_bits) * W + w) * a.out_cap;
+    const u64 bin_stride = (u64)W * a.out_cap;
+    u64 *my_ovf = a.ovf + (u64)blockIdx.x * a.ovf_cap;
     auto overflow_hash = [&](u64 h) {
         const u32 i = atomicAdd(&ovf_n, 1u);
         if (i < a.ovf_cap) my_ovf[i] = h;
         else *a.overflow = 1ULL;
     };
     auto flush_lines = [&](bool drain) {
-        return ring_flush<2048u>(ring, fill, flushed, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_hash);
+        return ring_flush<2048u>(ring, fill, flushed, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_hash, bin_stride);
     };
-    // A wave owns the input regions seg = wave, wave+16, ...; work unit = a slab of 8 x 64 entries whose
+    // A wave owns the input regions seg = 16 w + wave, + 16 W, ...; work unit = a slab of 8 x 64 entries whose
     // loads are all issued before the first append.  Every wave runs the same number of rounds so that
     // the flush barriers line up.
     constexpr int kLoads = 8;
     constexpr u32 kSlab = 64 * kLoads;
     const u32 *counts = a.in_count + (u64)s * a.nseg;
     u32 my_slabs = 0;
-    for (int seg = wave; seg < a.nseg; seg += kPartThreads / 64) my_slabs += (counts[seg] + kSlab - 1) / kSlab;
+    const int seg0 = w * (kPartThreads / 64) + wave, seg_step = W * (kPartThreads / 64);
+    for (int seg = seg0; seg < a.nseg; seg += seg_step) my_slabs += (counts[seg] + kSlab - 1) / kSlab;
     if (lane == 0) atomicMax(&rounds, my_slabs);
     __syncthreads();
     const u32 nrounds = rounds;
-    int seg = wave;
+    int seg = seg0;
     u32 off = 0;
     for (u32 r = 0; r < nrounds; ++r) {
         u64 v[kLoads];
 #pragma unroll
         for (int j = 0; j < kLoads; ++j) v[j] = 0;
-        while (seg < a.nseg && off >= counts[seg]) { seg += kPartThreads / 64; off = 0; }  // next non-empty region
+        while (seg < a.nseg && off >= counts[seg]) { seg += seg_step; off = 0; }  // next non-empty region
         if (seg < a.nseg) {
             const u32 cnt = counts[seg];
             const u64 *src = a.in + ((u64)seg * a.nbins + s) * a.in_cap + off;
@@ -300,10 +305,10 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     while (flush_lines(true)) {}
     for (int b = threadIdx.x; b < P2; b += kPartThreads) {
         const u32 f = flushed[b];
-        a.out_count[((u64)s << a.sub_bits) + b] = f < a.out_cap ? f : a.out_cap;
+        a.out_count[(((u64)s << a.sub_bits) + b) * W + w] = f < a.out_cap ? f : a.out_cap;
     }
     __syncthreads();
-    if (threadIdx.x == 0) a.ovf_count[s] = ovf_n < a.ovf_cap ? ovf_n : a.ovf_cap;
+    if (threadIdx.x == 0) a.ovf_count[blockIdx.x] = ovf_n < a.ovf_cap ? ovf_n : a.ovf_cap;
 }
 
 struct AggregateArgs {

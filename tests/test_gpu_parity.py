@@ -564,14 +564,14 @@ def test_dedupe_first_path_with_too_many_distinct_kmers(KCT):
     assert ded.consume_device(r.data_ptr(), r.numel(), N * L) == n
     dk, dc = ded.dump_arrays(1)
     assert np.array_equal(dk, sk) and np.array_equal(dc, sc)
-    # automatic choice: after a pass like that the table gives up on dedupe-first
+    # automatic choice: input like this never looks worth it (too few windows per k-mer the table already holds)
     auto = KCT(k, capacity=40_000_000)
     n0 = (N // 8) // 16 * 16                                               # (a 16-byte aligned cut of the stream)
     lo = n0 * (L + 1)
-    auto.consume_device(r.data_ptr(), lo, n0 * L)                          # few keys yet -> the next pass tries dedupe-first
+    auto.consume_device(r.data_ptr(), lo, n0 * L)
     auto.profile(True)
     auto.consume_device(r.data_ptr() + lo, r.numel() - lo, (N - n0) * L)
-    assert "aggregate_blocks_kernel<shadow>" in auto.profile_read()
+    assert "aggregate_blocks_kernel<shadow>" not in auto.profile_read()
     auto.consume_device(r.data_ptr(), r.numel(), N * L)
     ak, ac = auto.dump_arrays(1)
     assert np.array_equal(ak, sk) and np.array_equal(ac, 2 * sc)
