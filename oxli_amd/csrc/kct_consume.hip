@@ -60,6 +60,18 @@ template <>
 struct PartitionRawByK<0> {
     static void run(int, hipStream_t, int, const unsigned char *, u64, u64, const kct::PartitionArgs &) {}
 };
+// the compact variant (k <= 21): mix42 values, 32-bit entries
+template <int K>
+struct PartitionCompactByK {
+    static void run(int k, hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, u64 ntiles, const kct::PartitionArgs &a) {
+        if (k == K) hipLaunchKernelGGL((kct::partition_windows_kernel<1, K, 2>), dim3(grid), dim3(kct::kPartThreads), 0, s, stream, nbytes, k, ntiles, a);
+        else PartitionCompactByK<K - 1>::run(k, s, grid, stream, nbytes, ntiles, a);
+    }
+};
+template <>
+struct PartitionCompactByK<0> {
+    static void run(int, hipStream_t, int, const unsigned char *, u64, u64, const kct::PartitionArgs &) {}
+};
 template <>
 struct PartitionByK<0> {
     static void run(int k, hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, u64 ntiles, const kct::PartitionArgs &a) {
@@ -105,7 +117,7 @@ bool dedupe_pays(const kct_table *t, u64 npos) {
     if (t->force_path == 3) return true;
     if (t->force_path != 0 || !partition_pays(t, npos)) return false;  // the shadow mirrors the table's geometry
     // few distinct k-mers, each many times?  What the table (or the shadow) holds so far is the best guess.
-    const u64 known = std::max(t->n_keys, t->shadow_keys);
+    const u64 known = std::max({t->n_keys, t->shadow_keys, t->s32_keys});
     if (known == 0) return t->dedupe_hint;  // nothing counted yet (new or cleared table): go by how the last pass went
     // A flush costs ~0.11 ns per pending k-mer (one random table access each), a dedupe-first pass saves ~3-4 ps per
     // window (no MurmurHash3 in K1): converting pays once ~32 windows have been counted per distinct k-mer since the
@@ -130,7 +142,36 @@ kct_status ensure_shadow(kct_table *t, bool *ok) {
 }
 
 // Pending counts -> the real table.  The shadow keeps its keys (they will be met again), its counts return to zero.
+constexpr int kCompactBlockBits = 10;  // the compact shadow: 1024 blocks x 8192 slots
+constexpr u64 kCompactSlots = 1ULL << (kCompactBlockBits + kct::kBlockBitsMax);
+
+kct_status flush_compact(kct_table *t) {
+    if (!t->s32_dirty) return KCT_OK;
+    t->s32_dirty = false;
+    t->s32_windows = 0;
+    KCT_TRY(materialize(t));
+    KCT_TRY(t->d_spill.reserve(kCompactSlots * 16));
+    KCT_TRY(zero_counters(t));
+    {
+        ProfScope ps(t, "shadow32_flush_kernel");
+        hipLaunchKernelGGL(kct::shadow32_flush_kernel, dim3(merge_grid(kCompactSlots)), dim3(kct::kBlock), 0, t->stream, t->shadow32,
+                           (int)kct::kBlockBitsMax, kCompactSlots, view(t, kCompactSlots), (int)t->k, t->d_counters);
+    }
+    HIP_TRY(hipGetLastError());
+    u64 c[4], spilled;
+    KCT_TRY(read_counters(t, c, &spilled));
+    t->n_keys += c[kct::CTR_NEWKEYS];
+    if (spilled) {
+        u64 ignored = 0;
+        KCT_TRY(t->d_aux2.reserve(spilled * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(replay_spill(t, spilled, &ignored));
+    }
+    return KCT_OK;
+}
+
 kct_status flush_shadow(kct_table *t) {
+    KCT_TRY(flush_compact(t));
     if (!t->shadow_dirty) return KCT_OK;
     t->shadow_dirty = false;
     KCT_TRY(materialize(t));
@@ -150,6 +191,111 @@ kct_status flush_shadow(kct_table *t) {
         KCT_TRY(t->d_aux2.reserve(spilled * 16));
         HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
         KCT_TRY(replay_spill(t, spilled, &ignored));
+    }
+    return KCT_OK;
+}
+
+// Compact dedupe-first pass (k <= 21, one level): K1 MODE 2 writes 32-bit entries, aggregate_blocks32_kernel counts them
+// into the compact shadow (u32 keys, u32 counts).  Half the partition traffic of the 64-bit variant and half as many
+// ring flushes.  Same contract as consume_partitioned(raw = true).
+bool compact_pays(const kct_table *t, u64 npos) {
+    if (t->k > 21 || t->compact_off || !dedupe_pays(t, npos)) return false;
+    const u64 known = std::max(t->n_keys, t->s32_keys);
+    return known <= (u64)(kCompactSlots * 0.6);
+}
+
+kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled) {
+    *handled = false;
+    const int k = t->k;
+    const int pbits = kCompactBlockBits;
+    const u64 P = 1ULL << pbits;
+    const int nwg = t->num_cus;
+    const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
+    const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
+    const unsigned int region_cap = (region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P) + 15u) & ~15u;  // 16-entry lines
+    const unsigned int ovf_cap = (unsigned int)std::max<u64>(4096, tiles_per_wg * kct::kPartTile / 8);
+    if (t->s32_windows + npos >= (1ULL << 31)) KCT_TRY(flush_compact(t));  // u32 counts: no k-mer can have been seen 2^32 times
+    if (!t->shadow32) {
+        HIP_TRY(hipMalloc((void **)&t->shadow32, kCompactSlots * 8));
+        t->s32_empty = true;
+        t->s32_keys = 0;
+    }
+    KCT_TRY(materialize(t));
+    KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 4));
+    KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
+    KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
+    KCT_TRY(t->d_spill.reserve(npos * 16));
+    KCT_TRY(zero_counters(t));
+    du64 *d_overflow = t->d_counters + kNumCounters + 6;
+    unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
+
+    kct::PartitionArgs pa;
+    pa.mask = kCompactSlots - 1; pa.block_bits = kct::kBlockBitsMax; pa.pbits = pbits;
+    pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
+    pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
+    pa.ablate = t->ablate;
+    {
+        ProfScope ps(t, "partition_windows_kernel<compact>");
+        PartitionCompactByK<21>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
+    }
+    HIP_TRY(hipGetLastError());
+    kct::Aggregate32Args aa;
+    aa.words = t->shadow32; aa.block_bits = kct::kBlockBitsMax;
+    aa.scratch = (const unsigned int *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
+    aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
+    aa.fresh = t->s32_empty ? 1 : 0; aa.overflow = d_overflow;
+    aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
+    {
+        ProfScope ps(t, "aggregate_blocks32_kernel");
+        hipLaunchKernelGGL(kct::aggregate_blocks32_kernel, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, aa);
+    }
+    HIP_TRY(hipGetLastError());
+    u64 c[4], blocked;
+    KCT_TRY(read_counters(t, c, &blocked));
+    if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // K1 gave up: nothing was touched
+    *handled = true;
+    const u64 counted = c[kct::CTR_COUNTED], new_keys = c[kct::CTR_NEWKEYS];
+    t->s32_empty = false;
+    t->s32_dirty = true;
+    t->s32_keys += new_keys;
+    t->s32_windows += npos;
+    if (blocked) {
+        KCT_TRY(t->d_aux2.reserve(blocked * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, blocked * 16, hipMemcpyDeviceToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->d_counters + kNumCounters + 5, t->d_counters + kNumCounters, 8, hipMemcpyDeviceToDevice, t->stream));
+    }
+    HIP_TRY(hipMemsetAsync(t->d_counters, 0, (kNumCounters + 1) * sizeof(u64), t->stream));
+    {
+        ProfScope ps(t, "merge_overflow_kernel");
+        hipLaunchKernelGGL(kct::merge_overflow_kernel<2>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
+                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)nullptr, view(t, npos), t->d_counters, k);
+        if (blocked)
+            hipLaunchKernelGGL(kct::merge_mixed_pairs_kernel<2>, dim3(merge_grid(blocked)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_aux2.p,
+                               (const du64 *)(t->d_counters + kNumCounters + 5), (u64)blocked, view(t, npos), (int)k, t->d_counters);
+    }
+    HIP_TRY(hipGetLastError());
+    u64 c2[4], spilled2;
+    KCT_TRY(read_counters(t, c2, &spilled2));
+    if (t->debug)
+        fprintf(stderr, "[kct] compact dedupe pass: npos=%llu region_cap=%u counted=%llu new keys=%llu (total %llu) blocked=%llu merged=%llu spilled=%llu\n",
+                (unsigned long long)npos, region_cap, (unsigned long long)counted, (unsigned long long)new_keys, (unsigned long long)t->s32_keys,
+                (unsigned long long)blocked, (unsigned long long)c2[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled2);
+    *n_out += counted + c2[kct::CTR_TOTAL_ADDED];  // (see consume_partitioned about n and a MurmurHash3 value of 0)
+    t->n_keys += c2[kct::CTR_NEWKEYS];
+    if (spilled2) {
+        KCT_TRY(t->d_aux2.reserve(spilled2 * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled2 * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(replay_spill(t, spilled2, n_out));
+    }
+    if (new_keys * 3 > npos) {  // too few repeats for any dedupe-first variant
+        KCT_TRY(flush_compact(t));
+        if (t->force_path != 3) { t->dedupe_off = true; t->dedupe_hint = false; }
+    } else {
+        t->dedupe_hint = true;
+        if (blocked * 50 > npos || t->s32_keys > (u64)(kCompactSlots * 0.65)) {  // outgrown: the table-sized 64-bit shadow takes over
+            KCT_TRY(flush_compact(t));
+            t->compact_off = true;
+        }
     }
     return KCT_OK;
 }
@@ -245,7 +391,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     auto merge_overflows = [&](auto dedupe_tag, const du64 *abort) {
         // fold the overflow regions with the direct atomic path; the kernel reads the region lengths
         // (and the abandon flag) from device memory, so no host round trip sits between the launches
-        constexpr bool D = decltype(dedupe_tag)::value;
+        constexpr int D = decltype(dedupe_tag)::value ? 1 : 0;
         ProfScope ps(t, "merge_overflow_kernel");
         hipLaunchKernelGGL(kct::merge_overflow_kernel<D>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
                            (const unsigned int *)d_ovf_count, nwg, ovf_cap, abort, view(t, npos), t->d_counters, k);
@@ -356,6 +502,11 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         const u64 ramp = t->auto_sized ? std::max<u64>(1ULL << 20, 4 * t->cap) : ~0ULL;
         const u64 npos = std::min<u64>({chunk_limit, ramp, last_start + 1 - done});
         const u64 chunk_bytes = std::min<u64>(nbytes - done, npos + k - 1);
+        if (compact_pays(t, npos)) {
+            bool handled = false;
+            KCT_TRY(consume_compact(t, d_stream + done, chunk_bytes, npos, n_out, &handled));
+            if (handled) { done += npos; t->windows_since_read += npos; continue; }
+        }
         if (dedupe_pays(t, npos)) {
             bool handled = false;
             KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true));

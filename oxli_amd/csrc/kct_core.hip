@@ -56,7 +56,7 @@ kct_status use_consume(kct_table *t) {
 
 kct_status use(kct_table *t) {
     KCT_TRY(use_consume(t));
-    if (t->shadow_dirty) KCT_TRY(flush_shadow(t));   // reads must observe every earlier consume()
+    if (t->shadow_dirty || t->s32_dirty) KCT_TRY(flush_shadow(t));   // reads must observe every earlier consume()
     t->windows_since_read = 0;
     return KCT_OK;
 }
@@ -302,6 +302,7 @@ void kct_destroy(kct_table *t) {
     t->d_scratch2.release(); t->d_regions2.release(); t->d_irr2.release();
     t->h_stage.release(); t->h_pending.release();
     if (t->shadow) (void)hipFree(t->shadow);
+    if (t->shadow32) (void)hipFree(t->shadow32);
     for (auto &b : t->h_file) b.release();
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
@@ -312,6 +313,7 @@ kct_status kct_clear(kct_table *t) {
     t->pending_used = 0; t->pending_records = 0;  // buffered records are forgotten with everything else
     t->lazy_empty = true;  // the memset is issued by materialize() only if something needs it
     t->shadow_empty = true; t->shadow_dirty = false; t->shadow_keys = 0; t->dedupe_off = false;  // pending counts are forgotten too
+    t->s32_empty = true; t->s32_dirty = false; t->s32_keys = 0; t->s32_windows = 0; t->compact_off = false;
     t->n_keys = 0; t->consumed = 0; t->zero_present = false; t->zero_count = 0;
     return KCT_OK;
 }
@@ -613,6 +615,7 @@ kct_status kct_set_path(kct_table *t, int mode) {
     if (mode == 3 && t->k > 32) { set_err("the dedupe-first path needs k <= 32"); return KCT_ERR_ARG; }
     t->force_path = mode;
     t->dedupe_off = false;
+    t->compact_off = false;
     return KCT_OK;
 }
 

@@ -120,6 +120,10 @@ struct kct_table {
     bool shadow_empty = true;   // no keys yet: K2 starts its blocks from zeros instead of loading them
     bool shadow_dirty = false;  // pending counts exist: anything that reads `slots` flushes first (use())
     u64 shadow_keys = 0;
+    // compact variant (k <= 21): 1024 blocks x 8192 slots of u32 key + u32 count (64 MiB), independent of the table's size
+    unsigned int *shadow32 = nullptr;
+    bool s32_empty = true, s32_dirty = false, compact_off = false;
+    u64 s32_keys = 0, s32_windows = 0;  // keys it holds; window starts counted into it since its last flush (u32 counts!)
     u64 windows_since_read = 0; // window starts consumed since anything last read the table (use()): how long the caller's runs are
     bool dedupe_hint = false;   // the last dedupe-first pass paid off: a cleared table starts with that path again
     u64 n_keys = 0;        // distinct non-zero hashes in `slots`

@@ -205,6 +205,21 @@ __device__ __host__ __forceinline__ u64 unmix64(u64 x) {
     return x;
 }
 
+// The same on 42 bits (k <= 21: a packed k-mer is at most 42 bits): the compact dedupe-first path splits the result
+// into a 10-bit bin and a 32-bit entry.  Multiplications mod 2^42 by odd constants and the xor-shift by 21 (its own
+// inverse on 42 bits) are bijections of [0, 2^42).
+constexpr u64 kMask42 = (1ULL << 42) - 1;
+__device__ __host__ __forceinline__ u64 mix42(u64 x) {
+    x = (x * kMixA) & kMask42; x ^= x >> 21;
+    x = (x * kMixB) & kMask42; x ^= x >> 21;
+    return x;
+}
+__device__ __host__ __forceinline__ u64 unmix42(u64 x) {
+    x ^= x >> 21; x = (x * kMixBInv) & kMask42;
+    x ^= x >> 21; x = (x * kMixAInv) & kMask42;
+    return x;
+}
+
 // ---- tile pre-encoding (partitioned path, k <= 64) -------------------------------------------------
 // Sixteen ASCII bases held in a uint4 (byte 0 = first base) -> one 32-bit word of 2-bit codes with
 // the first base in bits 31:30, plus a 16-bit validity word with the first base in bit 15.

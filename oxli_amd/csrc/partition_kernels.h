@@ -1,6 +1,8 @@
 // partition_kernels.h -- the partitioned counting path: K1 partition_windows_kernel, K1b
 // repartition_kernel, K2 aggregate_blocks_kernel and merge_overflow_kernel.
 #pragma once
+#include <type_traits>
+
 #include "window_kernels.h"
 
 namespace kct {
@@ -39,9 +41,12 @@ namespace kct {
 //   step 2  groups of four adjacent lanes move one listed line, 16 bytes each: one whole-line store per
 //           group, and only as many wave instructions as there are lines.
 // Returns (workgroup-uniformly) whether the list was too short for everything that was ready.
-template <u32 LISTCAP, class Overflow>
-__device__ __forceinline__ bool ring_flush(u64 *ring, u32 *fill, u32 *flushed, u32 *flist, u32 *fcount, int P, u32 D,
-                                           u64 *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash, u64 bin_stride = 0) {
+// T = u64 (hashes / mix64 values, 8 per line) or u32 (the compact dedupe-first path: the bin number is the value's
+// upper half, 16 per line); a value handed to overflow_hash is always the full 64-bit one.
+template <u32 LISTCAP, class T, class Overflow>
+__device__ __forceinline__ bool ring_flush(T *ring, u32 *fill, u32 *flushed, u32 *flist, u32 *fcount, int P, u32 D,
+                                           T *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash, u64 bin_stride = 0) {
+    constexpr u32 CH = 64 / sizeof(T);  // positions per 64-byte line
     const u32 dmask = D - 1;
     if (bin_stride == 0) bin_stride = out_cap;  // distance between the regions of consecutive bins
     const int dshift = __builtin_ctz(D);  // D is a power of two: shifts instead of quarter-rate multiplies
@@ -49,11 +54,11 @@ __device__ __forceinline__ bool ring_flush(u64 *ring, u32 *fill, u32 *flushed, u
     for (int b = threadIdx.x; b < P; b += kPartThreads) {
         const u32 f0 = flushed[b], top = fill[b];
         u32 f = f0;
-        while (drain ? (int)(top - f) > 0 : top - f >= kChunk) {
+        while (drain ? (int)(top - f) > 0 : top - f >= CH) {
             const u32 slot = atomicAdd(fcount, 1u);
             if (slot >= LISTCAP) break;  // list full: this line waits for the next call
             flist[slot] = (u32)b | (f << 10) | (f - f0 >= D ? 0x80000000u : 0u);
-            f += kChunk;
+            f += CH;
         }
         flushed[b] = f;
     }
@@ -67,12 +72,18 @@ __device__ __forceinline__ bool ring_flush(u64 *ring, u32 *fill, u32 *flushed, u
             v = *src;
             *src = make_uint4(0, 0, 0, 0);
         }
-        if (f + kChunk <= out_cap) {
+        if (f + CH <= out_cap) {
             reinterpret_cast<uint4 *>(out_base + (u64)b * bin_stride + f)[q] = v;
-        } else {  // region full (badly skewed input): hand the entries to the overflow region
+        } else if constexpr (sizeof(T) == 8) {  // region full (badly skewed input): hand the entries to the overflow region
             const u64 e0 = ((u64)v.y << 32) | v.x, e1 = ((u64)v.w << 32) | v.z;
             if (e0) overflow_hash(e0);
             if (e1) overflow_hash(e1);
+        } else {
+            const u64 hi = ((u64)b << 32) | (1ULL << 63);  // compact values travel with bit 63 set (0 stays "nothing")
+            if (v.x) overflow_hash(hi | v.x);
+            if (v.y) overflow_hash(hi | v.y);
+            if (v.z) overflow_hash(hi | v.z);
+            if (v.w) overflow_hash(hi | v.w);
         }
     }
     __syncthreads();
@@ -94,10 +105,17 @@ struct PartitionArgs {
     int ablate;          // measurement only: bit 0 = skip the ring append, bit 1 = skip the flush phases
 };
 
-template <int KW, int KC, bool RAW = false>
+// MODE 0: MurmurHash3 values (u64 entries).  MODE 1 (dedupe-first, k <= 32): mix64(packed k-mer + 1) values (u64).
+// MODE 2 (compact dedupe-first, k <= 21): mix42(packed k-mer) values, of which the bin is the top 10 bits and the ring /
+// the scratch regions carry only the low 32 (u32 entries: half the partition traffic, a ring twice as deep, so a flush
+// every eight windows instead of four); a value whose low half is 0 -- the hole marker -- takes the overflow route.
+template <int KW, int KC, int MODE = 0>
 __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
                                                                          u64 ntiles, PartitionArgs a) {
-    __shared__ __attribute__((aligned(16))) u64 ring[kRingEntries];
+    using T = typename std::conditional<MODE == 2, u32, u64>::type;
+    constexpr int kEntries = kRingEntries * 8 / sizeof(T);  // the ring is 128 KiB either way
+    constexpr int kFlushEvery = MODE == 2 ? 8 : 4;          // windows between flushes
+    __shared__ __attribute__((aligned(16))) T ring[kEntries];
     __shared__ u32 fill[1024], flushed[1024];
     constexpr u32 kListCap = KW == 0 ? 1792 : 2048;  // the bytewise path's raw tile leaves a little less LDS
     __shared__ u32 flist[kListCap];  // lines ready to leave the ring: block | position << 10 | hole << 31
@@ -112,13 +130,13 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     __shared__ u32 ascii4[KW == 0 ? 1 : 256];  // four packed bases -> four ASCII bytes
     if constexpr (KW != 0) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
     const int P = 1 << a.pbits;
-    const u32 D = (u32)(kRingEntries >> a.pbits), dmask = D - 1;
-    const int dshift = 14 - a.pbits;  // log2 D
-    static_assert(kRingEntries == 1 << 14, "dshift assumes a 16384-entry ring");
-    for (int i = threadIdx.x; i < kRingEntries; i += kPartThreads) ring[i] = 0;
+    const u32 D = (u32)(kEntries >> a.pbits), dmask = D - 1;
+    const int dshift = (MODE == 2 ? 15 : 14) - a.pbits;  // log2 D
+    static_assert(kRingEntries == 1 << 14, "dshift assumes a 16384-entry (u64) ring");
+    for (int i = threadIdx.x; i < kEntries; i += kPartThreads) ring[i] = 0;
     for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
     if (threadIdx.x == 0) { ovf_n = 0; fcount = 0; }
-    u64 *my_scratch = a.scratch + (u64)blockIdx.x * P * a.region_cap;
+    T *my_scratch = reinterpret_cast<T *>(a.scratch) + (u64)blockIdx.x * P * a.region_cap;  // region_cap counts entries
 
     // A hash whose ring slot is still occupied (many lanes hitting one block in the same few steps:
     // homopolymers, tandem repeats) or whose region is full goes to this workgroup's overflow
@@ -132,7 +150,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         else *a.overflow = 1ULL;
     };
     auto flush_lines = [&](bool drain) {
-        return ring_flush<kListCap>(ring, fill, flushed, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_hash);
+        return ring_flush<kListCap, T>(ring, fill, flushed, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_hash);
     };
 
     // A tile is kPartTile + k - 1 <= 1024 + 16 sixteen-byte chunks: one per thread plus a halo that
@@ -179,30 +197,34 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         // block's flush mark is read as soon as its hash exists, but the returned position is only
         // consumed -- and the hash written into the ring -- after window j+1 has been hashed, so the
         // LDS round trip hides under ~130 VALU instructions instead of stalling the wave.
-        u64 pend_h = 0;
+        T pend_h = 0;
         u32 pend_b = 0, pend_pos = 0, pend_mark = 0;
         auto commit = [&]() {
             if (pend_h) {
                 if (pend_pos - pend_mark < D) ring[(pend_b << dshift) + (pend_pos & dmask)] = pend_h;  // slot's previous tenant is flushed
-                else overflow_hash(pend_h);                                                    // ring full: position stays a 0 hole
+                else overflow_hash(MODE == 2 ? (((u64)pend_b << 32) | pend_h | (1ULL << 63)) : (u64)pend_h);  // ring full: position stays a 0 hole
                 pend_h = 0;
             }
         };
         auto sink = [&](int j, bool good, u64 h) {
             commit();  // the previous window's append
             if (good && h != 0 && !(a.ablate & 1)) {
-                pend_b = (u32)(h >> a.block_bits) & (u32)(P - 1);  // bin = the pbits hash bits above the block (or super-bin) offset
-                pend_pos = atomicAdd(&fill[pend_b], 1u);
-                pend_mark = flushed[pend_b];
-                pend_h = h;
+                if (MODE == 2 && (u32)h == 0) overflow_hash(h);  // (one value in 2^32: its low half is the hole marker)
+                else {
+                    // bin = the pbits hash bits above the block (or super-bin) offset; the top bits in compact mode
+                    pend_b = MODE == 2 ? (u32)(h >> 32) & 1023u : (u32)(h >> a.block_bits) & (u32)(P - 1);
+                    pend_pos = atomicAdd(&fill[pend_b], 1u);
+                    pend_mark = flushed[pend_b];
+                    pend_h = (T)h;
+                }
             }
-            if ((j & 3) == 3 && !(a.ablate & 2)) {  // every fourth step: move every full line out
+            if ((j & (kFlushEvery - 1)) == kFlushEvery - 1 && !(a.ablate & 2)) {  // every fourth (eighth) step: move every full line out
                 commit();
                 flush_lines(false);
             }
         };
         if constexpr (KW == 0) walk_windows<0, 0, kPartWPT>(lds, k, sink);
-        else walk_windows_encoded<KW, KC, true, RAW>(tcodes, tvalid, k, sink, ascii4);
+        else walk_windows_encoded<KW, KC, true, MODE>(tcodes, tvalid, k, sink, ascii4);
         commit();
     }
     while (flush_lines(true)) {}  // drain: partial lines go out zero-padded; repeat while the list was too short
@@ -261,7 +283,7 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
         else *a.overflow = 1ULL;
     };
     auto flush_lines = [&](bool drain) {
-        return ring_flush<2048u>(ring, fill, flushed, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_hash, bin_stride);
+        return ring_flush<2048u, u64>(ring, fill, flushed, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_hash, bin_stride);
     };
     // A wave owns the input regions seg = 16 w + wave, + 16 W, ...; work unit = a slab of 8 x 64 entries whose
     // loads are all issued before the first append.  Every wave runs the same number of rounds so that
@@ -475,9 +497,10 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
 }
 
 // mix64 value of a packed canonical k-mer (dedupe-first path) -> its MurmurHash3 value
+template <int MODE = 1>
 __device__ __forceinline__ u64 hash_of_mixed(u64 m, int k, const u32 *lut) {
     Packed<1> p;
-    p.w[0] = unmix64(m) - 1ULL;
+    p.w[0] = MODE == 2 ? unmix42(m & kMask42) : unmix64(m) - 1ULL;  // (compact values travel with bit 63 set)
     left_align(p, k);
     return hash_packed<1, true>(p, k, lut);
 }
@@ -515,6 +538,7 @@ __global__ __launch_bounds__(kBlock) void shadow_flush_kernel(u64 *__restrict__ 
 }
 
 // {mix64 value, count} pairs that found their shadow block full -> the real table (same tallies)
+template <int MODE = 1>
 __global__ __launch_bounds__(kBlock) void merge_mixed_pairs_kernel(const u64 *__restrict__ pairs, const u64 *n_dev, u64 n_cap, TableView main,
                                                                    int k, u64 *counters) {
     __shared__ u32 ascii4[256];
@@ -526,9 +550,167 @@ __global__ __launch_bounds__(kBlock) void merge_mixed_pairs_kernel(const u64 *__
     n = n < n_cap ? n : n_cap;
     u64 tot = 0, nk = 0;
     for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
-        const u64 h = hash_of_mixed(pairs[2 * i], k, ascii4), c = pairs[2 * i + 1];
+        const u64 h = hash_of_mixed<MODE>(pairs[2 * i], k, ascii4), c = pairs[2 * i + 1];
         if (h == 0) continue;
         const AddResult r = table_add<false>(main, h, c);
+        if (!r.spilled) { tot += c; nk += r.claimed; }
+    }
+    tot = wave_sum(tot); nk = wave_sum(nk);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+    }
+}
+
+// ---- compact dedupe-first path (k <= 21): 32-bit entries, a shadow table of u32 keys and u32 counts ----------------
+// A mix42 value is 10 bits of bin and 32 bits of entry; within a bin the entry identifies the k-mer.  K1 (MODE 2)
+// wrote the entries; this is K2 for them: same block ownership, fingerprint fast path and deferred queue as
+// aggregate_blocks_kernel, at half the LDS and HBM bytes.  Slot = entry bits 0-12, fingerprint = bits 13-20.
+// Counts are u32: the host converts (flushes) before 2^31 windows have gone in.
+struct Aggregate32Args {
+    u32 *words;          // [blocks][S keys][S counts]
+    int block_bits;
+    const u32 *scratch;  // region (seg, b) at scratch + seg * seg_stride + b * block_stride (entries)
+    u64 seg_stride, block_stride;
+    const u32 *region_count;  // [blocks][nregions]
+    int nregions;
+    int fresh;
+    const u64 *overflow; // K1's abandon flag
+    u64 *spill; u64 spill_cap; u64 *spill_n;  // {mix42 value | bit 63, 1} pairs of entries that found their block full
+    u64 *counters;
+};
+
+__global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggregate32Args a) {
+    __shared__ __attribute__((aligned(16))) u32 tab[2 << kBlockBitsMax];  // S keys then S counts = 64 KiB
+    __shared__ u32 wq[(kPartThreads / 64) * kWaveQueue];
+    __shared__ __attribute__((aligned(16))) unsigned char tags[1 << kBlockBitsMax];
+    __shared__ u64 s_counted, s_new;
+    if (*a.overflow) return;
+    const int b = blockIdx.x;
+    const u32 S = 1u << a.block_bits, smask = S - 1;
+    u32 *gblock = a.words + ((u64)b << (a.block_bits + 1));
+    u32 *keys = tab, *cnts = tab + S;
+    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
+    uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+    auto tag_of = [](u32 e) -> u32 { const u32 t = (e >> 13) & 0xFFu; return t ? t : 1u; };
+    if (a.fresh) {
+        for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
+        for (u32 i = threadIdx.x; i < S / 16; i += kPartThreads) reinterpret_cast<uint4 *>(tags)[i] = make_uint4(0, 0, 0, 0);
+    } else {
+        for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < S; i += kPartThreads) { const u32 kk = keys[i]; tags[i] = (unsigned char)(kk ? tag_of(kk) : 0u); }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32 counted = 0, newkeys = 0;
+    auto insert = [&](u32 e) {
+        u32 g = e & smask & ~(u32)(kGroup - 1);
+        bool placed = false;
+        for (u32 round = 0; round < (S >> kGroupBits) && !placed; ++round) {
+            const uint4 q0 = *reinterpret_cast<const uint4 *>(keys + g), q1 = *reinterpret_cast<const uint4 *>(keys + g + 4);
+            const u32 k[kGroup] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            int sel = kGroup;
+#pragma unroll
+            for (int i = kGroup - 1; i >= 0; --i) if (k[i] == e || k[i] == 0) sel = i;
+            while (sel < kGroup) {
+                u32 ks = keys[g + sel];
+                if (ks == 0) {
+                    ks = atomicCAS(&keys[g + sel], 0u, e);
+                    if (ks == 0) { ++newkeys; ks = e; tags[g + sel] = (unsigned char)tag_of(e); }
+                }
+                if (ks == e) { atomicAdd(&cnts[g + sel], 1u); placed = true; break; }
+                ++sel;
+                while (sel < kGroup) { const u32 kk = keys[g + sel]; if (kk == e || kk == 0) break; ++sel; }
+            }
+            g = (g + kGroup) & smask;
+        }
+        if (placed) ++counted;
+        else {
+            const u64 si = atomicAdd(a.spill_n, 1ULL);
+            if (si < a.spill_cap) { a.spill[2 * si] = ((u64)b << 32) | e | (1ULL << 63); a.spill[2 * si + 1] = 1; }
+        }
+    };
+    u32 *myq = wq + wave * kWaveQueue;
+    u32 qn = 0;
+    auto drain = [&](u32 keep_below) {
+        while (qn > keep_below) {
+            const u32 take = qn < 64 ? qn : 64;
+            qn -= take;
+            if ((u32)lane < take) insert(myq[qn + lane]);
+        }
+    };
+    auto fast = [&](u32 e) {
+        bool miss = e != 0;
+        if (e != 0) {
+            const u32 g = e & smask & ~(u32)(kGroup - 1);
+            const u64 t8 = *reinterpret_cast<const u64 *>(tags + g);
+            const u64 x = t8 ^ ((u64)tag_of(e) * 0x0101010101010101ULL);
+            const u64 z = (x - 0x0101010101010101ULL) & ~x & 0x8080808080808080ULL;
+            if (z) {
+                const u32 idx = (u32)__builtin_ctzll(z) >> 3;
+                if (keys[g + idx] == e) { atomicAdd(&cnts[g + idx], 1u); ++counted; miss = false; }
+            }
+        }
+        const u64 m = __ballot(miss);
+        if (m) {
+            const u32 pos = qn + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+            if (miss) myq[pos] = e;
+            qn += (u32)__popcll(m);
+            if (qn > kWaveQueue - 64) drain(31);
+        }
+    };
+    constexpr int kInFlight = 12;
+    constexpr u32 kSlab = 64 * kInFlight;
+    const u32 *my_counts = a.region_count + (u64)b * a.nregions;
+    constexpr int kWaves = kPartThreads / 64;
+    for (int seg = wave; seg < a.nregions; seg += kWaves) {  // one level only: many short regions, one wave each
+        const u32 cnt = my_counts[seg];
+        const u32 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
+        for (u32 s0 = 0; s0 < cnt; s0 += kSlab) {  // 16-byte loads: a lane takes four consecutive entries (regions are padded with zeros to 16)
+            uint4 v[kInFlight / 4];
+#pragma unroll
+            for (int j = 0; j < kInFlight / 4; ++j) {
+                const u32 i = s0 + 4 * (lane + 64 * j);
+                v[j] = i < cnt ? *reinterpret_cast<const uint4 *>(region + i) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < kInFlight / 4; ++j) { fast(v[j].x); fast(v[j].y); fast(v[j].z); fast(v[j].w); }
+        }
+    }
+    drain(0);
+    u64 wc = wave_sum((u64)counted), wn = wave_sum((u64)newkeys);
+    if (lane == 0) { atomicAdd(&s_counted, wc); atomicAdd(&s_new, wn); }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
+    if (threadIdx.x == 0) {
+        u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_counted) atomicAdd(shard + CTR_COUNTED, s_counted);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+    }
+}
+
+// the compact shadow table's pending counts -> the real table (cf. shadow_flush_kernel)
+__global__ __launch_bounds__(kBlock) void shadow32_flush_kernel(u32 *__restrict__ shadow, int block_bits, u64 slots, TableView main, int k,
+                                                                u64 *counters) {
+    __shared__ u32 ascii4[256];
+    __shared__ u64 s_tot, s_new;
+    fill_ascii4_lut(ascii4, threadIdx.x, kBlock);
+    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; }
+    __syncthreads();
+    const u64 S = 1ULL << block_bits;
+    u64 tot = 0, nk = 0;
+    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < slots; s += (u64)gridDim.x * kBlock) {
+        const u64 blk = s >> block_bits, kw = (blk << (block_bits + 1)) + (s & (S - 1));
+        const u32 c = shadow[kw + S];
+        if (c == 0) continue;
+        shadow[kw + S] = 0;
+        const u64 h = hash_of_mixed<2>((blk << 32) | shadow[kw], k, ascii4);
+        if (h == 0) continue;  // lib.rs:589: hash 0 is skipped
+        const AddResult r = table_add<false>(main, h, (u64)c);
         if (!r.spilled) { tot += c; nk += r.claimed; }
     }
     tot = wave_sum(tot); nk = wave_sum(nk);
@@ -546,7 +728,7 @@ __global__ __launch_bounds__(kBlock) void merge_mixed_pairs_kernel(const u64 *__
 // equal (that is why they overflowed), so every wave first folds equal hashes: the lowest active
 // lane is the leader, all lanes holding the leader's hash retire into one add, repeat.
 // DEDUPE: the entries are mix64 values of packed k-mers (dedupe-first path); each group leader hashes its k-mer first.
-template <bool DEDUPE = false>
+template <int DEDUPE = 0>  // 0: hashes; 1: mix64 values; 2: mix42 values (bit 63 set)
 __global__ __launch_bounds__(kBlock) void merge_overflow_kernel(const u64 *__restrict__ regions, const u32 *__restrict__ counts,
                                                                 int nregions, u32 region_cap, const u64 *abort, TableView table,
                                                                 u64 *counters, int k = 0, const u64 *total = nullptr) {
@@ -578,7 +760,7 @@ __global__ __launch_bounds__(kBlock) void merge_overflow_kernel(const u64 *__res
                 if ((same >> lane) & 1ULL) pending = false;
             }
             if (is_leader) {
-                const u64 hh = DEDUPE ? hash_of_mixed(h, k, ascii4) : h;
+                const u64 hh = DEDUPE ? hash_of_mixed<(DEDUPE == 2 ? 2 : 1)>(h, k, ascii4) : h;
                 if (hh != 0) {
                     const AddResult res = table_add<false>(table, hh, c);
                     if (!res.spilled) { tot += c; nk += res.claimed; }

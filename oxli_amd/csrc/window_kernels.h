@@ -81,9 +81,10 @@ __device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, in
 // directly from the packed words (no k-1 warm-up steps); the WPT-1 following bases come out of two
 // shift registers.  WPT must be 16 (one code word per thread).
 // `lut` (LDS, kmer_device.h fill_ascii4_lut) switches the ASCII re-expansion to table look-ups.
-// RAW (k <= 32 only): the sink receives mix64(packed canonical k-mer + 1) instead of the MurmurHash3 value --
+// RAW = 1 (k <= 32 only): the sink receives mix64(packed canonical k-mer + 1) instead of the MurmurHash3 value --
 // the dedupe-first path counts k-mers first and hashes each distinct one once (partition_kernels.h).
-template <int KW, int KC, bool LUT = false, bool RAW = false, class Sink>
+// RAW = 2 (k <= 21): mix42(packed canonical k-mer), a 42-bit value, with bit 63 set.
+template <int KW, int KC, bool LUT = false, int RAW = 0, class Sink>
 __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const unsigned short *valid, int k_rt, Sink &&sink,
                                                      const u32 *lut = nullptr) {
     constexpr int WPT = 16, NW = 2 * KW + 1;  // code words covering bases 0 .. 15 + k
@@ -146,9 +147,12 @@ __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const uns
         u64 h = 0;
         if (good) {
             Packed<KW> c = less_eq(fw, rc) ? fw : rc;
-            if constexpr (RAW) {
-                static_assert(!RAW || KW == 1, "the dedupe-first path carries one 64-bit word per k-mer");
+            if constexpr (RAW == 1) {
+                static_assert(KW == 1, "the dedupe-first path carries one 64-bit word per k-mer");
                 h = mix64(c.w[0] + 1ULL);
+            } else if constexpr (RAW == 2) {
+                static_assert(KW == 1 && (KC == 0 || KC <= 21), "the compact dedupe-first path needs 2k <= 42 bits");
+                h = mix42(c.w[0]) | (1ULL << 63);  // bit 63: "not the zero hash" for the sink's h != 0 test; the sink drops it
             } else {
                 left_align(c, k);
                 h = hash_packed<KW, LUT>(c, k, lut);
