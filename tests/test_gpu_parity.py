@@ -542,6 +542,55 @@ def oref_histo(ref):
     return list(zip(vals.tolist(), freq.tolist()))
 
 
+def test_compact_dedupe_path_flushes_before_u32_counts_can_wrap_and_hands_over_when_outgrown(KCT):
+    """k <= 21 takes the compact variant (u32 counts in a fixed 8.4 M-slot shadow): it must convert before 2^31 windows
+    have gone in, and hand over to the table-sized 64-bit shadow when the input brings more k-mers than it holds."""
+    import torch
+
+    from oxli_amd import _lib
+    lib = _lib.load()
+    L, N, k = 150, 1_000_000, 21
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def make(G, seed):
+        g = torch.empty(G, dtype=torch.uint8, device="cuda")
+        r = torch.empty(N * (L + 1), dtype=torch.uint8, device="cuda")
+        assert lib.kct_synth_genome_device(g.data_ptr(), G, seed, stream) == 0
+        assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), G, 0, N, L, seed + 1, stream) == 0
+        torch.cuda.synchronize()
+        return r
+
+    ra = make(3_000_000, 11)
+    std = KCT(k, capacity=8_000_000)
+    std.set_path("partitioned")
+    n = std.consume_device(ra.data_ptr(), ra.numel(), N * L)
+    ka, ca = std.dump_arrays(1)
+    dev = KCT(k, capacity=8_000_000)
+    dev.set_path("dedupe")
+    dev.profile(True)
+    passes = 16                                                    # 16 x 1.5e8 window starts > 2^31
+    for _ in range(passes):
+        assert dev.consume_device(ra.data_ptr(), ra.numel(), N * L) == n
+    prof = dev.profile_read()
+    assert prof["aggregate_blocks32_kernel"][0] == passes and prof["shadow32_flush_kernel"][0] >= 1   # converted on the way
+    kd, cd = dev.dump_arrays(1)
+    assert np.array_equal(kd, ka) and np.array_equal(cd, passes * ca)
+    # a second genome: 3 M + 4 M distinct k-mers do not fit the compact shadow -> the 64-bit shadow takes over
+    rb = make(4_000_000, 1_000_000_021)        # (the generator indexes one stream by seed + position: seeds far apart)
+    nb = std.consume_device(rb.data_ptr(), rb.numel(), N * L)
+    dev.profile_reset()
+    for _ in range(3):
+        assert dev.consume_device(rb.data_ptr(), rb.numel(), N * L) == nb
+    prof = dev.profile_read()
+    assert "aggregate_blocks_kernel<shadow>" in prof, prof
+    std.consume_device(rb.data_ptr(), rb.numel(), N * L); std.consume_device(rb.data_ptr(), rb.numel(), N * L)
+    for _ in range(passes - 1):
+        std.consume_device(ra.data_ptr(), ra.numel(), N * L)
+    ks, cs = std.dump_arrays(1)
+    kd, cd = dev.dump_arrays(1)
+    assert np.array_equal(kd, ks) and np.array_equal(cd, cs)
+
+
 def test_dedupe_first_path_with_too_many_distinct_kmers(KCT):
     """All-distinct input overflows the scratch blocks: the overflow goes straight to the table (still exact), and the
     table stops choosing the dedupe-first path."""
