@@ -667,18 +667,46 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
     constexpr u32 kSlab = 64 * kInFlight;
     const u32 *my_counts = a.region_count + (u64)b * a.nregions;
     constexpr int kWaves = kPartThreads / 64;
-    for (int seg = wave; seg < a.nregions; seg += kWaves) {  // one level only: many short regions, one wave each
-        const u32 cnt = my_counts[seg];
-        const u32 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
-        for (u32 s0 = 0; s0 < cnt; s0 += kSlab) {  // 16-byte loads: a lane takes four consecutive entries (regions are padded with zeros to 16)
-            uint4 v[kInFlight / 4];
-#pragma unroll
-            for (int j = 0; j < kInFlight / 4; ++j) {
-                const u32 i = s0 + 4 * (lane + 64 * j);
-                v[j] = i < cnt ? *reinterpret_cast<const uint4 *>(region + i) : make_uint4(0, 0, 0, 0);
+    // One level only: nregions short regions per block, wave w takes regions w, w + 16, ...  Their sizes are fetched
+    // with ONE load (lane l holds the size of the wave's l-th region), and the slabs are double-buffered across region
+    // boundaries: a region is only ~2 KB, so a wave that waited for each one separately would keep too few bytes in flight.
+    const int my_nreg = (a.nregions - wave + kWaves - 1) / kWaves;  // regions of this wave (<= 64 supported in one go)
+    for (int r0 = 0; r0 < my_nreg; r0 += 64) {
+        const int nr = my_nreg - r0 < 64 ? my_nreg - r0 : 64;
+        const u32 my_cnt = lane < nr ? my_counts[wave + kWaves * (r0 + lane)] : 0u;
+        int ri = 0;      // cursor: region index within this batch, offset inside it
+        u32 off = 0;
+        auto load_slab = [&](uint4 (&v)[kInFlight / 4]) -> bool {
+            u32 cnt = 0;
+            while (ri < nr) {
+                cnt = (u32)__builtin_amdgcn_readlane((int)my_cnt, ri);
+                if (off < cnt) break;
+                ++ri; off = 0;
             }
 #pragma unroll
+            for (int j = 0; j < kInFlight / 4; ++j) v[j] = make_uint4(0, 0, 0, 0);
+            if (ri >= nr) return false;
+            const u32 *region = a.scratch + (u64)(wave + kWaves * (r0 + ri)) * a.seg_stride + (u64)b * a.block_stride;
+#pragma unroll
+            for (int j = 0; j < kInFlight / 4; ++j) {  // 16-byte loads: a lane takes four consecutive entries (regions are zero-padded to 16)
+                const u32 i = off + 4 * (lane + 64 * j);
+                if (i < cnt) v[j] = *reinterpret_cast<const uint4 *>(region + i);
+            }
+            off += kSlab;
+            return true;
+        };
+        auto count_slab = [&](const uint4 (&v)[kInFlight / 4]) {
+#pragma unroll
             for (int j = 0; j < kInFlight / 4; ++j) { fast(v[j].x); fast(v[j].y); fast(v[j].z); fast(v[j].w); }
+        };
+        uint4 va[kInFlight / 4], vb[kInFlight / 4];
+        bool more = load_slab(va);
+        while (more) {
+            more = load_slab(vb);
+            count_slab(va);
+            if (!more) break;
+            more = load_slab(va);
+            count_slab(vb);
         }
     }
     drain(0);
