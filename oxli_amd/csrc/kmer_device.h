@@ -206,16 +206,17 @@ __device__ __host__ __forceinline__ u64 unmix64(u64 x) {
 }
 
 // The same on 42 bits (k <= 21: a packed k-mer is at most 42 bits): the compact dedupe-first path splits the result
-// into a 10-bit bin and a 32-bit entry.  Multiplications mod 2^42 by odd constants and the xor-shift by 21 (its own
+// into a 10-bit bin and a 32-bit entry.  A multiplication mod 2^42 by an odd constant and the xor-shift by 21 (its own
 // inverse on 42 bits) are bijections of [0, 2^42).
 constexpr u64 kMask42 = (1ULL << 42) - 1;
+// One multiply and one xor-shift are enough here (bin = the product's top bits, which depend on every input bit; slot
+// and fingerprint = its low bits xor its bits 21..41): the spread over bins and home groups measured on 5 Mbp of random
+// sequence is the same as with two rounds, and K1 is issue-bound.
 __device__ __host__ __forceinline__ u64 mix42(u64 x) {
     x = (x * kMixA) & kMask42; x ^= x >> 21;
-    x = (x * kMixB) & kMask42; x ^= x >> 21;
     return x;
 }
 __device__ __host__ __forceinline__ u64 unmix42(u64 x) {
-    x ^= x >> 21; x = (x * kMixBInv) & kMask42;
     x ^= x >> 21; x = (x * kMixAInv) & kMask42;
     return x;
 }
