@@ -29,13 +29,15 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-STREAMING = ("partition_windows_kernel", "partition_windows_kernel<raw>", "aggregate_blocks_kernel")  # reads are wide coalesced streams
+STREAMING = ("partition_windows_kernel", "partition_windows_kernel<raw>", "partition_windows_kernel<compact>", "aggregate_blocks_kernel", "aggregate_blocks32_kernel")  # reads are wide coalesced streams
 
 
 def short(name):
     n = name.split("(")[0].replace("void ", "").replace("kct::", "").replace("(anonymous namespace)::", "")
     base = n.split("<")[0].strip()
-    if base == "partition_windows_kernel" and n.strip().endswith("true>"):
+    if base == "partition_windows_kernel" and n.strip().endswith(", 2>"):
+        base += "<compact>"  # the compact dedupe-first variant (32-bit entries)
+    elif base == "partition_windows_kernel" and (n.strip().endswith("true>") or n.strip().endswith(", 1>")):
         base += "<raw>"  # the dedupe-first variant (no MurmurHash3): a different kernel for every purpose
     return base
 
@@ -77,6 +79,6 @@ json.dump({"_how": "tools/collect_profiles.sh + tools/summarize_profiles.py; FET
           open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 if traffic:
     json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-for k in ("partition_windows_kernel", "partition_windows_kernel<raw>", "aggregate_blocks_kernel", "count_windows_kernel"):
+for k in ("partition_windows_kernel", "partition_windows_kernel<raw>", "partition_windows_kernel<compact>", "aggregate_blocks_kernel", "aggregate_blocks32_kernel", "count_windows_kernel"):
     if k in out and "derived" in out[k]:
         print(k, json.dumps(out[k]["derived"]))
