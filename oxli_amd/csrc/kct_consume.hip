@@ -243,7 +243,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     aa.words = t->shadow32; aa.block_bits = kct::kBlockBitsMax;
     aa.scratch = (const unsigned int *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
     aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
-    aa.fresh = t->s32_empty ? 1 : 0; aa.overflow = d_overflow;
+    aa.fresh = t->s32_empty ? 1 : 0; aa.overflow = d_overflow; aa.ablate = t->ablate;
     aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
     {
         ProfScope ps(t, "aggregate_blocks32_kernel");
