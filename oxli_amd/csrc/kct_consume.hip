@@ -224,7 +224,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 4));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
     KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
-    KCT_TRY(t->d_spill.reserve(npos * 16));
+    KCT_TRY(t->d_spill.reserve(2 * npos * 16));  // two lists: pairs that found their shadow block full, then the merges' own spills
     KCT_TRY(zero_counters(t));
     du64 *d_overflow = t->d_counters + kNumCounters + 6;
     unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
@@ -250,32 +250,30 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
         hipLaunchKernelGGL(kct::aggregate_blocks32_kernel, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, aa);
     }
     HIP_TRY(hipGetLastError());
+    // What does not fit the shadow goes to the real table in the same submission (no host round trip in between): K1's
+    // overflow regions, and the pairs that found their shadow block full (normally none; their number is read on the
+    // device).  These inserts spill -- if the table lacks room -- into the SECOND half of the spill buffer.
+    kct::TableView mv = view(t, npos);
+    mv.spill = (du64 *)t->d_spill.p + 2 * npos;
+    mv.spill_n = t->d_counters + kNumCounters + 5;
+    {
+        ProfScope ps(t, "merge_overflow_kernel");
+        hipLaunchKernelGGL(kct::merge_overflow_kernel<2>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
+                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, mv, t->d_counters, k);
+        hipLaunchKernelGGL(kct::merge_mixed_pairs_kernel<2>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_spill.p,
+                           (const du64 *)(t->d_counters + kNumCounters), (u64)npos, mv, (int)k, t->d_counters);
+    }
+    HIP_TRY(hipGetLastError());
     u64 c[4], blocked;
     KCT_TRY(read_counters(t, c, &blocked));
-    if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // K1 gave up: nothing was touched
+    if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // K1 gave up: every kernel after it exited early, nothing was touched
     *handled = true;
-    const u64 counted = c[kct::CTR_COUNTED], new_keys = c[kct::CTR_NEWKEYS];
+    const u64 counted = c[kct::CTR_COUNTED], new_keys = c[kct::CTR_NEW_BY_ZERO], spilled2 = t->h_counters[kNumCounters + 5];
+    const u64 *c2 = c;  // the merges' tallies: CTR_TOTAL_ADDED / CTR_NEWKEYS
     t->s32_empty = false;
     t->s32_dirty = true;
     t->s32_keys += new_keys;
     t->s32_windows += npos;
-    if (blocked) {
-        KCT_TRY(t->d_aux2.reserve(blocked * 16));
-        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, blocked * 16, hipMemcpyDeviceToDevice, t->stream));
-        HIP_TRY(hipMemcpyAsync(t->d_counters + kNumCounters + 5, t->d_counters + kNumCounters, 8, hipMemcpyDeviceToDevice, t->stream));
-    }
-    HIP_TRY(hipMemsetAsync(t->d_counters, 0, (kNumCounters + 1) * sizeof(u64), t->stream));
-    {
-        ProfScope ps(t, "merge_overflow_kernel");
-        hipLaunchKernelGGL(kct::merge_overflow_kernel<2>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
-                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)nullptr, view(t, npos), t->d_counters, k);
-        if (blocked)
-            hipLaunchKernelGGL(kct::merge_mixed_pairs_kernel<2>, dim3(merge_grid(blocked)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_aux2.p,
-                               (const du64 *)(t->d_counters + kNumCounters + 5), (u64)blocked, view(t, npos), (int)k, t->d_counters);
-    }
-    HIP_TRY(hipGetLastError());
-    u64 c2[4], spilled2;
-    KCT_TRY(read_counters(t, c2, &spilled2));
     if (t->debug)
         fprintf(stderr, "[kct] compact dedupe pass: npos=%llu region_cap=%u counted=%llu new keys=%llu (total %llu) blocked=%llu merged=%llu spilled=%llu\n",
                 (unsigned long long)npos, region_cap, (unsigned long long)counted, (unsigned long long)new_keys, (unsigned long long)t->s32_keys,
@@ -284,7 +282,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     t->n_keys += c2[kct::CTR_NEWKEYS];
     if (spilled2) {
         KCT_TRY(t->d_aux2.reserve(spilled2 * 16));
-        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled2 * 16, hipMemcpyDeviceToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, (du64 *)t->d_spill.p + 2 * npos, spilled2 * 16, hipMemcpyDeviceToDevice, t->stream));
         KCT_TRY(replay_spill(t, spilled2, n_out));
     }
     if (new_keys * 3 > npos) {  // too few repeats for any dedupe-first variant

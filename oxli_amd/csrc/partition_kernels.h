@@ -725,7 +725,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
     if (threadIdx.x == 0) {
         u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
         if (s_counted) atomicAdd(shard + CTR_COUNTED, s_counted);
-        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+        if (s_new) atomicAdd(shard + CTR_NEW_BY_ZERO, s_new);  // new SHADOW keys: kept apart from the merges' new table keys (CTR_NEWKEYS)
     }
 }
 
