@@ -591,6 +591,42 @@ def test_compact_dedupe_path_flushes_before_u32_counts_can_wrap_and_hands_over_w
     assert np.array_equal(kd, ks) and np.array_equal(cd, cs)
 
 
+def test_consume_file_through_the_dedupe_first_paths(KCT, tmp_path):
+    """File ingestion feeds 16 MiB chunks to the same pass machinery: with the dedupe-first paths forced, a FASTA of deep
+    coverage must give the table the standard path gives (several parser threads, chunks counted in any order)."""
+    import torch
+
+    from oxli_amd import _lib
+    lib = _lib.load()
+    G, L, N = 200_000, 150, 400_000
+    g = torch.empty(G, dtype=torch.uint8, device="cuda")
+    r = torch.empty(N * (L + 1), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.kct_synth_genome_device(g.data_ptr(), G, 77, stream) == 0
+    assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), G, 0, N, L, 78, stream) == 0
+    torch.cuda.synchronize()
+    reads = r.cpu().numpy().reshape(N, L + 1)[:, :L]
+    fa = tmp_path / "deep.fa"
+    with open(fa, "wb") as f:
+        for i in range(N):
+            f.write(b">r%d\n" % i); f.write(reads[i].tobytes()); f.write(b"\n")
+    for k in (21, 29):                                   # compact (k <= 21) and 64-bit (k <= 32) variants
+        std = KCT(k, capacity=G)
+        std.set_path("partitioned")
+        n = std.consume_file(str(fa))
+        assert n == N * (L - k + 1)
+        sk, sc = std.dump_arrays(1)
+        dev = KCT(k, capacity=G)
+        dev.set_path("dedupe")
+        dev.profile(True)
+        assert dev.consume_file(str(fa)) == n and dev.consume_file(str(fa)) == n
+        prof = dev.profile_read()
+        assert ("aggregate_blocks32_kernel" if k <= 21 else "aggregate_blocks_kernel<shadow>") in prof, prof
+        dk, dc = dev.dump_arrays(1)
+        assert np.array_equal(dk, sk) and np.array_equal(dc, 2 * sc)
+        assert dev.consumed == 2 * std.consumed
+
+
 def test_dedupe_first_path_with_too_many_distinct_kmers(KCT):
     """All-distinct input overflows the scratch blocks: the overflow goes straight to the table (still exact), and the
     table stops choosing the dedupe-first path."""
