@@ -127,11 +127,11 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     __shared__ __attribute__((aligned(16))) unsigned char lds[kTileBytes];
     __shared__ u32 tcodes[kTileWords];
     __shared__ unsigned short tvalid[kTileWords];
-    __shared__ u32 ascii4[KW == 0 ? 1 : 256];  // four packed bases -> four ASCII bytes
-    if constexpr (KW != 0) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
+    __shared__ u32 ascii4[(KW == 0 || MODE != 0) ? 1 : 256];  // four packed bases -> four ASCII bytes (only the hashing mode needs it)
+    if constexpr (KW != 0 && MODE == 0) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
     const int P = 1 << a.pbits;
     const u32 D = (u32)(kEntries >> a.pbits), dmask = D - 1;
-    const int dshift = (MODE == 2 ? 15 : 14) - a.pbits;  // log2 D
+    const int dshift = __builtin_ctz((unsigned)kEntries) - a.pbits;  // log2 D
     static_assert(kRingEntries == 1 << 14, "dshift assumes a 16384-entry (u64) ring");
     for (int i = threadIdx.x; i < kEntries; i += kPartThreads) ring[i] = 0;
     for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
