@@ -156,8 +156,6 @@ def main():
     if world > 1 and args.warmup:
         merge_across_ranks(table)  # warm the collective and the merge kernels too
     table.clear()
-    table.profile(True)
-    table.profile_reset()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -174,8 +172,6 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof = table.profile_read()
-    table.profile(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -190,6 +186,18 @@ def main():
     distinct = global_scalar_sum(len(table), "cuda") if world > 1 else len(table)
     total_counts = global_scalar_sum(table.sum_counts, "cuda") if world > 1 else table.sum_counts
     assert ablate or total_counts == world * kmers_per_step * args.steps, (total_counts, world * kmers_per_step * args.steps)
+
+    # Per-kernel device times for the roofline: the SAME steps once more with the library's HIP-event timing switched on
+    # (an event pair around every launch costs ~6 % at this step size, so it stays out of the region `value` is taken from).
+    table.clear()
+    table.profile(True)
+    table.profile_reset()
+    for s in range(args.steps):
+        step(s)
+    table.sync()
+    torch.cuda.synchronize()
+    prof = table.profile_read()
+    table.profile(False)
 
     value = n_all / elapsed
     b_alg = L / (L - k + 1) + 24.0
@@ -209,7 +217,8 @@ def main():
     traffic_step = (sum(t * prof[n][0] for n, t in zip(prof, step_traffic) if t) / args.steps) if any(step_traffic) else None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": pipe_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": pipe_gbs / HBM_PEAK_GBS, "traffic": traffic_step,
-                "basis": "algorithmic bytes per step (25.15 B/k-mer x k-mers) / sum of the device time of every kernel of the step; "
+                "basis": "algorithmic bytes per step (25.15 B/k-mer x k-mers) / sum of the device time of every kernel of the step, HIP events around "
+                         "every launch of a repetition of the timed steps (event timing off while `value` is taken); "
                          "traffic = PMC-measured HBM bytes per step summed over the kernels (profiles/pmc_traffic.json)",
                 "alg_bytes_per_kmer": b_alg, "kmers_per_step": kmers_per_step, "kernel_ms_per_step": all_ms / args.steps,
                 "dominant_kernel": {"name": dom, "avg_launch_ms": avg_ms, "launches": launches, "kmers_per_launch": kmers_per_launch,
