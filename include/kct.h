@@ -212,6 +212,11 @@ KCT_API kct_status kct_save(kct_table *t, const char *path, const char *tail_jso
 KCT_API kct_status kct_load(const char *path, int device, kct_table **out);
 KCT_API const char *kct_load_rest_json(void);
 
+/* Bulk ingest keeps its working buffers with the table between calls (partition scratch ~ 8-16 B per window of the
+ * largest pass, spill lists, shadow tables, pinned staging): several GB after a 10^8-window pass.  This gives them
+ * back (after converting anything pending); the table itself is untouched and the next ingest allocates again. */
+KCT_API kct_status kct_release_scratch(kct_table *t);
+
 /* Flush point (SURVEY.md 8b "kct_sync"): counts whatever deferred mode has buffered and waits for the table's
  * stream.  Every other call already returns with its device work finished, so this matters only in deferred
  * mode or after work the caller queued on the table's stream itself. */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "kct_export_by_owner_device": (ci, [vp, C.c_uint32, vp, sz, vp, u64p]),
     "kct_merge_pairs_device": (ci, [vp, vp, sz, u64p, u64p]),
     "kct_sync": (ci, [vp]),
+    "kct_release_scratch": (ci, [vp]),
     "kct_save": (ci, [vp, cp, cp]),
     "kct_load": (ci, [cp, ci, C.POINTER(vp)]),
     "kct_load_rest_json": (cp, []),

@@ -597,6 +597,19 @@ kct_status kct_set_stream(kct_table *t, void *hip_stream) {
 
 void *kct_get_stream(kct_table *t) { return t ? (void *)t->stream : nullptr; }
 
+kct_status kct_release_scratch(kct_table *t) {
+    KCT_TRY(use(t));  // nothing may be pending in a buffer that is about to go
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    for (DevBuf *b : {&t->d_stream, &t->d_spill, &t->d_aux, &t->d_aux2, &t->d_scratch, &t->d_regions, &t->d_irr, &t->d_sort, &t->d_scratch2,
+                      &t->d_regions2, &t->d_irr2})
+        b->release();
+    if (t->shadow) { (void)hipFree(t->shadow); t->shadow = nullptr; t->shadow_cap = 0; t->shadow_empty = true; t->shadow_keys = 0; }
+    if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; t->s32_empty = true; t->s32_keys = 0; t->s32_windows = 0; }
+    t->h_stage.release(); t->h_pending.release();
+    for (auto &b : t->h_file) b.release();
+    return KCT_OK;
+}
+
 kct_status kct_sync(kct_table *t) {
     KCT_TRY(use(t));  // flushes what deferred mode has buffered
     HIP_TRY(hipStreamSynchronize(t->stream));

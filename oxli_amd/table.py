@@ -520,6 +520,10 @@ class KmerCountTable:
             print(f"Version mismatch: loaded version is {t.version}, but current version is {VERSION}", file=sys.stderr)
         return t
 
+    def release_scratch(self):
+        """Gives back the working buffers bulk ingest keeps between calls (``kct_release_scratch``); the table stays."""
+        self._check(self._lib.kct_release_scratch(self._h))
+
     def sync(self):
         """Counts whatever deferred mode has buffered and waits for the table's stream (``kct_sync``)."""
         self._check(self._lib.kct_sync(self._h))

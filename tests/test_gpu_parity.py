@@ -534,6 +534,12 @@ def test_dedupe_first_pending_counts_are_seen_by_every_read(KCT):
     assert len(other) == 0 and other.sum_counts == 0 and other.get(probe) == 0
     assert other.consume_device(r.data_ptr(), r.numel(), N * L) == n1
     assert other.max == int(oref.dump_arrays()[1].max()) and other.histo(zero=False) == oref_histo(oref)
+    import torch as _t
+    free0 = _t.cuda.mem_get_info()[0]
+    other.release_scratch()                                       # working buffers go, the table and its answers stay
+    assert _t.cuda.mem_get_info()[0] > free0 + (1 << 26)
+    assert other.max == int(oref.dump_arrays()[1].max()) and len(other) == len(oref)
+    assert other.consume_device(r.data_ptr(), r.numel(), N * L) == n1 and other.sum_counts == 2 * oref.sum_counts
 
 
 def oref_histo(ref):
