@@ -19,8 +19,9 @@ for it in range(iters):
     L = int(rng.choice([50, 100, 150, 151, 250, 1000]))
     if L < k + 1:
         L = k + 30
-    G = int(rng.choice([2_000, 50_000, 400_000, 3_000_000]))
-    N = int(rng.integers(5_000_000 // L, 40_000_000 // L))
+    big = os.environ.get("STRESS_BIG") == "1"   # bigger genomes / passes: table-sized shadows, two partition levels
+    G = int(rng.choice([2_000, 50_000, 400_000, 3_000_000] + ([12_000_000, 40_000_000] if big else [])))
+    N = int(rng.integers(5_000_000 // L, (300_000_000 if big else 40_000_000) // L))
     N -= N % 16
     g = torch.empty(G, dtype=torch.uint8, device="cuda")
     r = torch.empty(N * (L + 1), dtype=torch.uint8, device="cuda")
@@ -39,7 +40,7 @@ for it in range(iters):
     cut = [0] + sorted(int(x) - int(x) % 16 for x in rng.integers(1, N, ncalls - 1)) + [N]
     sig = None
     for path in ("partitioned", "dedupe", "auto", "direct"):
-        if path == "direct" and N * L > 30_000_000:
+        if path == "direct" and N * L > (100_000_000 if big else 30_000_000):
             continue
         t = KmerCountTable(k, capacity=int(rng.choice([0, G, 4 * G])) or 0)
         t.set_path(path)
