@@ -122,7 +122,9 @@ bool dedupe_pays(const kct_table *t, u64 npos) {
     // A flush costs ~0.11 ns per pending k-mer (one random table access each), a dedupe-first pass saves ~3-4 ps per
     // window (no MurmurHash3 in K1): converting pays once ~32 windows have been counted per distinct k-mer since the
     // table was last read.  The caller's run so far is the evidence that reads are that rare.
-    return known * 32 <= t->windows_since_read + npos;
+    // (a table of up to 1024 blocks is flushed by partitioning the pairs: half the cost per k-mer)
+    const u64 per_key = (t->cap >> t->block_bits) <= 1024 ? 16 : 32;
+    return known * per_key <= t->windows_since_read + npos;
 }
 
 // The shadow mirrors the real table's capacity (the same k-mers live in both).  (Re)allocated empty when that changes.
@@ -145,10 +147,67 @@ kct_status ensure_shadow(kct_table *t, bool *ok) {
 constexpr int kCompactBlockBits = 10;  // the compact shadow: 1024 blocks x 8192 slots
 constexpr u64 kCompactSlots = 1ULL << (kCompactBlockBits + kct::kBlockBitsMax);
 
+// Tables of 16..1024 blocks: hash the pending k-mers, radix-partition the {hash, count} pairs by table block and merge
+// each block in LDS -- the table is read and written once, sequentially, instead of once per k-mer at random.
+kct_status flush_partitioned(kct_table *t, bool compact) {
+    const int pbits = log2_u64(t->cap >> t->block_bits);
+    const u64 P = 1ULL << pbits;
+    const u64 sslots = compact ? kCompactSlots : t->shadow_cap, skeys = compact ? t->s32_keys : t->shadow_keys;
+    const int nwg = (int)std::min<u64>(t->num_cus, sslots >> kct::kBlockBitsMax);  // a workgroup takes whole shadow blocks
+    const double fill = std::min(1.0, (double)skeys / (double)sslots);
+    const unsigned int region_cap = region_capacity((double)(sslots / nwg) * fill / (double)P);  // pairs per (workgroup, block)
+    KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 16));
+    KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
+    KCT_TRY(t->d_aux.reserve(sslots * 16));    // pairs that found ring or region full
+    KCT_TRY(t->d_spill.reserve(sslots * 16));  // pairs that found their table block full
+    KCT_TRY(zero_counters(t));
+    du64 *d_ovf_n = t->d_counters + kNumCounters + 5;
+    const bool fresh = t->lazy_empty;
+    kct::FlushPartitionArgs fa;
+    fa.shadow = compact ? (void *)t->shadow32 : (void *)t->shadow; fa.shadow_blocks = (unsigned int)(sslots >> kct::kBlockBitsMax); fa.k = t->k; fa.table_block_bits = t->block_bits; fa.pbits = pbits;
+    fa.scratch = (ulonglong2 *)t->d_scratch.p; fa.region_cap = region_cap; fa.region_count = (unsigned int *)t->d_regions.p;
+    fa.ovf = (du64 *)t->d_aux.p; fa.ovf_cap = sslots; fa.ovf_n = d_ovf_n;
+    {
+        ProfScope ps(t, "flush_partition_kernel");
+        if (compact) hipLaunchKernelGGL(kct::flush_partition_kernel<true>, dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
+        else hipLaunchKernelGGL(kct::flush_partition_kernel<false>, dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
+    }
+    HIP_TRY(hipGetLastError());
+    kct::AggregatePairsArgs pa;
+    pa.words = t->slots; pa.block_bits = t->block_bits;
+    pa.scratch = (const ulonglong2 *)t->d_scratch.p; pa.seg_stride = P * region_cap; pa.block_stride = region_cap;
+    pa.region_count = (const unsigned int *)t->d_regions.p; pa.nregions = nwg;
+    pa.fresh = fresh ? 1 : 0;
+    pa.spill = (du64 *)t->d_spill.p; pa.spill_cap = sslots; pa.spill_n = t->d_counters + kNumCounters; pa.counters = t->d_counters;
+    {
+        ProfScope ps(t, "aggregate_pairs_kernel");
+        hipLaunchKernelGGL(kct::aggregate_pairs_kernel, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, pa);
+    }
+    HIP_TRY(hipGetLastError());
+    t->lazy_empty = false;
+    // the (normally few) pairs that did not fit ring or region: the direct insert; the list length is read on the device
+    launch_merge_pairs(t, (const du64 *)t->d_aux.p, (const du64 *)t->d_aux.p + 1, sslots, (const du64 *)d_ovf_n, 2, view(t, sslots));
+    HIP_TRY(hipGetLastError());
+    u64 c[4], spilled;
+    KCT_TRY(read_counters(t, c, &spilled));
+    t->n_keys += c[kct::CTR_NEWKEYS];
+    if (spilled) {
+        u64 ignored = 0;
+        KCT_TRY(t->d_aux2.reserve(spilled * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(replay_spill(t, spilled, &ignored));
+    }
+    return KCT_OK;
+}
+
 kct_status flush_compact(kct_table *t) {
     if (!t->s32_dirty) return KCT_OK;
     t->s32_dirty = false;
     t->s32_windows = 0;
+    {
+        const u64 blocks = t->cap >> t->block_bits;
+        if (blocks >= 16 && blocks <= 1024 && t->block_bits == kct::kBlockBitsMax && !getenv("KCT_FLUSH_ATOMIC")) return flush_partitioned(t, true);
+    }
     KCT_TRY(materialize(t));
     KCT_TRY(t->d_spill.reserve(kCompactSlots * 16));
     KCT_TRY(zero_counters(t));
@@ -174,6 +233,12 @@ kct_status flush_shadow(kct_table *t) {
     KCT_TRY(flush_compact(t));
     if (!t->shadow_dirty) return KCT_OK;
     t->shadow_dirty = false;
+    {
+        const u64 blocks = t->cap >> t->block_bits, sblocks = t->shadow_cap >> kct::kBlockBitsMax;
+        if (blocks >= 16 && blocks <= 1024 && t->block_bits == kct::kBlockBitsMax && t->shadow_block_bits == kct::kBlockBitsMax && sblocks >= 1 &&
+            !getenv("KCT_FLUSH_ATOMIC"))
+            return flush_partitioned(t, false);
+    }
     KCT_TRY(materialize(t));
     KCT_TRY(t->d_spill.reserve(t->shadow_cap * 16));
     KCT_TRY(zero_counters(t));

@@ -159,6 +159,12 @@ kct_status merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u
     return KCT_OK;
 }
 
+void launch_merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n_cap, const du64 *n_dev, int stride, kct::TableView tv) {
+    ProfScope ps(t, "merge_pairs_kernel");
+    hipLaunchKernelGGL(kct::merge_pairs_kernel, dim3(256), dim3(kct::kBlock), 0, t->stream, d_keys, d_counts, n_cap, n_dev, (const du64 *)nullptr, stride,
+                       tv, t->d_counters);
+}
+
 // Re-hash into a table of new_cap slots (no-op if not larger).
 kct_status grow_to(kct_table *t, u64 new_cap) {
     new_cap = std::max(next_pow2(new_cap), kMinSlots);

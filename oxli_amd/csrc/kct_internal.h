@@ -189,6 +189,8 @@ int merge_grid(u64 n);
 kct_status grow_to(kct_table *t, u64 new_cap);
 kct_status maybe_grow(kct_table *t);
 kct_status merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n, int stride, u64 tallies[4]);
+// one launch of merge_pairs_kernel over at most n_cap pairs, their number read from *n_dev on the device; tallies go to d_counters
+void launch_merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n_cap, const du64 *n_dev, int stride, kct::TableView tv);
 kct_status replay_spill(kct_table *t, u64 spilled, u64 *n_out);
 kct_status point_add(kct_table *t, u64 h, u64 *count_out);
 // kct_consume.hip

@@ -78,6 +78,9 @@ __device__ __forceinline__ bool ring_flush(T *ring, u32 *fill, u32 *flushed, u32
             const u64 e0 = ((u64)v.y << 32) | v.x, e1 = ((u64)v.w << 32) | v.z;
             if (e0) overflow_hash(e0);
             if (e1) overflow_hash(e1);
+        } else if constexpr (sizeof(T) == 16) {  // {hash, count} pairs
+            const u64 h = ((u64)v.y << 32) | v.x, c = ((u64)v.w << 32) | v.z;
+            if (h) overflow_hash(h, c);
         } else {
             const u64 hi = ((u64)b << 32) | (1ULL << 63);  // compact values travel with bit 63 set (0 stays "nothing")
             if (v.x) overflow_hash(hi | v.x);
@@ -754,6 +757,150 @@ __global__ __launch_bounds__(kBlock) void shadow32_flush_kernel(u32 *__restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+    }
+}
+
+// ---- partitioned flush of the compact shadow (tables of up to 1024 blocks) -----------------------------------------
+// One random table access per pending k-mer (shadow32_flush_kernel) runs at HBM's random-access rate, ~0.1 ns each.
+// Here the {hash, count} pairs take the k-mers' own route instead: this kernel hashes every pending k-mer and
+// radix-partitions the PAIRS by table block through the LDS ring (16-byte entries, four per line), and
+// aggregate_pairs_kernel merges each block's pairs in LDS.  The table is read and written once, sequentially.
+struct FlushPartitionArgs {
+    void *shadow;        // compact shadow: [1024 blocks][8192 u32 keys][8192 u32 counts]; 64-bit shadow: u64 keys and counts
+    u32 shadow_blocks;   // 1024 for the compact one
+    int k;
+    int table_block_bits, pbits;  // the REAL table: slots per block, log2(blocks) (<= 10)
+    ulonglong2 *scratch; // [nwg][P][region_cap] pairs
+    u32 region_cap;      // pairs, multiple of 4
+    u32 *region_count;   // [P][nwg]
+    u64 *ovf; u64 ovf_cap; u64 *ovf_n;  // one shared list of pairs that found ring or region full (merge_pairs_kernel takes it)
+};
+
+template <bool COMPACT>
+__global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPartitionArgs a) {
+    using W = typename std::conditional<COMPACT, u32, u64>::type;  // shadow word
+    constexpr int kPairs = kRingEntries / 2;  // 8192 pairs = 128 KiB
+    __shared__ __attribute__((aligned(16))) ulonglong2 ring[kPairs];
+    __shared__ u32 fill[1024], flushed[1024];
+    __shared__ u32 flist[2048];
+    __shared__ u32 fcount;
+    __shared__ u32 ascii4[256];
+    fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
+    const int P = 1 << a.pbits;
+    const u32 D = (u32)(kPairs >> a.pbits), dmask = D - 1;
+    const int dshift = __builtin_ctz((unsigned)kPairs) - a.pbits;
+    for (int i = threadIdx.x; i < kPairs; i += kPartThreads) ring[i] = make_ulonglong2(0, 0);
+    for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
+    if (threadIdx.x == 0) fcount = 0;
+    __syncthreads();
+    ulonglong2 *my_scratch = a.scratch + (u64)blockIdx.x * P * a.region_cap;
+    auto overflow_pair = [&](u64 h, u64 c) {
+        const u64 i = atomicAdd(a.ovf_n, 1ULL);
+        if (i < a.ovf_cap) { a.ovf[2 * i] = h; a.ovf[2 * i + 1] = c; }  // (cap = every pending k-mer: cannot be exceeded)
+    };
+    auto flush_lines = [&](bool drain) {
+        return ring_flush<2048u, ulonglong2>(ring, fill, flushed, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_pair);
+    };
+    // this workgroup's share of the shadow: whole blocks, kBlocksPerWg of them, one row of 1024 slots per step
+    constexpr u32 S = 1u << kBlockBitsMax;
+    const u32 nblocks = a.shadow_blocks, per_wg = (nblocks + gridDim.x - 1) / gridDim.x;
+    for (u32 sb = blockIdx.x * per_wg; sb < nblocks && sb < (blockIdx.x + 1) * per_wg; ++sb) {
+        W *blk = reinterpret_cast<W *>(a.shadow) + ((u64)sb << (kBlockBitsMax + 1));
+        for (u32 row = 0; row < S / kPartThreads; ++row) {
+            const u32 i = row * kPartThreads + threadIdx.x;
+            const W c = blk[S + i];
+            if (c) {
+                blk[S + i] = 0;
+                const u64 h = COMPACT ? hash_of_mixed<2>(((u64)sb << 32) | blk[i], a.k, ascii4) : hash_of_mixed<1>((u64)blk[i], a.k, ascii4);
+                if (h) {  // lib.rs:589: hash 0 is skipped
+                    const u32 b = (u32)(h >> a.table_block_bits) & (u32)(P - 1);
+                    const u32 pos = atomicAdd(&fill[b], 1u);
+                    if (pos - flushed[b] < D) ring[(b << dshift) + (pos & dmask)] = make_ulonglong2(h, (u64)c);
+                    else overflow_pair(h, (u64)c);
+                }
+            }
+            if ((row & 1) == 1) flush_lines(false);  // ~600 pairs per row over up to 1024 bins of 8: every second row
+        }
+    }
+    while (flush_lines(true)) {}
+    for (int b = threadIdx.x; b < P; b += kPartThreads) {
+        const u32 f = flushed[b];
+        a.region_count[(u64)b * gridDim.x + blockIdx.x] = f < a.region_cap ? f : a.region_cap;
+    }
+}
+
+// One workgroup per table block: the block in LDS, its pairs merged with LDS atomics, the block stored back.
+// Few pairs per block (thousands, against 10^5 k-mers in a counting pass): the general insert alone will do.
+struct AggregatePairsArgs {
+    u64 *words; int block_bits;
+    const ulonglong2 *scratch; u64 seg_stride, block_stride;  // region (seg, b) at scratch + seg * seg_stride + b * block_stride
+    const u32 *region_count; int nregions;
+    int fresh;
+    u64 *spill; u64 spill_cap; u64 *spill_n;  // pairs that found their block full: grown-and-replayed by the host
+    u64 *counters;       // CTR_TOTAL_ADDED (counts placed), CTR_NEWKEYS
+};
+
+__global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(AggregatePairsArgs a) {
+    __shared__ __attribute__((aligned(16))) u64 tab[2 << kBlockBitsMax];
+    __shared__ u64 s_tot, s_new;
+    const int b = blockIdx.x;
+    const u32 S = 1u << a.block_bits, smask = S - 1;
+    u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
+    u64 *keys = tab, *cnts = tab + S;
+    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; }
+    uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+    if (a.fresh) for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
+    else for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    u64 tot = 0, nk = 0;
+    const u32 *my_counts = a.region_count + (u64)b * a.nregions;
+    // A region holds only a handful of pairs (one workgroup's share of one block): FOUR lanes take a region, so all 256
+    // regions are in flight at once and a group's loads are one 64-byte line.
+    const int q = threadIdx.x & 3;
+    for (int seg = threadIdx.x >> 2; seg < a.nregions; seg += kPartThreads / 4) {
+        const u32 cnt = my_counts[seg];
+        const ulonglong2 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
+        for (u32 i = q; i < cnt; i += 4) {
+            const ulonglong2 pr = region[i];
+            const u64 h = pr.x, c = pr.y;
+            if (h == 0) continue;  // hole / padding
+            u32 g = (u32)h & smask & ~(u32)(kGroup - 1);
+            bool placed = false;
+            for (u32 round = 0; round < (S >> kGroupBits) && !placed; ++round) {
+                const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(keys + g);
+                const ulonglong2 q0 = kp[0], q1 = kp[1], q2 = kp[2], q3 = kp[3];
+                const u64 kk[kGroup] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+                int sel = kGroup;  // first slot that holds h or is empty
+#pragma unroll
+                for (int sl = kGroup - 1; sl >= 0; --sl) if (kk[sl] == h || kk[sl] == 0) sel = sl;
+                while (sel < kGroup) {
+                    u64 ks = keys[g + sel];
+                    if (ks == 0) {
+                        ks = atomicCAS(&keys[g + sel], 0ULL, h);
+                        if (ks == 0) { ++nk; ks = h; }
+                    }
+                    if (ks == h) { atomicAdd(&cnts[g + sel], c); placed = true; break; }
+                    ++sel;  // another lane claimed that slot for a different key: try the following slots
+                    while (sel < kGroup) { const u64 k2 = keys[g + sel]; if (k2 == h || k2 == 0) break; ++sel; }
+                }
+                g = (g + kGroup) & smask;
+            }
+            if (placed) tot += c;
+            else {
+                const u64 si = atomicAdd(a.spill_n, 1ULL);
+                if (si < a.spill_cap) { a.spill[2 * si] = h; a.spill[2 * si + 1] = c; }
+            }
+        }
+    }
+    tot = wave_sum(tot); nk = wave_sum(nk);
+    if (lane == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
+    if (threadIdx.x == 0) {
+        u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
         if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
         if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
     }
