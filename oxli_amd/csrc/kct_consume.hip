@@ -149,28 +149,34 @@ constexpr u64 kCompactSlots = 1ULL << (kCompactBlockBits + kct::kBlockBitsMax);
 
 // Tables of 16..1024 blocks: hash the pending k-mers, radix-partition the {hash, count} pairs by table block and merge
 // each block in LDS -- the table is read and written once, sequentially, instead of once per k-mer at random.
-kct_status flush_partitioned(kct_table *t, bool compact) {
+// src 0 / 1: the compact / 64-bit shadow's pending counts; src 2: a flat list of n {hash, count} pairs (keys[i * stride],
+// counts[i * stride]) -- add(), load(), the multi-GPU merge.  tallies (may be null) += CTR_* of the pass.
+kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const du64 *counts, u64 n, int stride, u64 *tallies) {
+    const bool compact = src == 0;
     const int pbits = log2_u64(t->cap >> t->block_bits);
     const u64 P = 1ULL << pbits;
-    const u64 sslots = compact ? kCompactSlots : t->shadow_cap, skeys = compact ? t->s32_keys : t->shadow_keys;
-    const int nwg = (int)std::min<u64>(t->num_cus, sslots >> kct::kBlockBitsMax);  // a workgroup takes whole shadow blocks
+    const u64 sslots = src == 2 ? n : compact ? kCompactSlots : t->shadow_cap, skeys = src == 2 ? n : compact ? t->s32_keys : t->shadow_keys;
+    const int nwg = src == 2 ? (int)std::min<u64>(t->num_cus, (n + 8 * kct::kPartThreads - 1) / (8 * kct::kPartThreads))
+                             : (int)std::min<u64>(t->num_cus, sslots >> kct::kBlockBitsMax);  // a workgroup takes whole shadow blocks
     const double fill = std::min(1.0, (double)skeys / (double)sslots);
-    const unsigned int region_cap = region_capacity((double)(sslots / nwg) * fill / (double)P);  // pairs per (workgroup, block)
+    const unsigned int region_cap = region_capacity((double)(sslots / nwg + kct::kPartThreads) * fill / (double)P);  // pairs per (workgroup, block)
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 16));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
-    KCT_TRY(t->d_aux.reserve(sslots * 16));    // pairs that found ring or region full
+    KCT_TRY(t->d_pairs_ovf.reserve(sslots * 16));  // pairs that found ring or region full (its own buffer: d_aux may hold the input)
     KCT_TRY(t->d_spill.reserve(sslots * 16));  // pairs that found their table block full
     KCT_TRY(zero_counters(t));
     du64 *d_ovf_n = t->d_counters + kNumCounters + 5;
     const bool fresh = t->lazy_empty;
     kct::FlushPartitionArgs fa;
-    fa.shadow = compact ? (void *)t->shadow32 : (void *)t->shadow; fa.shadow_blocks = (unsigned int)(sslots >> kct::kBlockBitsMax); fa.k = t->k; fa.table_block_bits = t->block_bits; fa.pbits = pbits;
+    fa.shadow = compact ? (void *)t->shadow32 : (void *)t->shadow; fa.shadow_blocks = src == 2 ? 0u : (unsigned int)(sslots >> kct::kBlockBitsMax); fa.k = t->k;
+    fa.pair_keys = keys; fa.pair_counts = counts; fa.pair_stride = stride; fa.npairs = n; fa.table_block_bits = t->block_bits; fa.pbits = pbits;
     fa.scratch = (ulonglong2 *)t->d_scratch.p; fa.region_cap = region_cap; fa.region_count = (unsigned int *)t->d_regions.p;
-    fa.ovf = (du64 *)t->d_aux.p; fa.ovf_cap = sslots; fa.ovf_n = d_ovf_n;
+    fa.ovf = (du64 *)t->d_pairs_ovf.p; fa.ovf_cap = sslots; fa.ovf_n = d_ovf_n;
     {
         ProfScope ps(t, "flush_partition_kernel");
-        if (compact) hipLaunchKernelGGL(kct::flush_partition_kernel<true>, dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
-        else hipLaunchKernelGGL(kct::flush_partition_kernel<false>, dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
+        if (src == 0) hipLaunchKernelGGL(kct::flush_partition_kernel<0>, dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
+        else if (src == 1) hipLaunchKernelGGL(kct::flush_partition_kernel<1>, dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
+        else hipLaunchKernelGGL(kct::flush_partition_kernel<2>, dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
     }
     HIP_TRY(hipGetLastError());
     kct::AggregatePairsArgs pa;
@@ -186,18 +192,33 @@ kct_status flush_partitioned(kct_table *t, bool compact) {
     HIP_TRY(hipGetLastError());
     t->lazy_empty = false;
     // the (normally few) pairs that did not fit ring or region: the direct insert; the list length is read on the device
-    launch_merge_pairs(t, (const du64 *)t->d_aux.p, (const du64 *)t->d_aux.p + 1, sslots, (const du64 *)d_ovf_n, 2, view(t, sslots));
+    launch_merge_pairs(t, (const du64 *)t->d_pairs_ovf.p, (const du64 *)t->d_pairs_ovf.p + 1, sslots, (const du64 *)d_ovf_n, 2, view(t, sslots));
     HIP_TRY(hipGetLastError());
     u64 c[4], spilled;
     KCT_TRY(read_counters(t, c, &spilled));
     t->n_keys += c[kct::CTR_NEWKEYS];
-    if (spilled) {
-        u64 ignored = 0;
+    if (tallies) for (int i = 0; i < 4; ++i) tallies[i] += c[i];
+    if (spilled) {  // pairs that found their table block full: grow, then the direct insert (its tallies join ours)
         KCT_TRY(t->d_aux2.reserve(spilled * 16));
         HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
-        KCT_TRY(replay_spill(t, spilled, &ignored));
+        KCT_TRY(grow_to(t, t->cap * 2));
+        u64 tl[4] = {0, 0, 0, 0};
+        KCT_TRY(merge_pairs(t, (const du64 *)t->d_aux2.p, (const du64 *)t->d_aux2.p + 1, spilled, 2, tl));
+        if (tallies) for (int i = 0; i < 4; ++i) tallies[i] += tl[i];
     }
     return KCT_OK;
+}
+
+kct_status flush_partitioned(kct_table *t, bool compact) { return partitioned_pairs_pass(t, compact ? 0 : 1, nullptr, nullptr, 0, 0, nullptr); }
+
+// merge_pairs' fast route: tables of 16..1024 blocks, enough pairs to be worth two kernels
+bool pairs_partition_pays(const kct_table *t, u64 n) {
+    const u64 blocks = t->cap >> t->block_bits;
+    return blocks >= 16 && blocks <= 1024 && t->block_bits == kct::kBlockBitsMax && n >= (1ULL << 18) && !getenv("KCT_FLUSH_ATOMIC");
+}
+
+kct_status merge_pairs_partitioned(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n, int stride, u64 tallies[4]) {
+    return partitioned_pairs_pass(t, 2, d_keys, d_counts, n, stride, tallies);
 }
 
 kct_status flush_compact(kct_table *t) {

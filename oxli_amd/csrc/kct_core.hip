@@ -132,6 +132,7 @@ int merge_grid(u64 n) { return (int)std::min<u64>((n + kct::kBlock - 1) / kct::k
 kct_status grow_to(kct_table *t, u64 new_cap);
 
 kct_status merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n, int stride, u64 tallies[4]) {
+    if (pairs_partition_pays(t, n) && (const void *)d_keys != t->d_aux2.p) return merge_pairs_partitioned(t, d_keys, d_counts, n, stride, tallies);
     KCT_TRY(materialize(t));
     while (n > 0) {
         KCT_TRY(t->d_spill.reserve(n * 16));
@@ -305,7 +306,7 @@ void kct_destroy(kct_table *t) {
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     t->d_stream.release(); t->d_spill.release(); t->d_aux.release(); t->d_aux2.release();
     t->d_scratch.release(); t->d_regions.release(); t->d_irr.release(); t->d_sort.release();
-    t->d_scratch2.release(); t->d_regions2.release(); t->d_irr2.release();
+    t->d_scratch2.release(); t->d_regions2.release(); t->d_irr2.release(); t->d_pairs_ovf.release();
     t->h_stage.release(); t->h_pending.release();
     if (t->shadow) (void)hipFree(t->shadow);
     if (t->shadow32) (void)hipFree(t->shadow32);
@@ -607,7 +608,7 @@ kct_status kct_release_scratch(kct_table *t) {
     KCT_TRY(use(t));  // nothing may be pending in a buffer that is about to go
     HIP_TRY(hipStreamSynchronize(t->stream));
     for (DevBuf *b : {&t->d_stream, &t->d_spill, &t->d_aux, &t->d_aux2, &t->d_scratch, &t->d_regions, &t->d_irr, &t->d_sort, &t->d_scratch2,
-                      &t->d_regions2, &t->d_irr2})
+                      &t->d_regions2, &t->d_irr2, &t->d_pairs_ovf})
         b->release();
     if (t->shadow) { (void)hipFree(t->shadow); t->shadow = nullptr; t->shadow_cap = 0; t->shadow_empty = true; t->shadow_keys = 0; }
     if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; t->s32_empty = true; t->s32_keys = 0; t->s32_windows = 0; }

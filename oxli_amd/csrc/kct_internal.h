@@ -133,7 +133,7 @@ struct kct_table {
 
     du64 *d_counters = nullptr;  // kNumCounters tallies + 8 scratch words (device)
     u64 *h_counters = nullptr;   // pinned mirror
-    kcth::DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort, d_scratch2, d_regions2, d_irr2;
+    kcth::DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort, d_scratch2, d_regions2, d_irr2, d_pairs_ovf;
     kcth::PinnedBuf h_stage;
     std::vector<kcth::PinnedBuf> h_file;  // kct_consume_file's chunk buffers (two per parser thread), kept between calls
 
@@ -192,6 +192,9 @@ kct_status merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u
 // one launch of merge_pairs_kernel over at most n_cap pairs, their number read from *n_dev on the device; tallies go to d_counters
 void launch_merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n_cap, const du64 *n_dev, int stride, kct::TableView tv);
 kct_status replay_spill(kct_table *t, u64 spilled, u64 *n_out);
+// kct_consume.hip: {hash, count} pairs through the LDS-ring partition + per-block LDS merge (tables of up to 1024 blocks)
+bool pairs_partition_pays(const kct_table *t, u64 n);
+kct_status merge_pairs_partitioned(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n, int stride, u64 tallies[4]);
 kct_status point_add(kct_table *t, u64 h, u64 *count_out);
 // kct_consume.hip
 kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 *n_out);

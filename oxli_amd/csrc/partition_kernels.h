@@ -770,6 +770,7 @@ __global__ __launch_bounds__(kBlock) void shadow32_flush_kernel(u32 *__restrict_
 struct FlushPartitionArgs {
     void *shadow;        // compact shadow: [1024 blocks][8192 u32 keys][8192 u32 counts]; 64-bit shadow: u64 keys and counts
     u32 shadow_blocks;   // 1024 for the compact one
+    const u64 *pair_keys, *pair_counts; int pair_stride; u64 npairs;  // SRC 2: a flat list of {hash, count} pairs instead of a shadow
     int k;
     int table_block_bits, pbits;  // the REAL table: slots per block, log2(blocks) (<= 10)
     ulonglong2 *scratch; // [nwg][P][region_cap] pairs
@@ -778,8 +779,10 @@ struct FlushPartitionArgs {
     u64 *ovf; u64 ovf_cap; u64 *ovf_n;  // one shared list of pairs that found ring or region full (merge_pairs_kernel takes it)
 };
 
-template <bool COMPACT>
+// SRC 0: the compact shadow; 1: the 64-bit shadow; 2: a flat list of {hash, count} pairs (merges: add(), load(), the multi-GPU merge)
+template <int SRC>
 __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPartitionArgs a) {
+    constexpr bool COMPACT = SRC == 0;
     using W = typename std::conditional<COMPACT, u32, u64>::type;  // shadow word
     constexpr int kPairs = kRingEntries / 2;  // 8192 pairs = 128 KiB
     __shared__ __attribute__((aligned(16))) ulonglong2 ring[kPairs];
@@ -805,7 +808,22 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
     };
     // this workgroup's share of the shadow: whole blocks, kBlocksPerWg of them, one row of 1024 slots per step
     constexpr u32 S = 1u << kBlockBitsMax;
-    const u32 nblocks = a.shadow_blocks, per_wg = (nblocks + gridDim.x - 1) / gridDim.x;
+    if constexpr (SRC == 2) {
+        const u64 rows = (a.npairs + kPartThreads - 1) / kPartThreads, rows_per_wg = (rows + gridDim.x - 1) / gridDim.x;
+        for (u64 r = 0; r < rows_per_wg; ++r) {
+            const u64 i = ((u64)blockIdx.x * rows_per_wg + r) * kPartThreads + threadIdx.x;
+            const u64 h = i < a.npairs ? a.pair_keys[i * a.pair_stride] : 0ULL;
+            if (h) {
+                const u64 c = a.pair_counts[i * a.pair_stride];
+                const u32 b = (u32)(h >> a.table_block_bits) & (u32)(P - 1);
+                const u32 pos = atomicAdd(&fill[b], 1u);
+                if (pos - flushed[b] < D) ring[(b << dshift) + (pos & dmask)] = make_ulonglong2(h, c);
+                else overflow_pair(h, c);
+            }
+            flush_lines(false);  // a full row of pairs over up to 1024 bins of 8: every row
+        }
+    }
+    const u32 nblocks = SRC == 2 ? 0u : a.shadow_blocks, per_wg = (nblocks + gridDim.x - 1) / gridDim.x;
     for (u32 sb = blockIdx.x * per_wg; sb < nblocks && sb < (blockIdx.x + 1) * per_wg; ++sb) {
         W *blk = reinterpret_cast<W *>(a.shadow) + ((u64)sb << (kBlockBitsMax + 1));
         for (u32 row = 0; row < S / kPartThreads; ++row) {
@@ -844,18 +862,18 @@ struct AggregatePairsArgs {
 
 __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(AggregatePairsArgs a) {
     __shared__ __attribute__((aligned(16))) u64 tab[2 << kBlockBitsMax];
-    __shared__ u64 s_tot, s_new;
+    __shared__ u64 s_tot, s_new, s_nz;
     const int b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
     u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u64 *keys = tab, *cnts = tab + S;
-    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; }
+    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; s_nz = 0; }
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
     if (a.fresh) for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
     else for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    u64 tot = 0, nk = 0;
+    u64 tot = 0, nk = 0, nz = 0;
     const u32 *my_counts = a.region_count + (u64)b * a.nregions;
     // A region holds only a handful of pairs (one workgroup's share of one block): FOUR lanes take a region, so all 256
     // regions are in flight at once and a group's loads are one 64-byte line.
@@ -882,7 +900,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(Aggregate
                         ks = atomicCAS(&keys[g + sel], 0ULL, h);
                         if (ks == 0) { ++nk; ks = h; }
                     }
-                    if (ks == h) { atomicAdd(&cnts[g + sel], c); placed = true; break; }
+                    if (ks == h) { nz += atomicAdd(&cnts[g + sel], c) == 0; placed = true; break; }  // (lib.rs:801-803: new = count was 0)
                     ++sel;  // another lane claimed that slot for a different key: try the following slots
                     while (sel < kGroup) { const u64 k2 = keys[g + sel]; if (k2 == h || k2 == 0) break; ++sel; }
                 }
@@ -895,14 +913,15 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(Aggregate
             }
         }
     }
-    tot = wave_sum(tot); nk = wave_sum(nk);
-    if (lane == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); }
+    tot = wave_sum(tot); nk = wave_sum(nk); nz = wave_sum(nz);
+    if (lane == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); atomicAdd(&s_nz, nz); }
     __syncthreads();
     for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
     if (threadIdx.x == 0) {
         u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
         if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
         if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+        if (s_nz) atomicAdd(shard + CTR_NEW_BY_ZERO, s_nz);
     }
 }
 

@@ -373,3 +373,36 @@ def test_native_save_load_many_pieces(KCT, tmp_path):
         open(p, "w").write(bad)
         with pytest.raises(RuntimeError, match="Deserialization error"):
             KCT.load(p)
+
+
+def test_large_pair_merges_take_the_partitioned_route_and_tally_like_add(KCT, monkeypatch):
+    """A merge of >= 2^18 pairs into a table of up to 1024 blocks is radix-partitioned and merged per block in LDS.
+    Zero counts, key 0 and a live table: contents and the (total added, new keys) tallies must equal
+    plain dict arithmetic -- 'new' meaning the key's count was 0 before (lib.rs:801-803) -- on both routes."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    base_keys = rng.integers(1, 1 << 63, size=600_000, dtype=np.uint64)
+    for route in ("partitioned", "atomic"):
+        if route == "atomic":
+            monkeypatch.setenv("KCT_FLUSH_ATOMIC", "1")
+        t = KCT(21, capacity=3_000_000)
+        d = {}
+        t.profile(True)
+        for rnd in range(3):
+            idx = rng.choice(base_keys.size, size=400_000, replace=False)
+            keys = base_keys[idx].copy()                  # 400k distinct keys per call (add() merges a map: no repeats within a
+            keys[0] = 0                                   # call), many of them seen in earlier rounds; key 0 lives beside the table
+            counts = rng.integers(0, 5, size=keys.size, dtype=np.uint64)   # zero counts too
+            a, b = C.c_uint64(), C.c_uint64()
+            t._check(t._lib.kct_merge_host(t._h, keys.ctypes.data, counts.ctypes.data, keys.size, C.byref(a), C.byref(b)))
+            tot = new = 0
+            for h, c in zip(keys.tolist(), counts.tolist()):
+                if d.get(h, 0) == 0:
+                    new += 1
+                d[h] = d.get(h, 0) + c
+                tot += c
+            assert (a.value, b.value) == (tot, new), (route, rnd)
+        prof = t.profile_read()
+        assert ("aggregate_pairs_kernel" in prof) == (route == "partitioned"), prof
+        k, c = t.dump_arrays(1)
+        assert dict(zip(k.tolist(), c.tolist())) == d
