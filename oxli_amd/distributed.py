@@ -54,21 +54,49 @@ def exchange_pairs(pairs, send_counts, zero_count=0, group=None):
         # debugging aid (several ranks sharing one GPU, no RCCL): stage the collective through host memory
         out, zero_total = exchange_pairs(pairs.cpu(), send_counts, zero_count, group)
         return out.to(dev), zero_total
-    # 1) how much will I receive from each peer (tiny fixed-layout exchange)
-    meta = torch.zeros((world, 2), dtype=torch.int64)
-    meta[:, 0] = send_counts
-    meta[0, 1] = int(zero_count)
-    meta = meta.to(dev)
-    got = torch.empty_like(meta)
-    dist.all_to_all_single(got, meta, group=group)
-    got = got.cpu()
-    recv_counts = got[:, 0]
-    zero_total = int(got[:, 1].sum())
-    # 2) the pairs themselves: one collective moves hashes and counts together
-    out = torch.empty((int(recv_counts.sum()), 2), dtype=torch.int64, device=dev)
-    dist.all_to_all_single(out, pairs, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(),
-                           group=group)
-    return out, zero_total
+    import os
+    rank = dist.get_rank(group)
+    if os.environ.get("KCT_A2A_FALLBACK") != "1":
+        try:
+            # 1) how much will I receive from each peer (tiny fixed-layout exchange)
+            meta = torch.zeros((world, 2), dtype=torch.int64)
+            meta[:, 0] = send_counts
+            meta[0, 1] = int(zero_count)
+            meta = meta.to(dev)
+            got = torch.empty_like(meta)
+            dist.all_to_all_single(got, meta, group=group)
+            got = got.cpu()
+            recv_counts = got[:, 0]
+            zero_total = int(got[:, 1].sum())
+            # 2) the pairs themselves: one collective moves hashes and counts together
+            out = torch.empty((int(recv_counts.sum()), 2), dtype=torch.int64, device=dev)
+            dist.all_to_all_single(out, pairs, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(),
+                                   group=group)
+            return out, zero_total
+        except RuntimeError as e:  # a backend without (uneven) all-to-all: fall back to all-gather, every rank keeps its slice
+            import sys
+            print(f"[oxli_amd] all_to_all_single failed ({e}); exchanging with all_gather instead", file=sys.stderr)
+    # Fallback: every rank publishes its whole bucketed list (padded to the longest) and its bucket sizes; rank r keeps
+    # bucket r of everybody.  (world x the traffic of the all-to-all, but only all_gather is needed.)
+    meta = torch.zeros(world + 2, dtype=torch.int64)
+    meta[:world] = send_counts
+    meta[world] = int(zero_count)
+    meta[world + 1] = pairs.shape[0]
+    metas = [torch.empty_like(meta).to(dev) for _ in range(world)]
+    dist.all_gather(metas, meta.to(dev), group=group)
+    metas = torch.stack(metas).cpu()
+    longest = int(metas[:, world + 1].max())
+    padded = torch.zeros((max(longest, 1), 2), dtype=torch.int64, device=dev)
+    padded[: pairs.shape[0]] = pairs
+    lists = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(lists, padded, group=group)
+    parts = []
+    for src in range(world):
+        counts = metas[src, :world]
+        start = int(counts[:rank].sum())
+        parts.append(lists[src][start:start + int(counts[rank])])
+    out = torch.cat(parts) if parts else torch.empty((0, 2), dtype=torch.int64, device=dev)
+    return out, (int(metas[:, world].sum()) if rank == 0 else 0)  # key 0's owner is rank 0
 
 
 def global_scalar_sum(value: int, device, group=None) -> int:

@@ -23,8 +23,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, fallback=False):
     sys.path.insert(0, ROOT)
+    if fallback:
+        os.environ["KCT_A2A_FALLBACK"] = "1"  # the all_gather route of exchange_pairs
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -56,10 +58,10 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_owner_partitioned_merge_equals_single_table(tmp_path, world):
+@pytest.mark.parametrize("world,fallback", [(2, False), (3, False), (2, True)])
+def test_owner_partitioned_merge_equals_single_table(tmp_path, world, fallback):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), fallback), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     import oracle
     k, L, per_rank = 21, 150, 3000
