@@ -31,8 +31,10 @@ namespace kct {
 // =================================================================================================
 
 // ---- LDS write-combining ring shared by both partition levels ------------------------------------------
-// Bin b owns ring[b*D .. b*D+D).  An append takes position pos = fill[b]++ and lands in slot pos % D
-// unless the slot's previous tenant (position pos - D) has not left yet, i.e. pos - flushed[b] >= D;
+// Bin b owns ring[b*D .. b*D+D).  Its cursor word cur[b] holds `fill` (positions handed out) in the low half and
+// `flushed` (positions that have left the ring) in the high half, so ONE 64-bit LDS add returns both.  An append takes
+// position pos = fill++ and lands in slot pos % D unless the slot's previous tenant (position pos - D) has not left
+// yet, i.e. pos - flushed >= D;
 // such an append goes to the caller's overflow region and its position stays a HOLE in the sequence.
 // Position p of bin b is stored at offset p of the bin's output region (zeros = padding / holes).
 // ring_flush moves 64-byte lines (8 positions) out:
@@ -44,7 +46,7 @@ namespace kct {
 // T = u64 (hashes / mix64 values, 8 per line) or u32 (the compact dedupe-first path: the bin number is the value's
 // upper half, 16 per line); a value handed to overflow_hash is always the full 64-bit one.
 template <u32 LISTCAP, class T, class Overflow>
-__device__ __forceinline__ bool ring_flush(T *ring, u32 *fill, u32 *flushed, u32 *flist, u32 *fcount, int P, u32 D,
+__device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *fcount, int P, u32 D,
                                            T *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash, u64 bin_stride = 0) {
     constexpr u32 CH = 64 / sizeof(T);  // positions per 64-byte line
     const u32 dmask = D - 1;
@@ -52,7 +54,8 @@ __device__ __forceinline__ bool ring_flush(T *ring, u32 *fill, u32 *flushed, u32
     const int dshift = __builtin_ctz(D);  // D is a power of two: shifts instead of quarter-rate multiplies
     __syncthreads();  // appends of this interval are in the ring; *fcount == 0
     for (int b = threadIdx.x; b < P; b += kPartThreads) {
-        const u32 f0 = flushed[b], top = fill[b];
+        const u64 cw = cur[b];
+        const u32 f0 = (u32)(cw >> 32), top = (u32)cw;
         u32 f = f0;
         while (drain ? (int)(top - f) > 0 : top - f >= CH) {
             const u32 slot = atomicAdd(fcount, 1u);
@@ -60,7 +63,7 @@ __device__ __forceinline__ bool ring_flush(T *ring, u32 *fill, u32 *flushed, u32
             flist[slot] = (u32)b | (f << 10) | (f - f0 >= D ? 0x80000000u : 0u);
             f += CH;
         }
-        flushed[b] = f;
+        if (f != f0) atomicAdd(&cur[b], (u64)(f - f0) << 32);  // (appenders bump the low half concurrently)
     }
     __syncthreads();
     const u32 listed = *fcount, nlist = listed < LISTCAP ? listed : LISTCAP;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     constexpr int kEntries = kRingEntries * 8 / sizeof(T);  // the ring is 128 KiB either way
     constexpr int kFlushEvery = MODE == 2 ? 8 : 4;          // windows between flushes
     __shared__ __attribute__((aligned(16))) T ring[kEntries];
-    __shared__ u32 fill[1024], flushed[1024];
+    __shared__ u64 cur[1024];  // per bin: fill (low half) | flushed (high half)
     constexpr u32 kListCap = KW == 0 ? 1792 : 2048;  // the bytewise path's raw tile leaves a little less LDS
     __shared__ u32 flist[kListCap];  // lines ready to leave the ring: block | position << 10 | hole << 31
     __shared__ u32 fcount;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     const int dshift = __builtin_ctz((unsigned)kEntries) - a.pbits;  // log2 D
     static_assert(kRingEntries == 1 << 14, "dshift assumes a 16384-entry (u64) ring");
     for (int i = threadIdx.x; i < kEntries; i += kPartThreads) ring[i] = 0;
-    for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
+    for (int i = threadIdx.x; i < 1024; i += kPartThreads) cur[i] = 0;
     if (threadIdx.x == 0) { ovf_n = 0; fcount = 0; }
     T *my_scratch = reinterpret_cast<T *>(a.scratch) + (u64)blockIdx.x * P * a.region_cap;  // region_cap counts entries
 
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         else *a.overflow = 1ULL;
     };
     auto flush_lines = [&](bool drain) {
-        return ring_flush<kListCap, T>(ring, fill, flushed, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_hash);
+        return ring_flush<kListCap, T>(ring, cur, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_hash);
     };
 
     // A tile is kPartTile + k - 1 <= 1024 + 16 sixteen-byte chunks: one per thread plus a halo that
@@ -216,8 +219,9 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
                 else {
                     // bin = the pbits hash bits above the block (or super-bin) offset; the top bits in compact mode
                     pend_b = MODE == 2 ? (u32)(h >> 32) & 1023u : (u32)(h >> a.block_bits) & (u32)(P - 1);
-                    pend_pos = atomicAdd(&fill[pend_b], 1u);
-                    pend_mark = flushed[pend_b];
+                    const u64 cw = atomicAdd(&cur[pend_b], 1ULL);
+                    pend_pos = (u32)cw;
+                    pend_mark = (u32)(cw >> 32);
                     pend_h = (T)h;
                 }
             }
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     }
     while (flush_lines(true)) {}  // drain: partial lines go out zero-padded; repeat while the list was too short
     for (int b = threadIdx.x; b < P; b += kPartThreads) {
-        const u32 f = flushed[b];
+        const u32 f = (u32)(cur[b] >> 32);
         a.region_count[(u64)b * gridDim.x + blockIdx.x] = f < a.region_cap ? f : a.region_cap;
     }
     __syncthreads();
@@ -263,7 +267,7 @@ struct RepartitionArgs {
 
 __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionArgs a) {
     __shared__ __attribute__((aligned(16))) u64 ring[kRingEntries];
-    __shared__ u32 fill[1024], flushed[1024];
+    __shared__ u64 cur[1024];  // per bin: fill (low half) | flushed (high half)
     __shared__ u32 flist[2048];
     __shared__ u32 fcount, ovf_n, rounds;
     const int W = a.writers, s = blockIdx.x / W, w = blockIdx.x % W, P2 = 1 << a.sub_bits;
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     const int dshift = 14 - a.sub_bits;  // log2 D
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < kRingEntries; i += kPartThreads) ring[i] = 0;
-    for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
+    for (int i = threadIdx.x; i < 1024; i += kPartThreads) cur[i] = 0;
     if (threadIdx.x == 0) { fcount = 0; ovf_n = 0; rounds = 0; }
     if (threadIdx.x == 0 && *a.overflow) rounds = ~0u;  // K1 (or another super-bin) gave up on this pass
     __syncthreads();
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
         else *a.overflow = 1ULL;
     };
     auto flush_lines = [&](bool drain) {
-        return ring_flush<2048u, u64>(ring, fill, flushed, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_hash, bin_stride);
+        return ring_flush<2048u, u64>(ring, cur, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_hash, bin_stride);
     };
     // A wave owns the input regions seg = 16 w + wave, + 16 W, ...; work unit = a slab of 8 x 64 entries whose
     // loads are all issued before the first append.  Every wave runs the same number of rounds so that
@@ -320,8 +324,9 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
             const u64 h = v[j];
             if (h) {
                 const u32 b = (u32)(h >> a.block_bits) & (u32)(P2 - 1);
-                const u32 pos = atomicAdd(&fill[b], 1u);
-                if (pos - flushed[b] < D) ring[(b << dshift) + (pos & dmask)] = h;
+                const u64 cw = atomicAdd(&cur[b], 1ULL);
+                const u32 pos = (u32)cw;
+                if (pos - (u32)(cw >> 32) < D) ring[(b << dshift) + (pos & dmask)] = h;
                 else overflow_hash(h);
             }
             if ((j & 3) == 3) flush_lines(false);
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     }
     while (flush_lines(true)) {}
     for (int b = threadIdx.x; b < P2; b += kPartThreads) {
-        const u32 f = flushed[b];
+        const u32 f = (u32)(cur[b] >> 32);
         a.out_count[(((u64)s << a.sub_bits) + b) * W + w] = f < a.out_cap ? f : a.out_cap;
     }
     __syncthreads();
@@ -786,7 +791,7 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
     using W = typename std::conditional<COMPACT, u32, u64>::type;  // shadow word
     constexpr int kPairs = kRingEntries / 2;  // 8192 pairs = 128 KiB
     __shared__ __attribute__((aligned(16))) ulonglong2 ring[kPairs];
-    __shared__ u32 fill[1024], flushed[1024];
+    __shared__ u64 cur[1024];  // per bin: fill (low half) | flushed (high half)
     __shared__ u32 flist[2048];
     __shared__ u32 fcount;
     __shared__ u32 ascii4[256];
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
     const u32 D = (u32)(kPairs >> a.pbits), dmask = D - 1;
     const int dshift = __builtin_ctz((unsigned)kPairs) - a.pbits;
     for (int i = threadIdx.x; i < kPairs; i += kPartThreads) ring[i] = make_ulonglong2(0, 0);
-    for (int i = threadIdx.x; i < 1024; i += kPartThreads) { fill[i] = 0; flushed[i] = 0; }
+    for (int i = threadIdx.x; i < 1024; i += kPartThreads) cur[i] = 0;
     if (threadIdx.x == 0) fcount = 0;
     __syncthreads();
     ulonglong2 *my_scratch = a.scratch + (u64)blockIdx.x * P * a.region_cap;
@@ -804,7 +809,7 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
         if (i < a.ovf_cap) { a.ovf[2 * i] = h; a.ovf[2 * i + 1] = c; }  // (cap = every pending k-mer: cannot be exceeded)
     };
     auto flush_lines = [&](bool drain) {
-        return ring_flush<2048u, ulonglong2>(ring, fill, flushed, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_pair);
+        return ring_flush<2048u, ulonglong2>(ring, cur, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_pair);
     };
     // this workgroup's share of the shadow: whole blocks, kBlocksPerWg of them, one row of 1024 slots per step
     constexpr u32 S = 1u << kBlockBitsMax;
@@ -816,8 +821,9 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
             if (h) {
                 const u64 c = a.pair_counts[i * a.pair_stride];
                 const u32 b = (u32)(h >> a.table_block_bits) & (u32)(P - 1);
-                const u32 pos = atomicAdd(&fill[b], 1u);
-                if (pos - flushed[b] < D) ring[(b << dshift) + (pos & dmask)] = make_ulonglong2(h, c);
+                const u64 cw = atomicAdd(&cur[b], 1ULL);
+                const u32 pos = (u32)cw;
+                if (pos - (u32)(cw >> 32) < D) ring[(b << dshift) + (pos & dmask)] = make_ulonglong2(h, c);
                 else overflow_pair(h, c);
             }
             flush_lines(false);  // a full row of pairs over up to 1024 bins of 8: every row
@@ -834,8 +840,9 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
                 const u64 h = COMPACT ? hash_of_mixed<2>(((u64)sb << 32) | blk[i], a.k, ascii4) : hash_of_mixed<1>((u64)blk[i], a.k, ascii4);
                 if (h) {  // lib.rs:589: hash 0 is skipped
                     const u32 b = (u32)(h >> a.table_block_bits) & (u32)(P - 1);
-                    const u32 pos = atomicAdd(&fill[b], 1u);
-                    if (pos - flushed[b] < D) ring[(b << dshift) + (pos & dmask)] = make_ulonglong2(h, (u64)c);
+                    const u64 cw = atomicAdd(&cur[b], 1ULL);
+                    const u32 pos = (u32)cw;
+                    if (pos - (u32)(cw >> 32) < D) ring[(b << dshift) + (pos & dmask)] = make_ulonglong2(h, (u64)c);
                     else overflow_pair(h, (u64)c);
                 }
             }
@@ -844,7 +851,7 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
     }
     while (flush_lines(true)) {}
     for (int b = threadIdx.x; b < P; b += kPartThreads) {
-        const u32 f = flushed[b];
+        const u32 f = (u32)(cur[b] >> 32);
         a.region_count[(u64)b * gridDim.x + blockIdx.x] = f < a.region_cap ? f : a.region_cap;
     }
 }
