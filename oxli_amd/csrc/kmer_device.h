@@ -189,18 +189,17 @@ __device__ __forceinline__ u64 hash_packed(const Packed<KW> &a, int k, const u32
 // ---- a cheap bijection of u64 for the dedupe-first path ------------------------------------------------
 // mix64 scrambles a packed canonical k-mer (+1, so never 0) well enough to serve as a partition / slot / fingerprint
 // key in place of the MurmurHash3 value; unmix64 recovers the k-mer once its occurrences have been counted.
-// Every step is invertible (xor-shift by >= 32 is its own inverse; the constants are odd); 0 maps to 0.
-constexpr u64 kMixA = 0xbf58476d1ce4e5b9ULL, kMixB = 0x94d049bb133111ebULL;          // splitmix64's multipliers
-constexpr u64 kMixAInv = 0x96de1b173f119089ULL, kMixBInv = 0x319642b2d24d8ec3ULL;    // their inverses mod 2^64
+// Every step is invertible (xor-shift by 32 is its own inverse; the constant is odd); 0 maps to 0.  One multiply
+// between two xor-shifts spreads bins, home groups and fingerprints as evenly as two rounds did (5 Mbp of random sequence).
+constexpr u64 kMixA = 0xbf58476d1ce4e5b9ULL;     // splitmix64's first multiplier
+constexpr u64 kMixAInv = 0x96de1b173f119089ULL;  // its inverse mod 2^64
 __device__ __host__ __forceinline__ u64 mix64(u64 x) {
     x ^= x >> 32; x *= kMixA;
-    x ^= x >> 29; x *= kMixB;
     x ^= x >> 32;
     return x;
 }
 __device__ __host__ __forceinline__ u64 unmix64(u64 x) {
-    x ^= x >> 32; x *= kMixBInv;
-    x ^= x >> 29; x ^= x >> 58; x *= kMixAInv;
+    x ^= x >> 32; x *= kMixAInv;
     x ^= x >> 32;
     return x;
 }
