@@ -191,14 +191,16 @@ KCT_API kct_status kct_compare(kct_table *a, kct_table *b, uint64_t *common_out,
  * (lib.rs:610-655), in no particular order.  *n_out = size of the result; at most `cap` hashes are written. */
 KCT_API kct_status kct_set_op(kct_table *a, kct_table *b, int op, uint64_t *hashes_out, size_t cap, uint64_t *n_out);
 
-/* Deferred mode (off by default).  The reference is called once per record; one device pass per 150 bp
- * read is launch-bound (~80 us).  With deferred mode on, kct_consume(skip_bad != 0) only appends the record
- * to a pinned host buffer and returns; buffered records are counted in ONE device pass when the buffer
- * (64 MiB) fills or when any other call needs the table (get, len, dump, add, ...), so every read still
- * observes every earlier write.  *n_out then comes from a host-side scan for valid windows (the same
- * all-ACGT rule the device applies); it differs from the reference's n only if a window's true hash is 0
- * (probability 2^-64 per window).  Hashing and counting still happen on the device only.  Error mode
- * (skip_bad == 0) is never deferred. */
+/* Deferred mode (ON by default; `on` = 0 switches it off).  The reference is called once per record
+ * (README.md:96-98); one device pass per 150 bp read is launch-bound (~80 us, slower than the CPU loop it
+ * replaces).  In deferred mode kct_consume(skip_bad != 0) only appends the record to a pinned host buffer and
+ * returns; buffered records are counted in ONE device pass when the buffer (64 MiB) fills or when any other
+ * call needs the table (get, len, dump, add, ...), so every read still observes every earlier write.  *n_out
+ * then comes from a host-side scan for valid windows (the same all-ACGT rule the device applies); it differs
+ * from the reference's n only if a window's true hash is 0 (probability 2^-64 per window).  Hashing and
+ * counting still happen on the device only.  Error mode (skip_bad == 0) is never deferred: it counts what is
+ * buffered first, then runs synchronously.  A failure of the deferred pass itself (out of memory ...) is
+ * reported by the call that triggers it. */
 KCT_API kct_status kct_set_deferred(kct_table *t, int on);
 
 /* save / load in the reference's wire format (lib.rs:269-322): serde_json of the struct, gzip level 1.

@@ -111,4 +111,28 @@ __global__ __launch_bounds__(kBlock) void select_keys_kernel(const u64 *__restri
     }
 }
 
+// drop_hash (lib.rs:213-224) in place: one thread finds the key and closes the gap by backward shifting.  Probing is
+// linear from the home group's first slot and never leaves the block, so only the run of occupied slots behind the
+// key can be affected: a later key moves into the hole iff the hole still lies at or after its home in probe order.
+__global__ void remove_hash_kernel(u64 *words, TableGeom g, u64 h, u64 *found) {
+    const u64 w = table_find(words, g, h);
+    *found = w != ~0ULL;
+    if (w == ~0ULL) return;
+    const u64 S = block_slots(g), smask = S - 1, base = w & ~(2 * S - 1);  // first word of the key's block
+    u64 i = w - base, j = i;
+    for (u64 n = 1; n < S; ++n) {
+        j = (j + 1) & smask;
+        const u64 kj = words[base + j];
+        if (kj == 0) break;
+        const u64 home = kj & g.mask & smask & ~(u64)(kGroup - 1);
+        if (((j - home) & smask) >= ((j - i) & smask)) {
+            words[base + i] = kj;
+            words[base + S + i] = words[base + S + j];
+            i = j;
+        }
+    }
+    words[base + i] = 0;
+    words[base + S + i] = 0;
+}
+
 }  // namespace kct

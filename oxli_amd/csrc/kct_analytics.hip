@@ -158,7 +158,22 @@ kct_status kct_retain_counts(kct_table *t, uint64_t min_count, uint64_t max_coun
 
 kct_status kct_remove_hash(kct_table *t, uint64_t hash, uint64_t *removed_out) {
     KCT_TRY(use(t));
-    return retain(t, 0, ~0ULL, true, hash, removed_out);
+    u64 gone = 0;
+    if (hash == 0) {  // key 0 lives host-side
+        if (t->zero_present) { t->zero_present = false; t->zero_count = 0; gone = 1; }
+    } else if (live_words(t)) {  // O(probe run), like the reference's HashMap::remove: no scan, no rebuild
+        du64 *d_found = t->d_counters + kNumCounters + 4;
+        {
+            ProfScope ps(t, "remove_hash_kernel");
+            hipLaunchKernelGGL(kct::remove_hash_kernel, dim3(1), dim3(1), 0, t->stream, t->slots, geom(t), (u64)hash, d_found);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(t->h_counters, d_found, 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (t->h_counters[0]) { gone = 1; t->n_keys -= 1; }
+    }
+    if (removed_out) *removed_out = gone;
+    return KCT_OK;
 }
 
 kct_status kct_compare(kct_table *a, kct_table *b, uint64_t *common_out, uint64_t *dot_out) {

@@ -887,9 +887,11 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
             KCT_TRY(consume_stream(t, (const unsigned char *)t->d_stream.p, rec_off[r], &n_before));
             const u64 prefix = fbw + t->k - 1;  // bytes of r that its windows 0..fbw-1 cover
             if (fbw > 0) {
-                KCT_TRY(t->d_aux2.reserve(((prefix + 15) & ~(u64)15) + 16));
-                HIP_TRY(hipMemcpyAsync(t->d_aux2.p, (const char *)t->d_stream.p + rec_off[r], prefix, hipMemcpyDeviceToDevice, t->stream));
-                KCT_TRY(consume_stream(t, (const unsigned char *)t->d_aux2.p, prefix, &n_prefix));
+                // a 16-byte aligned copy of the prefix, in a buffer nothing inside consume_stream touches (its passes
+                // reallocate / overwrite d_aux2 and d_spill when they replay spills)
+                KCT_TRY(t->d_prefix.reserve(((prefix + 15) & ~(u64)15) + 16));
+                HIP_TRY(hipMemcpyAsync(t->d_prefix.p, (const char *)t->d_stream.p + rec_off[r], prefix, hipMemcpyDeviceToDevice, t->stream));
+                KCT_TRY(consume_stream(t, (const unsigned char *)t->d_prefix.p, prefix, &n_prefix));
             }
             t->consumed += offsets[r] - offsets[0];  // r raised before lib.rs:604
             *n_total = n_before + n_prefix;

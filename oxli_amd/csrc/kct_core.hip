@@ -75,6 +75,7 @@ kct::TableView view(kct_table *t, u64 spill_cap) {
     v.spill = (du64 *)t->d_spill.p;
     v.spill_cap = spill_cap;
     v.spill_n = t->d_counters + kNumCounters;  // scratch word 0
+    v.max_groups = kct::kMaxProbeGroups;
     return v;
 }
 
@@ -134,13 +135,21 @@ kct_status grow_to(kct_table *t, u64 new_cap);
 kct_status merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n, int stride, u64 tallies[4]) {
     if (pairs_partition_pays(t, n) && (const void *)d_keys != t->d_aux2.p) return merge_pairs_partitioned(t, d_keys, d_counts, n, stride, tallies);
     KCT_TRY(materialize(t));
+    // Round 1 probes kMaxProbeGroups groups per key (the hot paths' bound).  What spills is retried with whole-block
+    // probing: keys that merely share their low bits (count_hash / __setitem__ / load of arbitrary u64 keys -- the
+    // reference's HashMap takes any) then find room without the table growing.  Only what spills from a whole-block
+    // round (its block is FULL) or a table past its load limit makes the table grow.
+    bool whole_block = false;
+    u64 stuck = 0;
     while (n > 0) {
         KCT_TRY(t->d_spill.reserve(n * 16));
         KCT_TRY(zero_counters(t));
+        kct::TableView tv = view(t, n);
+        if (whole_block) tv.max_groups = 0;
         {
             ProfScope ps(t, "merge_pairs_kernel");
             hipLaunchKernelGGL(kct::merge_pairs_kernel, dim3(merge_grid(n)), dim3(kct::kBlock), 0, t->stream, d_keys, d_counts, n,
-                               (const du64 *)nullptr, (const du64 *)nullptr, stride, view(t, n), t->d_counters);
+                               (const du64 *)nullptr, (const du64 *)nullptr, stride, tv, t->d_counters);
         }
         HIP_TRY(hipGetLastError());
         u64 c[4], spilled;
@@ -148,10 +157,22 @@ kct_status merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u
         for (int i = 0; i < 4; ++i) tallies[i] += c[i];
         t->n_keys += c[kct::CTR_NEWKEYS];
         if (spilled == 0) break;
-        // the table is too full for these keys: move the spill list aside, grow, replay it
+        // move the spill list aside; then either probe further or grow, and replay it
         KCT_TRY(t->d_aux2.reserve(spilled * 16));
         HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
-        KCT_TRY(grow_to(t, spill_growth_target(t, spilled)));
+        const bool too_full = (double)(t->n_keys + 1) > kMaxLoad * (double)t->cap;
+        if (whole_block || too_full) {
+            // A block that is full although the table is nearly empty holds keys that agree in every bit a larger table
+            // would index with (e.g. i << 40): growing cannot separate them.  Give up cleanly instead of doubling until
+            // HBM runs out.
+            if (whole_block && !too_full && (double)t->n_keys < 0.05 * (double)t->cap && ++stuck >= 3) {
+                set_err("%llu keys do not fit: they collide in one %u-slot table block at every table size tried (their low bits agree)",
+                        (unsigned long long)spilled, 1u << t->block_bits);
+                return KCT_ERR_NOMEM;
+            }
+            KCT_TRY(grow_to(t, spill_growth_target(t, spilled)));
+        }
+        whole_block = true;
         d_keys = (const du64 *)t->d_aux2.p;
         d_counts = d_keys + 1;
         stride = 2;
@@ -166,41 +187,50 @@ void launch_merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, 
                        tv, t->d_counters);
 }
 
-// Re-hash into a table of new_cap slots (no-op if not larger).
+// Re-hash into a table of new_cap slots.  The new array is installed only once every key has been placed in it; on
+// failure the table is left as it was.
 kct_status grow_to(kct_table *t, u64 new_cap) {
     new_cap = std::max(next_pow2(new_cap), kMinSlots);
     if (new_cap <= t->cap) new_cap = t->cap * 2;
-    du64 *old = t->slots;
-    const u64 old_cap = t->cap, old_keys = t->n_keys;
-    const kct::TableGeom old_g = geom(t);
+    const u64 old_keys = t->n_keys;
     du64 *fresh = nullptr;
     KCT_TRY(alloc_slots(t->device, new_cap, t->stream, &fresh));
-    t->slots = fresh;
-    t->cap = new_cap;
-    set_geometry(t);
-    t->n_keys = 0;
-    if (t->lazy_empty) t->lazy_empty = false;  // the old array was never cleaned, but it holds no keys: drop it
-    if (old && old_keys > 0) {
-        // re-insert every occupied slot; the new table is at most ~half full so nothing spills
-        KCT_TRY(t->d_spill.reserve(16));
-        KCT_TRY(zero_counters(t));
-        {
-            ProfScope ps(t, "rehash_kernel");
-            hipLaunchKernelGGL(kct::rehash_kernel, dim3(merge_grid(old_cap)), dim3(kct::kBlock), 0, t->stream, (const du64 *)old, old_g,
-                               view(t, 0), t->d_counters);
+    u64 placed = 0;
+    if (t->slots && old_keys > 0 && !t->lazy_empty) {
+        // re-insert every occupied slot, probing whole blocks: a key that fitted the old block fits the new one
+        kct::TableView nv;
+        nv.words = fresh;
+        nv.g.mask = new_cap - 1;
+        nv.g.block_bits = std::min(kct::kBlockBitsMax, log2_u64(new_cap));
+        nv.spill = nullptr; nv.spill_cap = 0; nv.spill_n = t->d_counters + kNumCounters;
+        nv.max_groups = 0;
+        kct_status st = zero_counters(t);
+        if (st == KCT_OK) {
+            {
+                ProfScope ps(t, "rehash_kernel");
+                hipLaunchKernelGGL(kct::rehash_kernel, dim3(merge_grid(t->cap)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->slots, geom(t), nv,
+                                   t->d_counters);
+            }
+            if (hipGetLastError() != hipSuccess) { set_err("rehash_kernel launch failed"); st = KCT_ERR_HIP; }
         }
-        HIP_TRY(hipGetLastError());
-        u64 c[4], spilled;
-        KCT_TRY(read_counters(t, c, &spilled));
-        t->n_keys = c[kct::CTR_NEWKEYS];
-        if (spilled != 0 || t->n_keys != old_keys) {
-            set_err("re-hash lost keys: %llu of %llu placed, %llu spilled", (unsigned long long)t->n_keys,
-                    (unsigned long long)old_keys, (unsigned long long)spilled);
-            return KCT_ERR_HIP;
+        u64 c[4] = {0, 0, 0, 0}, spilled = 0;
+        if (st == KCT_OK) st = read_counters(t, c, &spilled);
+        placed = c[kct::CTR_NEWKEYS];
+        if (st == KCT_OK && (spilled != 0 || placed != old_keys)) {
+            set_err("re-hash lost keys: %llu of %llu placed, %llu spilled", (unsigned long long)placed, (unsigned long long)old_keys,
+                    (unsigned long long)spilled);
+            st = KCT_ERR_HIP;
         }
+        if (st != KCT_OK) { (void)hipStreamSynchronize(t->stream); (void)hipFree(fresh); return st; }
     } else {
         HIP_TRY(hipStreamSynchronize(t->stream));
     }
+    du64 *old = t->slots;
+    t->slots = fresh;
+    t->cap = new_cap;
+    set_geometry(t);
+    t->n_keys = placed;
+    t->lazy_empty = false;  // (a lazily cleared old array held no keys: it is simply dropped)
     if (old) HIP_TRY(hipFree(old));
     return KCT_OK;
 }
@@ -306,7 +336,7 @@ void kct_destroy(kct_table *t) {
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     t->d_stream.release(); t->d_spill.release(); t->d_aux.release(); t->d_aux2.release();
     t->d_scratch.release(); t->d_regions.release(); t->d_irr.release(); t->d_sort.release();
-    t->d_scratch2.release(); t->d_regions2.release(); t->d_irr2.release(); t->d_pairs_ovf.release();
+    t->d_scratch2.release(); t->d_regions2.release(); t->d_irr2.release(); t->d_pairs_ovf.release(); t->d_prefix.release();
     t->h_stage.release(); t->h_pending.release();
     if (t->shadow) (void)hipFree(t->shadow);
     if (t->shadow32) (void)hipFree(t->shadow32);
@@ -582,11 +612,32 @@ kct_status kct_add(kct_table *dst, kct_table *src, uint64_t *total_added, uint64
     // snapshot src (lib.rs:791-795), then fold it into dst (lib.rs:798-806)
     u64 n = 0;
     KCT_TRY(kct_len(src, &n));
-    std::vector<u64> hk(n ? n : 1), hc(n ? n : 1);
-    u64 got = 0;
-    KCT_TRY(kct_dump(src, hk.data(), hc.data(), n, 0, &got));
     u64 ta = 0, nk = 0;
-    KCT_TRY(kct_merge_host(dst, hk.data(), hc.data(), n, &ta, &nk));
+    if (dst->device == src->device && dst != src) {
+        // both tables on one GPU: compact src into a device buffer of dst's and merge from there -- nothing crosses PCIe
+        KCT_TRY(use(dst));  // (anything pending in dst is counted before its d_aux is borrowed)
+        const u64 n_dev = src->n_keys;
+        if (n_dev) {
+            KCT_TRY(dst->d_aux.reserve(n_dev * 16));
+            du64 *dk = (du64 *)dst->d_aux.p, *dc = dk + n_dev;
+            u64 got = 0;
+            KCT_TRY(kct_export_device(src, dk, dc, n_dev, &got));
+            if (got != n_dev) { set_err("table scan found %llu keys, expected %llu", (unsigned long long)got, (unsigned long long)n_dev); return KCT_ERR_HIP; }
+            KCT_TRY(use_device(dst));
+            KCT_TRY(kct_merge_device(dst, dk, dc, n_dev, &ta, &nk));
+        }
+        if (src->zero_present) {  // key 0 lives host-side in both tables (lib.rs:801-803: new when its current count is 0)
+            if (!dst->zero_present || dst->zero_count == 0) ++nk;
+            dst->zero_present = true;
+            dst->zero_count += src->zero_count;
+            ta += src->zero_count;
+        }
+    } else {
+        std::vector<u64> hk(n ? n : 1), hc(n ? n : 1);
+        u64 got = 0;
+        KCT_TRY(kct_dump(src, hk.data(), hc.data(), n, 0, &got));
+        KCT_TRY(kct_merge_host(dst, hk.data(), hc.data(), n, &ta, &nk));
+    }
     dst->consumed += src->consumed;  // lib.rs:808
     if (total_added) *total_added = ta;
     if (new_keys) *new_keys = nk;
@@ -608,7 +659,7 @@ kct_status kct_release_scratch(kct_table *t) {
     KCT_TRY(use(t));  // nothing may be pending in a buffer that is about to go
     HIP_TRY(hipStreamSynchronize(t->stream));
     for (DevBuf *b : {&t->d_stream, &t->d_spill, &t->d_aux, &t->d_aux2, &t->d_scratch, &t->d_regions, &t->d_irr, &t->d_sort, &t->d_scratch2,
-                      &t->d_regions2, &t->d_irr2, &t->d_pairs_ovf})
+                      &t->d_regions2, &t->d_irr2, &t->d_pairs_ovf, &t->d_prefix})
         b->release();
     if (t->shadow) { (void)hipFree(t->shadow); t->shadow = nullptr; t->shadow_cap = 0; t->shadow_empty = true; t->shadow_keys = 0; }
     if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; t->s32_empty = true; t->s32_keys = 0; t->s32_windows = 0; }

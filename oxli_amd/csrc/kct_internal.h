@@ -101,10 +101,10 @@ struct kct_table {
     int block_bits = 0;     // log2(slots per probing block) = min(13, log2 cap)
     bool lazy_empty = false;  // kct_clear() was called and the memset has not been issued yet
     int num_cus = 256;
-    // Opt-in deferred mode (kct_set_deferred): per-record consume() calls only append to a pinned host buffer
+    // Deferred mode (on by default; kct_set_deferred): per-record consume() calls only append to a pinned host buffer
     // and return; the buffered records are counted in one device pass when the buffer fills or anything reads
     // the table.  The k-mer count returned to the caller comes from a host-side validity scan.
-    bool deferred = false;
+    bool deferred = true;
     kcth::PinnedBuf h_pending;
     size_t pending_used = 0;
     u64 pending_records = 0;
@@ -133,7 +133,8 @@ struct kct_table {
 
     du64 *d_counters = nullptr;  // kNumCounters tallies + 8 scratch words (device)
     u64 *h_counters = nullptr;   // pinned mirror
-    kcth::DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort, d_scratch2, d_regions2, d_irr2, d_pairs_ovf;
+    kcth::DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort, d_scratch2, d_regions2, d_irr2, d_pairs_ovf,
+        d_prefix;  // error mode: the offending record's valid prefix (its own buffer: consume_stream reuses d_aux2 / d_spill)
     kcth::PinnedBuf h_stage;
     std::vector<kcth::PinnedBuf> h_file;  // kct_consume_file's chunk buffers (two per parser thread), kept between calls
 

@@ -23,7 +23,8 @@
 //   front of the CAS are safe: a stale EMPTY only sends the lane to the CAS, which returns the
 //   truth.
 // A lane that cannot place its key within kMaxProbeGroups groups appends {hash, count} to the
-// spill list; the host grows the table and replays the list, so nothing is ever dropped.
+// spill list; the host replays the list with whole-block probing (TableView::max_groups = 0) and grows
+// the table when it is too full, so nothing is ever dropped.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -49,6 +50,8 @@ struct TableView {
     u64 *spill;      // 2 * spill_cap words
     u64 spill_cap;
     u64 *spill_n;    // device counter
+    int max_groups;  // groups table_add probes before it spills: kMaxProbeGroups on the hot paths, the whole block
+                     // (0 = S / 8) for re-hash and spill replay, so that keys sharing their low bits still find room
 };
 
 // word index of the KEY of global slot s; its count sits S words further
@@ -83,7 +86,8 @@ __device__ __forceinline__ AddResult table_add(const TableView &t, u64 h, u64 c)
     const u64 S = block_slots(t.g);
     u64 s = home_group_slot(t.g, h);
     AddResult r{0, false, false, 0};
-    for (int probe = 0; probe < kMaxProbeGroups; ++probe) {
+    const int max_groups = t.max_groups > 0 ? t.max_groups : (int)(S >> kGroupBits);
+    for (int probe = 0; probe < max_groups; ++probe) {
         u64 *kw = t.words + key_word(t.g, s);
         // one 64-byte line: the eight candidate keys of this group
         const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(kw), b = *reinterpret_cast<const ulonglong2 *>(kw + 2);

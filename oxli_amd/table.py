@@ -34,11 +34,11 @@ class KmerCountTable:
     """Counts canonical k-mers by their sourmash-compatible 64-bit hash, on one MI355X.
 
     ``KmerCountTable(ksize, store_kmers=False)`` -- reference ``lib.rs:44-62``.
-    Extra keyword arguments (``capacity``, ``device``) size and place the device table and ``deferred``
-    batches per-record ``consume`` calls; they do not change any result.
+    Extra keyword arguments (``capacity``, ``device``) size and place the device table; ``deferred`` (default: the
+    library's, which is on) batches per-record ``consume`` calls into one device pass.  They do not change any result.
     """
 
-    def __init__(self, ksize, store_kmers=False, *, capacity=0, device=0, deferred=False):
+    def __init__(self, ksize, store_kmers=False, *, capacity=0, device=0, deferred=None):
         if not 0 <= int(ksize) <= 255:
             raise OverflowError("out of range integral type conversion attempted")  # pyo3's u8 extraction
         self._lib = L.load()
@@ -49,8 +49,8 @@ class KmerCountTable:
             raise RuntimeError(f"kct_create failed ({st}): {L.last_error()}")
         self.ksize = int(ksize)
         self.version = VERSION
-        if deferred:
-            self.set_deferred(True)
+        if deferred is not None:
+            self.set_deferred(bool(deferred))
         # lib.rs:37-38: optional hash -> canonical k-mer string map.  It is bookkeeping beside the counted
         # path and stays on the host, exactly like the reference's HashMap<u64, String>; the hashes that
         # key it still come from the device.
@@ -530,7 +530,7 @@ class KmerCountTable:
 
     def set_deferred(self, on=True):
         """Per-record ``consume()`` calls are buffered on the host and counted in one device pass when the buffer
-        fills or the table is read (see ``kct_set_deferred`` in include/kct.h).  Off by default."""
+        fills or the table is read (see ``kct_set_deferred`` in include/kct.h).  On by default."""
         self._check(self._lib.kct_set_deferred(self._h, 1 if on else 0))
 
     def set_path(self, mode):

@@ -19,12 +19,24 @@ import oracle  # noqa: E402  (the checker)
 from oracle import OracleTable  # noqa: E402
 
 
-@pytest.fixture(scope="module")
-def KCT():
+@pytest.fixture(scope="module", params=["default", "sync"])
+def KCT(request):
+    """The table class as users construct it ("default": per-record consume() calls are deferred and counted in one
+    device pass when the table is next read) and with every consume() a device pass of its own ("sync"), so that
+    each device path is also driven record by record."""
+    import functools
+
     import torch
     assert torch.cuda.is_available(), "these tests need the GPU"
     from oxli_amd import KmerCountTable
-    return KmerCountTable
+    if request.param == "default":
+        return KmerCountTable
+
+    @functools.wraps(KmerCountTable, updated=())
+    def make(*args, **kw):
+        kw.setdefault("deferred", False)
+        return KmerCountTable(*args, **kw)
+    return make
 
 
 def assert_same_table(dev, ref):
@@ -977,12 +989,12 @@ def test_partitioned_path_on_a_128_GiB_table(KCT):
     assert big.get_hash(int(sk[12345])) == int(sc[12345])
 
 
-# ---- deferred mode: per-record consume() buffered on the host, counted in one device pass ------------
+# ---- deferred mode (the default): per-record consume() buffered on the host, counted in one device pass ------------
 @pytest.mark.parametrize("k", [4, 21, 33, 70])
 def test_deferred_consume_matches_oracle(KCT, k):
     rng = random.Random(900 + k)
-    dev, ref = KCT(k, deferred=True), OracleTable(k)
-    plain = KCT(k)
+    dev, ref = KCT(k), OracleTable(k)      # default-constructed: deferred mode is the library's default
+    plain = KCT(k, deferred=False)         # every call a device pass of its own
     for i in range(400):
         kind = rng.random()
         if kind < 0.1:
@@ -1002,7 +1014,7 @@ def test_deferred_consume_matches_oracle(KCT, k):
 
 def test_deferred_error_mode_and_clear(KCT):
     k = 9
-    dev, ref = KCT(k, deferred=True), OracleTable(k)
+    dev, ref = KCT(k), OracleTable(k)
     dev.consume("ACGTACGTACGTTTGA"); ref.consume("ACGTACGTACGTTTGA")
     with pytest.raises(ValueError) as e_dev:
         dev.consume("ACGTACGTACNTACGTACGT", skip_bad_kmers=False)
@@ -1017,7 +1029,7 @@ def test_deferred_error_mode_and_clear(KCT):
     dev.sync()                       # kct_sync: an explicit flush point
     dev.set_deferred(False)          # switching off also counts what is buffered
     assert dev.get("GGGGGGGGG") == 5
-    other = KCT(k, deferred=True)
+    other = KCT(k)
     other.consume("GGGGGGGGGGGGG")
     dev.add(other)                   # src's buffered records are part of src
     assert dev.get("GGGGGGGGG") == 10
@@ -1028,7 +1040,7 @@ def test_deferred_buffer_rollover(KCT):
     k = 31
     rng = np.random.default_rng(5)
     read = "".join("ACGT"[i] for i in rng.integers(0, 4, 1 << 20))
-    dev = KCT(k, deferred=True)
+    dev = KCT(k)
     total = 0
     for i in range(70):
         total += dev.consume(read[i:] if i else read)
