@@ -97,12 +97,41 @@ unsigned int region_capacity(double avg) {
     return (unsigned int)((((u64)(avg * 1.15 + 8.0 * __builtin_sqrt(avg) + 64.0)) + 7) & ~7ULL);
 }
 
+// How a table of 2^bbits blocks is reached: K1 (or the first level of a pair flush) fans out to 2^pbits bins through its
+// LDS ring -- at most 1024 --, each holding 2^sub_bits table blocks that the second level (repartition_kernel) separates.
+// The second level wants >= 64 bins per super-bin: with 16 its lanes fight over a handful of LDS cursors (2.5x slower per
+// entry), so small two-level tables give the first level FEWER bins, and W workgroups share a super-bin so that the second
+// level still fills the chip.
+struct Levels {
+    int bbits, pbits, sub_bits;
+    bool two;
+    u64 P, B, W;
+};
+
+Levels levels_for(int bbits, int nwg) {
+    Levels L;
+    L.bbits = bbits;
+    L.two = bbits > 10;
+    L.pbits = bbits;
+    if (L.two) L.pbits = bbits <= 14 ? bbits - 6 : std::min(10, bbits - 7);
+    if (const char *e = getenv("KCT_PBITS")) if (L.two) L.pbits = std::max(bbits - 10, std::min(10, atoi(e)));  // measurement only
+    L.sub_bits = bbits - L.pbits;
+    L.P = 1ULL << L.pbits;
+    L.B = 1ULL << bbits;
+    L.W = L.two ? std::max<u64>(1, (u64)nwg / L.P) : 1;
+    return L;
+}
+
+// overflow regions: an eighth of a workgroup's entries, but few enough that ring positions (21 bits in ring_flush's line
+// list) cannot wrap before a hopelessly skewed pass is abandoned
+unsigned int overflow_capacity(u64 entries_per_wg) { return (unsigned int)std::min<u64>(1ULL << 20, std::max<u64>(4096, entries_per_wg / 8)); }
+
 // Dedupe-first pass (k <= 32).  Reads that cover a small genome deeply repeat every k-mer tens of times per pass, and
 // ~55 % of K1's instructions are MurmurHash3 plus the ASCII re-expansion.  So the pass counts PACKED k-mers: K1 (RAW)
-// partitions mix64(packed canonical k-mer + 1) values, and the unchanged K2 counts them into a SHADOW table -- 1024
-// blocks x 8192 slots in HBM with the real table's layout, keyed by those values -- holding counts that are PENDING:
+// partitions mix64(packed canonical k-mer + 1) values, and the unchanged K2 counts them into a SHADOW table -- in HBM, with
+// the real table's layout, keyed by those values -- holding counts that are PENDING:
 // the real (hash-keyed) table only gets them when something needs it (flush_shadow: every k-mer with a pending
-// count is hashed once and added with the direct insert).  Many passes, one conversion; MurmurHash3 and the table's
+// count is hashed once and added).  Many passes, one conversion; MurmurHash3 and the table's
 // random accesses are paid per distinct k-mer per flush instead of per occurrence.  Reads of the table flush first
 // (use()), so nothing observes the difference.  Chosen by dedupe_pays(); counts are identical either way.
 kct::TableGeom shadow_geom(const kct_table *t) {
@@ -112,6 +141,15 @@ kct::TableGeom shadow_geom(const kct_table *t) {
     return g;
 }
 
+// windows a dedupe-first pass must amortise per k-mer it leaves pending: a flush costs ~0.04-0.05 ns per pending k-mer when
+// the pairs are partitioned (~0.11 ns with one random table access each), a dedupe-first pass saves ~3-5 ps per window
+u64 windows_per_pending_key(const kct_table *t) { return partition_geometry_ok(t) && t->block_bits == kct::kBlockBitsMax ? 16 : 32; }
+
+// the dedupe probe of a large call into a table that knows nothing yet: few enough windows that the shadow could hold
+// every one of their k-mers, were they all distinct
+u64 probe_windows(const kct_table *t) { return std::min<u64>(1ULL << 26, std::max<u64>(1ULL << 22, t->cap / 2)); }
+kct_status flush_compact(kct_table *t);
+
 bool dedupe_pays(const kct_table *t, u64 npos) {
     if (t->k > 32 || t->dedupe_off || npos < (1ULL << 22) || !partition_geometry_ok(t)) return false;
     if (t->force_path == 3) return true;
@@ -119,12 +157,9 @@ bool dedupe_pays(const kct_table *t, u64 npos) {
     // few distinct k-mers, each many times?  What the table (or the shadow) holds so far is the best guess.
     const u64 known = std::max({t->n_keys, t->shadow_keys, t->s32_keys});
     if (known == 0) return t->dedupe_hint;  // nothing counted yet (new or cleared table): go by how the last pass went
-    // A flush costs ~0.11 ns per pending k-mer (one random table access each), a dedupe-first pass saves ~3-4 ps per
-    // window (no MurmurHash3 in K1): converting pays once ~32 windows have been counted per distinct k-mer since the
-    // table was last read.  The caller's run so far is the evidence that reads are that rare.
-    // (a table of up to 1024 blocks is flushed by partitioning the pairs: half the cost per k-mer)
-    const u64 per_key = (t->cap >> t->block_bits) <= 1024 ? 16 : 32;
-    return known * per_key <= t->windows_since_read + npos;
+    // Converting pays once ~16 (32) windows have been counted per distinct k-mer between two reads of the table.  The
+    // caller's run so far is the evidence that reads are that rare -- and nothing can read before the running call ends.
+    return known * windows_per_pending_key(t) <= t->windows_since_read + std::max(npos, t->call_windows_left);
 }
 
 // The shadow mirrors the real table's capacity (the same k-mers live in both).  (Re)allocated empty when that changes.
@@ -143,35 +178,62 @@ kct_status ensure_shadow(kct_table *t, bool *ok) {
     return KCT_OK;
 }
 
-// Pending counts -> the real table.  The shadow keeps its keys (they will be met again), its counts return to zero.
-constexpr int kCompactBlockBits = 10;  // the compact shadow: 1024 blocks x 8192 slots
-constexpr u64 kCompactSlots = 1ULL << (kCompactBlockBits + kct::kBlockBitsMax);
+// The compact shadow (k <= 21): 2^sbits blocks x 8192 slots of u32 key + u32 count.  A block index is the TOP sbits bits
+// of the 42-bit mix42 value, an entry its low 32 bits, so sbits >= 10.  Beside a table of up to 1024 blocks it is the
+// fixed 1024-block (64 MiB) one and K1's bins are its blocks; beside a larger table it has as many blocks as the table
+// (at least 2^16, so that the second partition level has >= 64 bins per super-bin) and K1's 1024 bins are super-bins.
+constexpr int kCompactBlockBits = 10;
+int compact_sbits_for(const kct_table *t) {
+    const int bbits = log2_u64(t->cap >> t->block_bits);
+    return bbits <= 10 ? kCompactBlockBits : std::max(16, bbits);
+}
+u64 compact_slots(const kct_table *t) { return 1ULL << (t->s32_sbits + kct::kBlockBitsMax); }
 
-// Tables of 16..1024 blocks: hash the pending k-mers, radix-partition the {hash, count} pairs by table block and merge
+kct_status ensure_shadow32(kct_table *t, bool *ok) {
+    *ok = true;
+    const int want = compact_sbits_for(t);
+    if (t->shadow32 && t->s32_sbits == want) return KCT_OK;
+    KCT_TRY(flush_compact(t));
+    if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; }
+    const u64 bytes = (1ULL << (want + kct::kBlockBitsMax)) * 8;
+    size_t free_b = 0, total_b = 0;
+    if (want > kCompactBlockBits && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 3.0 * (double)bytes)) { *ok = false; return KCT_OK; }
+    if (hipMalloc((void **)&t->shadow32, bytes) != hipSuccess) { (void)hipGetLastError(); t->shadow32 = nullptr; *ok = false; return KCT_OK; }  // no room: this table does without
+    t->s32_sbits = want;
+    t->s32_empty = true;
+    t->s32_keys = 0;
+    return KCT_OK;
+}
+
+// {hash, count} pairs into the table by the k-mers' own route: hash the pending k-mers (or take a flat pair list),
+// radix-partition the PAIRS by table block through the LDS ring (one level for up to 1024 blocks, two beyond) and merge
 // each block in LDS -- the table is read and written once, sequentially, instead of once per k-mer at random.
 // src 0 / 1: the compact / 64-bit shadow's pending counts; src 2: a flat list of n {hash, count} pairs (keys[i * stride],
 // counts[i * stride]) -- add(), load(), the multi-GPU merge.  tallies (may be null) += CTR_* of the pass.
 kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const du64 *counts, u64 n, int stride, u64 *tallies) {
     const bool compact = src == 0;
-    const int pbits = log2_u64(t->cap >> t->block_bits);
-    const u64 P = 1ULL << pbits;
-    const u64 sslots = src == 2 ? n : compact ? kCompactSlots : t->shadow_cap, skeys = src == 2 ? n : compact ? t->s32_keys : t->shadow_keys;
+    const Levels L = levels_for(log2_u64(t->cap >> t->block_bits), t->num_cus);
+    const u64 P = L.P;
+    const u64 sslots = src == 2 ? n : compact ? compact_slots(t) : t->shadow_cap;
+    const u64 npairs = std::max<u64>(1, src == 2 ? n : compact ? t->s32_keys : t->shadow_keys);  // at most this many pairs exist
     const int nwg = src == 2 ? (int)std::min<u64>(t->num_cus, (n + 8 * kct::kPartThreads - 1) / (8 * kct::kPartThreads))
                              : (int)std::min<u64>(t->num_cus, sslots >> kct::kBlockBitsMax);  // a workgroup takes whole shadow blocks
-    const double fill = std::min(1.0, (double)skeys / (double)sslots);
-    const unsigned int region_cap = region_capacity((double)(sslots / nwg + kct::kPartThreads) * fill / (double)P);  // pairs per (workgroup, block)
+    const double fill = std::min(1.0, (double)npairs / (double)sslots);
+    const unsigned int region_cap = region_capacity((double)(sslots / nwg + kct::kPartThreads) * fill / (double)P);  // pairs per (workgroup, bin)
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 16));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
-    KCT_TRY(t->d_pairs_ovf.reserve(sslots * 16));  // pairs that found ring or region full (its own buffer: d_aux may hold the input)
-    KCT_TRY(t->d_spill.reserve(sslots * 16));  // pairs that found their table block full
+    KCT_TRY(t->d_pairs_ovf.reserve(npairs * 16 + 64));  // pairs that found ring or region full (its own buffer: d_aux may hold the input)
+    KCT_TRY(t->d_spill.reserve(npairs * 16 + 64));      // pairs that found their table block full
     KCT_TRY(zero_counters(t));
     du64 *d_ovf_n = t->d_counters + kNumCounters + 5;
     const bool fresh = t->lazy_empty;
     kct::FlushPartitionArgs fa;
     fa.shadow = compact ? (void *)t->shadow32 : (void *)t->shadow; fa.shadow_blocks = src == 2 ? 0u : (unsigned int)(sslots >> kct::kBlockBitsMax); fa.k = t->k;
-    fa.pair_keys = keys; fa.pair_counts = counts; fa.pair_stride = stride; fa.npairs = n; fa.table_block_bits = t->block_bits; fa.pbits = pbits;
+    fa.shadow_sbits = t->s32_sbits;
+    fa.pair_keys = keys; fa.pair_counts = counts; fa.pair_stride = stride; fa.npairs = n;
+    fa.table_block_bits = t->block_bits + L.sub_bits; fa.pbits = L.pbits;  // (two levels: the first-level bins are super-bins)
     fa.scratch = (ulonglong2 *)t->d_scratch.p; fa.region_cap = region_cap; fa.region_count = (unsigned int *)t->d_regions.p;
-    fa.ovf = (du64 *)t->d_pairs_ovf.p; fa.ovf_cap = sslots; fa.ovf_n = d_ovf_n;
+    fa.ovf = (du64 *)t->d_pairs_ovf.p; fa.ovf_cap = npairs; fa.ovf_n = d_ovf_n;
     {
         ProfScope ps(t, "flush_partition_kernel");
         if (src == 0) hipLaunchKernelGGL(kct::flush_partition_kernel<0>, dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
@@ -183,16 +245,34 @@ kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const
     pa.words = t->slots; pa.block_bits = t->block_bits;
     pa.scratch = (const ulonglong2 *)t->d_scratch.p; pa.seg_stride = P * region_cap; pa.block_stride = region_cap;
     pa.region_count = (const unsigned int *)t->d_regions.p; pa.nregions = nwg;
+    if (L.two) {
+        const unsigned int out_cap = (region_capacity((double)npairs / (double)L.B / (double)L.W) + 3u) & ~3u;  // pairs per (block, writer): whole lines
+        KCT_TRY(t->d_scratch2.reserve(L.B * L.W * out_cap * 16));
+        KCT_TRY(t->d_regions2.reserve(L.B * L.W * 4));
+        kct::RepartitionArgs ra;
+        ra.mask = t->cap - 1; ra.block_bits = t->block_bits; ra.sub_bits = L.sub_bits;
+        ra.in = t->d_scratch.p; ra.in_cap = region_cap; ra.in_count = (const unsigned int *)t->d_regions.p;
+        ra.nseg = nwg; ra.nbins = (int)P; ra.writers = (int)L.W;
+        ra.out = t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
+        ra.ovf = (du64 *)t->d_pairs_ovf.p; ra.ovf_cap = (unsigned int)std::min<u64>(npairs, 0xFFFFFFFFu); ra.ovf_count = nullptr; ra.overflow = nullptr; ra.ovf_n = d_ovf_n;
+        {
+            ProfScope ps(t, "repartition_kernel<pairs>");
+            hipLaunchKernelGGL(kct::repartition_kernel<ulonglong2>, dim3((unsigned)(P * L.W)), dim3(kct::kPartThreads), 0, t->stream, ra);
+        }
+        HIP_TRY(hipGetLastError());
+        pa.scratch = (const ulonglong2 *)t->d_scratch2.p; pa.seg_stride = out_cap; pa.block_stride = L.W * out_cap;
+        pa.region_count = (const unsigned int *)t->d_regions2.p; pa.nregions = (int)L.W;
+    }
     pa.fresh = fresh ? 1 : 0;
-    pa.spill = (du64 *)t->d_spill.p; pa.spill_cap = sslots; pa.spill_n = t->d_counters + kNumCounters; pa.counters = t->d_counters;
+    pa.spill = (du64 *)t->d_spill.p; pa.spill_cap = npairs; pa.spill_n = t->d_counters + kNumCounters; pa.counters = t->d_counters;
     {
         ProfScope ps(t, "aggregate_pairs_kernel");
-        hipLaunchKernelGGL(kct::aggregate_pairs_kernel, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, pa);
+        hipLaunchKernelGGL(kct::aggregate_pairs_kernel, dim3((unsigned)L.B), dim3(kct::kPartThreads), 0, t->stream, pa);
     }
     HIP_TRY(hipGetLastError());
     t->lazy_empty = false;
     // the (normally few) pairs that did not fit ring or region: the direct insert; the list length is read on the device
-    launch_merge_pairs(t, (const du64 *)t->d_pairs_ovf.p, (const du64 *)t->d_pairs_ovf.p + 1, sslots, (const du64 *)d_ovf_n, 2, view(t, sslots));
+    launch_merge_pairs(t, (const du64 *)t->d_pairs_ovf.p, (const du64 *)t->d_pairs_ovf.p + 1, npairs, (const du64 *)d_ovf_n, 2, view(t, npairs));
     HIP_TRY(hipGetLastError());
     u64 c[4], spilled;
     KCT_TRY(read_counters(t, c, &spilled));
@@ -211,10 +291,13 @@ kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const
 
 kct_status flush_partitioned(kct_table *t, bool compact) { return partitioned_pairs_pass(t, compact ? 0 : 1, nullptr, nullptr, 0, 0, nullptr); }
 
-// merge_pairs' fast route: tables of 16..1024 blocks, enough pairs to be worth two kernels
+// The partitioned pair route reads and writes the whole table once: worth it for a table of up to 1024 blocks (128 MiB)
+// from 2^18 pairs on, for a larger one once the pairs are a sixteenth of its slots (a random table access costs ~0.1 ns,
+// streaming a slot ~7 ps).
 bool pairs_partition_pays(const kct_table *t, u64 n) {
     const u64 blocks = t->cap >> t->block_bits;
-    return blocks >= 16 && blocks <= 1024 && t->block_bits == kct::kBlockBitsMax && n >= (1ULL << 18) && !getenv("KCT_FLUSH_ATOMIC");
+    if (!partition_geometry_ok(t) || t->block_bits != kct::kBlockBitsMax || getenv("KCT_FLUSH_ATOMIC")) return false;
+    return blocks <= 1024 ? n >= (1ULL << 18) : n >= t->cap / 16;
 }
 
 kct_status merge_pairs_partitioned(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n, int stride, u64 tallies[4]) {
@@ -225,17 +308,16 @@ kct_status flush_compact(kct_table *t) {
     if (!t->s32_dirty) return KCT_OK;
     t->s32_dirty = false;
     t->s32_windows = 0;
-    {
-        const u64 blocks = t->cap >> t->block_bits;
-        if (blocks >= 16 && blocks <= 1024 && t->block_bits == kct::kBlockBitsMax && !getenv("KCT_FLUSH_ATOMIC")) return flush_partitioned(t, true);
-    }
+    const u64 blocks = t->cap >> t->block_bits;
+    if (pairs_partition_pays(t, std::max<u64>(t->s32_keys, blocks <= 1024 ? (1ULL << 18) : 0))) return flush_partitioned(t, true);
+    const u64 slots = compact_slots(t);
     KCT_TRY(materialize(t));
-    KCT_TRY(t->d_spill.reserve(kCompactSlots * 16));
+    KCT_TRY(t->d_spill.reserve(std::max<u64>(t->s32_keys, 1) * 16));
     KCT_TRY(zero_counters(t));
     {
         ProfScope ps(t, "shadow32_flush_kernel");
-        hipLaunchKernelGGL(kct::shadow32_flush_kernel, dim3(merge_grid(kCompactSlots)), dim3(kct::kBlock), 0, t->stream, t->shadow32,
-                           (int)kct::kBlockBitsMax, kCompactSlots, view(t, kCompactSlots), (int)t->k, t->d_counters);
+        hipLaunchKernelGGL(kct::shadow32_flush_kernel, dim3(merge_grid(slots)), dim3(kct::kBlock), 0, t->stream, t->shadow32,
+                           (int)kct::kBlockBitsMax, slots, view(t, std::max<u64>(t->s32_keys, 1)), (int)t->k, t->d_counters, t->s32_sbits);
     }
     HIP_TRY(hipGetLastError());
     u64 c[4], spilled;
@@ -256,17 +338,17 @@ kct_status flush_shadow(kct_table *t) {
     t->shadow_dirty = false;
     {
         const u64 blocks = t->cap >> t->block_bits, sblocks = t->shadow_cap >> kct::kBlockBitsMax;
-        if (blocks >= 16 && blocks <= 1024 && t->block_bits == kct::kBlockBitsMax && t->shadow_block_bits == kct::kBlockBitsMax && sblocks >= 1 &&
-            !getenv("KCT_FLUSH_ATOMIC"))
+        if (t->shadow_block_bits == kct::kBlockBitsMax && sblocks >= 1 &&
+            pairs_partition_pays(t, std::max<u64>(t->shadow_keys, blocks <= 1024 ? (1ULL << 18) : 0)))
             return flush_partitioned(t, false);
     }
     KCT_TRY(materialize(t));
-    KCT_TRY(t->d_spill.reserve(t->shadow_cap * 16));
+    KCT_TRY(t->d_spill.reserve(std::max<u64>(t->shadow_keys, 1) * 16));
     KCT_TRY(zero_counters(t));
     {
         ProfScope ps(t, "shadow_flush_kernel");
         hipLaunchKernelGGL(kct::shadow_flush_kernel, dim3(merge_grid(t->shadow_cap)), dim3(kct::kBlock), 0, t->stream, t->shadow, shadow_geom(t),
-                           view(t, t->shadow_cap), (int)t->k, t->d_counters);
+                           view(t, std::max<u64>(t->shadow_keys, 1)), (int)t->k, t->d_counters);
     }
     HIP_TRY(hipGetLastError());
     u64 c[4], spilled;
@@ -281,47 +363,80 @@ kct_status flush_shadow(kct_table *t) {
     return KCT_OK;
 }
 
-// Compact dedupe-first pass (k <= 21, one level): K1 MODE 2 writes 32-bit entries, aggregate_blocks32_kernel counts them
-// into the compact shadow (u32 keys, u32 counts).  Half the partition traffic of the 64-bit variant and half as many
-// ring flushes.  Same contract as consume_partitioned(raw = true).
-bool compact_pays(const kct_table *t, u64 npos) {
-    if (t->k > 21 || t->compact_off || !dedupe_pays(t, npos)) return false;
-    const u64 known = std::max(t->n_keys, t->s32_keys);
-    return known <= (u64)(kCompactSlots * 0.6);
+// What a dedupe-first pass found, for the caller's decisions.
+struct DedupeOutcome {
+    u64 new_keys = 0;   // k-mers the pass met for the first time (new shadow keys + what went past the shadow)
+    u64 blocked = 0;    // entries that found their shadow block full
+};
+
+// After a dedupe-first pass: too few repeats to be worth it, or the shadow is filling up?  `probe`: the pass was the
+// bounded sample of a large call (consume_stream decides from its new-key ratio instead).
+kct_status after_dedupe_pass(kct_table *t, bool compact, u64 npos, const DedupeOutcome &o, bool probe) {
+    if (!probe && t->force_path != 3 && o.new_keys * 3 > npos) {  // too few repeats for any dedupe-first variant
+        KCT_TRY(flush_shadow(t));
+        t->dedupe_off = true;
+        t->dedupe_hint = false;
+        return KCT_OK;
+    }
+    if (!probe) t->dedupe_hint = true;
+    if (compact) {
+        if (o.blocked * 50 > npos || (double)t->s32_keys > kMaxLoad * (double)compact_slots(t)) {  // outgrown
+            KCT_TRY(flush_compact(t));
+            // The k-mers live in the table too: normally it is as full as the shadow and grows before the next pass
+            // (maybe_grow), and a table of another geometry gets a new shadow (ensure_shadow32).  If it stays as it is,
+            // the table-sized 64-bit shadow takes over.
+            if ((double)t->n_keys <= kMaxLoad * (double)t->cap) t->compact_off = true;
+        }
+    } else if (o.blocked * 50 > npos && t->force_path != 3) {
+        KCT_TRY(flush_shadow(t));
+        t->dedupe_off = true;
+        t->dedupe_hint = false;
+    }
+    return KCT_OK;
 }
 
-kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled) {
+// Compact dedupe-first pass (k <= 21): K1 MODE 2 writes 32-bit entries, aggregate_blocks32_kernel counts them
+// into the compact shadow (u32 keys, u32 counts).  Half the partition traffic of the 64-bit variant and half as many
+// ring flushes.  With a shadow of more than 1024 blocks a second partition level (repartition_kernel<u32>) sits between.
+// Same contract as consume_partitioned(raw = true).
+bool compact_pays(const kct_table *t, u64 npos) {
+    if (t->k > 21 || t->compact_off || !dedupe_pays(t, npos)) return false;
+    if (compact_sbits_for(t) > kCompactBlockBits) return true;  // a shadow as large as the table
+    const u64 known = std::max(t->n_keys, t->s32_keys);
+    return known <= (u64)((double)(1ULL << (kCompactBlockBits + kct::kBlockBitsMax)) * 0.6);
+}
+
+kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled, bool probe) {
     *handled = false;
     const int k = t->k;
-    const int pbits = kCompactBlockBits;
-    const u64 P = 1ULL << pbits;
+    {
+        bool ok = true;
+        KCT_TRY(ensure_shadow32(t, &ok));
+        if (!ok) { t->compact_off = true; return KCT_OK; }
+    }
+    const int sbits = t->s32_sbits;
+    const bool two_level = sbits > kCompactBlockBits;
+    const int pbits = kCompactBlockBits, sub_bits = sbits - pbits;  // K1's bins are always the value's top 10 bits
+    const u64 P = 1ULL << pbits, B = 1ULL << sbits;
     const int nwg = t->num_cus;
     const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
     const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
     const unsigned int region_cap = (region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P) + 15u) & ~15u;  // 16-entry lines
-    const unsigned int ovf_cap = (unsigned int)std::max<u64>(4096, tiles_per_wg * kct::kPartTile / 8);
-    if (t->s32_windows + npos >= (1ULL << 31)) KCT_TRY(flush_compact(t));  // u32 counts: no k-mer can have been seen 2^32 times
-    if (!t->shadow32) {
-        if (hipMalloc((void **)&t->shadow32, kCompactSlots * 8) != hipSuccess) {  // no room: this table does without
-            (void)hipGetLastError();
-            t->shadow32 = nullptr;
-            t->compact_off = true;
-            return KCT_OK;
-        }
-        t->s32_empty = true;
-        t->s32_keys = 0;
-    }
+    const unsigned int ovf_cap = overflow_capacity(tiles_per_wg * kct::kPartTile);
     KCT_TRY(materialize(t));
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 4));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
     KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
-    KCT_TRY(t->d_spill.reserve(2 * npos * 16));  // two lists: pairs that found their shadow block full, then the merges' own spills
+    // spill lists: pairs that found their shadow block full (at most one per window), then the merges' own spills -- in the
+    // same buffer when everything is one submission (one level), in a buffer sized after the fact otherwise
+    KCT_TRY(t->d_spill.reserve((two_level ? 1 : 2) * npos * 16));
     KCT_TRY(zero_counters(t));
     du64 *d_overflow = t->d_counters + kNumCounters + 6;
+    du64 *d_carry = t->d_counters + kNumCounters + 7;
     unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
 
     kct::PartitionArgs pa;
-    pa.mask = kCompactSlots - 1; pa.block_bits = kct::kBlockBitsMax; pa.pbits = pbits;
+    pa.mask = compact_slots(t) - 1; pa.block_bits = kct::kBlockBitsMax; pa.pbits = pbits;
     pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
     pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
     pa.ablate = t->ablate;
@@ -331,62 +446,99 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     }
     HIP_TRY(hipGetLastError());
     kct::Aggregate32Args aa;
-    aa.words = t->shadow32; aa.block_bits = kct::kBlockBitsMax;
+    aa.words = t->shadow32; aa.block_bits = kct::kBlockBitsMax; aa.sbits = sbits;
+    aa.carry_bits = 31;
+    if (const char *e = getenv("KCT_CARRY_BITS")) aa.carry_bits = std::max(2, std::min(31, atoi(e)));  // tests only
     aa.scratch = (const unsigned int *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
     aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
+    unsigned int ovf2_cap = 0, *d_ovf2_count = nullptr;
+    if (two_level) {
+        // second level: one workgroup per super-bin spreads its entries over the super-bin's 2^sub_bits shadow blocks
+        const unsigned int out_cap = (region_capacity((double)npos / (double)B) + 15u) & ~15u;
+        ovf2_cap = overflow_capacity(npos / P);
+        KCT_TRY(t->d_scratch2.reserve(B * out_cap * 4));
+        KCT_TRY(t->d_regions2.reserve(B * 4));
+        KCT_TRY(t->d_irr2.reserve(P * ovf2_cap * 8 + P * 4));
+        d_ovf2_count = (unsigned int *)((du64 *)t->d_irr2.p + P * ovf2_cap);
+        kct::RepartitionArgs ra;
+        ra.mask = compact_slots(t) - 1; ra.block_bits = kct::kBlockBitsMax; ra.sub_bits = sub_bits;
+        ra.in = t->d_scratch.p; ra.in_cap = region_cap; ra.in_count = (const unsigned int *)t->d_regions.p;
+        ra.nseg = nwg; ra.nbins = (int)P; ra.writers = 1;
+        ra.out = t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
+        ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow; ra.ovf_n = nullptr;
+        {
+            ProfScope ps(t, "repartition_kernel<compact>");
+            hipLaunchKernelGGL(kct::repartition_kernel<unsigned int>, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, ra);
+        }
+        HIP_TRY(hipGetLastError());
+        aa.scratch = (const unsigned int *)t->d_scratch2.p; aa.seg_stride = out_cap; aa.block_stride = out_cap;
+        aa.region_count = (const unsigned int *)t->d_regions2.p; aa.nregions = 1;
+    }
     aa.fresh = t->s32_empty ? 1 : 0; aa.overflow = d_overflow; aa.ablate = t->ablate;
-    aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
+    aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.carry_total = d_carry; aa.counters = t->d_counters;
     {
         ProfScope ps(t, "aggregate_blocks32_kernel");
-        hipLaunchKernelGGL(kct::aggregate_blocks32_kernel, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, aa);
+        hipLaunchKernelGGL(kct::aggregate_blocks32_kernel, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
     }
     HIP_TRY(hipGetLastError());
-    // What does not fit the shadow goes to the real table in the same submission (no host round trip in between): K1's
-    // overflow regions, and the pairs that found their shadow block full (normally none; their number is read on the
-    // device).  These inserts spill -- if the table lacks room -- into the SECOND half of the spill buffer.
+    // What does not fit the shadow goes to the real table: K1's (and the second level's) overflow regions, and the pairs
+    // that found their shadow block full (normally none).  One level: in the same submission (no host round trip in
+    // between; the pair count is read on the device), spilling -- if the table lacks room -- into the SECOND half of the
+    // spill buffer.  Two levels (passes of 10^8+ windows): after the counters have been read, into a list of the right size.
+    u64 c[4], blocked;
     kct::TableView mv = view(t, npos);
-    mv.spill = (du64 *)t->d_spill.p + 2 * npos;
+    if (two_level) {
+        KCT_TRY(read_counters(t, c, &blocked));
+        if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // K1 / K1b gave up: K2 exited early, nothing was touched
+        const u64 spill2_cap = blocked + (u64)nwg * ovf_cap + P * ovf2_cap;
+        KCT_TRY(t->d_pairs_ovf.reserve(spill2_cap * 16 + 64));
+        mv.spill = (du64 *)t->d_pairs_ovf.p;
+        mv.spill_cap = spill2_cap;
+    } else {
+        mv.spill = (du64 *)t->d_spill.p + 2 * npos;
+    }
     mv.spill_n = t->d_counters + kNumCounters + 5;
     {
         ProfScope ps(t, "merge_overflow_kernel");
         hipLaunchKernelGGL(kct::merge_overflow_kernel<2>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
                            (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, mv, t->d_counters, k);
+        if (two_level)
+            hipLaunchKernelGGL(kct::merge_overflow_kernel<2>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
+                               (const unsigned int *)d_ovf2_count, (int)P, ovf2_cap, (const du64 *)d_overflow, mv, t->d_counters, k);
         hipLaunchKernelGGL(kct::merge_mixed_pairs_kernel<2>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_spill.p,
                            (const du64 *)(t->d_counters + kNumCounters), (u64)npos, mv, (int)k, t->d_counters);
     }
     HIP_TRY(hipGetLastError());
-    u64 c[4], blocked;
-    KCT_TRY(read_counters(t, c, &blocked));
+    u64 c2[4], blocked2;
+    KCT_TRY(read_counters(t, c2, &blocked2));
+    if (!two_level) { for (int i = 0; i < 4; ++i) c[i] = c2[i]; blocked = blocked2; }
     if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // K1 gave up: every kernel after it exited early, nothing was touched
     *handled = true;
-    const u64 counted = c[kct::CTR_COUNTED], new_keys = c[kct::CTR_NEW_BY_ZERO], spilled2 = t->h_counters[kNumCounters + 5];
-    const u64 *c2 = c;  // the merges' tallies: CTR_TOTAL_ADDED / CTR_NEWKEYS
+    // (two levels: the second read holds the first submission's tallies too -- the counters were not zeroed in between)
+    const u64 counted = c2[kct::CTR_COUNTED], new_keys = c2[kct::CTR_NEW_BY_ZERO], spilled2 = t->h_counters[kNumCounters + 5];
+    const u64 carried = t->h_counters[kNumCounters + 7];  // u32-count carries: pairs that are not new windows
     t->s32_empty = false;
     t->s32_dirty = true;
     t->s32_keys += new_keys;
     t->s32_windows += npos;
     if (t->debug)
-        fprintf(stderr, "[kct] compact dedupe pass: npos=%llu region_cap=%u counted=%llu new keys=%llu (total %llu) blocked=%llu merged=%llu spilled=%llu\n",
-                (unsigned long long)npos, region_cap, (unsigned long long)counted, (unsigned long long)new_keys, (unsigned long long)t->s32_keys,
-                (unsigned long long)blocked, (unsigned long long)c2[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled2);
-    *n_out += counted + c2[kct::CTR_TOTAL_ADDED];  // (see consume_partitioned about n and a MurmurHash3 value of 0)
+        fprintf(stderr, "[kct] compact dedupe pass%s: npos=%llu blocks=%llu region_cap=%u counted=%llu new keys=%llu (total %llu) blocked=%llu merged=%llu spilled=%llu carried=%llu\n",
+                probe ? " (probe)" : "", (unsigned long long)npos, (unsigned long long)B, region_cap, (unsigned long long)counted, (unsigned long long)new_keys,
+                (unsigned long long)t->s32_keys, (unsigned long long)blocked, (unsigned long long)c2[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled2,
+                (unsigned long long)carried);
+    *n_out += counted + c2[kct::CTR_TOTAL_ADDED] - carried;  // (see consume_partitioned about n and a MurmurHash3 value of 0)
     t->n_keys += c2[kct::CTR_NEWKEYS];
     if (spilled2) {
         KCT_TRY(t->d_aux2.reserve(spilled2 * 16));
-        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, (du64 *)t->d_spill.p + 2 * npos, spilled2 * 16, hipMemcpyDeviceToDevice, t->stream));
-        KCT_TRY(replay_spill(t, spilled2, n_out));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, mv.spill, spilled2 * 16, hipMemcpyDeviceToDevice, t->stream));
+        u64 replayed = 0;
+        KCT_TRY(replay_spill(t, spilled2, &replayed));
+        *n_out += replayed;  // (a carry pair that spills again is rare enough to ignore in n: it needs a count past 2^31 AND a full table)
     }
-    if (new_keys * 3 > npos) {  // too few repeats for any dedupe-first variant
-        KCT_TRY(flush_compact(t));
-        if (t->force_path != 3) { t->dedupe_off = true; t->dedupe_hint = false; }
-    } else {
-        t->dedupe_hint = true;
-        if (blocked * 50 > npos || t->s32_keys > (u64)(kCompactSlots * 0.65)) {  // outgrown: the table-sized 64-bit shadow takes over
-            KCT_TRY(flush_compact(t));
-            t->compact_off = true;
-        }
-    }
-    return KCT_OK;
+    DedupeOutcome o;
+    o.new_keys = new_keys + c2[kct::CTR_NEWKEYS];
+    o.blocked = blocked;
+    return after_dedupe_pass(t, true, npos, o, probe);
 }
 
 // One pass of the partitioned path over window starts [0, npos) of d_stream.  *handled = false
@@ -395,7 +547,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
 // raw = true (dedupe-first, k <= 32): K1 emits mix64(packed k-mer) values, K2 counts them into the shadow table
 //        (same geometry); what does not fit (overflow regions, pairs that found their block full) is hashed and goes
 //        to the real table at once.
-kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled, bool raw) {
+kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled, bool raw, bool probe = false) {
     *handled = false;
     const int k = t->k;
     if (raw) {
@@ -405,22 +557,15 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         KCT_TRY(materialize(t));  // what does not fit the shadow goes straight to the real table
     }
     du64 *words = raw ? t->shadow : t->slots;
-    const int bbits = log2_u64(t->cap >> t->block_bits);      // log2(table blocks)
-    const bool two_level = bbits > 10;
-    // K1 fans out to 2^pbits bins, each holding 2^sub_bits table blocks that K1b separates.  K1b wants >= 64 bins per
-    // super-bin: with 16 its lanes fight over a handful of LDS cursors (2.5x slower per k-mer), so small tables give K1
-    // FEWER bins, and W workgroups share a super-bin so that K1b still fills the chip.
-    int pbits = bbits;
-    if (two_level) pbits = bbits <= 14 ? bbits - 6 : std::min(10, bbits - 7);
-    if (const char *e = getenv("KCT_PBITS")) if (two_level) pbits = std::max(bbits - 10, std::min(10, atoi(e)));  // measurement only
-    const int sub_bits = bbits - pbits;                       // ... each holding 2^sub_bits table blocks
-    const u64 P = 1ULL << pbits, B = 1ULL << bbits;
     const int nwg = t->num_cus;
-    const u64 W = two_level ? std::max<u64>(1, (u64)nwg / P) : 1;  // K1b workgroups per super-bin
+    const Levels L = levels_for(log2_u64(t->cap >> t->block_bits), nwg);
+    const bool two_level = L.two;
+    const int bbits = L.bbits, pbits = L.pbits, sub_bits = L.sub_bits;
+    const u64 P = L.P, B = L.B, W = L.W;
     const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
     const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
     const unsigned int region_cap = region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P);
-    const unsigned int ovf_cap = (unsigned int)std::max<u64>(4096, tiles_per_wg * kct::kPartTile / 8);
+    const unsigned int ovf_cap = overflow_capacity(tiles_per_wg * kct::kPartTile);
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 8));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
     KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
@@ -453,20 +598,20 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     } else {
         // second level: one workgroup per super-bin spreads its hashes over the super-bin's blocks
         const unsigned int out_cap = region_capacity((double)npos / (double)B / (double)W);
-        ovf2_cap = (unsigned int)std::max<u64>(4096, npos / P / W / 8);
+        ovf2_cap = overflow_capacity(npos / P / W);
         KCT_TRY(t->d_scratch2.reserve(B * W * out_cap * 8));
         KCT_TRY(t->d_regions2.reserve(B * W * 4));
         KCT_TRY(t->d_irr2.reserve(P * W * ovf2_cap * 8 + P * W * 4));
         d_ovf2_count = (unsigned int *)((du64 *)t->d_irr2.p + P * W * ovf2_cap);
         kct::RepartitionArgs ra;
         ra.mask = t->cap - 1; ra.block_bits = t->block_bits; ra.sub_bits = sub_bits;
-        ra.in = (const du64 *)t->d_scratch.p; ra.in_cap = region_cap; ra.in_count = (const unsigned int *)t->d_regions.p;
+        ra.in = t->d_scratch.p; ra.in_cap = region_cap; ra.in_count = (const unsigned int *)t->d_regions.p;
         ra.nseg = nwg; ra.nbins = (int)P; ra.writers = (int)W;
-        ra.out = (du64 *)t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
-        ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow;
+        ra.out = t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
+        ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow; ra.ovf_n = nullptr;
         {
             ProfScope ps(t, "repartition_kernel");
-            hipLaunchKernelGGL(kct::repartition_kernel, dim3((unsigned)(P * W)), dim3(kct::kPartThreads), 0, t->stream, ra);
+            hipLaunchKernelGGL(kct::repartition_kernel<du64>, dim3((unsigned)(P * W)), dim3(kct::kPartThreads), 0, t->stream, ra);
         }
         HIP_TRY(hipGetLastError());
         aa.scratch = (const du64 *)t->d_scratch2.p; aa.seg_stride = out_cap; aa.block_stride = W * out_cap;
@@ -499,8 +644,8 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         (void)hipMemcpy(oc.data(), d_ovf_count, nwg * 4, hipMemcpyDeviceToHost);
         u64 tot = 0;
         for (auto v : oc) tot += v;
-        fprintf(stderr, "[kct] partitioned pass%s: npos=%llu blocks=%llu levels=%d region_cap=%u overflow(K1)=%llu counted=%llu merged=%llu new=%llu spilled=%llu abandon=%llu\n",
-                raw ? " (shadow)" : "", (unsigned long long)npos, (unsigned long long)B, two_level ? 2 : 1, region_cap, (unsigned long long)tot,
+        fprintf(stderr, "[kct] partitioned pass%s%s: npos=%llu blocks=%llu levels=%d region_cap=%u overflow(K1)=%llu counted=%llu merged=%llu new=%llu spilled=%llu abandon=%llu\n",
+                raw ? " (shadow)" : "", probe ? " (probe)" : "", (unsigned long long)npos, (unsigned long long)B, two_level ? 2 : 1, region_cap, (unsigned long long)tot,
                 (unsigned long long)c[kct::CTR_COUNTED], (unsigned long long)c[kct::CTR_TOTAL_ADDED], (unsigned long long)c[kct::CTR_NEWKEYS],
                 (unsigned long long)spilled, (unsigned long long)t->h_counters[kNumCounters + 6]);
     }
@@ -546,18 +691,28 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled2 * 16, hipMemcpyDeviceToDevice, t->stream));
         KCT_TRY(replay_spill(t, spilled2, n_out));
     }
-    // Too few repeats to be worth it, or the shadow is filling up: convert what is pending and go back to hashing every window.
-    if (t->force_path != 3 && (new_shadow * 3 > npos || blocked * 50 > npos)) {
-        KCT_TRY(flush_shadow(t));
-        t->dedupe_off = true;
-        t->dedupe_hint = false;
-    } else t->dedupe_hint = true;
+    DedupeOutcome o;
+    o.new_keys = new_shadow + c2[kct::CTR_NEWKEYS];
+    o.blocked = blocked;
+    KCT_TRY(after_dedupe_pass(t, false, npos, o, probe));
     // the shadow holds as many keys as the table would: grow both (the table's growth re-creates the shadow, flushed)
-    if ((double)t->shadow_keys > kMaxLoad * (double)t->shadow_cap) {
+    if (t->shadow && (double)t->shadow_keys > kMaxLoad * (double)t->shadow_cap) {
         KCT_TRY(flush_shadow(t));
         KCT_TRY(grow_to(t, t->cap * 2));
     }
     return KCT_OK;
+}
+
+// From the share r of a uniform sample's n draws that were first sightings: x = n / D solves r = (1 - e^-x) / x.
+double draws_per_distinct(double r) {
+    if (r >= 0.9995) return 0.0;   // (nearly) every draw new: D is beyond what the sample can see
+    if (r <= 0.0) return 1e9;
+    double lo = 1e-6, hi = 1e6;    // (1 - e^-x) / x falls monotonically from 1 to 0
+    for (int i = 0; i < 80; ++i) {
+        const double mid = __builtin_sqrt(lo * hi);
+        if ((1.0 - __builtin_exp(-mid)) / mid > r) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 
 // Counts every good window of a device-resident record stream.  *n_out = k-mers counted.
@@ -570,17 +725,37 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
     const u64 cap_at_entry = t->cap;
     // Launch chunk.  The partitioned path on a large table re-reads and re-writes every table block
     // once per pass, so it wants passes of several windows per slot; its scratch + spill lists cost
-    // ~36 B per window start, which bounds the pass by HBM (this is what 288 GB is for).  Decided
+    // ~26-36 B per window start, which bounds the pass by HBM (this is what 288 GB is for).  Decided
     // once per call: buffers this table already holds are reused, so they count as available.
     u64 chunk_limit = kChunkPositions;
     if (t->force_path != 1 && partition_geometry_ok(t) && (t->cap >> t->block_bits) > 1024) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const u64 held = t->d_scratch.cap + t->d_scratch2.cap + t->d_spill.cap + t->d_irr.cap + t->d_irr2.cap;
-            const u64 by_mem = ((u64)free_b + held) / 2 / 36;
-            chunk_limit = std::max<u64>(kChunkPositions, std::min<u64>(4 * t->cap, by_mem));
+            double avail = (double)free_b + (double)held;
+            // a shadow table this call may still have to allocate; per window: two levels of 4- or 8-byte entries with
+            // 20 % of slack, and a 16-byte spill-list slot
+            const bool may_dedupe = t->k <= 32 && !t->dedupe_off && t->force_path != 2, may_compact = may_dedupe && t->k <= 21 && !t->compact_off;
+            if (may_compact && !(t->shadow32 && t->s32_sbits == compact_sbits_for(t))) avail -= (double)(1ULL << (compact_sbits_for(t) + kct::kBlockBitsMax)) * 8.0;
+            else if (may_dedupe && !may_compact && !(t->shadow && t->shadow_cap == t->cap)) avail -= (double)t->cap * 16.0;
+            const double per_window = may_compact ? 26.0 : 36.0;
+            const u64 by_mem = avail > 0 ? (u64)(avail * 0.8 / per_window) : 0;
+            chunk_limit = std::max<u64>(kChunkPositions, std::min<u64>(8 * t->cap, by_mem));
             chunk_limit &= ~(u64)0xFFFF;  // keeps `d_stream + done` 16-byte aligned
         }
+    }
+    // A large call into a table that knows nothing about its input (no keys, no hint from earlier passes): is this deep
+    // coverage of few k-mers (dedupe-first pays) or mostly distinct ones?  The first 2^22..2^26 windows go through the
+    // dedupe-first path as a PROBE; the share of first sightings among them gives the number of distinct k-mers the
+    // input draws from (as if uniformly -- position-sorted input shows its repeats even sooner), hence the windows per
+    // distinct k-mer of the whole call.  Either way the probe's k-mers are counted; a wrong guess costs speed only.
+    const u64 call_windows = last_start + 1;
+    bool probe = t->force_path == 0 && t->k <= 32 && !t->dedupe_off && !t->dedupe_hint && !t->auto_sized &&
+                 std::max({t->n_keys, t->shadow_keys, t->s32_keys}) == 0 && call_windows >= 8 * probe_windows(t) &&
+                 partition_geometry_ok(t) && partition_pays(t, call_windows);
+    if (call_windows > chunk_limit) {  // passes of equal size
+        const u64 passes = (call_windows + chunk_limit - 1) / chunk_limit;
+        chunk_limit = std::min(chunk_limit, (((call_windows + passes - 1) / passes) + 0xFFFF) & ~(u64)0xFFFF);
     }
     while (done <= last_start) {
         KCT_TRY(maybe_grow(t));
@@ -589,11 +764,31 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         // per slot, so that what cannot be placed (and must be replayed after growing) stays small while
         // the table finds its size; launches grow with it.
         const u64 ramp = t->auto_sized ? std::max<u64>(1ULL << 20, 4 * t->cap) : ~0ULL;
-        const u64 npos = std::min<u64>({chunk_limit, ramp, last_start + 1 - done});
+        const u64 npos = std::min<u64>({probe ? probe_windows(t) : chunk_limit, ramp, last_start + 1 - done});
         const u64 chunk_bytes = std::min<u64>(nbytes - done, npos + k - 1);
+        t->call_windows_left = last_start + 1 - done;
+        if (probe) {
+            probe = false;
+            const u64 keys_before = std::max(t->shadow_keys, t->s32_keys), table_before = t->n_keys;
+            bool handled = false;
+            if (t->k <= 21 && !t->compact_off) KCT_TRY(consume_compact(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true));
+            if (!handled && !t->dedupe_off) KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true, true));
+            if (handled) {
+                done += npos; t->windows_since_read += npos;
+                const u64 fresh_keys = (std::max(t->shadow_keys, t->s32_keys) - keys_before) + (t->n_keys - table_before);
+                const double x = draws_per_distinct((double)fresh_keys / (double)npos);          // probe windows per distinct k-mer
+                const double per_key = x * (double)call_windows / (double)npos;                  // ... of the whole call
+                const bool pays = per_key >= (double)windows_per_pending_key(t);
+                if (t->debug) fprintf(stderr, "[kct] dedupe probe: %llu windows, %llu first sightings -> ~%.3g windows per distinct k-mer over the call: %s\n",
+                                      (unsigned long long)npos, (unsigned long long)fresh_keys, per_key, pays ? "dedupe-first" : "hash every window");
+                if (pays) t->dedupe_hint = true;
+                else { KCT_TRY(flush_shadow(t)); t->dedupe_off = true; }
+                continue;
+            }
+        }
         if (compact_pays(t, npos)) {
             bool handled = false;
-            KCT_TRY(consume_compact(t, d_stream + done, chunk_bytes, npos, n_out, &handled));
+            KCT_TRY(consume_compact(t, d_stream + done, chunk_bytes, npos, n_out, &handled, false));
             if (handled) { done += npos; t->windows_since_read += npos; continue; }
         }
         if (dedupe_pays(t, npos)) {
@@ -629,6 +824,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         done += npos;
         t->windows_since_read += npos;
     }
+    t->call_windows_left = 0;
     if (t->auto_sized && t->cap == cap_at_entry && nbytes >= (1u << 20)) t->auto_sized = false;  // the table has found its size
     return KCT_OK;
 }

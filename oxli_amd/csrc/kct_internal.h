@@ -120,11 +120,14 @@ struct kct_table {
     bool shadow_empty = true;   // no keys yet: K2 starts its blocks from zeros instead of loading them
     bool shadow_dirty = false;  // pending counts exist: anything that reads `slots` flushes first (use())
     u64 shadow_keys = 0;
-    // compact variant (k <= 21): 1024 blocks x 8192 slots of u32 key + u32 count (64 MiB), independent of the table's size
+    // compact variant (k <= 21): 2^s32_sbits blocks x 8192 slots of u32 key + u32 count -- 1024 blocks (64 MiB) beside a table
+    // of up to 1024 blocks, otherwise as many blocks as the table has (at least 2^16): two partition levels
     unsigned int *shadow32 = nullptr;
+    int s32_sbits = 10;
     bool s32_empty = true, s32_dirty = false, compact_off = false;
     u64 s32_keys = 0, s32_windows = 0;  // keys it holds; window starts counted into it since its last flush (u32 counts!)
     u64 windows_since_read = 0; // window starts consumed since anything last read the table (use()): how long the caller's runs are
+    u64 call_windows_left = 0;  // window starts the running consume call still has to count (no read can come before them)
     bool dedupe_hint = false;   // the last dedupe-first pass paid off: a cleared table starts with that path again
     u64 n_keys = 0;        // distinct non-zero hashes in `slots`
     u64 consumed = 0;      // lib.rs:36

@@ -45,9 +45,11 @@ namespace kct {
 // Returns (workgroup-uniformly) whether the list was too short for everything that was ready.
 // T = u64 (hashes / mix64 values, 8 per line) or u32 (the compact dedupe-first path: the bin number is the value's
 // upper half, 16 per line); a value handed to overflow_hash is always the full 64-bit one.
+// ovf_hi (u32 rings only): the upper half of a value handed to overflow_hash -- 0 = derive it from the bin (K1: the bin
+// IS the value's top 10 bits), otherwise a fixed word (K1b: the super-bin, the sub-bin bits are inside the entry).
 template <u32 LISTCAP, class T, class Overflow>
 __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *fcount, int P, u32 D,
-                                           T *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash, u64 bin_stride = 0) {
+                                           T *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash, u64 bin_stride = 0, u64 ovf_hi = 0) {
     constexpr u32 CH = 64 / sizeof(T);  // positions per 64-byte line
     const u32 dmask = D - 1;
     if (bin_stride == 0) bin_stride = out_cap;  // distance between the regions of consecutive bins
@@ -85,7 +87,7 @@ __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *f
             const u64 h = ((u64)v.y << 32) | v.x, c = ((u64)v.w << 32) | v.z;
             if (h) overflow_hash(h, c);
         } else {
-            const u64 hi = ((u64)b << 32) | (1ULL << 63);  // compact values travel with bit 63 set (0 stays "nothing")
+            const u64 hi = ovf_hi ? ovf_hi : (((u64)b << 32) | (1ULL << 63));  // compact values travel with bit 63 set (0 stays "nothing")
             if (v.x) overflow_hash(hi | v.x);
             if (v.y) overflow_hash(hi | v.y);
             if (v.z) overflow_hash(hi | v.z);
@@ -250,53 +252,70 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
 // workgroup writes a given block's region, so K2 then reads a single region per block.
 struct RepartitionArgs {
     u64 mask;            // table capacity - 1
-    int block_bits;      // log2(slots per block)
-    int sub_bits;        // log2(blocks per super-bin); ring depth D = kRingEntries >> sub_bits >= 16
-    const u64 *in;       // K1's regions: region (seg, s) at in + (seg * nbins + s) * in_cap
+    int block_bits;      // log2(slots per block) (u64 / pair entries: the sub-bin is hash bits block_bits ...)
+    int sub_bits;        // log2(blocks per super-bin); ring depth D = ring entries >> sub_bits >= 16
+    const void *in;      // K1's regions: region (seg, s) at in + (seg * nbins + s) * in_cap entries
     u32 in_cap;
     const u32 *in_count; // [nbins][nseg]
     int nseg, nbins;
     int writers;         // workgroups per super-bin (W): each takes every W-th group of 16 input regions, so that
                          // W x nbins workgroups fill the chip even when there are few super-bins
-    u64 *out;            // region of (block b, writer w) at out + (b * W + w) * out_cap
-    u32 out_cap;         // multiple of kChunk
+    void *out;           // region of (block b, writer w) at out + (b * W + w) * out_cap entries
+    u32 out_cap;         // multiple of a 64-byte line of entries
     u32 *out_count;      // [blocks][W]
-    u64 *ovf; u32 ovf_cap; u32 *ovf_count;  // per workgroup overflow regions
+    u64 *ovf; u32 ovf_cap; u32 *ovf_count;  // per workgroup overflow regions (u64 values; pairs: two words each)
     u64 *overflow;       // abandon flag (shared with K1)
+    u64 *ovf_n;          // pairs only: ONE shared overflow list instead of per-workgroup regions (ovf_cap = its capacity)
 };
 
+// T = u64 (MurmurHash3 / mix64 values; sub-bin = value bits block_bits...), u32 (compact dedupe-first entries: the low 32
+// bits of a mix42 value whose top 10 bits chose the super-bin; sub-bin = the entry's top sub_bits bits) or ulonglong2
+// ({hash, count} pairs of a shadow flush / pair merge; sub-bin from the hash).
+// The NEXT slab's loads are issued before the current slab is appended (two register buffers): the flush barriers keep
+// the sixteen waves in step, so without the prefetch every HBM round trip was fully exposed.
+template <class T>
 __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionArgs a) {
-    __shared__ __attribute__((aligned(16))) u64 ring[kRingEntries];
+    constexpr bool kPair = sizeof(T) == 16, kCompact = sizeof(T) == 4;
+    constexpr int kEntries = kRingEntries * 8 / sizeof(T);  // 128 KiB of ring
+    constexpr int kLoads = 64 / sizeof(T);                   // 64 bytes per lane per slab
+    constexpr int kFlushEvery = kLoads / 2;                  // appends per thread between flushes: a quarter of the ring
+    constexpr u32 kSlab = 64 * kLoads;
+    __shared__ __attribute__((aligned(16))) T ring[kEntries];
     __shared__ u64 cur[1024];  // per bin: fill (low half) | flushed (high half)
     __shared__ u32 flist[2048];
     __shared__ u32 fcount, ovf_n, rounds;
     const int W = a.writers, s = blockIdx.x / W, w = blockIdx.x % W, P2 = 1 << a.sub_bits;
-    const u32 D = (u32)(kRingEntries >> a.sub_bits), dmask = D - 1;
-    const int dshift = 14 - a.sub_bits;  // log2 D
+    const u32 D = (u32)(kEntries >> a.sub_bits), dmask = D - 1;
+    const int dshift = __builtin_ctz((unsigned)kEntries) - a.sub_bits;  // log2 D
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < kRingEntries; i += kPartThreads) ring[i] = 0;
+    T zero;
+    memset(&zero, 0, sizeof zero);
+    for (int i = threadIdx.x; i < kEntries; i += kPartThreads) ring[i] = zero;
     for (int i = threadIdx.x; i < 1024; i += kPartThreads) cur[i] = 0;
     if (threadIdx.x == 0) { fcount = 0; ovf_n = 0; rounds = 0; }
-    if (threadIdx.x == 0 && *a.overflow) rounds = ~0u;  // K1 (or another super-bin) gave up on this pass
+    if (threadIdx.x == 0 && a.overflow && *a.overflow) rounds = ~0u;  // K1 (or another super-bin) gave up on this pass
     __syncthreads();
     if (rounds == ~0u) return;  // read through LDS so that the whole workgroup takes the same branch
     __syncthreads();
-    u64 *my_out = a.out + (((u64)s << a.sub_bits) * W + w) * a.out_cap;
+    T *my_out = reinterpret_cast<T *>(a.out) + (((u64)s << a.sub_bits) * W + w) * a.out_cap;
     const u64 bin_stride = (u64)W * a.out_cap;
     u64 *my_ovf = a.ovf + (u64)blockIdx.x * a.ovf_cap;
-    auto overflow_hash = [&](u64 h) {
+    const u64 ovf_hi = kCompact ? (((u64)s << 32) | (1ULL << 63)) : 0ULL;
+    auto overflow_one = [&](u64 h) {
         const u32 i = atomicAdd(&ovf_n, 1u);
         if (i < a.ovf_cap) my_ovf[i] = h;
         else *a.overflow = 1ULL;
     };
-    auto flush_lines = [&](bool drain) {
-        return ring_flush<2048u, u64>(ring, cur, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_hash, bin_stride);
+    auto overflow_pair = [&](u64 h, u64 c) {
+        const u64 i = atomicAdd(a.ovf_n, 1ULL);
+        if (i < a.ovf_cap) { a.ovf[2 * i] = h; a.ovf[2 * i + 1] = c; }  // (cap = every pair: cannot be exceeded)
     };
-    // A wave owns the input regions seg = 16 w + wave, + 16 W, ...; work unit = a slab of 8 x 64 entries whose
-    // loads are all issued before the first append.  Every wave runs the same number of rounds so that
-    // the flush barriers line up.
-    constexpr int kLoads = 8;
-    constexpr u32 kSlab = 64 * kLoads;
+    auto flush_lines = [&](bool drain) {
+        if constexpr (kPair) return ring_flush<2048u, T>(ring, cur, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_pair, bin_stride);
+        else return ring_flush<2048u, T>(ring, cur, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_one, bin_stride, ovf_hi);
+    };
+    // A wave owns the input regions seg = 16 w + wave, + 16 W, ...; work unit = a slab of 64 lanes x 64 bytes.  Every wave
+    // runs the same number of rounds so that the flush barriers line up.
     const u32 *counts = a.in_count + (u64)s * a.nseg;
     u32 my_slabs = 0;
     const int seg0 = w * (kPartThreads / 64) + wave, seg_step = W * (kPartThreads / 64);
@@ -306,39 +325,56 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     const u32 nrounds = rounds;
     int seg = seg0;
     u32 off = 0;
-    for (u32 r = 0; r < nrounds; ++r) {
-        u64 v[kLoads];
+    auto is_set = [](const T &v) -> bool {
+        if constexpr (kPair) return v.x != 0;
+        else return v != 0;
+    };
+    auto load_slab = [&](T (&v)[kLoads]) {
 #pragma unroll
-        for (int j = 0; j < kLoads; ++j) v[j] = 0;
+        for (int j = 0; j < kLoads; ++j) v[j] = zero;
         while (seg < a.nseg && off >= counts[seg]) { seg += seg_step; off = 0; }  // next non-empty region
         if (seg < a.nseg) {
             const u32 cnt = counts[seg];
-            const u64 *src = a.in + ((u64)seg * a.nbins + s) * a.in_cap + off;
+            const T *src = reinterpret_cast<const T *>(a.in) + ((u64)seg * a.nbins + s) * a.in_cap + off;
             const u32 left = cnt - off;
 #pragma unroll
-            for (int j = 0; j < kLoads; ++j) { const u32 i = lane + 64 * j; v[j] = i < left ? src[i] : 0ULL; }
+            for (int j = 0; j < kLoads; ++j) { const u32 i = lane + 64 * j; if (i < left) v[j] = src[i]; }
             off += kSlab;
         }
+    };
+    T va[kLoads], vb[kLoads];
+    if (nrounds) load_slab(va);
+    for (u32 r = 0; r < nrounds; ++r) {
+        if (r + 1 < nrounds) load_slab(vb);
 #pragma unroll
         for (int j = 0; j < kLoads; ++j) {
-            const u64 h = v[j];
-            if (h) {
-                const u32 b = (u32)(h >> a.block_bits) & (u32)(P2 - 1);
+            const T e = va[j];
+            if (is_set(e)) {
+                u32 b;
+                if constexpr (kPair) b = (u32)(e.x >> a.block_bits) & (u32)(P2 - 1);
+                else if constexpr (kCompact) b = e >> (32 - a.sub_bits);
+                else b = (u32)(e >> a.block_bits) & (u32)(P2 - 1);
                 const u64 cw = atomicAdd(&cur[b], 1ULL);
                 const u32 pos = (u32)cw;
-                if (pos - (u32)(cw >> 32) < D) ring[(b << dshift) + (pos & dmask)] = h;
-                else overflow_hash(h);
+                if (pos - (u32)(cw >> 32) < D) ring[(b << dshift) + (pos & dmask)] = e;
+                else if constexpr (kPair) overflow_pair(e.x, e.y);
+                else if constexpr (kCompact) overflow_one(ovf_hi | e);
+                else overflow_one(e);
             }
-            if ((j & 3) == 3) flush_lines(false);
+            if ((j % kFlushEvery) == kFlushEvery - 1) flush_lines(false);
         }
+#pragma unroll
+        for (int j = 0; j < kLoads; ++j) va[j] = vb[j];
     }
     while (flush_lines(true)) {}
     for (int b = threadIdx.x; b < P2; b += kPartThreads) {
         const u32 f = (u32)(cur[b] >> 32);
         a.out_count[(((u64)s << a.sub_bits) + b) * W + w] = f < a.out_cap ? f : a.out_cap;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) a.ovf_count[blockIdx.x] = ovf_n < a.ovf_cap ? ovf_n : a.ovf_cap;
+    if constexpr (!kPair) {
+        __syncthreads();
+        if (threadIdx.x == 0) a.ovf_count[blockIdx.x] = ovf_n < a.ovf_cap ? ovf_n : a.ovf_cap;
+    }
 }
 
 struct AggregateArgs {
@@ -483,13 +519,45 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
             const u64 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
             for (u32 s0 = 0; s0 < cnt; s0 += kSlab) do_slab(region + s0, cnt - s0);
         }
-    } else {  // two levels: one long region per block, its slabs dealt round-robin to the waves
-        u32 slab_id = 0;
-        for (int seg = 0; seg < a.nregions; ++seg) {
-            const u32 cnt = my_counts[seg];
-            const u64 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
-            for (u32 s0 = 0; s0 < cnt; s0 += kSlab, ++slab_id)
-                if ((slab_id & (kWaves - 1)) == (u32)wave) do_slab(region + s0, cnt - s0);
+    } else {  // two levels: a few long regions per block, their slabs dealt round-robin to the waves
+        // The wave's NEXT slab is loaded before the current one is counted: with one long stream per block the waves would
+        // otherwise all wait for HBM at the same moments.
+        int seg = 0;
+        u32 base = 0, g = (u32)wave, cnt = a.nregions > 0 ? my_counts[0] : 0u;  // base = global index of seg's first slab
+        auto load_slab = [&](u64 (&v)[kInFlight]) -> bool {
+#pragma unroll
+            for (int j = 0; j < kInFlight; ++j) v[j] = 0ULL;
+            while (seg < a.nregions) {
+                const u32 nsl = (cnt + kSlab - 1) / kSlab;
+                if (g < base + nsl) break;
+                base += nsl; ++seg;
+                cnt = seg < a.nregions ? my_counts[seg] : 0u;
+            }
+            if (seg >= a.nregions) return false;
+            const u32 s0 = (g - base) * kSlab, left = cnt - s0;
+            const u64 *src = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride + s0;
+#pragma unroll
+            for (int j = 0; j < kInFlight; ++j) { const u32 i = lane + 64 * j; if (i < left) v[j] = src[i]; }
+            g += kWaves;
+            return true;
+        };
+        auto count_slab = [&](const u64 (&v)[kInFlight]) {
+            if (a.ablate & 16) {
+#pragma unroll
+                for (int j = 0; j < kInFlight; ++j) counted += (u32)v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < kInFlight; ++j) fast(v[j]);
+            }
+        };
+        u64 va[kInFlight], vb[kInFlight];
+        bool more = load_slab(va);
+        while (more) {
+            more = load_slab(vb);
+            count_slab(va);
+            if (!more) break;
+            more = load_slab(va);
+            count_slab(vb);
         }
     }
     drain(0);
@@ -588,8 +656,13 @@ struct Aggregate32Args {
     int fresh;
     const u64 *overflow; // K1's abandon flag
     u64 *spill; u64 spill_cap; u64 *spill_n;  // {mix42 value | bit 63, 1} pairs of entries that found their block full
+    u64 *carry_total;    // counts are u32: what a count would lose by wrapping leaves as a {value, 2^31 or 2^32} pair on the
+                         // spill list (it goes to the real table's u64 count); their sum is kept here, because those pairs
+                         // are not new windows
     u64 *counters;
     int ablate;          // measurement only: bit 4 (16) = loads only
+    int sbits;           // log2(blocks of the shadow): a block index is the TOP sbits bits of the 42-bit value (>= 10)
+    int carry_bits;      // 31; tests lower it (KCT_CARRY_BITS) to drive the carry code with small counts
 };
 
 // (Two workgroups per CU -- 78 KiB of LDS and 60 VGPRs each, with a shorter queue -- were measured: 5 % slower.)
@@ -598,24 +671,49 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
     __shared__ __attribute__((aligned(16))) u32 tab[2 << kBlockBitsMax];  // S keys then S counts = 64 KiB
     __shared__ u32 wq[(kPartThreads / 64) * kWaveQueue32];
     __shared__ __attribute__((aligned(16))) unsigned char tags[1 << kBlockBitsMax];
-    __shared__ u64 s_counted, s_new;
+    __shared__ u64 s_counted, s_new, s_entries;
     if (*a.overflow) return;
     const int b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
     u32 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u32 *keys = tab, *cnts = tab + S;
-    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
+    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; s_entries = 0; }
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
     auto tag_of = [](u32 e) -> u32 { const u32 t = (e >> 13) & 0xFFu; return t ? t : 1u; };
+    // the 42-bit value of an entry of this block: its top 10 bits are the block index's top 10, the entry is its low 32
+    const u64 value_hi = ((u64)((u32)b >> (a.sbits - 10)) << 32) | (1ULL << 63);
+    const u32 carry_at = 1u << a.carry_bits;
+    auto carry_out = [&](u32 e, u64 amount) {
+        const u64 si = atomicAdd(a.spill_n, 1ULL);
+        if (si < a.spill_cap) { a.spill[2 * si] = value_hi | e; a.spill[2 * si + 1] = amount; }
+        atomicAdd(a.carry_total, amount);
+    };
     if (a.fresh) {
         for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
         for (u32 i = threadIdx.x; i < S / 16; i += kPartThreads) reinterpret_cast<uint4 *>(tags)[i] = make_uint4(0, 0, 0, 0);
     } else {
         for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
         __syncthreads();
-        for (u32 i = threadIdx.x; i < S; i += kPartThreads) { const u32 kk = keys[i]; tags[i] = (unsigned char)(kk ? tag_of(kk) : 0u); }
+        for (u32 i = threadIdx.x; i < S; i += kPartThreads) {
+            const u32 kk = keys[i];
+            tags[i] = (unsigned char)(kk ? tag_of(kk) : 0u);
+            // invariant of the u32 counts: below 2^31 when a pass starts (the upper half moves on to the real table)
+            if (cnts[i] >= carry_at) { cnts[i] -= carry_at; carry_out(kk, (u64)carry_at); }
+        }
+    }
+    // ... and a block that receives 2^31 entries or more in this pass (a k-mer repeated billions of times) watches every
+    // add for a wrap; all other blocks cannot overflow a count and use the plain add.
+    {
+        u64 mine = 0;
+        for (int r = threadIdx.x; r < a.nregions; r += kPartThreads) mine += a.region_count[(u64)b * a.nregions + r];
+        if (mine) atomicAdd(&s_entries, mine);
     }
     __syncthreads();
+    const bool careful = s_entries >= (u64)carry_at;
+    auto add_one = [&](u32 idx, u32 e) {
+        if (!careful) atomicAdd(&cnts[idx], 1u);
+        else if (atomicAdd(&cnts[idx], 1u) == 0xFFFFFFFFu) carry_out(e, 1ULL << 32);
+    };
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32 counted = 0, newkeys = 0;
     auto insert = [&](u32 e) {
@@ -633,7 +731,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
                     ks = atomicCAS(&keys[g + sel], 0u, e);
                     if (ks == 0) { ++newkeys; ks = e; tags[g + sel] = (unsigned char)tag_of(e); }
                 }
-                if (ks == e) { atomicAdd(&cnts[g + sel], 1u); placed = true; break; }
+                if (ks == e) { add_one(g + sel, e); placed = true; break; }
                 ++sel;
                 while (sel < kGroup) { const u32 kk = keys[g + sel]; if (kk == e || kk == 0) break; ++sel; }
             }
@@ -642,7 +740,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
         if (placed) ++counted;
         else {
             const u64 si = atomicAdd(a.spill_n, 1ULL);
-            if (si < a.spill_cap) { a.spill[2 * si] = ((u64)b << 32) | e | (1ULL << 63); a.spill[2 * si + 1] = 1; }
+            if (si < a.spill_cap) { a.spill[2 * si] = value_hi | e; a.spill[2 * si + 1] = 1; }
         }
     };
     u32 *myq = wq + wave * kWaveQueue32;
@@ -663,7 +761,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
             const u64 z = (x - 0x0101010101010101ULL) & ~x & 0x8080808080808080ULL;
             if (z) {
                 const u32 idx = (u32)__builtin_ctzll(z) >> 3;
-                if (keys[g + idx] == e) { atomicAdd(&cnts[g + idx], 1u); ++counted; miss = false; }
+                if (keys[g + idx] == e) { add_one(g + idx, e); ++counted; miss = false; }
             }
         }
         const u64 m = __ballot(miss);
@@ -678,10 +776,54 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
     constexpr u32 kSlab = 64 * kInFlight;
     const u32 *my_counts = a.region_count + (u64)b * a.nregions;
     constexpr int kWaves = kPartThreads / 64;
+    auto count_slab = [&](const uint4 (&v)[kInFlight / 4]) {
+        if (a.ablate & 16) {
+#pragma unroll
+            for (int j = 0; j < kInFlight / 4; ++j) counted += v[j].x + v[j].y + v[j].z + v[j].w;
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < kInFlight / 4; ++j) { fast(v[j].x); fast(v[j].y); fast(v[j].z); fast(v[j].w); }
+    };
+    if (a.nregions < kWaves) {
+        // Two levels (large shadow): a few long regions per block (one per K1b writer); their slabs of 768 entries are dealt
+        // round-robin to the waves, the next slab in flight while the current one is counted.
+        int seg = 0;
+        u32 base = 0, g = (u32)wave, cnt = a.nregions > 0 ? my_counts[0] : 0u;
+        auto load_slab = [&](uint4 (&v)[kInFlight / 4]) -> bool {
+#pragma unroll
+            for (int j = 0; j < kInFlight / 4; ++j) v[j] = make_uint4(0, 0, 0, 0);
+            while (seg < a.nregions) {
+                const u32 nsl = (cnt + kSlab - 1) / kSlab;
+                if (g < base + nsl) break;
+                base += nsl; ++seg;
+                cnt = seg < a.nregions ? my_counts[seg] : 0u;
+            }
+            if (seg >= a.nregions) return false;
+            const u32 s0 = (g - base) * kSlab;
+            const u32 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
+#pragma unroll
+            for (int j = 0; j < kInFlight / 4; ++j) {  // regions are zero-padded to 16 entries
+                const u32 i = s0 + 4 * (lane + 64 * j);
+                if (i < cnt) v[j] = *reinterpret_cast<const uint4 *>(region + i);
+            }
+            g += kWaves;
+            return true;
+        };
+        uint4 va[kInFlight / 4], vb[kInFlight / 4];
+        bool more = load_slab(va);
+        while (more) {
+            more = load_slab(vb);
+            count_slab(va);
+            if (!more) break;
+            more = load_slab(va);
+            count_slab(vb);
+        }
+    }
     // One level only: nregions short regions per block, wave w takes regions w, w + 16, ...  Their sizes are fetched
     // with ONE load (lane l holds the size of the wave's l-th region), and the slabs are double-buffered across region
     // boundaries: a region is only ~2 KB, so a wave that waited for each one separately would keep too few bytes in flight.
-    const int my_nreg = (a.nregions - wave + kWaves - 1) / kWaves;  // regions of this wave (<= 64 supported in one go)
+    const int my_nreg = a.nregions < kWaves ? 0 : (a.nregions - wave + kWaves - 1) / kWaves;  // regions of this wave (<= 64 supported in one go)
     for (int r0 = 0; r0 < my_nreg; r0 += 64) {
         const int nr = my_nreg - r0 < 64 ? my_nreg - r0 : 64;
         const u32 my_cnt = lane < nr ? my_counts[wave + kWaves * (r0 + lane)] : 0u;
@@ -705,15 +847,6 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
             }
             off += kSlab;
             return true;
-        };
-        auto count_slab = [&](const uint4 (&v)[kInFlight / 4]) {
-            if (a.ablate & 16) {
-#pragma unroll
-                for (int j = 0; j < kInFlight / 4; ++j) counted += v[j].x + v[j].y + v[j].z + v[j].w;
-                return;
-            }
-#pragma unroll
-            for (int j = 0; j < kInFlight / 4; ++j) { fast(v[j].x); fast(v[j].y); fast(v[j].z); fast(v[j].w); }
         };
         uint4 va[kInFlight / 4], vb[kInFlight / 4];
         bool more = load_slab(va);
@@ -739,7 +872,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
 
 // the compact shadow table's pending counts -> the real table (cf. shadow_flush_kernel)
 __global__ __launch_bounds__(kBlock) void shadow32_flush_kernel(u32 *__restrict__ shadow, int block_bits, u64 slots, TableView main, int k,
-                                                                u64 *counters) {
+                                                                u64 *counters, int sbits) {
     __shared__ u32 ascii4[256];
     __shared__ u64 s_tot, s_new;
     fill_ascii4_lut(ascii4, threadIdx.x, kBlock);
@@ -752,7 +885,7 @@ __global__ __launch_bounds__(kBlock) void shadow32_flush_kernel(u32 *__restrict_
         const u32 c = shadow[kw + S];
         if (c == 0) continue;
         shadow[kw + S] = 0;
-        const u64 h = hash_of_mixed<2>((blk << 32) | shadow[kw], k, ascii4);
+        const u64 h = hash_of_mixed<2>(((blk >> (sbits - 10)) << 32) | shadow[kw], k, ascii4);
         if (h == 0) continue;  // lib.rs:589: hash 0 is skipped
         const AddResult r = table_add<false>(main, h, (u64)c);
         if (!r.spilled) { tot += c; nk += r.claimed; }
@@ -774,7 +907,8 @@ __global__ __launch_bounds__(kBlock) void shadow32_flush_kernel(u32 *__restrict_
 // aggregate_pairs_kernel merges each block's pairs in LDS.  The table is read and written once, sequentially.
 struct FlushPartitionArgs {
     void *shadow;        // compact shadow: [1024 blocks][8192 u32 keys][8192 u32 counts]; 64-bit shadow: u64 keys and counts
-    u32 shadow_blocks;   // 1024 for the compact one
+    u32 shadow_blocks;   // 1024 for the one-level compact shadow
+    int shadow_sbits;    // compact shadow: log2(shadow_blocks) (a block index is the top sbits bits of the 42-bit value)
     const u64 *pair_keys, *pair_counts; int pair_stride; u64 npairs;  // SRC 2: a flat list of {hash, count} pairs instead of a shadow
     int k;
     int table_block_bits, pbits;  // the REAL table: slots per block, log2(blocks) (<= 10)
@@ -837,7 +971,8 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
             const W c = blk[S + i];
             if (c) {
                 blk[S + i] = 0;
-                const u64 h = COMPACT ? hash_of_mixed<2>(((u64)sb << 32) | blk[i], a.k, ascii4) : hash_of_mixed<1>((u64)blk[i], a.k, ascii4);
+                const u64 h = COMPACT ? hash_of_mixed<2>(((u64)(sb >> (a.shadow_sbits - 10)) << 32) | blk[i], a.k, ascii4)
+                                      : hash_of_mixed<1>((u64)blk[i], a.k, ascii4);
                 if (h) {  // lib.rs:589: hash 0 is skipped
                     const u32 b = (u32)(h >> a.table_block_bits) & (u32)(P - 1);
                     const u64 cw = atomicAdd(&cur[b], 1ULL);
@@ -882,42 +1017,51 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(Aggregate
     const int lane = threadIdx.x & 63;
     u64 tot = 0, nk = 0, nz = 0;
     const u32 *my_counts = a.region_count + (u64)b * a.nregions;
-    // A region holds only a handful of pairs (one workgroup's share of one block): FOUR lanes take a region, so all 256
-    // regions are in flight at once and a group's loads are one 64-byte line.
-    const int q = threadIdx.x & 3;
-    for (int seg = threadIdx.x >> 2; seg < a.nregions; seg += kPartThreads / 4) {
-        const u32 cnt = my_counts[seg];
-        const ulonglong2 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
-        for (u32 i = q; i < cnt; i += 4) {
-            const ulonglong2 pr = region[i];
-            const u64 h = pr.x, c = pr.y;
-            if (h == 0) continue;  // hole / padding
-            u32 g = (u32)h & smask & ~(u32)(kGroup - 1);
-            bool placed = false;
-            for (u32 round = 0; round < (S >> kGroupBits) && !placed; ++round) {
-                const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(keys + g);
-                const ulonglong2 q0 = kp[0], q1 = kp[1], q2 = kp[2], q3 = kp[3];
-                const u64 kk[kGroup] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
-                int sel = kGroup;  // first slot that holds h or is empty
+    auto merge_pair = [&](const ulonglong2 pr) {
+        const u64 h = pr.x, c = pr.y;
+        if (h == 0) return;  // hole / padding
+        u32 g = (u32)h & smask & ~(u32)(kGroup - 1);
+        bool placed = false;
+        for (u32 round = 0; round < (S >> kGroupBits) && !placed; ++round) {
+            const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(keys + g);
+            const ulonglong2 q0 = kp[0], q1 = kp[1], q2 = kp[2], q3 = kp[3];
+            const u64 kk[kGroup] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+            int sel = kGroup;  // first slot that holds h or is empty
 #pragma unroll
-                for (int sl = kGroup - 1; sl >= 0; --sl) if (kk[sl] == h || kk[sl] == 0) sel = sl;
-                while (sel < kGroup) {
-                    u64 ks = keys[g + sel];
-                    if (ks == 0) {
-                        ks = atomicCAS(&keys[g + sel], 0ULL, h);
-                        if (ks == 0) { ++nk; ks = h; }
-                    }
-                    if (ks == h) { nz += atomicAdd(&cnts[g + sel], c) == 0; placed = true; break; }  // (lib.rs:801-803: new = count was 0)
-                    ++sel;  // another lane claimed that slot for a different key: try the following slots
-                    while (sel < kGroup) { const u64 k2 = keys[g + sel]; if (k2 == h || k2 == 0) break; ++sel; }
+            for (int sl = kGroup - 1; sl >= 0; --sl) if (kk[sl] == h || kk[sl] == 0) sel = sl;
+            while (sel < kGroup) {
+                u64 ks = keys[g + sel];
+                if (ks == 0) {
+                    ks = atomicCAS(&keys[g + sel], 0ULL, h);
+                    if (ks == 0) { ++nk; ks = h; }
                 }
-                g = (g + kGroup) & smask;
+                if (ks == h) { nz += atomicAdd(&cnts[g + sel], c) == 0; placed = true; break; }  // (lib.rs:801-803: new = count was 0)
+                ++sel;  // another lane claimed that slot for a different key: try the following slots
+                while (sel < kGroup) { const u64 k2 = keys[g + sel]; if (k2 == h || k2 == 0) break; ++sel; }
             }
-            if (placed) tot += c;
-            else {
-                const u64 si = atomicAdd(a.spill_n, 1ULL);
-                if (si < a.spill_cap) { a.spill[2 * si] = h; a.spill[2 * si + 1] = c; }
-            }
+            g = (g + kGroup) & smask;
+        }
+        if (placed) tot += c;
+        else {
+            const u64 si = atomicAdd(a.spill_n, 1ULL);
+            if (si < a.spill_cap) { a.spill[2 * si] = h; a.spill[2 * si + 1] = c; }
+        }
+    };
+    if (a.nregions >= 64) {
+        // One level: a region holds only a handful of pairs (one workgroup's share of one block): FOUR lanes take a region,
+        // so all 256 regions are in flight at once and a group's loads are one 64-byte line.
+        const int q = threadIdx.x & 3;
+        for (int seg = threadIdx.x >> 2; seg < a.nregions; seg += kPartThreads / 4) {
+            const u32 cnt = my_counts[seg];
+            const ulonglong2 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
+            for (u32 i = q; i < cnt; i += 4) merge_pair(region[i]);
+        }
+    } else {
+        // Two levels: a few long regions per block (one per second-level writer), the whole workgroup strides over each.
+        for (int seg = 0; seg < a.nregions; ++seg) {
+            const u32 cnt = my_counts[seg];
+            const ulonglong2 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
+            for (u32 i = threadIdx.x; i < cnt; i += kPartThreads) merge_pair(region[i]);
         }
     }
     tot = wave_sum(tot); nk = wave_sum(nk); nz = wave_sum(nz);

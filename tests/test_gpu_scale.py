@@ -1,0 +1,187 @@
+"""BASELINE.json's configurations at FULL size on one MI355X (``-m gpu``), and the device paths that only large tables
+take (two partition levels, table-sized shadows, the two-level pair flush, the dedupe probe).
+
+What is checked without an oracle run over 10^10 k-mers (the oracle does ~6x10^6 k-mers/s):
+
+* ``n == reads x (L - k + 1) == sum_counts``, ``consumed == reads x L``, ``len`` inside the bounds the genome gives;
+* consuming the same stream again doubles ``sum_counts`` and ``max``, quadruples the sum of squared counts, adds no key;
+* the automatic path and the DIRECT path (one HBM atomic per k-mer -- the simplest kernel, oracle-checked on every
+  small case in test_gpu_parity.py) agree on ``len``, ``sum_counts``, ``min``, ``max``, the sum of squared counts, and
+  on the count of every key of a sample of 10^5-10^6 keys;
+* a slice of a few thousand reads through the ORACLE: every key the oracle finds is present with at least its count.
+
+Smaller inputs into tables of more than 1024 blocks are compared with the oracle's table bit for bit.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402  (the checker)
+from oracle import OracleTable  # noqa: E402
+
+SEED_G, SEED_R = 42, 1337
+
+# BASELINE.json configs[2..4] on ONE GPU (8-GPU configs: one rank's shard of the reads), plus the north-star sentence's
+# own workload: 100 M x 150 bp at k=21 on one MI355X.
+FULL = {
+    "C3": dict(reads=100_000_000, L=150, k=31, genome=500_000_000),
+    "C4-shard": dict(reads=12_500_000, L=150, k=21, genome=500_000_000),
+    "C5-shard": dict(reads=1_250_000, L=10_000, k=51, genome=387_500_000),
+    "NS-k21": dict(reads=100_000_000, L=150, k=21, genome=500_000_000),
+}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from oxli_amd import KmerCountTable, _lib
+    return torch, KmerCountTable, _lib.load()
+
+
+def synth(gpu, G, R, L, first=0, seed_g=SEED_G, seed_r=SEED_R):
+    torch, _, lib = gpu
+    g = torch.empty(G, dtype=torch.uint8, device="cuda")
+    r = torch.empty(R * (L + 1), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.kct_synth_genome_device(g.data_ptr(), G, seed_g, stream) == 0
+    assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), G, first, R, L, seed_r, stream) == 0
+    torch.cuda.synchronize()
+    return g, r
+
+
+def stats(t):
+    lo, hi, sq = t._count_stats()
+    return len(t), t.sum_counts, lo, hi, sq
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_config(gpu, name):
+    torch, KCT, _ = gpu
+    c = FULL[name]
+    R, L, k, G = c["reads"], c["L"], c["k"], c["genome"]
+    free, _total = torch.cuda.mem_get_info()
+    if free < 250 * (1 << 30):
+        pytest.skip("needs a whole MI355X (250 GiB of free HBM)")
+    g, r = synth(gpu, G, R, L)
+    del g
+    n_expect = R * (L - k + 1)
+    t = KCT(k, capacity=G)
+    t.profile(True)
+    n = t.consume_device(r.data_ptr(), r.numel(), R * L)
+    prof = t.profile_read()
+    assert n == n_expect
+    assert t.consumed == R * L
+    distinct, total, lo, hi, sq = stats(t)
+    assert total == n_expect and lo >= 1
+    # every genome position is the start of one canonical k-mer; a position is missed with probability e^-(windows per position)
+    assert 0.9 * G * (1.0 - np.exp(-n_expect / G)) <= distinct <= G - k + 1
+    assert "count_windows_kernel" not in prof, prof            # the partitioned paths carried it
+    assert "repartition_kernel" in prof or "repartition_kernel<compact>" in prof, prof   # ... through two levels
+    # an oracle slice: the first 3000 reads (the first 40 long ones)
+    ns = 3000 if L <= 1000 else 40
+    sub = r[: ns * (L + 1)].cpu().numpy().reshape(ns, L + 1)
+    ref = OracleTable(k)
+    for i in range(ns):
+        ref.consume(sub[i, :L])
+    rk, rc = ref.dump_arrays()
+    got = np.array(t.get_hash_array(rk), dtype=np.uint64)
+    assert np.all(got >= rc)
+    # a sample of keys for the path comparison: the slice's keys plus keys that are absent
+    sample = np.concatenate([rk, rk ^ np.uint64(0x5555555555555555)])
+    sample_counts = np.array(t.get_hash_array(sample), dtype=np.uint64)
+    # the same stream again: every count doubles, no key is new
+    assert t.consume_device(r.data_ptr(), r.numel(), R * L) == n_expect
+    d2, total2, lo2, hi2, sq2 = stats(t)
+    assert (d2, total2, lo2, hi2) == (distinct, 2 * n_expect, 2 * lo, 2 * hi)
+    assert sq2 == pytest.approx(4.0 * sq, rel=1e-12)
+    assert np.array_equal(np.array(t.get_hash_array(sample), dtype=np.uint64), 2 * sample_counts)
+    t.release_scratch()
+    del t
+    torch.cuda.empty_cache()
+    # the direct path on the same stream
+    d = KCT(k, capacity=G)
+    d.set_path("direct")
+    assert d.consume_device(r.data_ptr(), r.numel(), R * L) == n_expect
+    dd, dtotal, dlo, dhi, dsq = stats(d)
+    assert (dd, dtotal, dlo, dhi) == (distinct, n_expect, lo, hi)
+    assert dsq == pytest.approx(sq, rel=1e-12)
+    assert np.array_equal(np.array(d.get_hash_array(sample), dtype=np.uint64), sample_counts)
+
+
+def _oracle_table(reads, L, k):
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    tab, kmers, _ = oracle.baseline_consume(reads, L, k, threads, native=False)
+    return tab, kmers
+
+
+@pytest.mark.parametrize("k,path,G,R", [(21, "dedupe", 6_000_000, 300_000), (31, "dedupe", 6_000_000, 300_000),
+                                        (21, "auto", 3_000_000, 600_000), (31, "auto", 3_000_000, 600_000),
+                                        (21, "auto", 6_000_000, 600_000),
+                                        (17, "partitioned", 6_000_000, 300_000), (51, "auto", 6_000_000, 300_000)])
+def test_tables_of_more_than_1024_blocks_match_the_oracle(gpu, k, path, G, R):
+    """2^24 slots = 2048 blocks: two partition levels.  k=21 takes the compact two-level dedupe-first path (a 4 GiB
+    compact shadow, repartition_kernel<compact>), k=31 the 64-bit one.  With "auto" and k <= 32 the 8x10^7-window call
+    is large enough for the dedupe PROBE (2^23 windows) to decide: ~26 windows per distinct k-mer with the 3 Mbp genome
+    (dedupe-first goes on), ~13 with the 6 Mbp one (the rest of the call hashes every window).  Reading the table
+    converts the pending k-mers through the two-level pair flush.  The oracle counts the same reads on the host."""
+    torch, KCT, _ = gpu
+    L = 150
+    genome = oracle.synth_genome(G, 5)
+    reads = oracle.synth_reads(genome, 0, R, L, 9)
+    ref, n_ref = _oracle_table(reads, L, k)
+    dev_reads = torch.from_numpy(reads.reshape(-1)).cuda()
+    t = KCT(k, capacity=6_000_000)
+    assert t.capacity == 1 << 24
+    t.set_path(path)
+    t.profile(True)
+    assert t.consume_device(dev_reads.data_ptr(), dev_reads.numel(), R * L) == n_ref == R * (L - k + 1)
+    prof = t.profile_read()
+    if k == 21 and path != "partitioned":
+        assert "repartition_kernel<compact>" in prof and "aggregate_blocks32_kernel" in prof, prof
+    elif k == 31:
+        assert "repartition_kernel" in prof and "aggregate_blocks_kernel<shadow>" in prof, prof
+    else:
+        assert "repartition_kernel" in prof and "aggregate_blocks_kernel" in prof, prof
+    if path == "auto" and k <= 32:   # the probe's verdict: the hashing K1 ran for the rest of the call, or not at all
+        assert ("partition_windows_kernel" in prof) == (G == 6_000_000), prof
+    dk, dc = t.dump_arrays(1)
+    if k <= 32 and path != "partitioned":
+        assert "repartition_kernel<pairs>" in t.profile_read(), t.profile_read()   # the two-level pair flush ran
+    rk, rc = ref.dump_arrays()
+    assert np.array_equal(dk, rk) and np.array_equal(dc, rc)
+    assert len(t) == len(ref) and t.sum_counts == n_ref
+    # a second pass into the live table and shadow, then a third after a read
+    assert t.consume_device(dev_reads.data_ptr(), dev_reads.numel(), R * L) == n_ref
+    assert t.get_hash(int(rk[1234])) == 2 * int(rc[1234])
+    assert t.consume_device(dev_reads.data_ptr(), dev_reads.numel() // 2, R * L // 2) == n_ref // 2
+    dk, dc = t.dump_arrays(1)
+    half, _ = _oracle_table(reads[: R // 2], L, k)
+    hk, hc = half.dump_arrays()
+    want = dict(zip(rk.tolist(), (2 * rc).tolist()))
+    for h, c in zip(hk.tolist(), hc.tolist()):
+        want[h] += c
+    assert np.array_equal(dk, rk) and dc.tolist() == [want[h] for h in rk.tolist()]
+
+
+def test_compact_counts_carry_into_the_table(gpu, monkeypatch):
+    """The compact shadow's counts are u32; what would not fit moves on to the real table's u64 count as a carry pair.
+    KCT_CARRY_BITS=4 makes that happen at 16 instead of 2^31: results must not change."""
+    torch, KCT, _ = gpu
+    monkeypatch.setenv("KCT_CARRY_BITS", "4")
+    G, L, R, k = 100_000, 150, 60_000, 21
+    genome = oracle.synth_genome(G, 3)
+    reads = oracle.synth_reads(genome, 0, R, L, 4)
+    ref, n_ref = _oracle_table(reads, L, k)
+    dev_reads = torch.from_numpy(reads.reshape(-1)).cuda()
+    t = KCT(k, capacity=G)
+    t.set_path("dedupe")
+    for _ in range(3):   # pending counts of ~80 per k-mer pass 16 again and again
+        assert t.consume_device(dev_reads.data_ptr(), dev_reads.numel(), R * L) == n_ref
+    dk, dc = t.dump_arrays(1)
+    rk, rc = ref.dump_arrays()
+    assert np.array_equal(dk, rk) and np.array_equal(dc, 3 * rc)
+    assert t.sum_counts == 3 * n_ref
