@@ -122,6 +122,14 @@ Levels levels_for(int bbits, int nwg) {
     return L;
 }
 
+// second partition level: lines of a bin that leave the ring together -- 2 or 4 when the ring is deep enough (its depth in
+// lines per bin >= 8x that), so that the scattered 64-byte stores become 128- or 256-byte ones
+unsigned int repartition_min_lines(int ring_entries, int sub_bits, int entry_bytes) {
+    if (const char *e = getenv("KCT_K1B_LINES")) return (unsigned int)std::max(1, std::min(4, atoi(e)));  // measurement only
+    const int lines_per_bin = (ring_entries >> sub_bits) * entry_bytes / 64;
+    return lines_per_bin >= 32 ? 4u : lines_per_bin >= 16 ? 2u : 1u;
+}
+
 // overflow regions: an eighth of a workgroup's entries, but few enough that ring positions (21 bits in ring_flush's line
 // list) cannot wrap before a hopelessly skewed pass is abandoned
 unsigned int overflow_capacity(u64 entries_per_wg) { return (unsigned int)std::min<u64>(1ULL << 20, std::max<u64>(4096, entries_per_wg / 8)); }
@@ -145,9 +153,11 @@ kct::TableGeom shadow_geom(const kct_table *t) {
 // the pairs are partitioned (~0.11 ns with one random table access each), a dedupe-first pass saves ~3-5 ps per window
 u64 windows_per_pending_key(const kct_table *t) { return partition_geometry_ok(t) && t->block_bits == kct::kBlockBitsMax ? 16 : 32; }
 
-// the dedupe probe of a large call into a table that knows nothing yet: few enough windows that the shadow could hold
-// every one of their k-mers, were they all distinct
-u64 probe_windows(const kct_table *t) { return std::min<u64>(1ULL << 26, std::max<u64>(1ULL << 22, t->cap / 2)); }
+// The dedupe probe of a large call into a table that knows nothing yet: 2^22 window starts counted into a SMALL shadow
+// (1024 blocks: one partition level, whatever the table's size) that could hold every one of their k-mers, were they all
+// distinct.  ~0.5 ms, and 4 million draws fix the number of distinct k-mers behind the input to about a percent.
+constexpr u64 kProbeWindows = 1ULL << 22;
+constexpr u64 kProbeShadowSlots = 1ULL << (10 + kct::kBlockBitsMax);
 kct_status flush_compact(kct_table *t);
 
 bool dedupe_pays(const kct_table *t, u64 npos) {
@@ -162,17 +172,18 @@ bool dedupe_pays(const kct_table *t, u64 npos) {
     return known * windows_per_pending_key(t) <= t->windows_since_read + std::max(npos, t->call_windows_left);
 }
 
-// The shadow mirrors the real table's capacity (the same k-mers live in both).  (Re)allocated empty when that changes.
-kct_status ensure_shadow(kct_table *t, bool *ok) {
+// The shadow mirrors the real table's capacity (the same k-mers live in both) -- except for the dedupe probe's, which is
+// small.  (Re)allocated empty, after converting what is pending, when the wanted capacity changes.
+kct_status ensure_shadow(kct_table *t, u64 want_cap, bool *ok) {
     *ok = true;
-    if (t->shadow && t->shadow_cap == t->cap) return KCT_OK;
+    if (t->shadow && t->shadow_cap == want_cap) return KCT_OK;
     KCT_TRY(flush_shadow(t));
     if (t->shadow) { (void)hipFree(t->shadow); t->shadow = nullptr; t->shadow_cap = 0; }
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 3.0 * (double)t->cap * 16.0) { *ok = false; return KCT_OK; }  // not with HBM this tight
-    if (hipMalloc((void **)&t->shadow, t->cap * 16) != hipSuccess) { (void)hipGetLastError(); t->shadow = nullptr; *ok = false; return KCT_OK; }
-    t->shadow_cap = t->cap;
-    t->shadow_block_bits = t->block_bits;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 3.0 * (double)want_cap * 16.0) { *ok = false; return KCT_OK; }  // not with HBM this tight
+    if (hipMalloc((void **)&t->shadow, want_cap * 16) != hipSuccess) { (void)hipGetLastError(); t->shadow = nullptr; *ok = false; return KCT_OK; }
+    t->shadow_cap = want_cap;
+    t->shadow_block_bits = std::min(kct::kBlockBitsMax, log2_u64(want_cap));
     t->shadow_empty = true;
     t->shadow_keys = 0;
     return KCT_OK;
@@ -189,9 +200,8 @@ int compact_sbits_for(const kct_table *t) {
 }
 u64 compact_slots(const kct_table *t) { return 1ULL << (t->s32_sbits + kct::kBlockBitsMax); }
 
-kct_status ensure_shadow32(kct_table *t, bool *ok) {
+kct_status ensure_shadow32(kct_table *t, int want, bool *ok) {
     *ok = true;
-    const int want = compact_sbits_for(t);
     if (t->shadow32 && t->s32_sbits == want) return KCT_OK;
     KCT_TRY(flush_compact(t));
     if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; }
@@ -246,7 +256,7 @@ kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const
     pa.scratch = (const ulonglong2 *)t->d_scratch.p; pa.seg_stride = P * region_cap; pa.block_stride = region_cap;
     pa.region_count = (const unsigned int *)t->d_regions.p; pa.nregions = nwg;
     if (L.two) {
-        const unsigned int out_cap = (region_capacity((double)npairs / (double)L.B / (double)L.W) + 3u) & ~3u;  // pairs per (block, writer): whole lines
+        const unsigned int out_cap = (region_capacity((double)npairs / (double)L.B / (double)L.W) + 15u) & ~15u;  // pairs per (block, writer): 256-byte multiples
         KCT_TRY(t->d_scratch2.reserve(L.B * L.W * out_cap * 16));
         KCT_TRY(t->d_regions2.reserve(L.B * L.W * 4));
         kct::RepartitionArgs ra;
@@ -255,6 +265,7 @@ kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const
         ra.nseg = nwg; ra.nbins = (int)P; ra.writers = (int)L.W;
         ra.out = t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
         ra.ovf = (du64 *)t->d_pairs_ovf.p; ra.ovf_cap = (unsigned int)std::min<u64>(npairs, 0xFFFFFFFFu); ra.ovf_count = nullptr; ra.overflow = nullptr; ra.ovf_n = d_ovf_n;
+        ra.min_lines = repartition_min_lines(kct::kRingEntries / 2, L.sub_bits, 16);
         {
             ProfScope ps(t, "repartition_kernel<pairs>");
             hipLaunchKernelGGL(kct::repartition_kernel<ulonglong2>, dim3((unsigned)(P * L.W)), dim3(kct::kPartThreads), 0, t->stream, ra);
@@ -411,7 +422,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     const int k = t->k;
     {
         bool ok = true;
-        KCT_TRY(ensure_shadow32(t, &ok));
+        KCT_TRY(ensure_shadow32(t, probe ? kCompactBlockBits : compact_sbits_for(t), &ok));  // (the probe's shadow is the small one, swapped in by the caller)
         if (!ok) { t->compact_off = true; return KCT_OK; }
     }
     const int sbits = t->s32_sbits;
@@ -454,7 +465,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     unsigned int ovf2_cap = 0, *d_ovf2_count = nullptr;
     if (two_level) {
         // second level: one workgroup per super-bin spreads its entries over the super-bin's 2^sub_bits shadow blocks
-        const unsigned int out_cap = (region_capacity((double)npos / (double)B) + 15u) & ~15u;
+        const unsigned int out_cap = (region_capacity((double)npos / (double)B) + 63u) & ~63u;  // 256-byte multiples
         ovf2_cap = overflow_capacity(npos / P);
         KCT_TRY(t->d_scratch2.reserve(B * out_cap * 4));
         KCT_TRY(t->d_regions2.reserve(B * 4));
@@ -466,6 +477,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
         ra.nseg = nwg; ra.nbins = (int)P; ra.writers = 1;
         ra.out = t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
         ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow; ra.ovf_n = nullptr;
+        ra.min_lines = repartition_min_lines(kct::kRingEntries * 2, sub_bits, 4);
         {
             ProfScope ps(t, "repartition_kernel<compact>");
             hipLaunchKernelGGL(kct::repartition_kernel<unsigned int>, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, ra);
@@ -522,7 +534,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     t->s32_keys += new_keys;
     t->s32_windows += npos;
     if (t->debug)
-        fprintf(stderr, "[kct] compact dedupe pass%s: npos=%llu blocks=%llu region_cap=%u counted=%llu new keys=%llu (total %llu) blocked=%llu merged=%llu spilled=%llu carried=%llu\n",
+        KCT_DBG(t, "compact dedupe pass%s: npos=%llu blocks=%llu region_cap=%u counted=%llu new keys=%llu (total %llu) blocked=%llu merged=%llu spilled=%llu carried=%llu\n",
                 probe ? " (probe)" : "", (unsigned long long)npos, (unsigned long long)B, region_cap, (unsigned long long)counted, (unsigned long long)new_keys,
                 (unsigned long long)t->s32_keys, (unsigned long long)blocked, (unsigned long long)c2[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled2,
                 (unsigned long long)carried);
@@ -552,13 +564,16 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     const int k = t->k;
     if (raw) {
         bool ok = true;
-        KCT_TRY(ensure_shadow(t, &ok));
+        KCT_TRY(ensure_shadow(t, probe ? std::min(t->cap, kProbeShadowSlots) : t->cap, &ok));  // (the probe's shadow is a small one)
         if (!ok) { t->dedupe_off = true; return KCT_OK; }
         KCT_TRY(materialize(t));  // what does not fit the shadow goes straight to the real table
     }
     du64 *words = raw ? t->shadow : t->slots;
+    // the geometry K1 / K1b / K2 work in: the table's, or the shadow's
+    const u64 gcap = raw ? t->shadow_cap : t->cap;
+    const int gbb = raw ? t->shadow_block_bits : t->block_bits;
     const int nwg = t->num_cus;
-    const Levels L = levels_for(log2_u64(t->cap >> t->block_bits), nwg);
+    const Levels L = levels_for(log2_u64(gcap >> gbb), nwg);
     const bool two_level = L.two;
     const int bbits = L.bbits, pbits = L.pbits, sub_bits = L.sub_bits;
     const u64 P = L.P, B = L.B, W = L.W;
@@ -576,7 +591,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     const bool fresh = raw ? t->shadow_empty : t->lazy_empty;
 
     kct::PartitionArgs pa;
-    pa.mask = t->cap - 1; pa.block_bits = t->block_bits + sub_bits; pa.pbits = pbits;
+    pa.mask = gcap - 1; pa.block_bits = gbb + sub_bits; pa.pbits = pbits;
     pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
     pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
     pa.ablate = t->ablate;  // measurement only; wrong counts when set
@@ -588,7 +603,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     HIP_TRY(hipGetLastError());
 
     kct::AggregateArgs aa;
-    aa.words = words; aa.block_bits = t->block_bits; aa.pbits = bbits;
+    aa.words = words; aa.block_bits = gbb; aa.pbits = bbits;
     aa.fresh = fresh ? 1 : 0; aa.overflow = d_overflow; aa.ablate = pa.ablate;
     aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
     unsigned int ovf2_cap = 0, *d_ovf2_count = nullptr;
@@ -597,18 +612,19 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
     } else {
         // second level: one workgroup per super-bin spreads its hashes over the super-bin's blocks
-        const unsigned int out_cap = region_capacity((double)npos / (double)B / (double)W);
+        const unsigned int out_cap = (region_capacity((double)npos / (double)B / (double)W) + 31u) & ~31u;  // 256-byte multiples
         ovf2_cap = overflow_capacity(npos / P / W);
         KCT_TRY(t->d_scratch2.reserve(B * W * out_cap * 8));
         KCT_TRY(t->d_regions2.reserve(B * W * 4));
         KCT_TRY(t->d_irr2.reserve(P * W * ovf2_cap * 8 + P * W * 4));
         d_ovf2_count = (unsigned int *)((du64 *)t->d_irr2.p + P * W * ovf2_cap);
         kct::RepartitionArgs ra;
-        ra.mask = t->cap - 1; ra.block_bits = t->block_bits; ra.sub_bits = sub_bits;
+        ra.mask = gcap - 1; ra.block_bits = gbb; ra.sub_bits = sub_bits;
         ra.in = t->d_scratch.p; ra.in_cap = region_cap; ra.in_count = (const unsigned int *)t->d_regions.p;
         ra.nseg = nwg; ra.nbins = (int)P; ra.writers = (int)W;
         ra.out = t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
         ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow; ra.ovf_n = nullptr;
+        ra.min_lines = repartition_min_lines(kct::kRingEntries, sub_bits, 8);
         {
             ProfScope ps(t, "repartition_kernel");
             hipLaunchKernelGGL(kct::repartition_kernel<du64>, dim3((unsigned)(P * W)), dim3(kct::kPartThreads), 0, t->stream, ra);
@@ -644,7 +660,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         (void)hipMemcpy(oc.data(), d_ovf_count, nwg * 4, hipMemcpyDeviceToHost);
         u64 tot = 0;
         for (auto v : oc) tot += v;
-        fprintf(stderr, "[kct] partitioned pass%s%s: npos=%llu blocks=%llu levels=%d region_cap=%u overflow(K1)=%llu counted=%llu merged=%llu new=%llu spilled=%llu abandon=%llu\n",
+        KCT_DBG(t, "partitioned pass%s%s: npos=%llu blocks=%llu levels=%d region_cap=%u overflow(K1)=%llu counted=%llu merged=%llu new=%llu spilled=%llu abandon=%llu\n",
                 raw ? " (shadow)" : "", probe ? " (probe)" : "", (unsigned long long)npos, (unsigned long long)B, two_level ? 2 : 1, region_cap, (unsigned long long)tot,
                 (unsigned long long)c[kct::CTR_COUNTED], (unsigned long long)c[kct::CTR_TOTAL_ADDED], (unsigned long long)c[kct::CTR_NEWKEYS],
                 (unsigned long long)spilled, (unsigned long long)t->h_counters[kNumCounters + 6]);
@@ -696,7 +712,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     o.blocked = blocked;
     KCT_TRY(after_dedupe_pass(t, false, npos, o, probe));
     // the shadow holds as many keys as the table would: grow both (the table's growth re-creates the shadow, flushed)
-    if (t->shadow && (double)t->shadow_keys > kMaxLoad * (double)t->shadow_cap) {
+    if (t->shadow && t->shadow_cap == t->cap && (double)t->shadow_keys > kMaxLoad * (double)t->shadow_cap) {
         KCT_TRY(flush_shadow(t));
         KCT_TRY(grow_to(t, t->cap * 2));
     }
@@ -745,14 +761,16 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         }
     }
     // A large call into a table that knows nothing about its input (no keys, no hint from earlier passes): is this deep
-    // coverage of few k-mers (dedupe-first pays) or mostly distinct ones?  The first 2^22..2^26 windows go through the
+    // coverage of few k-mers (dedupe-first pays) or mostly distinct ones?  The first 2^22 window starts go through the
     // dedupe-first path as a PROBE; the share of first sightings among them gives the number of distinct k-mers the
     // input draws from (as if uniformly -- position-sorted input shows its repeats even sooner), hence the windows per
     // distinct k-mer of the whole call.  Either way the probe's k-mers are counted; a wrong guess costs speed only.
     const u64 call_windows = last_start + 1;
+    KCT_DBG(t, "consume_stream: %llu window starts, chunk limit %llu, table %llu slots\n", (unsigned long long)call_windows, (unsigned long long)chunk_limit,
+            (unsigned long long)t->cap);
     bool probe = t->force_path == 0 && t->k <= 32 && !t->dedupe_off && !t->dedupe_hint && !t->auto_sized &&
-                 std::max({t->n_keys, t->shadow_keys, t->s32_keys}) == 0 && call_windows >= 8 * probe_windows(t) &&
-                 partition_geometry_ok(t) && partition_pays(t, call_windows);
+                 std::max({t->n_keys, t->shadow_keys, t->s32_keys}) == 0 && call_windows >= 8 * kProbeWindows &&
+                 t->cap >= kProbeShadowSlots && partition_geometry_ok(t) && partition_pays(t, call_windows);
     if (call_windows > chunk_limit) {  // passes of equal size
         const u64 passes = (call_windows + chunk_limit - 1) / chunk_limit;
         chunk_limit = std::min(chunk_limit, (((call_windows + passes - 1) / passes) + 0xFFFF) & ~(u64)0xFFFF);
@@ -764,23 +782,38 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         // per slot, so that what cannot be placed (and must be replayed after growing) stays small while
         // the table finds its size; launches grow with it.
         const u64 ramp = t->auto_sized ? std::max<u64>(1ULL << 20, 4 * t->cap) : ~0ULL;
-        const u64 npos = std::min<u64>({probe ? probe_windows(t) : chunk_limit, ramp, last_start + 1 - done});
+        const u64 npos = std::min<u64>({probe ? kProbeWindows : chunk_limit, ramp, last_start + 1 - done});
         const u64 chunk_bytes = std::min<u64>(nbytes - done, npos + k - 1);
         t->call_windows_left = last_start + 1 - done;
         if (probe) {
             probe = false;
-            const u64 keys_before = std::max(t->shadow_keys, t->s32_keys), table_before = t->n_keys;
+            // The probe counts into its own small shadow, swapped in for this pass.  (Nothing is pending and no shadow holds
+            // a key -- that is when a probe is made -- so the table-sized shadows are simply set aside.)  A table of up to
+            // 1024 blocks has a small shadow anyway: no swap, and what the probe counted stays pending.
+            const bool use_compact = t->k <= 21 && !t->compact_off;
+            const bool swap32 = use_compact && compact_sbits_for(t) != kCompactBlockBits, swap64 = !use_compact && t->cap > kProbeShadowSlots;
+            unsigned int *big32 = t->shadow32; const int big_sbits = t->s32_sbits;
+            du64 *big64 = t->shadow; const u64 big_cap = t->shadow_cap; const int big_bb = t->shadow_block_bits;
+            if (swap32) { t->shadow32 = t->probe_shadow32; t->s32_sbits = kCompactBlockBits; t->s32_empty = true; }
+            if (swap64) { t->shadow = t->probe_shadow; t->shadow_cap = t->shadow ? kProbeShadowSlots : 0; t->shadow_block_bits = kct::kBlockBitsMax; t->shadow_empty = true; }
+            const u64 table_before = t->n_keys, n_before = *n_out;
             bool handled = false;
-            if (t->k <= 21 && !t->compact_off) KCT_TRY(consume_compact(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true));
-            if (!handled && !t->dedupe_off) KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true, true));
+            kct_status st = KCT_OK;
+            if (use_compact) st = consume_compact(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true);
+            if (st == KCT_OK && !handled && !t->dedupe_off) st = consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true, true);
+            const u64 fresh_keys = std::max(t->shadow_keys, t->s32_keys) + (t->n_keys - table_before);
+            if (st == KCT_OK && (swap32 || swap64)) st = flush_shadow(t);  // the probe's k-mers move on to the table before its shadow is set aside
+            if (swap32) { t->probe_shadow32 = t->shadow32; t->shadow32 = big32; t->s32_sbits = big_sbits; t->s32_empty = true; t->s32_keys = 0; t->s32_dirty = false; }
+            if (swap64) { t->probe_shadow = t->shadow; t->shadow = big64; t->shadow_cap = big_cap; t->shadow_block_bits = big_bb; t->shadow_empty = true; t->shadow_keys = 0; t->shadow_dirty = false; }
+            KCT_TRY(st);
             if (handled) {
                 done += npos; t->windows_since_read += npos;
-                const u64 fresh_keys = (std::max(t->shadow_keys, t->s32_keys) - keys_before) + (t->n_keys - table_before);
-                const double x = draws_per_distinct((double)fresh_keys / (double)npos);          // probe windows per distinct k-mer
-                const double per_key = x * (double)call_windows / (double)npos;                  // ... of the whole call
+                const u64 valid = std::max<u64>(1, *n_out - n_before);                           // window starts that held a k-mer
+                const double x = draws_per_distinct((double)fresh_keys / (double)valid);         // the probe's k-mers per distinct k-mer
+                const double per_key = x * (double)call_windows / (double)npos;                  // ... the whole call's
                 const bool pays = per_key >= (double)windows_per_pending_key(t);
-                if (t->debug) fprintf(stderr, "[kct] dedupe probe: %llu windows, %llu first sightings -> ~%.3g windows per distinct k-mer over the call: %s\n",
-                                      (unsigned long long)npos, (unsigned long long)fresh_keys, per_key, pays ? "dedupe-first" : "hash every window");
+                KCT_DBG(t, "dedupe probe: %llu k-mers, %llu first sightings -> ~%.3g k-mers per distinct k-mer over the call: %s\n",
+                        (unsigned long long)valid, (unsigned long long)fresh_keys, per_key, pays ? "dedupe-first" : "hash every window");
                 if (pays) t->dedupe_hint = true;
                 else { KCT_TRY(flush_shadow(t)); t->dedupe_off = true; }
                 continue;
@@ -825,6 +858,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         t->windows_since_read += npos;
     }
     t->call_windows_left = 0;
+    KCT_DBG(t, "consume_stream: done\n");
     if (t->auto_sized && t->cap == cap_at_entry && nbytes >= (1u << 20)) t->auto_sized = false;  // the table has found its size
     return KCT_OK;
 }

@@ -18,6 +18,11 @@ void set_err(const char *fmt, ...) {
     va_end(ap);
 }
 
+double now_ms() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
 void prof_collect(kct_table *t) {
     if (t->prof_pending.empty()) return;
     (void)hipStreamSynchronize(t->stream);
@@ -56,7 +61,11 @@ kct_status use_consume(kct_table *t) {
 
 kct_status use(kct_table *t) {
     KCT_TRY(use_consume(t));
-    if (t->shadow_dirty || t->s32_dirty) KCT_TRY(flush_shadow(t));   // reads must observe every earlier consume()
+    if (t->shadow_dirty || t->s32_dirty) {   // reads must observe every earlier consume()
+        KCT_DBG(t, "use(): converting pending counts (%llu / %llu shadow keys)\n", (unsigned long long)t->shadow_keys, (unsigned long long)t->s32_keys);
+        KCT_TRY(flush_shadow(t));
+        KCT_DBG(t, "use(): converted\n");
+    }
     t->windows_since_read = 0;
     return KCT_OK;
 }
@@ -87,8 +96,10 @@ void set_geometry(kct_table *t) { t->block_bits = std::min(kct::kBlockBitsMax, l
 // Anything else that touches `slots` calls this first.
 kct_status materialize(kct_table *t) {
     if (t->lazy_empty) {
+        KCT_DBG(t, "materialize: memset of %llu slots\n", (unsigned long long)t->cap);
         HIP_TRY(hipMemsetAsync(t->slots, 0, t->cap * 16, t->stream));
         t->lazy_empty = false;
+        if (t->debug) { HIP_TRY(hipStreamSynchronize(t->stream)); KCT_DBG(t, "materialize: done\n"); }
     }
     return KCT_OK;
 }
@@ -340,6 +351,8 @@ void kct_destroy(kct_table *t) {
     t->h_stage.release(); t->h_pending.release();
     if (t->shadow) (void)hipFree(t->shadow);
     if (t->shadow32) (void)hipFree(t->shadow32);
+    if (t->probe_shadow) (void)hipFree(t->probe_shadow);
+    if (t->probe_shadow32) (void)hipFree(t->probe_shadow32);
     for (auto &b : t->h_file) b.release();
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
@@ -663,6 +676,8 @@ kct_status kct_release_scratch(kct_table *t) {
         b->release();
     if (t->shadow) { (void)hipFree(t->shadow); t->shadow = nullptr; t->shadow_cap = 0; t->shadow_empty = true; t->shadow_keys = 0; }
     if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; t->s32_empty = true; t->s32_keys = 0; t->s32_windows = 0; }
+    if (t->probe_shadow) { (void)hipFree(t->probe_shadow); t->probe_shadow = nullptr; }
+    if (t->probe_shadow32) { (void)hipFree(t->probe_shadow32); t->probe_shadow32 = nullptr; }
     t->h_stage.release(); t->h_pending.release();
     for (auto &b : t->h_file) b.release();
     return KCT_OK;
@@ -687,6 +702,7 @@ kct_status kct_set_path(kct_table *t, int mode) {
     t->force_path = mode;
     t->dedupe_off = false;
     t->compact_off = false;
+    t->dedupe_hint = false;  // what earlier passes taught this table about its input is forgotten too
     return KCT_OK;
 }
 

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -27,6 +28,8 @@ namespace kcth {
 
 extern thread_local char g_err[512];
 void set_err(const char *fmt, ...);
+double now_ms();  // steady clock, for KCT_DEBUG lines
+#define KCT_DBG(t, ...) do { if ((t)->debug) { fprintf(stderr, "[kct %11.3f ms] ", kcth::now_ms()); fprintf(stderr, __VA_ARGS__); } } while (0)
 
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
@@ -126,6 +129,9 @@ struct kct_table {
     int s32_sbits = 10;
     bool s32_empty = true, s32_dirty = false, compact_off = false;
     u64 s32_keys = 0, s32_windows = 0;  // keys it holds; window starts counted into it since its last flush (u32 counts!)
+    // the dedupe probe's own small shadows (kept between calls, swapped in for the probe pass only)
+    du64 *probe_shadow = nullptr;
+    unsigned int *probe_shadow32 = nullptr;
     u64 windows_since_read = 0; // window starts consumed since anything last read the table (use()): how long the caller's runs are
     u64 call_windows_left = 0;  // window starts the running consume call still has to count (no read can come before them)
     bool dedupe_hint = false;   // the last dedupe-first pass paid off: a cleared table starts with that path again

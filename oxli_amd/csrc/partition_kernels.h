@@ -49,7 +49,10 @@ namespace kct {
 // IS the value's top 10 bits), otherwise a fixed word (K1b: the super-bin, the sub-bin bits are inside the entry).
 template <u32 LISTCAP, class T, class Overflow>
 __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *fcount, int P, u32 D,
-                                           T *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash, u64 bin_stride = 0, u64 ovf_hi = 0) {
+                                           T *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash, u64 bin_stride = 0, u64 ovf_hi = 0,
+                                           u32 min_lines = 1) {
+    // min_lines: a bin's lines leave the ring only that many at a time (adjacent lane groups then store adjacent lines:
+    // 128- or 256-byte writes instead of lone 64-byte ones); the drain takes whatever is left.
     constexpr u32 CH = 64 / sizeof(T);  // positions per 64-byte line
     const u32 dmask = D - 1;
     if (bin_stride == 0) bin_stride = out_cap;  // distance between the regions of consecutive bins
@@ -59,11 +62,12 @@ __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *f
         const u64 cw = cur[b];
         const u32 f0 = (u32)(cw >> 32), top = (u32)cw;
         u32 f = f0;
-        while (drain ? (int)(top - f) > 0 : top - f >= CH) {
-            const u32 slot = atomicAdd(fcount, 1u);
-            if (slot >= LISTCAP) break;  // list full: this line waits for the next call
-            flist[slot] = (u32)b | (f << 10) | (f - f0 >= D ? 0x80000000u : 0u);
-            f += CH;
+        while (drain ? (int)(top - f) > 0 : top - f >= CH * min_lines) {
+            const u32 want = drain ? 1u : min_lines;
+            const u32 slot = atomicAdd(fcount, want);
+            const u32 fit = slot >= LISTCAP ? 0u : (LISTCAP - slot < want ? LISTCAP - slot : want);  // every slot below LISTCAP gets written
+            for (u32 l = 0; l < fit; ++l, f += CH) flist[slot + l] = (u32)b | (f << 10) | (f - f0 >= D ? 0x80000000u : 0u);
+            if (fit < want) break;  // list full: the remaining lines wait for the next call
         }
         if (f != f0) atomicAdd(&cur[b], (u64)(f - f0) << 32);  // (appenders bump the low half concurrently)
     }
@@ -266,6 +270,7 @@ struct RepartitionArgs {
     u64 *ovf; u32 ovf_cap; u32 *ovf_count;  // per workgroup overflow regions (u64 values; pairs: two words each)
     u64 *overflow;       // abandon flag (shared with K1)
     u64 *ovf_n;          // pairs only: ONE shared overflow list instead of per-workgroup regions (ovf_cap = its capacity)
+    u32 min_lines;       // 64-byte lines of a bin that leave the ring together (1, 2 or 4; needs a ring depth of >= 4x that)
 };
 
 // T = u64 (MurmurHash3 / mix64 values; sub-bin = value bits block_bits...), u32 (compact dedupe-first entries: the low 32
@@ -311,8 +316,8 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
         if (i < a.ovf_cap) { a.ovf[2 * i] = h; a.ovf[2 * i + 1] = c; }  // (cap = every pair: cannot be exceeded)
     };
     auto flush_lines = [&](bool drain) {
-        if constexpr (kPair) return ring_flush<2048u, T>(ring, cur, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_pair, bin_stride);
-        else return ring_flush<2048u, T>(ring, cur, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_one, bin_stride, ovf_hi);
+        if constexpr (kPair) return ring_flush<2048u, T>(ring, cur, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_pair, bin_stride, 0ULL, a.min_lines);
+        else return ring_flush<2048u, T>(ring, cur, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_one, bin_stride, ovf_hi, a.min_lines);
     };
     // A wave owns the input regions seg = 16 w + wave, + 16 W, ...; work unit = a slab of 64 lanes x 64 bytes.  Every wave
     // runs the same number of rounds so that the flush barriers line up.

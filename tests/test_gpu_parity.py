@@ -560,9 +560,10 @@ def oref_histo(ref):
     return list(zip(vals.tolist(), freq.tolist()))
 
 
-def test_compact_dedupe_path_flushes_before_u32_counts_can_wrap_and_hands_over_when_outgrown(KCT):
-    """k <= 21 takes the compact variant (u32 counts in a fixed 8.4 M-slot shadow): it must convert before 2^31 windows
-    have gone in, and hand over to the table-sized 64-bit shadow when the input brings more k-mers than it holds."""
+def test_compact_dedupe_path_over_many_passes_and_when_outgrown(KCT):
+    """k <= 21 takes the compact variant (u32 key + u32 count shadow).  Pending counts pile up over many passes without a
+    conversion in between (more than 2^31 window starts in all); and when the input brings more k-mers than the 8.4 M-slot
+    shadow of a small table holds, the table grows and a shadow of the new geometry (two partition levels) takes over."""
     import torch
 
     from oxli_amd import _lib
@@ -579,28 +580,29 @@ def test_compact_dedupe_path_flushes_before_u32_counts_can_wrap_and_hands_over_w
         return r
 
     ra = make(3_000_000, 11)
-    std = KCT(k, capacity=8_000_000)
+    std = KCT(k, capacity=5_000_000)
     std.set_path("partitioned")
     n = std.consume_device(ra.data_ptr(), ra.numel(), N * L)
     ka, ca = std.dump_arrays(1)
-    dev = KCT(k, capacity=8_000_000)
+    dev = KCT(k, capacity=5_000_000)
+    assert dev.capacity == 1 << 23                                 # 1024 blocks: the small compact shadow, one level
     dev.set_path("dedupe")
     dev.profile(True)
     passes = 16                                                    # 16 x 1.5e8 window starts > 2^31
     for _ in range(passes):
         assert dev.consume_device(ra.data_ptr(), ra.numel(), N * L) == n
     prof = dev.profile_read()
-    assert prof["aggregate_blocks32_kernel"][0] == passes and prof["shadow32_flush_kernel"][0] >= 1   # converted on the way
+    assert prof["aggregate_blocks32_kernel"][0] == passes and "flush_partition_kernel" not in prof   # all of it still pending
     kd, cd = dev.dump_arrays(1)
     assert np.array_equal(kd, ka) and np.array_equal(cd, passes * ca)
-    # a second genome: 3 M + 4 M distinct k-mers do not fit the compact shadow -> the 64-bit shadow takes over
+    # a second genome: 3 M + 4 M distinct k-mers do not fit the small shadow (nor 65 % of the table): both grow
     rb = make(4_000_000, 1_000_000_021)        # (the generator indexes one stream by seed + position: seeds far apart)
     nb = std.consume_device(rb.data_ptr(), rb.numel(), N * L)
     dev.profile_reset()
     for _ in range(3):
         assert dev.consume_device(rb.data_ptr(), rb.numel(), N * L) == nb
     prof = dev.profile_read()
-    assert "aggregate_blocks_kernel<shadow>" in prof, prof
+    assert dev.capacity > 1 << 23 and "repartition_kernel<compact>" in prof, (dev.capacity, prof)
     std.consume_device(rb.data_ptr(), rb.numel(), N * L); std.consume_device(rb.data_ptr(), rb.numel(), N * L)
     for _ in range(passes - 1):
         std.consume_device(ra.data_ptr(), ra.numel(), N * L)

@@ -140,14 +140,16 @@ def test_tables_of_more_than_1024_blocks_match_the_oracle(gpu, k, path, G, R):
     t.profile(True)
     assert t.consume_device(dev_reads.data_ptr(), dev_reads.numel(), R * L) == n_ref == R * (L - k + 1)
     prof = t.profile_read()
-    if k == 21 and path != "partitioned":
+    # "auto": the probe's verdict -- dedupe-first goes on (3 Mbp genome), or the rest of the call hashes every window
+    dedupe_first = path == "dedupe" or (path == "auto" and k <= 32 and G == 3_000_000)
+    if dedupe_first and k == 21:
         assert "repartition_kernel<compact>" in prof and "aggregate_blocks32_kernel" in prof, prof
-    elif k == 31:
+    elif dedupe_first:
         assert "repartition_kernel" in prof and "aggregate_blocks_kernel<shadow>" in prof, prof
     else:
         assert "repartition_kernel" in prof and "aggregate_blocks_kernel" in prof, prof
-    if path == "auto" and k <= 32:   # the probe's verdict: the hashing K1 ran for the rest of the call, or not at all
-        assert ("partition_windows_kernel" in prof) == (G == 6_000_000), prof
+    if path == "auto" and k <= 32:
+        assert ("partition_windows_kernel" in prof) == (not dedupe_first), prof
     dk, dc = t.dump_arrays(1)
     if k <= 32 and path != "partitioned":
         assert "repartition_kernel<pairs>" in t.profile_read(), t.profile_read()   # the two-level pair flush ran
