@@ -378,6 +378,7 @@ kct_status flush_shadow(kct_table *t) {
 struct DedupeOutcome {
     u64 new_keys = 0;   // k-mers the pass met for the first time (new shadow keys + what went past the shadow)
     u64 blocked = 0;    // entries that found their shadow block full
+    u64 counted = 0;    // entries counted into the shadow (dry runs)
 };
 
 // After a dedupe-first pass: too few repeats to be worth it, or the shadow is filling up?  `probe`: the pass was the
@@ -417,7 +418,10 @@ bool compact_pays(const kct_table *t, u64 npos) {
     return known <= (u64)((double)(1ULL << (kCompactBlockBits + kct::kBlockBitsMax)) * 0.6);
 }
 
-kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled, bool probe) {
+// dry (the probe of a large table, counting into its own small shadow): K1 and K2 only -- nothing reaches the real table,
+// no state changes, *n_out stays; what the pass saw comes back in *dry.
+kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled, bool probe,
+                           DedupeOutcome *dry = nullptr) {
     *handled = false;
     const int k = t->k;
     {
@@ -434,7 +438,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
     const unsigned int region_cap = (region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P) + 15u) & ~15u;  // 16-entry lines
     const unsigned int ovf_cap = overflow_capacity(tiles_per_wg * kct::kPartTile);
-    KCT_TRY(materialize(t));
+    if (!dry) KCT_TRY(materialize(t));
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 4));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
     KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
@@ -498,6 +502,15 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     // between; the pair count is read on the device), spilling -- if the table lacks room -- into the SECOND half of the
     // spill buffer.  Two levels (passes of 10^8+ windows): after the counters have been read, into a list of the right size.
     u64 c[4], blocked;
+    if (dry) {
+        KCT_TRY(read_counters(t, c, &blocked));
+        if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;
+        *handled = true;
+        dry->counted = c[kct::CTR_COUNTED]; dry->new_keys = c[kct::CTR_NEW_BY_ZERO]; dry->blocked = blocked;
+        KCT_DBG(t, "compact dedupe pass (dry probe): npos=%llu counted=%llu new keys=%llu blocked=%llu\n", (unsigned long long)npos,
+                (unsigned long long)dry->counted, (unsigned long long)dry->new_keys, (unsigned long long)blocked);
+        return KCT_OK;
+    }
     kct::TableView mv = view(t, npos);
     if (two_level) {
         KCT_TRY(read_counters(t, c, &blocked));
@@ -559,14 +572,15 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
 // raw = true (dedupe-first, k <= 32): K1 emits mix64(packed k-mer) values, K2 counts them into the shadow table
 //        (same geometry); what does not fit (overflow regions, pairs that found their block full) is hashed and goes
 //        to the real table at once.
-kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled, bool raw, bool probe = false) {
+kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled, bool raw, bool probe = false,
+                               DedupeOutcome *dry = nullptr) {
     *handled = false;
     const int k = t->k;
     if (raw) {
         bool ok = true;
         KCT_TRY(ensure_shadow(t, probe ? std::min(t->cap, kProbeShadowSlots) : t->cap, &ok));  // (the probe's shadow is a small one)
         if (!ok) { t->dedupe_off = true; return KCT_OK; }
-        KCT_TRY(materialize(t));  // what does not fit the shadow goes straight to the real table
+        if (!dry) KCT_TRY(materialize(t));  // what does not fit the shadow goes straight to the real table
     }
     du64 *words = raw ? t->shadow : t->slots;
     // the geometry K1 / K1b / K2 work in: the table's, or the shadow's
@@ -667,6 +681,10 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     }
     if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // abandoned: K2 and the merges exited early, nothing was touched
     *handled = true;
+    if (dry) {  // (raw only) the probe of a large table: K1 and K2 into its own small shadow, nothing else
+        dry->counted = c[kct::CTR_COUNTED]; dry->new_keys = c[kct::CTR_NEWKEYS]; dry->blocked = spilled;
+        return KCT_OK;
+    }
     if (!raw) {
         t->lazy_empty = false;
         *n_out += c[kct::CTR_COUNTED] + c[kct::CTR_TOTAL_ADDED];
@@ -787,32 +805,40 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         t->call_windows_left = last_start + 1 - done;
         if (probe) {
             probe = false;
-            // The probe counts into its own small shadow, swapped in for this pass.  (Nothing is pending and no shadow holds
-            // a key -- that is when a probe is made -- so the table-sized shadows are simply set aside.)  A table of up to
-            // 1024 blocks has a small shadow anyway: no swap, and what the probe counted stays pending.
+            // A table of up to 1024 blocks has a small shadow anyway: the probe is an ordinary dedupe-first pass whose counts stay
+            // pending.  A larger table's probe is a DRY RUN into a small shadow of its own, swapped in for this pass (nothing is
+            // pending and no shadow holds a key -- that is when a probe is made -- so the table-sized shadows are simply set
+            // aside): nothing reaches the real table, which may stay lazily empty, and the probe's windows are counted again with
+            // the rest of the call.
             const bool use_compact = t->k <= 21 && !t->compact_off;
             const bool swap32 = use_compact && compact_sbits_for(t) != kCompactBlockBits, swap64 = !use_compact && t->cap > kProbeShadowSlots;
+            const bool dry_run = swap32 || swap64;
             unsigned int *big32 = t->shadow32; const int big_sbits = t->s32_sbits;
             du64 *big64 = t->shadow; const u64 big_cap = t->shadow_cap; const int big_bb = t->shadow_block_bits;
             if (swap32) { t->shadow32 = t->probe_shadow32; t->s32_sbits = kCompactBlockBits; t->s32_empty = true; }
             if (swap64) { t->shadow = t->probe_shadow; t->shadow_cap = t->shadow ? kProbeShadowSlots : 0; t->shadow_block_bits = kct::kBlockBitsMax; t->shadow_empty = true; }
             const u64 table_before = t->n_keys, n_before = *n_out;
+            DedupeOutcome seen;
             bool handled = false;
             kct_status st = KCT_OK;
-            if (use_compact) st = consume_compact(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true);
-            if (st == KCT_OK && !handled && !t->dedupe_off) st = consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true, true);
-            const u64 fresh_keys = std::max(t->shadow_keys, t->s32_keys) + (t->n_keys - table_before);
-            if (st == KCT_OK && (swap32 || swap64)) st = flush_shadow(t);  // the probe's k-mers move on to the table before its shadow is set aside
-            if (swap32) { t->probe_shadow32 = t->shadow32; t->shadow32 = big32; t->s32_sbits = big_sbits; t->s32_empty = true; t->s32_keys = 0; t->s32_dirty = false; }
-            if (swap64) { t->probe_shadow = t->shadow; t->shadow = big64; t->shadow_cap = big_cap; t->shadow_block_bits = big_bb; t->shadow_empty = true; t->shadow_keys = 0; t->shadow_dirty = false; }
+            if (use_compact) st = consume_compact(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true, dry_run ? &seen : nullptr);
+            if (st == KCT_OK && !handled && !t->dedupe_off && (!dry_run || swap64))
+                st = consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true, true, dry_run ? &seen : nullptr);
+            if (swap32) { t->probe_shadow32 = t->shadow32; t->shadow32 = big32; t->s32_sbits = big_sbits; t->s32_empty = true; }
+            if (swap64) { t->probe_shadow = t->shadow; t->shadow = big64; t->shadow_cap = big_cap; t->shadow_block_bits = big_bb; t->shadow_empty = true; }
             KCT_TRY(st);
             if (handled) {
-                done += npos; t->windows_since_read += npos;
-                const u64 valid = std::max<u64>(1, *n_out - n_before);                           // window starts that held a k-mer
+                u64 valid, fresh_keys;
+                if (dry_run) { valid = std::max<u64>(1, seen.counted + seen.blocked); fresh_keys = seen.new_keys + seen.blocked; }
+                else {
+                    done += npos; t->windows_since_read += npos;
+                    valid = std::max<u64>(1, *n_out - n_before);                                 // window starts that held a k-mer
+                    fresh_keys = std::max(t->shadow_keys, t->s32_keys) + (t->n_keys - table_before);
+                }
                 const double x = draws_per_distinct((double)fresh_keys / (double)valid);         // the probe's k-mers per distinct k-mer
                 const double per_key = x * (double)call_windows / (double)npos;                  // ... the whole call's
                 const bool pays = per_key >= (double)windows_per_pending_key(t);
-                KCT_DBG(t, "dedupe probe: %llu k-mers, %llu first sightings -> ~%.3g k-mers per distinct k-mer over the call: %s\n",
+                KCT_DBG(t, "dedupe probe%s: %llu k-mers, %llu first sightings -> ~%.3g k-mers per distinct k-mer over the call: %s\n", dry_run ? " (dry run)" : "",
                         (unsigned long long)valid, (unsigned long long)fresh_keys, per_key, pays ? "dedupe-first" : "hash every window");
                 if (pays) t->dedupe_hint = true;
                 else { KCT_TRY(flush_shadow(t)); t->dedupe_off = true; }

@@ -151,7 +151,7 @@ def test_tables_of_more_than_1024_blocks_match_the_oracle(gpu, k, path, G, R):
     if path == "auto" and k <= 32:
         assert ("partition_windows_kernel" in prof) == (not dedupe_first), prof
     dk, dc = t.dump_arrays(1)
-    if k <= 32 and path != "partitioned":
+    if dedupe_first:
         assert "repartition_kernel<pairs>" in t.profile_read(), t.profile_read()   # the two-level pair flush ran
     rk, rc = ref.dump_arrays()
     assert np.array_equal(dk, rk) and np.array_equal(dc, rc)
