@@ -1,30 +1,47 @@
 #!/usr/bin/env python3
 """bench.py -- k-mers/sec through consume (BASELINE.json metric) on N MI355X of one node.
 
-The job: every rank streams batches of synthetic reads (already resident in HBM) into its own
-device table with kct_consume_device -- a "step" is one batch of R reads per GPU -- and, when
-N > 1, ONE final owner-partitioned RCCL all-to-all turns the per-rank tables into the global table
-(oxli_amd.distributed.merge_across_ranks; reference semantics: add(), lib.rs:778-837).  The table
-is empty when the timed region starts, the final merge is INSIDE the timed region, and `value` =
-all k-mers counted by all ranks / that time.  Work per GPU is fixed as N grows (weak scaling):
-step s of rank r counts reads [(s*N + r)*R, (s*N + r + 1)*R) of one read stream, so no read is
-counted twice and every step brings new reads (up to --batches distinct batches per rank are kept
-resident and cycled).
+HEADLINE (`value`, `ms_per_step`): BASELINE.json configs[1] ("C2") -- every rank streams K batches ("steps") of
+R = 1 M synthetic 150 bp reads, already resident in HBM, into its own device table with kct_consume_device at k = 21
+(reads drawn from a 5 Mbp synthetic genome, SEED_G 42 / SEED_R 1337; table sized for 5 M distinct keys), then converts
+what the dedupe-first path left pending; when N > 1 ONE owner-partitioned RCCL all-to-all (oxli_amd.distributed.
+merge_across_ranks; reference semantics: add(), lib.rs:778-837) turns the per-rank tables into the global table.
+That K-step JOB -- table empty when the clock starts, exactly K steps, conversion and merge inside the timed region,
+barrier + synchronize on both sides, max over ranks -- is REPEATED until >= 0.5 s have been timed; `value` is the
+median job's rate (min / max / repeats beside it).  Step s of rank r counts reads [(s*N + r)*R, (s*N + r + 1)*R) of
+one read stream: as many distinct batches as steps (up to 64) are resident, so no read is counted twice inside a job.
+The table keeps what earlier passes taught it about its input (the dedupe hint), so this is the STEADY-STATE rate of a
+table that is filled again and again; the hint-free rate is `configs.cold_C2`.
 
-Default workload = BASELINE.json configs[1] ("C2"): R = 1 M reads x 150 bp, k = 21, reads drawn
-from a 5 Mbp synthetic genome (SEED_G 42, SEED_R 1337), device table sized for 5 M distinct keys.
+`configs` (rank 0, N = 1): the other workloads BASELINE.json / the north-star sentence name, each timed on a table
+whose buffers exist (first call untimed) but which is empty and knows nothing about its input (`kmers_per_s`, "cold"),
+each with per-kernel device times, the algorithmic HBM fraction and a correctness gate (n, sum_counts, and -- the large
+ones -- len / min / max / sum of squared counts and ~10^6 sampled keys equal to the DIRECT path's table, plus an oracle
+slice when the CPU checker is enabled):
+  cold_C2        one 1 M-read pass into an empty, hint-free table + conversion
+  e2e_C2         the same batch from HOST memory through kct_consume_batch (pack + H2D + count; PCIe-inclusive)
+  per_record     the reference's own loop, `for rec: table.consume(rec)` (README.md:96-98), on a default table
+  north_star_k21 100 M x 150 bp, k=21, genome 500 Mbp, one GPU (the north-star sentence)
+  C3             100 M x 150 bp, k=31, genome 500 Mbp        (BASELINE.json configs[2])
+  C4_shard       one GPU's eighth of configs[3]: 12.5 M x 150 bp, k=21, same genome
+  C5_shard       one GPU's eighth of configs[4]: 1.25 M x 10 kbp, k=51
 
-The JSON line also carries
-  roofline     : the dominant kernel (count_windows_kernel), its ALGORITHMIC bytes per launch
-                 (k-mers per launch x (L/(L-k+1) + 24) B) over its average launch
-                 duration measured with HIP events on the table's stream inside the timed region.
-  cpu_baseline : the CPU restatement of the reference path (oracle/, "port") timed on this
-                 host on a bounded sample of the same read stream (rank 0, N = 1 only).
+`roofline`: bound "hbm"; `achieved` = ALGORITHMIC bytes per step (k-mers x (L/(L-k+1) + 24) B) / the summed
+device time of every kernel of the step (HIP events on the table's stream, in an instrumented repetition of the job;
+`value` is taken with the events off); `traffic` / `measured_frac` = PMC-measured HBM bytes per step (profiles/
+pmc_r02.json, only if it was collected from THIS source tree -- stamped with a hash of the kernel sources -- else null);
+`valu` = the ceiling that actually binds K1 (VALU instructions per window and issue-slot use from the same PMC file).
+`cpu_baseline`: the CPU restatement of the reference path (oracle/, "port") on this host: 1 thread (the reference's
+consume is single-threaded under the GIL), reads sharded over threads with a tree merge (reference-shaped "rayon"), and
+the key space sharded over all cores with nothing to merge (the best CPU row; `value`), medians of 3.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
+import math
 import os
+import statistics
 import sys
 import time
 
@@ -32,7 +49,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED_G, SEED_R = 42, 1337
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured for a plain copy)
+
+BIG = {  # name -> reads, read length, k, genome
+    "north_star_k21": (100_000_000, 150, 21, 500_000_000),
+    "C3": (100_000_000, 150, 31, 500_000_000),
+    "C4_shard": (12_500_000, 150, 21, 500_000_000),
+    "C5_shard": (1_250_000, 10_000, 51, 387_500_000),
+}
+ALL_CONFIGS = ["cold_C2", "e2e_C2", "per_record"] + list(BIG)
 
 
 def parse():
@@ -44,61 +69,107 @@ def parse():
     p.add_argument("--read-len", type=int, default=150)
     p.add_argument("--k", type=int, default=21)
     p.add_argument("--genome", type=int, default=5_000_000)
-    p.add_argument("--cpu-sample-reads", type=int, default=200_000)
-    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step job until this much has been timed")
+    p.add_argument("--max-repeats", type=int, default=400)
+    p.add_argument("--configs", default="all", help="'all', 'none' or a comma list of " + ",".join(ALL_CONFIGS))
+    p.add_argument("--no-headline", action="store_true", help="profiling aid: run only --configs")
+    p.add_argument("--no-cpu-baseline", action="store_true", help="also drops the oracle slices of the correctness gates")
     p.add_argument("--no-verify", action="store_true")
-    p.add_argument("--batches", type=int, default=8, help="distinct read batches resident per GPU (cycled over the steps)")
+    p.add_argument("--cpu-reads-1t", type=int, default=200_000)
+    p.add_argument("--cpu-reads-mt", type=int, default=2_000_000)
     p.add_argument("--path", choices=["auto", "direct", "partitioned", "dedupe"], default="auto")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo lets several ranks share one GPU for debugging")
     return p.parse_args()
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch from a committed rocprofv3 --pmc summary (profiles/*.json), else None."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def source_sha():
+    """Hash of the kernel sources: ties a committed PMC summary to the build it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "oxli_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_summary():
+    """profiles/pmc_r02.json if it was collected from this source tree, else {} (every PMC-derived field becomes null)."""
     try:
-        with open(path) as f:
-            return json.load(f).get(kernel.replace("<shadow>", ""), {}).get("hbm_bytes_per_launch")  # (K2 on the shadow table is K2)
+        with open(os.path.join(ROOT, "profiles", "pmc_r02.json")) as f:
+            d = json.load(f)
+        return d if d.get("source_sha") == source_sha() else {}
     except (OSError, ValueError):
-        return None
+        return {}
+
+
+def kernel_report(prof, kmers, b_alg, pmc_cfg):
+    """Per-kernel ms, the algorithmic fraction over the summed kernel time and -- when PMC data of this build exists --
+    measured HBM bytes, the measured fraction of peak and K1's VALU figures."""
+    all_ms = sum(v[1] for v in prof.values())
+    out = {"kernels_ms": {n: round(v[1], 4) for n, v in prof.items()}, "kernel_ms_total": round(all_ms, 4)}
+    if all_ms:
+        out["alg_frac"] = round(kmers * b_alg / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    traffic = None
+    if pmc_cfg:
+        per_launch = pmc_cfg.get("kernels", {})
+        got = [(per_launch[n]["hbm_bytes_per_launch"] * v[0]) for n, v in prof.items() if n in per_launch and "hbm_bytes_per_launch" in per_launch[n]]
+        if got:
+            traffic = sum(got)
+            out["hbm_bytes_measured"] = traffic
+            out["hbm_bytes_per_kmer"] = round(traffic / kmers, 3)
+            if all_ms:
+                out["measured_frac"] = round(traffic / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return out, traffic
 
 
 def cpu_baseline(args, log):
-    """Reference-shaped CPU path (oracle 'port') on a bounded sample of the same stream."""
+    """Reference-shaped CPU path (oracle 'port') on bounded samples of the same stream; medians of three runs."""
     import oracle
     try:
         oracle.build(native=True)
         native = True
     except Exception:  # noqa: BLE001 -- fall back to the portable build that travelled with the repo
         native = False
+    L, k = args.read_len, args.k
     genome = oracle.synth_genome(args.genome, SEED_G)
     cores = len(os.sched_getaffinity(0))
-    n1 = min(args.cpu_sample_reads, args.reads)
-    reads1 = oracle.synth_reads(genome, 0, n1, args.read_len, SEED_R)
-    _, km1, s1 = oracle.baseline_consume(reads1, args.read_len, args.k, 1, native)
-    log(f"cpu baseline: 1 thread {km1 / s1 / 1e6:.2f} Mk-mers/s on {n1} reads")
-    # "rayon-style" best case: private table per thread over contiguous shards + parallel tree merge;
-    # the best thread count is found by trying a few (more threads = more duplicate keys to merge)
-    nT = min(args.reads, 1_000_000)
-    readsT = reads1 if nT == n1 else oracle.synth_reads(genome, 0, nT, args.read_len, SEED_R)
-    tried, tabT = {}, None
-    for T in sorted({t for t in (8, 32, 128, cores) if 1 < t <= cores}):
-        tabT, km, s = oracle.baseline_consume(readsT, args.read_len, args.k, T, native)
-        tried[T] = km / s
-        log(f"cpu baseline: {T} threads {km / s / 1e6:.2f} Mk-mers/s on {nT} reads")
-    if tabT is None:  # single-core host: the verification table still has to cover the nT-read sample
-        tabT, _, _ = oracle.baseline_consume(readsT, args.read_len, args.k, 1, native)
-    rates = dict(tried)
-    rates[1] = km1 / s1
-    best_T = max(rates, key=rates.get)
-    best = (rates[best_T], best_T)
-    out = {"value": best[0], "unit": "k-mers/s", "cores": best[1], "kind": "port",
-           "sample": f"first {nT} reads of the same stream; private table per thread + parallel tree merge with add() "
-                     f"semantics, merge timed; thread counts tried {sorted(tried)} of {cores} host cores; "
-                     f"1 thread on first {n1} reads: {km1 / s1:.4g} k-mers/s",
-           "value_1thread": km1 / s1, "by_threads": {str(k): v for k, v in tried.items()}, "host_cores": cores,
-           "native_build": native}
-    return out, (readsT, tabT)
+    n1 = min(args.cpu_reads_1t, args.reads)
+    nT = max(n1, args.cpu_reads_mt)
+    readsT = oracle.synth_reads(genome, 0, nT, L, SEED_R)
+    med = statistics.median
+
+    def rate(fn):
+        runs = []
+        for _ in range(3):
+            _t, km, s = fn()
+            runs.append(km / s)
+        return med(runs), runs
+
+    r1, runs1 = rate(lambda: oracle.baseline_consume(readsT[:n1], L, k, 1, native))
+    log(f"cpu baseline: 1 thread {r1 / 1e6:.2f} Mk-mers/s on {n1} reads (median of 3)")
+    # reference-shaped multi-thread ("rayon-style"): reads sharded, private tables, parallel tree merge with add() semantics
+    by_threads = {}
+    for T in sorted({t for t in (8, 32, 128) if 1 < t <= cores}):
+        by_threads[T], _ = rate(lambda T=T: oracle.baseline_consume(readsT, L, k, T, native))
+        log(f"cpu baseline: reads sharded over {T} threads + tree merge {by_threads[T] / 1e6:.2f} Mk-mers/s on {nT} reads")
+    # best CPU: key space sharded over all cores, no merge
+    sharded = {}
+    for T in sorted({t for t in (32, 64, cores) if 1 < t <= cores} or {1}):
+        sharded[T], _ = rate(lambda T=T: oracle.sharded_consume(readsT, L, k, T, 262144, native))
+        log(f"cpu baseline: key space sharded over {T} threads {sharded[T] / 1e6:.2f} Mk-mers/s on {nT} reads")
+    best_T = max(sharded, key=sharded.get)
+    best_rayon = max(by_threads.values()) if by_threads else r1
+    value, cores_used, shape = sharded[best_T], best_T, "key space sharded over threads, nothing to merge"
+    if best_rayon > value:
+        value, cores_used, shape = best_rayon, max(by_threads, key=by_threads.get), "reads sharded over threads, tree merge"
+    tab1, _, _ = oracle.baseline_consume(readsT[:n1], L, k, min(cores, 16), native)   # the verification table of the n1-read sample
+    out = {"value": value, "unit": "k-mers/s", "cores": cores_used, "kind": "port",
+           "sample": f"first {nT} reads of the same stream ({nT * (L - k + 1)} k-mers), median of 3 runs; best of: {shape}; "
+                     f"1 thread on the first {n1} reads: {r1:.4g} k-mers/s; the >= 10x target is quoted against `value`",
+           "value_1thread": r1, "reads_sharded_tree_merge": {str(t): round(v) for t, v in by_threads.items()},
+           "keyspace_sharded": {str(t): round(v) for t, v in sharded.items()}, "host_cores": cores, "native_build": native}
+    return out, (readsT[:n1], tab1)
 
 
 def main():
@@ -132,17 +203,43 @@ def main():
     lib = _lib.load()
     L, k, R, G = args.read_len, args.k, args.reads, args.genome
     kmers_per_step = R * (L - k + 1)
+    b_alg = L / (L - k + 1) + 24.0
     stream = torch.cuda.current_stream().cuda_stream
+    ablate = bool(os.environ.get("KCT_ABLATE"))  # timing experiments that deliberately skip work: no result checks
+    pmc = pmc_summary()
+    med = statistics.median
+    want = ALL_CONFIGS if args.configs == "all" else [] if args.configs == "none" else [c for c in args.configs.split(",") if c]
+    for c in want:
+        if c not in ALL_CONFIGS:
+            raise SystemExit(f"unknown config {c!r}; choose from {ALL_CONFIGS}")
+    checker = rank == 0 and world == 1 and not args.no_cpu_baseline   # the CPU oracle as the checker of the gates
+    if checker:
+        import oracle
+
+    def synth(G_, R_, L_, first=0):
+        g = torch.empty(G_, dtype=torch.uint8, device="cuda")
+        r = torch.empty(R_ * (L_ + 1), dtype=torch.uint8, device="cuda")
+        assert lib.kct_synth_genome_device(g.data_ptr(), G_, SEED_G, stream) == 0
+        assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), G_, first, R_, L_, SEED_R, stream) == 0
+        torch.cuda.synchronize()
+        return g, r
+
+    result = {
+        "metric": "k-mers/sec (consume) at k=%d, %d bp reads" % (k, L), "value": None, "unit": "k-mers/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic" if not ablate else "INVALID (KCT_ABLATE set: work skipped)",
+    }
+
+    # ------------------------------------------------------------------------------------------ headline: C2
     genome = torch.empty(G, dtype=torch.uint8, device="cuda")
     assert lib.kct_synth_genome_device(genome.data_ptr(), G, SEED_G, stream) == 0
-    nb = max(1, min(args.batches, args.steps))
+    nb = max(1, min(args.steps, 64))
     batches = []
     for b in range(nb):
         reads = torch.empty(R * (L + 1), dtype=torch.uint8, device="cuda")
         assert lib.kct_synth_reads_device(reads.data_ptr(), genome.data_ptr(), G, (b * world + rank) * R, R, L, SEED_R, stream) == 0
         batches.append(reads)
     torch.cuda.synchronize()
-
     table = KmerCountTable(k, capacity=G, device=local)
     table.set_stream(stream)
     table.set_path(args.path)
@@ -151,106 +248,249 @@ def main():
         reads = batches[s % nb]
         return table.consume_device(reads.data_ptr(), reads.numel(), R * L)
 
-    for s in range(args.warmup):
-        step(s)
-    if world > 1 and args.warmup:
-        merge_across_ranks(table)  # warm the collective and the merge kernels too
-    table.clear()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    n_total = 0
-    for s in range(args.steps):
-        n_total += step(s)
-    t_merge = time.perf_counter()
-    if world > 1:
-        merge_across_ranks(table)
-    table.sync()  # counts still pending in the dedupe-first path's shadow table are converted inside the timed region
-    torch.cuda.synchronize()
-    merge_ms = (time.perf_counter() - t_merge) * 1e3
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        n_all = global_scalar_sum(n_total, "cuda")
-    else:
-        n_all = n_total
-    ablate = bool(os.environ.get("KCT_ABLATE"))  # timing experiments that deliberately skip work: no result checks
-    assert ablate or n_total == kmers_per_step * args.steps, (n_total, kmers_per_step * args.steps)
+    def job():
+        """clear, K steps, conversion (+ merge): (seconds [max over ranks], k-mers of this rank, merge ms, pairs received)"""
+        table.clear()
+        if world > 1:
+            table.resize(G)  # (the merge left an owner-sized table: back to a rank's private capacity, outside the timed region)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        n = 0
+        for s in range(args.steps):
+            n += step(s)
+        t_merge = time.perf_counter()
+        recv = merge_across_ranks(table) if world > 1 else 0
+        table.sync()  # counts still pending in the dedupe-first path's shadow table are converted inside the timed region
+        torch.cuda.synchronize()
+        merge_ms = (time.perf_counter() - t_merge) * 1e3
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, n, merge_ms, recv
 
-    # invariants of the finished job (cheap, outside the timed region)
-    distinct = global_scalar_sum(len(table), "cuda") if world > 1 else len(table)
-    total_counts = global_scalar_sum(table.sum_counts, "cuda") if world > 1 else table.sum_counts
-    assert ablate or total_counts == world * kmers_per_step * args.steps, (total_counts, world * kmers_per_step * args.steps)
+    if not args.no_headline:
+        for s in range(args.warmup):
+            step(s)
+        if world > 1 and args.warmup:
+            merge_across_ranks(table)  # warm the collective and the merge kernels too
+        first = job()  # (also teaches a fresh table that the dedupe-first path pays: the steady state)
+        repeats = int(min(args.max_repeats, max(5 if world == 1 else 3, math.ceil(args.min_seconds / max(first[0], 1e-6)))))
+        if world > 1:  # every rank must run the same number of jobs
+            t = torch.tensor([repeats], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            repeats = int(t.item())
+        runs = [job() for _ in range(repeats)]
+        n_total = runs[-1][1]
+        assert ablate or all(r[1] == kmers_per_step * args.steps for r in runs), (n_total, kmers_per_step * args.steps)
+        n_all = global_scalar_sum(n_total, "cuda") if world > 1 else n_total
+        times = sorted(r[0] for r in runs)
+        elapsed = med(times)
+        value = n_all / elapsed
+        # invariants of the finished job (cheap, outside the timed region)
+        distinct = global_scalar_sum(len(table), "cuda") if world > 1 else len(table)
+        total_counts = global_scalar_sum(table.sum_counts, "cuda") if world > 1 else table.sum_counts
+        assert ablate or total_counts == world * kmers_per_step * args.steps, (total_counts, world * kmers_per_step * args.steps)
+        # Per-kernel device times: the SAME job once more with the library's HIP-event timing switched on (an event pair
+        # around every launch costs ~6 % at this step size, so it stays out of the jobs `value` is taken from).
+        table.clear()
+        table.profile(True)
+        table.profile_reset()
+        for s in range(args.steps):
+            step(s)
+        table.sync()
+        torch.cuda.synchronize()
+        prof = table.profile_read()
+        table.profile(False)
+        rep, traffic_job = kernel_report(prof, kmers_per_step * args.steps, b_alg, pmc.get("C2"))
+        all_ms = rep["kernel_ms_total"]
+        dom = max(prof, key=lambda n_: prof[n_][1]) if prof else "none"
+        launches, ms = prof.get(dom, (0, 0.0))
+        pipe_gbs = kmers_per_step * args.steps * b_alg / (all_ms * 1e-3) / 1e9 if all_ms else float("nan")
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": pipe_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pipe_gbs / HBM_PEAK_GBS,
+                    "traffic": traffic_job / args.steps if traffic_job else None,
+                    "measured_frac": (traffic_job / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_job and all_ms else None,
+                    "basis": "achieved = algorithmic bytes per step (25.15 B/k-mer x k-mers) / summed device time of every kernel of the step (HIP "
+                             "events, instrumented repetition); traffic = PMC HBM bytes per step and measured_frac = traffic / kernel time / peak, "
+                             "from profiles/pmc_r02.json when it matches this source tree (else null)",
+                    "alg_bytes_per_kmer": b_alg, "kmers_per_step": kmers_per_step, "kernel_ms_per_step": all_ms / args.steps,
+                    "frac_of_wall": kmers_per_step * b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                    "dominant_kernel": {"name": dom, "avg_launch_ms": ms / launches if launches else None, "launches": launches},
+                    "kernels_ms_per_step": {n_: round(v[1] / args.steps, 4) for n_, v in prof.items()},
+                    "valu": pmc.get("C2", {}).get("valu"), "atomics": pmc.get("C2", {}).get("atomics"), "pmc_source_sha": pmc.get("source_sha")}
+        result.update({
+            "value": value, "ms_per_step": elapsed / args.steps * 1e3,
+            "repeats": repeats, "timed_seconds": sum(times), "value_min": n_all / times[-1], "value_max": n_all / times[0],
+            "config": {"workload": f"C2: {R} x {L} bp synthetic reads per GPU per step, k={k}, genome {G} bp (seed {SEED_G}/{SEED_R}), "
+                                   f"device hash table in HBM ({table.capacity} slots x 16 B); steady state (table cleared, dedupe hint kept)",
+                       "reads_per_gpu": R, "read_len": L, "k": k, "genome": G, "distinct_kmers": distinct, "distinct_batches_per_gpu": nb,
+                       "job": f"{args.steps} steps into an empty table + conversion of pending counts" +
+                              (f" + one RCCL owner all-to-all merge ({med([r[2] for r in runs]):.3f} ms on rank 0, {runs[-1][3]} pairs received)" if world > 1 else ""),
+                       "world": world, "backend": args.backend if world > 1 else None},
+            "roofline": roofline,
+        })
+        if world > 1:
+            recv_all = [None] * world
+            dist.all_gather_object(recv_all, int(runs[-1][3]))
+            result["config"]["pairs_received_per_rank"] = recv_all
+            result["config"]["merge_ms_rank0_median"] = med([r[2] for r in runs])
 
-    # Per-kernel device times for the roofline: the SAME steps once more with the library's HIP-event timing switched on
-    # (an event pair around every launch costs ~6 % at this step size, so it stays out of the region `value` is taken from).
-    table.clear()
-    table.profile(True)
-    table.profile_reset()
-    for s in range(args.steps):
-        step(s)
-    table.sync()
-    torch.cuda.synchronize()
-    prof = table.profile_read()
-    table.profile(False)
+    # ------------------------------------------------------------------------------------------ the other configs
+    configs = {}
 
-    value = n_all / elapsed
-    b_alg = L / (L - k + 1) + 24.0
-    # dominant kernel = the one with the most device time inside the timed region
-    dom = max(prof, key=lambda n: prof[n][1]) if prof else "none"
-    launches, ms = prof.get(dom, (0, 0.0))
-    avg_ms = ms / launches if launches else float("nan")
-    kmers_per_launch = kmers_per_step * args.steps / launches if launches else 0
-    achieved = kmers_per_launch * b_alg / (avg_ms * 1e-3) / 1e9 if launches else float("nan")
-    all_ms = sum(v[1] for v in prof.values())
-    pipe_gbs = kmers_per_step * args.steps * b_alg / (all_ms * 1e-3) / 1e9 if all_ms else float("nan")
-    # The step is a PIPELINE of kernels that each see every k-mer (partition, then count): dividing the algorithmic bytes
-    # by the dominant kernel's time alone would flatter the path (and exceeds the peak once a kernel no longer hashes), so
-    # `achieved` / `frac` divide by the SUM of all kernels' device time per step; the dominant kernel's own figures,
-    # measured HBM traffic included, sit in `dominant_kernel`.
-    step_traffic = [pmc_traffic(n) for n in prof]
-    traffic_step = (sum(t * prof[n][0] for n, t in zip(prof, step_traffic) if t) / args.steps) if any(step_traffic) else None
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": pipe_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": pipe_gbs / HBM_PEAK_GBS, "traffic": traffic_step,
-                "basis": "algorithmic bytes per step (25.15 B/k-mer x k-mers) / sum of the device time of every kernel of the step, HIP events around "
-                         "every launch of a repetition of the timed steps (event timing off while `value` is taken); "
-                         "traffic = PMC-measured HBM bytes per step summed over the kernels (profiles/pmc_traffic.json)",
-                "alg_bytes_per_kmer": b_alg, "kmers_per_step": kmers_per_step, "kernel_ms_per_step": all_ms / args.steps,
-                "dominant_kernel": {"name": dom, "avg_launch_ms": avg_ms, "launches": launches, "kmers_per_launch": kmers_per_launch,
-                                    "achieved_alone": achieved, "frac_alone": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom)},
-                "kernels_ms_per_step": {n: round(v[1] / args.steps, 4) for n, v in prof.items()}}
+    def timed_call(t, fn, cold):
+        """One call on an existing table: cleared, and (cold) made to forget what it learnt about its input."""
+        t.clear()
+        if cold:
+            t.set_path(args.path)  # (resets the dedupe hint)
+        t.profile(True)
+        t.profile_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = fn()
+        t.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = t.profile_read()
+        t.profile(False)
+        return dt, n, prof
 
-    result = {
-        "metric": "k-mers/sec (consume) at k=%d, %d bp reads" % (k, L),
-        "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64", "data": "synthetic" if not ablate else "INVALID (KCT_ABLATE set: work skipped)",
-        "config": {"workload": f"C2: {R} x {L} bp synthetic reads per GPU, k={k}, genome {G} bp (seed {SEED_G}/{SEED_R}), "
-                               f"device hash table in HBM ({table.capacity} slots x 16 B)",
-                   "reads_per_gpu": R, "read_len": L, "k": k, "genome": G, "distinct_kmers": distinct,
-                   "distinct_batches_per_gpu": nb,
-                   "step": "consume one batch of reads into the rank's table" +
-                           (f"; one final RCCL owner all-to-all merge inside the timed region ({merge_ms:.3f} ms on rank 0)" if world > 1 else "")},
-        "roofline": roofline,
-    }
+    def table_stats(t):
+        lo, hi, sq = t._count_stats()
+        return [len(t), t.sum_counts, lo, hi, sq]
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle
-        base, (sample_reads, sample_table) = cpu_baseline(args, log)
+    if rank == 0 and world == 1 and want:
+        del batches[1:]
+        torch.cuda.empty_cache()
+        reads0 = batches[0]
+        if "cold_C2" in want:
+            runs = [timed_call(table, lambda: table.consume_device(reads0.data_ptr(), reads0.numel(), R * L), True) for _ in range(9)]
+            dt, n, prof = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
+            rep, _ = kernel_report(prof, kmers_per_step, b_alg, pmc.get("cold_C2"))
+            ok = all(r[1] == kmers_per_step for r in runs) and table.sum_counts == kmers_per_step
+            configs["cold_C2"] = {"kmers_per_s": kmers_per_step / dt, "seconds": dt, "runs": len(runs), "gate": {"n_and_sum_counts": bool(ok)}, **rep}
+            assert ablate or ok
+        host = None
+        if "e2e_C2" in want or "per_record" in want:
+            host = reads0.cpu().numpy().reshape(R, L + 1)
+        if "e2e_C2" in want:
+            flat = np.ascontiguousarray(host[:, :L]).reshape(-1)
+            offsets = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
+            runs = [timed_call(table, lambda: table.consume_batch((flat, offsets)), False) for _ in range(5)]
+            dt, n, prof = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
+            rep, _ = kernel_report(prof, kmers_per_step, b_alg, None)
+            ok = all(r[1] == kmers_per_step for r in runs) and table.sum_counts == kmers_per_step
+            configs["e2e_C2"] = {"kmers_per_s": kmers_per_step / dt, "seconds": dt, "runs": len(runs),
+                                 "what": "kct_consume_batch from pageable host memory: pack into the record stream + H2D + count + conversion",
+                                 "gate": {"n_and_sum_counts": bool(ok)}, **rep}
+            assert ablate or ok
+        if "per_record" in want:
+            recs = [host[i, :L].tobytes() for i in range(R)]
+            t2 = KmerCountTable(k)          # default-constructed, as the README's loop would
+            t0 = time.perf_counter()
+            n = 0
+            consume = t2.consume
+            for rec in recs:
+                n += consume(rec)
+            total = t2.sum_counts           # (the first read of the table counts what the loop buffered)
+            dt = time.perf_counter() - t0
+            ok = n == kmers_per_step == total
+            configs["per_record"] = {"kmers_per_s": n / dt, "seconds": dt, "calls": R, "us_per_call": dt / R * 1e6,
+                                     "what": "for rec in reads: table.consume(rec) on KmerCountTable(21), Python loop and the final read included",
+                                     "gate": {"n_and_sum_counts": bool(ok)}}
+            assert ablate or ok
+            del t2, recs
+        del host
+    del batches, genome
+    if not args.no_headline:
+        sample_table = table
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1:
+        for name in [c for c in want if c in BIG]:
+            Rb, Lb, kb, Gb = BIG[name]
+            free, _tot = torch.cuda.mem_get_info()
+            if free < 230 * (1 << 30):
+                configs[name] = {"skipped": f"needs a whole MI355X: {free >> 30} GiB free"}
+                continue
+            log(f"config {name}: {Rb} x {Lb} bp, k={kb}, genome {Gb}")
+            g, r = synth(Gb, Rb, Lb)
+            del g
+            n_exp = Rb * (Lb - kb + 1)
+            balg = Lb / (Lb - kb + 1) + 24.0
+            t = KmerCountTable(kb, capacity=Gb)
+            t.set_path(args.path)
+            call = lambda: t.consume_device(r.data_ptr(), r.numel(), Rb * Lb)  # noqa: E731
+            t0 = time.perf_counter()
+            n_first = call()
+            t.sync()
+            first_s = time.perf_counter() - t0   # includes every allocation
+            cold = [timed_call(t, call, True) for _ in range(3)]
+            dt, n, prof = sorted(cold, key=lambda x: x[0])[1]
+            st = table_stats(t)
+            warm = timed_call(t, call, False)
+            rep, _ = kernel_report(prof, n_exp, balg, pmc.get(name))
+            gate = {"n": bool(n == n_exp == n_first and all(c_[1] == n_exp for c_ in cold) and warm[1] == n_exp), "sum_counts": bool(st[1] == n_exp)}
+            entry = {"kmers": n_exp, "kmers_per_s": n_exp / dt, "seconds": dt, "seconds_min_max": [min(c_[0] for c_ in cold), max(c_[0] for c_ in cold)],
+                     "kmers_per_s_warm": n_exp / warm[0], "seconds_first_call": first_s, "table_slots": t.capacity, "distinct": st[0], **rep}
+            if not args.no_verify:
+                # sampled keys: k-mer hashes of the first reads through the device's own hash kernel, plus keys that are absent
+                ns = 2000 if Lb <= 1000 else 30
+                sub = r[: ns * (Lb + 1)].cpu().numpy().reshape(ns, Lb + 1)
+                hs = np.unique(np.concatenate([t.hash_windows(sub[i, :Lb].tobytes()) for i in range(ns)]))
+                hs = hs[hs != 0]
+                sample = np.concatenate([hs, hs ^ np.uint64(0x5555555555555555)])
+                got = np.array(t.get_hash_array(sample), dtype=np.uint64)
+                if checker:  # an oracle slice: every key of the slice is present with at least the slice's count
+                    ref = oracle.OracleTable(kb)
+                    for i in range(ns):
+                        ref.consume(sub[i, :Lb])
+                    rk, rc = ref.dump_arrays()
+                    gate["oracle_slice"] = bool(np.array_equal(rk, hs) and np.all(np.array(t.get_hash_array(rk), dtype=np.uint64) >= rc))
+                t.release_scratch()
+                del t
+                torch.cuda.empty_cache()
+                d = KmerCountTable(kb, capacity=Gb)
+                d.set_path("direct")
+                t0 = time.perf_counter()
+                nd = d.consume_device(r.data_ptr(), r.numel(), Rb * Lb)
+                entry["direct_path_kmers_per_s"] = n_exp / (time.perf_counter() - t0)
+                sd = table_stats(d)
+                gate["equals_direct_path"] = bool(nd == n_exp and sd[:4] == st[:4] and math.isclose(sd[4], st[4], rel_tol=1e-12) and
+                                                  np.array_equal(np.array(d.get_hash_array(sample), dtype=np.uint64), got))
+                gate["sampled_keys"] = int(sample.size)
+                del d
+            else:
+                del t
+            entry["gate"] = gate
+            configs[name] = entry
+            log(f"config {name}: {entry['kmers_per_s']:.3g} k-mers/s cold, {entry['kmers_per_s_warm']:.3g} warm, gate {gate}")
+            assert ablate or all(v for kk, v in gate.items() if kk != "sampled_keys"), (name, gate)
+            del r
+            torch.cuda.empty_cache()
+    if configs:
+        result["configs"] = configs
+
+    # ------------------------------------------------------------------------------------------ CPU baseline + final check
+    if checker and not args.no_headline:
+        base, (sample_reads, sample_ref) = cpu_baseline(args, log)
         result["cpu_baseline"] = base
-        result["speedup_vs_cpu_baseline"] = value / base["value"]
+        result["speedup_vs_cpu_baseline"] = result["value"] / base["value"]
+        if "north_star_k21" in configs and "kmers_per_s" in configs["north_star_k21"]:
+            result["north_star_speedup_vs_cpu_baseline"] = configs["north_star_k21"]["kmers_per_s"] / base["value"]
         if not args.no_verify:
             # the same sample through the GPU must give the oracle's table bit for bit
             ns = sample_reads.shape[0]
-            table.clear()
-            n = table.consume_device(batches[0].data_ptr(), ns * (L + 1), ns * L)
-            dk, dc = table.dump_arrays(1)
-            rk, rc = sample_table.dump_arrays()
+            dev = torch.from_numpy(np.ascontiguousarray(sample_reads).reshape(-1)).cuda()
+            sample_table.clear()
+            n = sample_table.consume_device(dev.data_ptr(), dev.numel(), ns * L)
+            dk, dc = sample_table.dump_arrays(1)
+            rk, rc = sample_ref.dump_arrays()
             ok = n == ns * (L - k + 1) and np.array_equal(dk, rk) and np.array_equal(dc, rc)
             result["verified_vs_oracle"] = bool(ok)
             assert ok, "GPU table differs from the CPU oracle on the baseline sample"

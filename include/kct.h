@@ -68,6 +68,11 @@ KCT_API kct_status kct_clear(kct_table *t);
 /* Ensure room for `distinct` keys without further growth. */
 KCT_API kct_status kct_reserve(kct_table *t, uint64_t distinct);
 
+/* Give the table the capacity that suits `distinct` keys (at least what it holds) -- smaller than it is, if that is
+ * enough: the keys are re-inserted into a fresh array.  What the multi-GPU merge calls so that an owner's table is
+ * sized for its slice of the key space, not for the whole genome. */
+KCT_API kct_status kct_resize(kct_table *t, uint64_t distinct);
+
 /* ---- hashing ----------------------------------------------------------------------------
  * KmerCountTable::hash_kmer(kmer)                                            lib.rs:65-81
  * WRONG_KSIZE if (uint8_t)len != ksize (the reference compares `len as u8`), INVALID_DNA if

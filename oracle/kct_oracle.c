@@ -504,3 +504,99 @@ orc_table *orc_baseline_consume(const uint8_t *reads, uint64_t nreads, uint32_t 
     free(jobs); free(tid);
     return dst;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * The same per-record work with the KEY SPACE sharded instead of the reads ("best CPU" row of the
+ * bench): thread i hashes its slice of a batch of reads exactly as orc_consume does (upper-cased copy,
+ * reverse complement, bytewise min, MurmurHash3 -- lib.rs:576-600) but hands every hash to the thread
+ * that owns its slice of hash space; after a barrier each owner counts what it was handed into its
+ * own table (count_hash, lib.rs:100-104).  No two threads ever hold the same key, so there is nothing
+ * to merge (the reference's add(), lib.rs:778-837, never runs).  *seconds covers both phases of every
+ * batch.  The per-owner tables are folded into one AFTER the clock stops, for the caller's check.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint64_t *v; size_t n, cap; } hbuf;
+
+typedef struct {
+    const uint8_t *reads; uint64_t nreads, batch; uint32_t L; uint8_t k;
+    int id, threads;
+    hbuf *out;              /* [threads][threads]: out[id * threads + owner] */
+    orc_table **tables;     /* [threads] */
+    pthread_barrier_t *bar;
+    uint64_t n;
+} sharded_job;
+
+static void hbuf_push(hbuf *b, uint64_t h) {
+    if (b->n == b->cap) {
+        b->cap = b->cap ? 2 * b->cap : 4096;
+        b->v = (uint64_t *)realloc(b->v, b->cap * sizeof(uint64_t));
+    }
+    b->v[b->n++] = h;
+}
+
+static void *sharded_run(void *p) {
+    sharded_job *j = (sharded_job *)p;
+    const int T = j->threads;
+    orc_table *mine = j->tables[j->id];
+    uint64_t n = 0;
+    for (uint64_t b0 = 0; b0 < j->nreads; b0 += j->batch) {
+        const uint64_t bn = j->nreads - b0 < j->batch ? j->nreads - b0 : j->batch;
+        const uint64_t lo = b0 + bn * (uint64_t)j->id / (uint64_t)T, hi = b0 + bn * (uint64_t)(j->id + 1) / (uint64_t)T;
+        for (int o = 0; o < T; ++o) j->out[(size_t)j->id * T + o].n = 0;
+        for (uint64_t r = lo; r < hi; ++r) {   /* phase 1: hash my reads, route by owner */
+            seq_iter it;
+            uint64_t h;
+            int rc;
+            if (iter_init(&it, j->reads + r * (uint64_t)(j->L + 1), j->L, j->k, 1, 42) != ORC_OK) continue;
+            while ((rc = iter_next(&it, &h)) != 0) {
+                if (rc == 2 || h == 0) continue;
+                const int owner = (int)(((h >> 32) * (uint64_t)T) >> 32);
+                hbuf_push(&j->out[(size_t)j->id * T + owner], h);
+                ++n;
+            }
+            iter_free(&it);
+            mine->consumed += j->L;
+        }
+        pthread_barrier_wait(j->bar);
+        for (int src = 0; src < T; ++src) {     /* phase 2: count what I own */
+            const hbuf *b = &j->out[(size_t)src * T + j->id];
+            for (size_t i = 0; i < b->n; ++i) orc_count_hash(mine, b->v[i]);
+        }
+        pthread_barrier_wait(j->bar);
+    }
+    j->n = n;
+    return NULL;
+}
+
+orc_table *orc_sharded_consume(const uint8_t *reads, uint64_t nreads, uint32_t L, uint8_t k, int threads, uint64_t batch,
+                               uint64_t *kmers, double *seconds) {
+    if (threads < 1) threads = 1;
+    if (batch < (uint64_t)threads) batch = (uint64_t)threads;
+    const int T = threads;
+    sharded_job *jobs = (sharded_job *)calloc((size_t)T, sizeof *jobs);
+    pthread_t *tid = (pthread_t *)calloc((size_t)T, sizeof *tid);
+    hbuf *out = (hbuf *)calloc((size_t)T * T, sizeof *out);
+    orc_table **tables = (orc_table **)calloc((size_t)T, sizeof *tables);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)T);
+    for (int i = 0; i < T; ++i) tables[i] = orc_new(k);
+    double t0 = now_s();
+    for (int i = 0; i < T; ++i) {
+        jobs[i].reads = reads; jobs[i].nreads = nreads; jobs[i].batch = batch; jobs[i].L = L; jobs[i].k = k;
+        jobs[i].id = i; jobs[i].threads = T; jobs[i].out = out; jobs[i].tables = tables; jobs[i].bar = &bar;
+        pthread_create(&tid[i], NULL, sharded_run, &jobs[i]);
+    }
+    uint64_t n = 0;
+    for (int i = 0; i < T; ++i) { pthread_join(tid[i], NULL); n += jobs[i].n; }
+    *seconds = now_s() - t0;
+    *kmers = n;
+    for (int i = 1; i < T; ++i) {   /* untimed: one table for the caller's check (the owners' key sets are disjoint) */
+        uint64_t a, b;
+        orc_add(tables[0], tables[i], &a, &b);
+        orc_free(tables[i]);
+    }
+    orc_table *dst = tables[0];
+    for (size_t i = 0; i < (size_t)T * T; ++i) free(out[i].v);
+    pthread_barrier_destroy(&bar);
+    free(out); free(tables); free(jobs); free(tid);
+    return dst;
+}

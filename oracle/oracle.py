@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ORC_OK, ORC_ERR_WRONG_KSIZE, ORC_ERR_INVALID_DNA, ORC_ERR_BAD_KMER, ORC_ERR_KSIZE_MISMATCH = 0, 1, 2, 3, 4
 
 __all__ = ["OracleTable", "murmur64", "hash_kmer", "seq_to_hashes", "synth_genome", "synth_reads",
-           "baseline_consume", "build", "lib", "mix64"]
+           "baseline_consume", "sharded_consume", "build", "lib", "mix64"]
 
 
 def build(native=False):
@@ -70,6 +70,8 @@ def lib(native=False):
         L.orc_synth_reads.argtypes = [vp, vp, u64, u64, u64, C.c_uint32, u64]
         L.orc_baseline_consume.restype = vp
         L.orc_baseline_consume.argtypes = [vp, u64, C.c_uint32, C.c_uint8, C.c_int, u64p, C.POINTER(C.c_double)]
+        L.orc_sharded_consume.restype = vp
+        L.orc_sharded_consume.argtypes = [vp, u64, C.c_uint32, C.c_uint8, C.c_int, u64, u64p, C.POINTER(C.c_double)]
         _libs[native] = L
     return _libs[native]
 
@@ -226,4 +228,14 @@ def baseline_consume(reads, L, k, threads=1, native=True):
     reads = np.ascontiguousarray(reads)
     kmers, secs = C.c_uint64(), C.c_double()
     h = Lb.orc_baseline_consume(reads.ctypes.data, reads.shape[0], L, k, threads, C.byref(kmers), C.byref(secs))
+    return OracleTable(k, _handle=h, _lib=Lb), kmers.value, secs.value
+
+
+def sharded_consume(reads, L, k, threads, batch=262144, native=True):
+    """The same per-record CPU work with the KEY SPACE sharded over ``threads`` (each thread owns a slice of hash space
+    and a private table; nothing to merge).  Returns (OracleTable folded together after the clock stopped, kmers, seconds)."""
+    Lb = lib(native)
+    reads = np.ascontiguousarray(reads)
+    kmers, secs = C.c_uint64(), C.c_double()
+    h = Lb.orc_sharded_consume(reads.ctypes.data, reads.shape[0], L, k, threads, batch, C.byref(kmers), C.byref(secs))
     return OracleTable(k, _handle=h, _lib=Lb), kmers.value, secs.value

@@ -30,6 +30,7 @@ SIGNATURES = {
     "kct_destroy": (None, [vp]),
     "kct_clear": (ci, [vp]),
     "kct_reserve": (ci, [vp, u64]),
+    "kct_resize": (ci, [vp, u64]),
     "kct_hash_kmer": (ci, [vp, vp, sz, u64p]),
     "kct_hash_windows": (ci, [vp, vp, sz, vp, sz, u64p, u64p]),
     "kct_count_hash": (ci, [vp, u64, u64p]),

@@ -200,9 +200,16 @@ void launch_merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, 
 
 // Re-hash into a table of new_cap slots.  The new array is installed only once every key has been placed in it; on
 // failure the table is left as it was.
+kct_status rehash_into(kct_table *t, u64 new_cap);
+
 kct_status grow_to(kct_table *t, u64 new_cap) {
     new_cap = std::max(next_pow2(new_cap), kMinSlots);
     if (new_cap <= t->cap) new_cap = t->cap * 2;
+    return rehash_into(t, new_cap);
+}
+
+// every key into a fresh array of new_cap slots (a power of two with room for them)
+kct_status rehash_into(kct_table *t, u64 new_cap) {
     const u64 old_keys = t->n_keys;
     du64 *fresh = nullptr;
     KCT_TRY(alloc_slots(t->device, new_cap, t->stream, &fresh));
@@ -374,6 +381,29 @@ kct_status kct_reserve(kct_table *t, uint64_t distinct) {
     t->auto_sized = false;
     if (want > t->cap) return grow_to(t, want);
     return KCT_OK;
+}
+
+kct_status kct_resize(kct_table *t, uint64_t distinct) {
+    KCT_TRY(use(t));
+    u64 want = std::max(next_pow2((u64)((double)std::max<u64>(distinct, t->n_keys) / kMaxLoad) + 1), kMinSlots);
+    t->auto_sized = false;
+    if (want == t->cap) return KCT_OK;
+    // shadows and scratch were sized for the old geometry (nothing is pending after use())
+    if (t->shadow) { (void)hipFree(t->shadow); t->shadow = nullptr; t->shadow_cap = 0; t->shadow_empty = true; t->shadow_keys = 0; }
+    if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; t->s32_empty = true; t->s32_keys = 0; t->s32_windows = 0; }
+    if (want > t->cap) return grow_to(t, want);
+    // smaller: a fresh array of the wanted size, the keys re-inserted (grow_to's re-hash works either way)
+    if (t->n_keys == 0 || t->lazy_empty) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        du64 *fresh = nullptr;
+        KCT_TRY(alloc_slots(t->device, want, t->stream, &fresh));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        HIP_TRY(hipFree(t->slots));
+        t->slots = fresh; t->cap = want; set_geometry(t);
+        t->n_keys = 0; t->lazy_empty = false;
+        return KCT_OK;
+    }
+    return rehash_into(t, want);
 }
 
 kct_status kct_count_hash(kct_table *t, uint64_t hash, uint64_t *count_out) {

@@ -21,7 +21,7 @@ in the HIP library.
 import torch
 import torch.distributed as dist
 
-__all__ = ["owner_of", "partition_by_owner", "exchange_pairs", "merge_across_ranks", "global_scalar_sum"]
+__all__ = ["owner_of", "partition_by_owner", "exchange_route", "exchange_pairs", "merge_across_ranks", "global_scalar_sum"]
 
 
 def owner_of(hashes_i64: torch.Tensor, world: int) -> torch.Tensor:
@@ -40,7 +40,21 @@ def partition_by_owner(hashes_i64, counts_i64, world):
     return torch.stack([hashes_i64[order], counts_i64[order]], dim=1).contiguous(), send_counts
 
 
-def exchange_pairs(pairs, send_counts, zero_count=0, group=None):
+def exchange_route(group=None):
+    """Which collective moves the pairs: "all_to_all" (RCCL / gloo ``all_to_all_single`` with uneven splits) or
+    "all_gather" (every rank publishes its whole bucketed list; world x the traffic, for back ends without an uneven
+    all-to-all).  Chosen up front -- ``KCT_A2A_FALLBACK=1`` asks for the second -- and agreed between the ranks with one
+    tiny all-reduce, so that every rank issues the same collectives; an error in a collective is never caught (the
+    communicator is unusable after one anyway, and a rank that switched routes alone would hang the others)."""
+    import os
+    mine = 1 if os.environ.get("KCT_A2A_FALLBACK") == "1" else 0
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([mine], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return "all_gather" if int(t.item()) else "all_to_all"
+
+
+def exchange_pairs(pairs, send_counts, zero_count=0, group=None, route=None):
     """All-to-all of owner-bucketed pairs.  ``pairs`` is an int64 tensor [n, 2] = (hash, count),
     owner p's rows contiguous and in rank order.  Returns (recv_pairs [m, 2], zero_total).
 
@@ -52,32 +66,29 @@ def exchange_pairs(pairs, send_counts, zero_count=0, group=None):
     dev = pairs.device
     if dev.type == "cuda" and dist.get_backend(group) == "gloo":
         # debugging aid (several ranks sharing one GPU, no RCCL): stage the collective through host memory
-        out, zero_total = exchange_pairs(pairs.cpu(), send_counts, zero_count, group)
+        out, zero_total = exchange_pairs(pairs.cpu(), send_counts, zero_count, group, route)
         return out.to(dev), zero_total
-    import os
     rank = dist.get_rank(group)
-    if os.environ.get("KCT_A2A_FALLBACK") != "1":
-        try:
-            # 1) how much will I receive from each peer (tiny fixed-layout exchange)
-            meta = torch.zeros((world, 2), dtype=torch.int64)
-            meta[:, 0] = send_counts
-            meta[0, 1] = int(zero_count)
-            meta = meta.to(dev)
-            got = torch.empty_like(meta)
-            dist.all_to_all_single(got, meta, group=group)
-            got = got.cpu()
-            recv_counts = got[:, 0]
-            zero_total = int(got[:, 1].sum())
-            # 2) the pairs themselves: one collective moves hashes and counts together
-            out = torch.empty((int(recv_counts.sum()), 2), dtype=torch.int64, device=dev)
-            dist.all_to_all_single(out, pairs, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(),
-                                   group=group)
-            return out, zero_total
-        except RuntimeError as e:  # a backend without (uneven) all-to-all: fall back to all-gather, every rank keeps its slice
-            import sys
-            print(f"[oxli_amd] all_to_all_single failed ({e}); exchanging with all_gather instead", file=sys.stderr)
-    # Fallback: every rank publishes its whole bucketed list (padded to the longest) and its bucket sizes; rank r keeps
-    # bucket r of everybody.  (world x the traffic of the all-to-all, but only all_gather is needed.)
+    if route is None:
+        route = exchange_route(group)
+    if route == "all_to_all":
+        # 1) how much will I receive from each peer (tiny fixed-layout exchange)
+        meta = torch.zeros((world, 2), dtype=torch.int64)
+        meta[:, 0] = send_counts
+        meta[0, 1] = int(zero_count)
+        meta = meta.to(dev)
+        got = torch.empty_like(meta)
+        dist.all_to_all_single(got, meta, group=group)
+        got = got.cpu()
+        recv_counts = got[:, 0]
+        zero_total = int(got[:, 1].sum())
+        # 2) the pairs themselves: one collective moves hashes and counts together
+        out = torch.empty((int(recv_counts.sum()), 2), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(out, pairs, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(),
+                               group=group)
+        return out, zero_total
+    # all_gather route: every rank publishes its whole bucketed list (padded to the longest) and its bucket sizes; rank r
+    # keeps bucket r of everybody.
     meta = torch.zeros(world + 2, dtype=torch.int64)
     meta[:world] = send_counts
     meta[world] = int(zero_count)
@@ -118,6 +129,13 @@ def merge_across_ranks(table, group=None):
     Device work is native: ``kct_export_by_owner_device`` buckets the table by owner in two
     kernels, ``kct_merge_pairs_device`` folds what arrives.  ``partition_by_owner`` above is the
     same bucketing in torch ops (what the CPU gloo test exercises).
+
+    After the exchange the table is RESIZED for what this rank owns (``kct_resize``): while counting, a rank's private
+    table has to hold every k-mer its reads touch (close to the whole genome), but an owner's table holds 1/world of
+    the key space (2^27 slots per GPU for C4 instead of 2^30).
+
+    A ``store_kmers`` table is refused: its hash -> k-mer map lives on the host of the rank that saw the k-mer, and this
+    exchange moves (hash, count) pairs only.
     """
     import ctypes as C
 
@@ -126,6 +144,8 @@ def merge_across_ranks(table, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return 0
+    if getattr(table, "store_kmers", False):
+        raise ValueError("merge_across_ranks moves (hash, count) pairs only: a store_kmers table would lose its hash -> k-mer map")
     dev = torch.device("cuda", torch.cuda.current_device())
     n = len(table)
     pairs = torch.empty((max(n, 1), 2), dtype=torch.int64, device=dev)
@@ -138,6 +158,7 @@ def merge_across_ranks(table, group=None):
     torch.cuda.synchronize()
     consumed = table.consumed
     table.clear()
+    table.resize(recv.shape[0])  # an owner's table: sized for its slice of the key space
     if zero:
         zk, zc = np.zeros(1, dtype=np.uint64), np.array([zero], dtype=np.uint64)
         table._check(table._lib.kct_merge_host(table._h, zk.ctypes.data, zc.ctypes.data, 1, None, None))

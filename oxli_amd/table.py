@@ -520,6 +520,11 @@ class KmerCountTable:
             print(f"Version mismatch: loaded version is {t.version}, but current version is {VERSION}", file=sys.stderr)
         return t
 
+    def resize(self, distinct):
+        """Capacity for ``distinct`` keys (never less than the table holds), smaller than now if that is enough
+        (``kct_resize``)."""
+        self._check(self._lib.kct_resize(self._h, int(distinct)))
+
     def release_scratch(self):
         """Gives back the working buffers bulk ingest keeps between calls (``kct_release_scratch``); the table stays."""
         self._check(self._lib.kct_release_scratch(self._h))

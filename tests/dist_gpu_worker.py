@@ -1,0 +1,68 @@
+"""Worker of tests/test_gpu_distributed.py: one of several ranks that SHARE one GPU (gloo between them), each with its
+own device table.  Every rank counts its shard of one read stream, merge_across_ranks() makes the tables the owner
+partitions of the global table, and rank 0 checks their union against the oracle's count of the whole stream.
+
+    python -m torch.distributed.run --nproc-per-node W tests/dist_gpu_worker.py <k> <reads per rank> <genome>
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    k, per_rank, G = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    L = 150
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from oxli_amd import KmerCountTable
+    from oxli_amd.distributed import global_scalar_sum, merge_across_ranks, owner_of
+
+    genome = oracle.synth_genome(G, 42)
+    reads = oracle.synth_reads(genome, rank * per_rank, per_rank, L, 1337)
+    dev_reads = torch.from_numpy(reads.reshape(-1)).cuda()
+    t = KmerCountTable(k, capacity=G)
+    n = t.consume_device(dev_reads.data_ptr(), dev_reads.numel(), per_rank * L)
+    assert n == per_rank * (L - k + 1)
+    if rank == 1:
+        for _ in range(3):
+            t.count_hash(0)            # key 0 lives beside the device table; its owner is rank 0
+    cap_private = t.capacity
+    recv = merge_across_ranks(t)
+    assert recv > 0
+    keys, counts = t.dump_arrays(1)
+    nz = keys != 0
+    assert np.all(owner_of(torch.from_numpy(keys[nz].view(np.int64).copy()), world).numpy() == rank)   # only my slice of hash space
+    assert t.capacity <= cap_private   # an owner's table is sized for its slice
+    total = global_scalar_sum(t.sum_counts, "cpu")
+    assert total == world * per_rank * (L - k + 1) + 3, total
+    assert global_scalar_sum(t.consumed, "cpu") == world * per_rank * L
+    parts = [None] * world
+    dist.all_gather_object(parts, (keys, counts))
+    if rank == 0:
+        ref = oracle.OracleTable(k)
+        allreads = oracle.synth_reads(genome, 0, world * per_rank, L, 1337)
+        tab, _, _ = oracle.baseline_consume(allreads, L, k, min(8, len(os.sched_getaffinity(0))), native=False)
+        for _ in range(3):
+            tab.count_hash(0)
+        rk, rc = tab.dump_arrays()
+        gk = np.concatenate([p[0] for p in parts])
+        gc = np.concatenate([p[1] for p in parts])
+        order = np.argsort(gk, kind="stable")
+        assert gk.size == np.unique(gk).size, "owner partitions overlap"
+        assert np.array_equal(gk[order], rk) and np.array_equal(gc[order], rc), "union of the owner tables differs from the oracle"
+        del ref
+        print(f"DIST_GPU_OK world={world} distinct={rk.size}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
