@@ -280,7 +280,7 @@ def main():
         if world > 1 and args.warmup:
             merge_across_ranks(table)  # warm the collective and the merge kernels too
         first = job()  # (also teaches a fresh table that the dedupe-first path pays: the steady state)
-        repeats = int(min(args.max_repeats, max(5 if world == 1 else 3, math.ceil(args.min_seconds / max(first[0], 1e-6)))))
+        repeats = int(min(args.max_repeats, max(5 if world == 1 else 3, math.ceil(1.15 * args.min_seconds / max(first[0], 1e-6)))))
         if world > 1:  # every rank must run the same number of jobs
             t = torch.tensor([repeats], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -397,7 +397,7 @@ kct_status after_dedupe_pass(kct_table *t, bool compact, u64 npos, const DedupeO
             // The k-mers live in the table too: normally it is as full as the shadow and grows before the next pass
             // (maybe_grow), and a table of another geometry gets a new shadow (ensure_shadow32).  If it stays as it is,
             // the table-sized 64-bit shadow takes over.
-            if ((double)t->n_keys <= kMaxLoad * (double)t->cap) t->compact_off = true;
+            if (compact_sbits_for(t) == t->s32_sbits && (double)t->n_keys <= kMaxLoad * (double)t->cap) t->compact_off = true;
         }
     } else if (o.blocked * 50 > npos && t->force_path != 3) {
         KCT_TRY(flush_shadow(t));

@@ -42,6 +42,13 @@ struct Murmur {
         k2 *= kC2; k2 = rotl64(k2, 33); k2 *= kC1; h2 ^= k2;
         h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
     }
+    // the same with k1 * c1 and k2 * c2 already formed (pre-multiplied tables)
+    __device__ __forceinline__ void block_premul(u64 k1c1, u64 k2c2) {
+        k1c1 = rotl64(k1c1, 31); k1c1 *= kC2; h1 ^= k1c1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2c2 = rotl64(k2c2, 33); k2c2 *= kC1; h2 ^= k2c2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
     // rem = number of tail bytes (1..15); k1/k2 already hold only those bytes (rest zero)
     __device__ __forceinline__ void tail(u64 k1, u64 k2, int rem) {
         if (rem > 8) { k2 *= kC2; k2 = rotl64(k2, 33); k2 *= kC1; h2 ^= k2; }
@@ -166,16 +173,43 @@ __device__ __forceinline__ void left_align(Packed<KW> &a, int k) {
     a = o;
 }
 
+// Pre-multiplied tables (K1's hashing mode): MurmurHash3 starts every 8-byte word with k *= c1 (first word of a block,
+// and of the tail) or k *= c2 (second word).  A word is two table look-ups d0 | d1 << 32, so
+//     k * c  =  d0 * c  +  (d1 * c) << 32          (mod 2^64)
+// and with mul[b] = ascii4(b) * c held as u64 the product is one 8-byte read, one 4-byte read (only the low half of the
+// second product survives the shift) and ONE 32-bit add -- instead of a 64 x 64 multiply (v_mad_u64_u32 + 2 v_mul_lo_u32 +
+// adds).  2 x 256 x 8 B of LDS.
+__device__ __forceinline__ void fill_premul_luts(u64 *mul1, u64 *mul2, int tid, int nthreads) {
+    for (int b = tid; b < 256; b += nthreads) {
+        u32 v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v |= ((0x54474341u >> (8 * ((b >> (6 - 2 * j)) & 3))) & 0xFFu) << (8 * j);  // "ACGT"[code]
+        mul1[b] = (u64)v * kC1;
+        mul2[b] = (u64)v * kC2;
+    }
+}
+__device__ __forceinline__ u64 premul_word(const u64 *mul, u32 b_lo, u32 b_hi) {  // (ascii4(b_lo) | ascii4(b_hi) << 32) * c
+    const u64 lo = mul[b_lo];
+    const u32 hi = reinterpret_cast<const u32 *>(mul)[2 * b_hi];  // low half of the second product
+    return lo + ((u64)hi << 32);
+}
+
 // MurmurHash3_x64_128(seed 42).h1 of the ASCII text of a left-aligned packed k-mer.
 // One 32-bit chunk of the packed form = 16 bases = exactly one 16-byte murmur block.
 template <int KW, bool LUT = false>
-__device__ __forceinline__ u64 hash_packed(const Packed<KW> &a, int k, const u32 *lut = nullptr) {
+__device__ __forceinline__ u64 hash_packed(const Packed<KW> &a, int k, const u32 *lut = nullptr, const u64 *mul1 = nullptr, const u64 *mul2 = nullptr) {
     Murmur m;
     const int nblocks = k >> 4, rem = k & 15;
 #pragma unroll
     for (int b = 0; b < 2 * KW; ++b) {
         if (b * 16 < k) {
             u32 chunk = (b & 1) ? (u32)a.w[b >> 1] : (u32)(a.w[b >> 1] >> 32);
+            if constexpr (LUT) {
+                if (mul1 && b < nblocks) {  // a whole block: both words through the pre-multiplied tables
+                    m.block_premul(premul_word(mul1, chunk >> 24, (chunk >> 16) & 0xFFu), premul_word(mul2, (chunk >> 8) & 0xFFu, chunk & 0xFFu));
+                    continue;
+                }
+            }
             u64 k1, k2;
             if constexpr (LUT) expand16_lut(lut, chunk, k1, k2);
             else expand16(chunk, k1, k2);

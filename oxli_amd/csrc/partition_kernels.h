@@ -141,6 +141,15 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     __shared__ unsigned short tvalid[kTileWords];
     __shared__ u32 ascii4[(KW == 0 || MODE != 0) ? 1 : 256];  // four packed bases -> four ASCII bytes (only the hashing mode needs it)
     if constexpr (KW != 0 && MODE == 0) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
+#ifdef KCT_PREMUL_LUT
+    // MurmurHash3's first multiply of every whole 16-base block comes out of pre-multiplied tables (kmer_device.h)
+    constexpr bool kPremul = KW != 0 && MODE == 0 && (KC == 0 || KC >= 16);
+    __shared__ u64 mul1[kPremul ? 256 : 1], mul2[kPremul ? 256 : 1];
+    if constexpr (kPremul) fill_premul_luts(mul1, mul2, threadIdx.x, kPartThreads);
+    const u64 *pm1 = kPremul ? mul1 : nullptr, *pm2 = kPremul ? mul2 : nullptr;
+#else
+    const u64 *pm1 = nullptr, *pm2 = nullptr;
+#endif
     const int P = 1 << a.pbits;
     const u32 D = (u32)(kEntries >> a.pbits), dmask = D - 1;
     const int dshift = __builtin_ctz((unsigned)kEntries) - a.pbits;  // log2 D
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
             }
         };
         if constexpr (KW == 0) walk_windows<0, 0, kPartWPT>(lds, k, sink);
-        else walk_windows_encoded<KW, KC, true, MODE>(tcodes, tvalid, k, sink, ascii4);
+        else walk_windows_encoded<KW, KC, true, MODE>(tcodes, tvalid, k, sink, ascii4, pm1, pm2);
         commit();
     }
     while (flush_lines(true)) {}  // drain: partial lines go out zero-padded; repeat while the list was too short
@@ -714,7 +723,11 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
         if (mine) atomicAdd(&s_entries, mine);
     }
     __syncthreads();
+#ifdef KCT_NO_CAREFUL
+    const bool careful = false;
+#else
     const bool careful = s_entries >= (u64)carry_at;
+#endif
     auto add_one = [&](u32 idx, u32 e) {
         if (!careful) atomicAdd(&cnts[idx], 1u);
         else if (atomicAdd(&cnts[idx], 1u) == 0xFFFFFFFFu) carry_out(e, 1ULL << 32);

@@ -86,7 +86,7 @@ __device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, in
 // RAW = 2 (k <= 21): mix42(packed canonical k-mer), a 42-bit value, with bit 63 set.
 template <int KW, int KC, bool LUT = false, int RAW = 0, class Sink>
 __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const unsigned short *valid, int k_rt, Sink &&sink,
-                                                     const u32 *lut = nullptr) {
+                                                     const u32 *lut = nullptr, const u64 *mul1 = nullptr, const u64 *mul2 = nullptr) {
     constexpr int WPT = 16, NW = 2 * KW + 1;  // code words covering bases 0 .. 15 + k
     const int k = KC > 0 ? KC : k_rt;
     u32 w[NW];
@@ -155,7 +155,7 @@ __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const uns
                 h = mix42(c.w[0]) | (1ULL << 63);  // bit 63: "not the zero hash" for the sink's h != 0 test; the sink drops it
             } else {
                 left_align(c, k);
-                h = hash_packed<KW, LUT>(c, k, lut);
+                h = hash_packed<KW, LUT>(c, k, lut, mul1, mul2);
             }
         }
         sink(j, good, h);
