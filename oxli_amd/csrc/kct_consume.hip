@@ -429,6 +429,8 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
         KCT_TRY(ensure_shadow32(t, probe ? kCompactBlockBits : compact_sbits_for(t), &ok));  // (the probe's shadow is the small one, swapped in by the caller)
         if (!ok) { t->compact_off = true; return KCT_OK; }
     }
+    // u32 counts: a pending count grows by at most 1/256 of the window starts consumed (aggregate_blocks32_kernel)
+    if (t->s32_dirty && t->s32_windows + npos >= (1ULL << 39)) KCT_TRY(flush_compact(t));
     const int sbits = t->s32_sbits;
     const bool two_level = sbits > kCompactBlockBits;
     const int pbits = kCompactBlockBits, sub_bits = sbits - pbits;  // K1's bins are always the value's top 10 bits
@@ -447,7 +449,6 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     KCT_TRY(t->d_spill.reserve((two_level ? 1 : 2) * npos * 16));
     KCT_TRY(zero_counters(t));
     du64 *d_overflow = t->d_counters + kNumCounters + 6;
-    du64 *d_carry = t->d_counters + kNumCounters + 7;
     unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
 
     kct::PartitionArgs pa;
@@ -462,8 +463,6 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     HIP_TRY(hipGetLastError());
     kct::Aggregate32Args aa;
     aa.words = t->shadow32; aa.block_bits = kct::kBlockBitsMax; aa.sbits = sbits;
-    aa.carry_bits = 31;
-    if (const char *e = getenv("KCT_CARRY_BITS")) aa.carry_bits = std::max(2, std::min(31, atoi(e)));  // tests only
     aa.scratch = (const unsigned int *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
     aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
     unsigned int ovf2_cap = 0, *d_ovf2_count = nullptr;
@@ -491,7 +490,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
         aa.region_count = (const unsigned int *)t->d_regions2.p; aa.nregions = 1;
     }
     aa.fresh = t->s32_empty ? 1 : 0; aa.overflow = d_overflow; aa.ablate = t->ablate;
-    aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.carry_total = d_carry; aa.counters = t->d_counters;
+    aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
     {
         ProfScope ps(t, "aggregate_blocks32_kernel");
         hipLaunchKernelGGL(kct::aggregate_blocks32_kernel, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
@@ -541,24 +540,20 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     *handled = true;
     // (two levels: the second read holds the first submission's tallies too -- the counters were not zeroed in between)
     const u64 counted = c2[kct::CTR_COUNTED], new_keys = c2[kct::CTR_NEW_BY_ZERO], spilled2 = t->h_counters[kNumCounters + 5];
-    const u64 carried = t->h_counters[kNumCounters + 7];  // u32-count carries: pairs that are not new windows
     t->s32_empty = false;
     t->s32_dirty = true;
     t->s32_keys += new_keys;
     t->s32_windows += npos;
     if (t->debug)
-        KCT_DBG(t, "compact dedupe pass%s: npos=%llu blocks=%llu region_cap=%u counted=%llu new keys=%llu (total %llu) blocked=%llu merged=%llu spilled=%llu carried=%llu\n",
+        KCT_DBG(t, "compact dedupe pass%s: npos=%llu blocks=%llu region_cap=%u counted=%llu new keys=%llu (total %llu) blocked=%llu merged=%llu spilled=%llu\n",
                 probe ? " (probe)" : "", (unsigned long long)npos, (unsigned long long)B, region_cap, (unsigned long long)counted, (unsigned long long)new_keys,
-                (unsigned long long)t->s32_keys, (unsigned long long)blocked, (unsigned long long)c2[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled2,
-                (unsigned long long)carried);
-    *n_out += counted + c2[kct::CTR_TOTAL_ADDED] - carried;  // (see consume_partitioned about n and a MurmurHash3 value of 0)
+                (unsigned long long)t->s32_keys, (unsigned long long)blocked, (unsigned long long)c2[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled2);
+    *n_out += counted + c2[kct::CTR_TOTAL_ADDED];  // (see consume_partitioned about n and a MurmurHash3 value of 0)
     t->n_keys += c2[kct::CTR_NEWKEYS];
     if (spilled2) {
         KCT_TRY(t->d_aux2.reserve(spilled2 * 16));
         HIP_TRY(hipMemcpyAsync(t->d_aux2.p, mv.spill, spilled2 * 16, hipMemcpyDeviceToDevice, t->stream));
-        u64 replayed = 0;
-        KCT_TRY(replay_spill(t, spilled2, &replayed));
-        *n_out += replayed;  // (a carry pair that spills again is rare enough to ignore in n: it needs a count past 2^31 AND a full table)
+        KCT_TRY(replay_spill(t, spilled2, n_out));
     }
     DedupeOutcome o;
     o.new_keys = new_keys + c2[kct::CTR_NEWKEYS];

@@ -141,15 +141,12 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     __shared__ unsigned short tvalid[kTileWords];
     __shared__ u32 ascii4[(KW == 0 || MODE != 0) ? 1 : 256];  // four packed bases -> four ASCII bytes (only the hashing mode needs it)
     if constexpr (KW != 0 && MODE == 0) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
-#ifdef KCT_PREMUL_LUT
-    // MurmurHash3's first multiply of every whole 16-base block comes out of pre-multiplied tables (kmer_device.h)
+    // MurmurHash3's first multiply of every whole 16-base block comes out of pre-multiplied tables (kmer_device.h):
+    // K1 -1 % at k = 21, -2 % at k = 31, -4 % at k = 51
     constexpr bool kPremul = KW != 0 && MODE == 0 && (KC == 0 || KC >= 16);
     __shared__ u64 mul1[kPremul ? 256 : 1], mul2[kPremul ? 256 : 1];
     if constexpr (kPremul) fill_premul_luts(mul1, mul2, threadIdx.x, kPartThreads);
     const u64 *pm1 = kPremul ? mul1 : nullptr, *pm2 = kPremul ? mul2 : nullptr;
-#else
-    const u64 *pm1 = nullptr, *pm2 = nullptr;
-#endif
     const int P = 1 << a.pbits;
     const u32 D = (u32)(kEntries >> a.pbits), dmask = D - 1;
     const int dshift = __builtin_ctz((unsigned)kEntries) - a.pbits;  // log2 D
@@ -659,7 +656,9 @@ __global__ __launch_bounds__(kBlock) void merge_mixed_pairs_kernel(const u64 *__
 // A mix42 value is 10 bits of bin and 32 bits of entry; within a bin the entry identifies the k-mer.  K1 (MODE 2)
 // wrote the entries; this is K2 for them: same block ownership, fingerprint fast path and deferred queue as
 // aggregate_blocks_kernel, at half the LDS and HBM bytes.  Slot = entry bits 0-12, fingerprint = bits 13-20.
-// Counts are u32: the host converts (flushes) before 2^31 windows have gone in.
+// Counts are u32.  No entry reaches this kernel without passing an LDS ring, and a ring bin lets at most D of the 8192 (K1)
+// or 8192 (K1b) appends of a flush interval through (the rest take the overflow route to the real table's u64 counts): a
+// k-mer's pending count grows by at most 1/256 of the window starts consumed.  The host converts before 2^39 of them.
 struct Aggregate32Args {
     u32 *words;          // [blocks][S keys][S counts]
     int block_bits;
@@ -670,13 +669,9 @@ struct Aggregate32Args {
     int fresh;
     const u64 *overflow; // K1's abandon flag
     u64 *spill; u64 spill_cap; u64 *spill_n;  // {mix42 value | bit 63, 1} pairs of entries that found their block full
-    u64 *carry_total;    // counts are u32: what a count would lose by wrapping leaves as a {value, 2^31 or 2^32} pair on the
-                         // spill list (it goes to the real table's u64 count); their sum is kept here, because those pairs
-                         // are not new windows
     u64 *counters;
     int ablate;          // measurement only: bit 4 (16) = loads only
     int sbits;           // log2(blocks of the shadow): a block index is the TOP sbits bits of the 42-bit value (>= 10)
-    int carry_bits;      // 31; tests lower it (KCT_CARRY_BITS) to drive the carry code with small counts
 };
 
 // (Two workgroups per CU -- 78 KiB of LDS and 60 VGPRs each, with a shorter queue -- were measured: 5 % slower.)
@@ -685,53 +680,26 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
     __shared__ __attribute__((aligned(16))) u32 tab[2 << kBlockBitsMax];  // S keys then S counts = 64 KiB
     __shared__ u32 wq[(kPartThreads / 64) * kWaveQueue32];
     __shared__ __attribute__((aligned(16))) unsigned char tags[1 << kBlockBitsMax];
-    __shared__ u64 s_counted, s_new, s_entries;
+    __shared__ u64 s_counted, s_new;
     if (*a.overflow) return;
     const int b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
     u32 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u32 *keys = tab, *cnts = tab + S;
-    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; s_entries = 0; }
+    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
     auto tag_of = [](u32 e) -> u32 { const u32 t = (e >> 13) & 0xFFu; return t ? t : 1u; };
     // the 42-bit value of an entry of this block: its top 10 bits are the block index's top 10, the entry is its low 32
     const u64 value_hi = ((u64)((u32)b >> (a.sbits - 10)) << 32) | (1ULL << 63);
-    const u32 carry_at = 1u << a.carry_bits;
-    auto carry_out = [&](u32 e, u64 amount) {
-        const u64 si = atomicAdd(a.spill_n, 1ULL);
-        if (si < a.spill_cap) { a.spill[2 * si] = value_hi | e; a.spill[2 * si + 1] = amount; }
-        atomicAdd(a.carry_total, amount);
-    };
     if (a.fresh) {
         for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
         for (u32 i = threadIdx.x; i < S / 16; i += kPartThreads) reinterpret_cast<uint4 *>(tags)[i] = make_uint4(0, 0, 0, 0);
     } else {
         for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
         __syncthreads();
-        for (u32 i = threadIdx.x; i < S; i += kPartThreads) {
-            const u32 kk = keys[i];
-            tags[i] = (unsigned char)(kk ? tag_of(kk) : 0u);
-            // invariant of the u32 counts: below 2^31 when a pass starts (the upper half moves on to the real table)
-            if (cnts[i] >= carry_at) { cnts[i] -= carry_at; carry_out(kk, (u64)carry_at); }
-        }
-    }
-    // ... and a block that receives 2^31 entries or more in this pass (a k-mer repeated billions of times) watches every
-    // add for a wrap; all other blocks cannot overflow a count and use the plain add.
-    {
-        u64 mine = 0;
-        for (int r = threadIdx.x; r < a.nregions; r += kPartThreads) mine += a.region_count[(u64)b * a.nregions + r];
-        if (mine) atomicAdd(&s_entries, mine);
+        for (u32 i = threadIdx.x; i < S; i += kPartThreads) { const u32 kk = keys[i]; tags[i] = (unsigned char)(kk ? tag_of(kk) : 0u); }
     }
     __syncthreads();
-#ifdef KCT_NO_CAREFUL
-    const bool careful = false;
-#else
-    const bool careful = s_entries >= (u64)carry_at;
-#endif
-    auto add_one = [&](u32 idx, u32 e) {
-        if (!careful) atomicAdd(&cnts[idx], 1u);
-        else if (atomicAdd(&cnts[idx], 1u) == 0xFFFFFFFFu) carry_out(e, 1ULL << 32);
-    };
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32 counted = 0, newkeys = 0;
     auto insert = [&](u32 e) {
@@ -749,7 +717,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
                     ks = atomicCAS(&keys[g + sel], 0u, e);
                     if (ks == 0) { ++newkeys; ks = e; tags[g + sel] = (unsigned char)tag_of(e); }
                 }
-                if (ks == e) { add_one(g + sel, e); placed = true; break; }
+                if (ks == e) { atomicAdd(&cnts[g + sel], 1u); placed = true; break; }
                 ++sel;
                 while (sel < kGroup) { const u32 kk = keys[g + sel]; if (kk == e || kk == 0) break; ++sel; }
             }
@@ -779,7 +747,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
             const u64 z = (x - 0x0101010101010101ULL) & ~x & 0x8080808080808080ULL;
             if (z) {
                 const u32 idx = (u32)__builtin_ctzll(z) >> 3;
-                if (keys[g + idx] == e) { add_one(g + idx, e); ++counted; miss = false; }
+                if (keys[g + idx] == e) { atomicAdd(&cnts[g + idx], 1u); ++counted; miss = false; }
             }
         }
         const u64 m = __ballot(miss);

@@ -167,23 +167,3 @@ def test_tables_of_more_than_1024_blocks_match_the_oracle(gpu, k, path, G, R):
     for h, c in zip(hk.tolist(), hc.tolist()):
         want[h] += c
     assert np.array_equal(dk, rk) and dc.tolist() == [want[h] for h in rk.tolist()]
-
-
-def test_compact_counts_carry_into_the_table(gpu, monkeypatch):
-    """The compact shadow's counts are u32; what would not fit moves on to the real table's u64 count as a carry pair.
-    KCT_CARRY_BITS=4 makes that happen at 16 instead of 2^31: results must not change."""
-    torch, KCT, _ = gpu
-    monkeypatch.setenv("KCT_CARRY_BITS", "4")
-    G, L, R, k = 100_000, 150, 60_000, 21
-    genome = oracle.synth_genome(G, 3)
-    reads = oracle.synth_reads(genome, 0, R, L, 4)
-    ref, n_ref = _oracle_table(reads, L, k)
-    dev_reads = torch.from_numpy(reads.reshape(-1)).cuda()
-    t = KCT(k, capacity=G)
-    t.set_path("dedupe")
-    for _ in range(3):   # pending counts of ~80 per k-mer pass 16 again and again
-        assert t.consume_device(dev_reads.data_ptr(), dev_reads.numel(), R * L) == n_ref
-    dk, dc = t.dump_arrays(1)
-    rk, rc = ref.dump_arrays()
-    assert np.array_equal(dk, rk) and np.array_equal(dc, 3 * rc)
-    assert t.sum_counts == 3 * n_ref
