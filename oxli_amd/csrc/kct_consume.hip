@@ -134,6 +134,10 @@ unsigned int repartition_min_lines(int ring_entries, int sub_bits, int entry_byt
 // list) cannot wrap before a hopelessly skewed pass is abandoned
 unsigned int overflow_capacity(u64 entries_per_wg) { return (unsigned int)std::min<u64>(1ULL << 20, std::max<u64>(4096, entries_per_wg / 8)); }
 
+kct_status failed_blocks(kct_table *t, u64 nblocks, kct::FailedBlocks *fb);
+kct_status recount_failed(kct_table *t, int mode, const void *scratch, u64 seg_stride, u64 block_stride, const unsigned int *region_count, int nregions,
+                          u64 nfailed, u64 entries, int sbits, u64 tallies[4]);
+
 // Dedupe-first pass (k <= 32).  Reads that cover a small genome deeply repeat every k-mer tens of times per pass, and
 // ~55 % of K1's instructions are MurmurHash3 plus the ASCII re-expansion.  So the pass counts PACKED k-mers: K1 (RAW)
 // partitions mix64(packed canonical k-mer + 1) values, and the unchanged K2 counts them into a SHADOW table -- in HBM, with
@@ -233,7 +237,6 @@ kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 16));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
     KCT_TRY(t->d_pairs_ovf.reserve(npairs * 16 + 64));  // pairs that found ring or region full (its own buffer: d_aux may hold the input)
-    KCT_TRY(t->d_spill.reserve(npairs * 16 + 64));      // pairs that found their table block full
     KCT_TRY(zero_counters(t));
     du64 *d_ovf_n = t->d_counters + kNumCounters + 5;
     const bool fresh = t->lazy_empty;
@@ -275,28 +278,31 @@ kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const
         pa.region_count = (const unsigned int *)t->d_regions2.p; pa.nregions = (int)L.W;
     }
     pa.fresh = fresh ? 1 : 0;
-    pa.spill = (du64 *)t->d_spill.p; pa.spill_cap = npairs; pa.spill_n = t->d_counters + kNumCounters; pa.counters = t->d_counters;
+    KCT_TRY(failed_blocks(t, L.B, &pa.failed));
+    pa.counters = t->d_counters;
     {
         ProfScope ps(t, "aggregate_pairs_kernel");
         hipLaunchKernelGGL(kct::aggregate_pairs_kernel, dim3((unsigned)L.B), dim3(kct::kPartThreads), 0, t->stream, pa);
     }
     HIP_TRY(hipGetLastError());
     t->lazy_empty = false;
-    // the (normally few) pairs that did not fit ring or region: the direct insert; the list length is read on the device
-    launch_merge_pairs(t, (const du64 *)t->d_pairs_ovf.p, (const du64 *)t->d_pairs_ovf.p + 1, npairs, (const du64 *)d_ovf_n, 2, view(t, npairs));
-    HIP_TRY(hipGetLastError());
+    // the (normally few) pairs that did not fit ring or region: the direct insert, into a spill list of their number
     u64 c[4], spilled;
     KCT_TRY(read_counters(t, c, &spilled));
+    const u64 nfailed = t->h_counters[kNumCounters + 7], failed_entries = t->h_counters[kNumCounters + 3];
+    const u64 n_ovf = std::min<u64>(t->h_counters[kNumCounters + 5], npairs);
     t->n_keys += c[kct::CTR_NEWKEYS];
     if (tallies) for (int i = 0; i < 4; ++i) tallies[i] += c[i];
-    if (spilled) {  // pairs that found their table block full: grow, then the direct insert (its tallies join ours)
-        KCT_TRY(t->d_aux2.reserve(spilled * 16));
-        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
-        KCT_TRY(grow_to(t, t->cap * 2));
-        u64 tl[4] = {0, 0, 0, 0};
-        KCT_TRY(merge_pairs(t, (const du64 *)t->d_aux2.p, (const du64 *)t->d_aux2.p + 1, spilled, 2, tl));
-        if (tallies) for (int i = 0; i < 4; ++i) tallies[i] += tl[i];
+    u64 tl[4] = {0, 0, 0, 0};
+    if (n_ovf) {
+        // (a copy: merge_pairs may take the partitioned route again, which writes d_pairs_ovf)
+        KCT_TRY(t->d_aux2.reserve(n_ovf * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_pairs_ovf.p, n_ovf * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(merge_pairs(t, (const du64 *)t->d_aux2.p, (const du64 *)t->d_aux2.p + 1, n_ovf, 2, tl));
     }
+    if (nfailed)  // table blocks that overflowed: the table grows, their pairs are merged with the direct insert
+        KCT_TRY(recount_failed(t, 3, pa.scratch, pa.seg_stride, pa.block_stride, pa.region_count, pa.nregions, nfailed, failed_entries, 0, tl));
+    if (tallies) for (int i = 0; i < 4; ++i) tallies[i] += tl[i];
     return KCT_OK;
 }
 
@@ -343,8 +349,22 @@ kct_status flush_compact(kct_table *t) {
     return KCT_OK;
 }
 
+kct_status flush_shadow64(kct_table *t);
+
 kct_status flush_shadow(kct_table *t) {
     KCT_TRY(flush_compact(t));
+    KCT_TRY(flush_shadow64(t));
+    if (t->pending_pairs) {  // pairs that dedupe-first passes set aside while the table was lazily empty
+        const u64 n = t->pending_pairs;
+        t->pending_pairs = 0;
+        u64 tl[4] = {0, 0, 0, 0};
+        KCT_TRY(merge_pairs(t, (const du64 *)t->d_pending.p, (const du64 *)t->d_pending.p + 1, n, 2, tl));
+        HIP_TRY(hipMemsetAsync(t->d_counters + kNumCounters + 8, 0, 8, t->stream));
+    }
+    return KCT_OK;
+}
+
+kct_status flush_shadow64(kct_table *t) {
     if (!t->shadow_dirty) return KCT_OK;
     t->shadow_dirty = false;
     {
@@ -371,6 +391,77 @@ kct_status flush_shadow(kct_table *t) {
         HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
         KCT_TRY(replay_spill(t, spilled, &ignored));
     }
+    return KCT_OK;
+}
+
+// The list K2 writes the numbers of the blocks it abandons to; the counters are d_counters scratch words 7 (blocks) and 3
+// (their entries), zeroed with the tallies.
+kct_status failed_blocks(kct_table *t, u64 nblocks, kct::FailedBlocks *fb) {
+    KCT_TRY(t->d_failed.reserve(nblocks * 4 + 64));
+    fb->list = (unsigned int *)t->d_failed.p;
+    fb->n = t->d_counters + kNumCounters + 7;
+    fb->entries = t->d_counters + kNumCounters + 3;
+    return KCT_OK;
+}
+
+// Overflow entries of a pass, exactly (the per-workgroup counts are read back; waits for the stream).
+kct_status overflow_total(kct_table *t, const unsigned int *d_counts_a, size_t na, const unsigned int *d_counts_b, size_t nb, u64 *total) {
+    std::vector<unsigned int> c(na + nb);
+    if (na) HIP_TRY(hipMemcpyAsync(c.data(), d_counts_a, na * 4, hipMemcpyDeviceToHost, t->stream));
+    if (nb) HIP_TRY(hipMemcpyAsync(c.data() + na, d_counts_b, nb * 4, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    *total = 0;
+    for (unsigned int v : c) *total += v;
+    return KCT_OK;
+}
+
+// The abandoned blocks' entries -> the real table with the direct insert (recount_failed_kernel), after making room.
+// mode 0: hashes that the TABLE's own blocks could not take (the table grows first); 1 / 2: mix64 / compact entries of
+// shadow blocks (hashed on the way); 3: {hash, count} pairs of a pair merge (the table grows first).
+// tallies[] += CTR_* of what was placed, replays included.
+kct_status recount_failed(kct_table *t, int mode, const void *scratch, u64 seg_stride, u64 block_stride, const unsigned int *region_count, int nregions,
+                          u64 nfailed, u64 entries, int sbits, u64 tallies[4]) {
+    KCT_DBG(t, "recounting %llu abandoned blocks (%llu entries, mode %d)\n", (unsigned long long)nfailed, (unsigned long long)entries, mode);
+    if (mode == 0 || mode == 3) KCT_TRY(grow_to(t, spill_growth_target(t, entries)));
+    KCT_TRY(materialize(t));
+    KCT_TRY(t->d_spill.reserve(std::max<u64>(entries, 1) * 16));
+    HIP_TRY(hipMemsetAsync(t->d_counters, 0, (kNumCounters + 1) * sizeof(u64), t->stream));  // tallies and the spill cursor
+    const kct::TableView tv = view(t, std::max<u64>(entries, 1));
+    const unsigned grid = (unsigned)std::min<u64>(nfailed, 2048);
+    const unsigned int *fl = (const unsigned int *)t->d_failed.p;
+    {
+        ProfScope ps(t, "recount_failed_kernel");
+        if (mode == 0) hipLaunchKernelGGL(kct::recount_failed_kernel<0>, dim3(grid), dim3(kct::kBlock), 0, t->stream, scratch, seg_stride, block_stride, region_count, nregions, fl, nfailed, tv, t->d_counters, (int)t->k, sbits);
+        else if (mode == 1) hipLaunchKernelGGL(kct::recount_failed_kernel<1>, dim3(grid), dim3(kct::kBlock), 0, t->stream, scratch, seg_stride, block_stride, region_count, nregions, fl, nfailed, tv, t->d_counters, (int)t->k, sbits);
+        else if (mode == 2) hipLaunchKernelGGL(kct::recount_failed_kernel<2>, dim3(grid), dim3(kct::kBlock), 0, t->stream, scratch, seg_stride, block_stride, region_count, nregions, fl, nfailed, tv, t->d_counters, (int)t->k, sbits);
+        else hipLaunchKernelGGL(kct::recount_failed_kernel<3>, dim3(grid), dim3(kct::kBlock), 0, t->stream, scratch, seg_stride, block_stride, region_count, nregions, fl, nfailed, tv, t->d_counters, (int)t->k, sbits);
+    }
+    HIP_TRY(hipGetLastError());
+    u64 c[4], spilled;
+    KCT_TRY(read_counters(t, c, &spilled));
+    for (int i = 0; i < 4; ++i) tallies[i] += c[i];
+    t->n_keys += c[kct::CTR_NEWKEYS];
+    if (spilled) {
+        KCT_TRY(t->d_aux2.reserve(spilled * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(grow_to(t, spill_growth_target(t, spilled)));
+        KCT_TRY(merge_pairs(t, (const du64 *)t->d_aux2.p, (const du64 *)t->d_aux2.p + 1, spilled, 2, tallies));
+    }
+    return KCT_OK;
+}
+
+// Room in the pending pair list for every overflow entry of a pass (the per-workgroup counts are read back: exact).
+kct_status reserve_pending(kct_table *t, const unsigned int *d_counts_a, size_t na, const unsigned int *d_counts_b, size_t nb, kct::PendingList *pl) {
+    std::vector<unsigned int> c(na + nb);
+    if (na) HIP_TRY(hipMemcpyAsync(c.data(), d_counts_a, na * 4, hipMemcpyDeviceToHost, t->stream));
+    if (nb) HIP_TRY(hipMemcpyAsync(c.data() + na, d_counts_b, nb * 4, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    u64 total = 0;
+    for (unsigned int v : c) total += v;
+    KCT_TRY(t->d_pending.reserve_keep((t->pending_pairs + total) * 16 + 64, t->pending_pairs * 16, t->stream));
+    pl->pairs = (du64 *)t->d_pending.p;
+    pl->cap = t->pending_pairs + total;
+    pl->n = t->d_counters + kNumCounters + 8;
     return KCT_OK;
 }
 
@@ -440,13 +531,13 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
     const unsigned int region_cap = (region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P) + 15u) & ~15u;  // 16-entry lines
     const unsigned int ovf_cap = overflow_capacity(tiles_per_wg * kct::kPartTile);
-    if (!dry) KCT_TRY(materialize(t));
+    if (!dry && !two_level) KCT_TRY(materialize(t));  // (two levels: only if something must go to the table at once, below)
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 4));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
     KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
-    // spill lists: pairs that found their shadow block full (at most one per window), then the merges' own spills -- in the
-    // same buffer when everything is one submission (one level), in a buffer sized after the fact otherwise
-    KCT_TRY(t->d_spill.reserve((two_level ? 1 : 2) * npos * 16));
+    // the overflow merges' own spill list (entries the real table has no room for): one level -- everything is one
+    // submission -- sized for every overflow region being full; two levels: sized after the fact, below
+    if (!two_level) KCT_TRY(t->d_spill.reserve((u64)nwg * ovf_cap * 16));
     KCT_TRY(zero_counters(t));
     du64 *d_overflow = t->d_counters + kNumCounters + 6;
     unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
@@ -490,73 +581,83 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
         aa.region_count = (const unsigned int *)t->d_regions2.p; aa.nregions = 1;
     }
     aa.fresh = t->s32_empty ? 1 : 0; aa.overflow = d_overflow; aa.ablate = t->ablate;
-    aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
+    KCT_TRY(failed_blocks(t, B, &aa.failed));
+    aa.counters = t->d_counters;
     {
         ProfScope ps(t, "aggregate_blocks32_kernel");
         hipLaunchKernelGGL(kct::aggregate_blocks32_kernel, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
     }
     HIP_TRY(hipGetLastError());
-    // What does not fit the shadow goes to the real table: K1's (and the second level's) overflow regions, and the pairs
-    // that found their shadow block full (normally none).  One level: in the same submission (no host round trip in
-    // between; the pair count is read on the device), spilling -- if the table lacks room -- into the SECOND half of the
-    // spill buffer.  Two levels (passes of 10^8+ windows): after the counters have been read, into a list of the right size.
-    u64 c[4], blocked;
+    // What does not fit the shadow goes to the real table: K1's (and the second level's) overflow regions with the direct
+    // insert, and -- after the pass -- the entries of shadow blocks that K2 had to abandon (normally none).  One level: the
+    // overflow merge rides in the same submission (no host round trip).  Two levels (passes of 10^8+ windows): after the
+    // counters have been read; a table that is still lazily empty stays untouched (pending pair list).
+    u64 c[4], unused;
     if (dry) {
-        KCT_TRY(read_counters(t, c, &blocked));
+        KCT_TRY(read_counters(t, c, &unused));
         if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;
         *handled = true;
-        dry->counted = c[kct::CTR_COUNTED]; dry->new_keys = c[kct::CTR_NEW_BY_ZERO]; dry->blocked = blocked;
+        dry->counted = c[kct::CTR_COUNTED]; dry->new_keys = c[kct::CTR_NEW_BY_ZERO]; dry->blocked = t->h_counters[kNumCounters + 3];
         KCT_DBG(t, "compact dedupe pass (dry probe): npos=%llu counted=%llu new keys=%llu blocked=%llu\n", (unsigned long long)npos,
-                (unsigned long long)dry->counted, (unsigned long long)dry->new_keys, (unsigned long long)blocked);
+                (unsigned long long)dry->counted, (unsigned long long)dry->new_keys, (unsigned long long)dry->blocked);
         return KCT_OK;
     }
-    kct::TableView mv = view(t, npos);
+    kct::TableView mv = view(t, (u64)nwg * ovf_cap);
+    kct::PendingList pend;  // a lazily empty table stays untouched: the overflow entries wait in the pending pair list
     if (two_level) {
-        KCT_TRY(read_counters(t, c, &blocked));
+        KCT_TRY(read_counters(t, c, &unused));
         if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // K1 / K1b gave up: K2 exited early, nothing was touched
-        const u64 spill2_cap = blocked + (u64)nwg * ovf_cap + P * ovf2_cap;
-        KCT_TRY(t->d_pairs_ovf.reserve(spill2_cap * 16 + 64));
-        mv.spill = (du64 *)t->d_pairs_ovf.p;
-        mv.spill_cap = spill2_cap;
-    } else {
-        mv.spill = (du64 *)t->d_spill.p + 2 * npos;
+        if (t->lazy_empty && t->h_counters[kNumCounters + 7] == 0) KCT_TRY(reserve_pending(t, d_ovf_count, nwg, d_ovf2_count, P, &pend));
+        else {
+            u64 total = 0;
+            KCT_TRY(overflow_total(t, d_ovf_count, nwg, d_ovf2_count, P, &total));
+            KCT_TRY(materialize(t));
+            KCT_TRY(t->d_spill.reserve(std::max<u64>(total, 1) * 16));
+            mv = view(t, std::max<u64>(total, 1));
+        }
     }
     mv.spill_n = t->d_counters + kNumCounters + 5;
     {
         ProfScope ps(t, "merge_overflow_kernel");
         hipLaunchKernelGGL(kct::merge_overflow_kernel<2>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
-                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, mv, t->d_counters, k);
+                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, mv, t->d_counters, k, (const du64 *)nullptr, pend);
         if (two_level)
             hipLaunchKernelGGL(kct::merge_overflow_kernel<2>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
-                               (const unsigned int *)d_ovf2_count, (int)P, ovf2_cap, (const du64 *)d_overflow, mv, t->d_counters, k);
-        hipLaunchKernelGGL(kct::merge_mixed_pairs_kernel<2>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_spill.p,
-                           (const du64 *)(t->d_counters + kNumCounters), (u64)npos, mv, (int)k, t->d_counters);
+                               (const unsigned int *)d_ovf2_count, (int)P, ovf2_cap, (const du64 *)d_overflow, mv, t->d_counters, k, (const du64 *)nullptr, pend);
     }
     HIP_TRY(hipGetLastError());
-    u64 c2[4], blocked2;
-    KCT_TRY(read_counters(t, c2, &blocked2));
-    if (!two_level) { for (int i = 0; i < 4; ++i) c[i] = c2[i]; blocked = blocked2; }
+    u64 c2[4];
+    KCT_TRY(read_counters(t, c2, &unused));
     if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // K1 gave up: every kernel after it exited early, nothing was touched
     *handled = true;
     // (two levels: the second read holds the first submission's tallies too -- the counters were not zeroed in between)
     const u64 counted = c2[kct::CTR_COUNTED], new_keys = c2[kct::CTR_NEW_BY_ZERO], spilled2 = t->h_counters[kNumCounters + 5];
+    const u64 nfailed = t->h_counters[kNumCounters + 7], blocked = t->h_counters[kNumCounters + 3];  // abandoned shadow blocks, their entries
     t->s32_empty = false;
     t->s32_dirty = true;
     t->s32_keys += new_keys;
     t->s32_windows += npos;
-    if (t->debug)
-        KCT_DBG(t, "compact dedupe pass%s: npos=%llu blocks=%llu region_cap=%u counted=%llu new keys=%llu (total %llu) blocked=%llu merged=%llu spilled=%llu\n",
-                probe ? " (probe)" : "", (unsigned long long)npos, (unsigned long long)B, region_cap, (unsigned long long)counted, (unsigned long long)new_keys,
-                (unsigned long long)t->s32_keys, (unsigned long long)blocked, (unsigned long long)c2[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled2);
+    if (pend.pairs) t->pending_pairs = t->h_counters[kNumCounters + 8];
+    KCT_DBG(t, "compact dedupe pass%s: npos=%llu blocks=%llu region_cap=%u counted=%llu new keys=%llu (total %llu) abandoned=%llu blocks / %llu entries merged=%llu spilled=%llu\n",
+            probe ? " (probe)" : "", (unsigned long long)npos, (unsigned long long)B, region_cap, (unsigned long long)counted, (unsigned long long)new_keys,
+            (unsigned long long)t->s32_keys, (unsigned long long)nfailed, (unsigned long long)blocked, (unsigned long long)c2[kct::CTR_TOTAL_ADDED],
+            (unsigned long long)spilled2);
     *n_out += counted + c2[kct::CTR_TOTAL_ADDED];  // (see consume_partitioned about n and a MurmurHash3 value of 0)
     t->n_keys += c2[kct::CTR_NEWKEYS];
+    u64 new_in_table = c2[kct::CTR_NEWKEYS];
     if (spilled2) {
         KCT_TRY(t->d_aux2.reserve(spilled2 * 16));
         HIP_TRY(hipMemcpyAsync(t->d_aux2.p, mv.spill, spilled2 * 16, hipMemcpyDeviceToDevice, t->stream));
         KCT_TRY(replay_spill(t, spilled2, n_out));
     }
+    if (nfailed) {  // shadow blocks that overflowed: their entries are hashed and counted into the real table
+        u64 tl[4] = {0, 0, 0, 0};
+        KCT_TRY(recount_failed(t, 2, aa.scratch, aa.seg_stride, aa.block_stride, aa.region_count, aa.nregions, nfailed, blocked, sbits, tl));
+        *n_out += tl[kct::CTR_TOTAL_ADDED];
+        new_in_table += tl[kct::CTR_NEWKEYS];
+    }
     DedupeOutcome o;
-    o.new_keys = new_keys + c2[kct::CTR_NEWKEYS];
+    o.new_keys = new_keys + new_in_table;
     o.blocked = blocked;
     return after_dedupe_pass(t, true, npos, o, probe);
 }
@@ -575,7 +676,6 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         bool ok = true;
         KCT_TRY(ensure_shadow(t, probe ? std::min(t->cap, kProbeShadowSlots) : t->cap, &ok));  // (the probe's shadow is a small one)
         if (!ok) { t->dedupe_off = true; return KCT_OK; }
-        if (!dry) KCT_TRY(materialize(t));  // what does not fit the shadow goes straight to the real table
     }
     du64 *words = raw ? t->shadow : t->slots;
     // the geometry K1 / K1b / K2 work in: the table's, or the shadow's
@@ -593,7 +693,9 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 8));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
     KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
-    KCT_TRY(t->d_spill.reserve(npos * 16));
+    // the overflow merges' own spill list (entries the real table has no room for): one level -- everything is one
+    // submission -- sized for every overflow region being full; two levels: sized after the fact, below
+    if (!two_level) KCT_TRY(t->d_spill.reserve((u64)nwg * ovf_cap * 16));
     KCT_TRY(zero_counters(t));
     du64 *d_overflow = t->d_counters + kNumCounters + 6;
     unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
@@ -614,7 +716,8 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     kct::AggregateArgs aa;
     aa.words = words; aa.block_bits = gbb; aa.pbits = bbits;
     aa.fresh = fresh ? 1 : 0; aa.overflow = d_overflow; aa.ablate = pa.ablate;
-    aa.spill = (du64 *)t->d_spill.p; aa.spill_cap = npos; aa.spill_n = t->d_counters + kNumCounters; aa.counters = t->d_counters;
+    KCT_TRY(failed_blocks(t, B, &aa.failed));
+    aa.counters = t->d_counters;
     unsigned int ovf2_cap = 0, *d_ovf2_count = nullptr;
     if (!two_level) {
         aa.scratch = (const du64 *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
@@ -647,81 +750,103 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         hipLaunchKernelGGL(kct::aggregate_blocks_kernel, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
     }
     HIP_TRY(hipGetLastError());
-    auto merge_overflows = [&](auto dedupe_tag, const du64 *abort) {
-        // fold the overflow regions with the direct atomic path; the kernel reads the region lengths
-        // (and the abandon flag) from device memory, so no host round trip sits between the launches
-        constexpr int D = decltype(dedupe_tag)::value ? 1 : 0;
+    // K1's (and K1b's) overflow regions go to the real table with the direct insert; so do -- after the pass -- the entries of
+    // blocks that K2 had to abandon (normally none).  A counting pass into a table of one level: the overflow merge rides in
+    // the same submission.  Otherwise the counters are read first: a shadow pass keeps K2's tallies (shadow keys) apart from
+    // the merges' (table keys) and can leave a lazily empty table untouched (the overflow entries then wait in the pending
+    // pair list); two levels size the merges' spill list exactly.
+    kct::PendingList pend;
+    kct::TableView mv = view(t, (u64)nwg * ovf_cap);
+    u64 c[4] = {0, 0, 0, 0}, unused;
+    if (raw || two_level) {
+        KCT_TRY(read_counters(t, c, &unused));
+        if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // abandoned by K1 / K1b: K2 exited early, nothing was touched
+        if (dry) {  // (raw only) the probe of a large table: K1 and K2 into its own small shadow, nothing else
+            *handled = true;
+            dry->counted = c[kct::CTR_COUNTED]; dry->new_keys = c[kct::CTR_NEWKEYS]; dry->blocked = t->h_counters[kNumCounters + 3];
+            return KCT_OK;
+        }
+        if (raw) HIP_TRY(hipMemsetAsync(t->d_counters, 0, (kNumCounters + 1) * sizeof(u64), t->stream));  // the tallies (and the unused spill cursor) only
+        if (raw && two_level && t->lazy_empty && t->h_counters[kNumCounters + 7] == 0) KCT_TRY(reserve_pending(t, d_ovf_count, nwg, d_ovf2_count, P * W, &pend));
+        else {
+            if (raw) KCT_TRY(materialize(t));
+            if (two_level) {
+                u64 total = 0;
+                KCT_TRY(overflow_total(t, d_ovf_count, nwg, d_ovf2_count, P * W, &total));
+                KCT_TRY(t->d_spill.reserve(std::max<u64>(total, 1) * 16));
+                mv = view(t, std::max<u64>(total, 1));
+            }
+        }
+    }
+    const u64 nfailed_k2 = t->h_counters[kNumCounters + 7], failed_entries_k2 = t->h_counters[kNumCounters + 3];  // (valid after a round trip)
+    {
+        // the kernel reads the region lengths (and the abandon flag) from device memory
         ProfScope ps(t, "merge_overflow_kernel");
-        hipLaunchKernelGGL(kct::merge_overflow_kernel<D>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
-                           (const unsigned int *)d_ovf_count, nwg, ovf_cap, abort, view(t, npos), t->d_counters, k);
-        if (two_level)
-            hipLaunchKernelGGL(kct::merge_overflow_kernel<D>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
-                               (const unsigned int *)d_ovf2_count, (int)(P * W), ovf2_cap, abort, view(t, npos), t->d_counters, k);
-    };
-    if (!raw) {
-        merge_overflows(std::false_type{}, (const du64 *)d_overflow);
-        HIP_TRY(hipGetLastError());
+        if (raw) {
+            hipLaunchKernelGGL(kct::merge_overflow_kernel<1>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
+                               (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, mv, t->d_counters, k, (const du64 *)nullptr, pend);
+            if (two_level)
+                hipLaunchKernelGGL(kct::merge_overflow_kernel<1>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
+                                   (const unsigned int *)d_ovf2_count, (int)(P * W), ovf2_cap, (const du64 *)d_overflow, mv, t->d_counters, k, (const du64 *)nullptr, pend);
+        } else {
+            hipLaunchKernelGGL(kct::merge_overflow_kernel<0>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
+                               (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, mv, t->d_counters, k);
+            if (two_level)
+                hipLaunchKernelGGL(kct::merge_overflow_kernel<0>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
+                                   (const unsigned int *)d_ovf2_count, (int)(P * W), ovf2_cap, (const du64 *)d_overflow, mv, t->d_counters, k);
+        }
     }
-    u64 c[4], spilled;
-    KCT_TRY(read_counters(t, c, &spilled));
-    if (t->debug) {
-        std::vector<unsigned int> oc(nwg);
-        (void)hipMemcpy(oc.data(), d_ovf_count, nwg * 4, hipMemcpyDeviceToHost);
-        u64 tot = 0;
-        for (auto v : oc) tot += v;
-        KCT_DBG(t, "partitioned pass%s%s: npos=%llu blocks=%llu levels=%d region_cap=%u overflow(K1)=%llu counted=%llu merged=%llu new=%llu spilled=%llu abandon=%llu\n",
-                raw ? " (shadow)" : "", probe ? " (probe)" : "", (unsigned long long)npos, (unsigned long long)B, two_level ? 2 : 1, region_cap, (unsigned long long)tot,
-                (unsigned long long)c[kct::CTR_COUNTED], (unsigned long long)c[kct::CTR_TOTAL_ADDED], (unsigned long long)c[kct::CTR_NEWKEYS],
-                (unsigned long long)spilled, (unsigned long long)t->h_counters[kNumCounters + 6]);
-    }
+    HIP_TRY(hipGetLastError());
+    u64 c2[4], spilled;
+    KCT_TRY(read_counters(t, c2, &spilled));  // counting pass: K2's tallies and the merges' together; shadow pass: the merges' only
+    const u64 nfailed = raw ? nfailed_k2 : t->h_counters[kNumCounters + 7], failed_entries = raw ? failed_entries_k2 : t->h_counters[kNumCounters + 3];
+    KCT_DBG(t, "partitioned pass%s%s: npos=%llu blocks=%llu levels=%d region_cap=%u counted=%llu merged=%llu new=%llu spilled=%llu abandoned=%llu blocks / %llu entries abandon=%llu\n",
+            raw ? " (shadow)" : "", probe ? " (probe)" : "", (unsigned long long)npos, (unsigned long long)B, two_level ? 2 : 1, region_cap,
+            (unsigned long long)(raw ? c[kct::CTR_COUNTED] : c2[kct::CTR_COUNTED]), (unsigned long long)c2[kct::CTR_TOTAL_ADDED],
+            (unsigned long long)(raw ? c[kct::CTR_NEWKEYS] : c2[kct::CTR_NEWKEYS]), (unsigned long long)spilled, (unsigned long long)nfailed,
+            (unsigned long long)failed_entries, (unsigned long long)t->h_counters[kNumCounters + 6]);
     if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // abandoned: K2 and the merges exited early, nothing was touched
     *handled = true;
-    if (dry) {  // (raw only) the probe of a large table: K1 and K2 into its own small shadow, nothing else
-        dry->counted = c[kct::CTR_COUNTED]; dry->new_keys = c[kct::CTR_NEWKEYS]; dry->blocked = spilled;
-        return KCT_OK;
-    }
+    if (pend.pairs) t->pending_pairs = t->h_counters[kNumCounters + 8];
     if (!raw) {
         t->lazy_empty = false;
-        *n_out += c[kct::CTR_COUNTED] + c[kct::CTR_TOTAL_ADDED];
-        t->n_keys += c[kct::CTR_NEWKEYS];
+        *n_out += c2[kct::CTR_COUNTED] + c2[kct::CTR_TOTAL_ADDED];
+        t->n_keys += c2[kct::CTR_NEWKEYS];
         if (spilled) {
             KCT_TRY(t->d_aux2.reserve(spilled * 16));
             HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
             KCT_TRY(replay_spill(t, spilled, n_out));
         }
+        if (nfailed) {  // table blocks that overflowed: the table grows, their entries are counted with the direct insert
+            u64 tl[4] = {0, 0, 0, 0};
+            KCT_TRY(recount_failed(t, 0, aa.scratch, aa.seg_stride, aa.block_stride, aa.region_count, aa.nregions, nfailed, failed_entries, 0, tl));
+            *n_out += tl[kct::CTR_TOTAL_ADDED];
+        }
         return KCT_OK;
     }
-    // ---- shadow pass: c = entries counted into the shadow / new shadow keys; `spilled` = pairs that found their block full
-    const u64 counted = c[kct::CTR_COUNTED], new_shadow = c[kct::CTR_NEWKEYS], blocked = spilled;
+    // ---- shadow pass: c = entries counted into the shadow / new shadow keys; c2 = what the merges put into the real table
+    const u64 counted = c[kct::CTR_COUNTED], new_shadow = c[kct::CTR_NEWKEYS], blocked = failed_entries;
     t->shadow_empty = false;
     t->shadow_dirty = true;
     t->shadow_keys += new_shadow;
-    if (blocked) {
-        KCT_TRY(t->d_aux2.reserve(blocked * 16));
-        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, blocked * 16, hipMemcpyDeviceToDevice, t->stream));
-        HIP_TRY(hipMemcpyAsync(t->d_counters + kNumCounters + 5, t->d_counters + kNumCounters, 8, hipMemcpyDeviceToDevice, t->stream));
-    }
-    HIP_TRY(hipMemsetAsync(t->d_counters, 0, (kNumCounters + 1) * sizeof(u64), t->stream));  // the tallies and the spill cursor, not the copied pair count
-    merge_overflows(std::true_type{}, (const du64 *)nullptr);
-    if (blocked) {
-        ProfScope ps(t, "merge_mixed_pairs_kernel");
-        hipLaunchKernelGGL(kct::merge_mixed_pairs_kernel, dim3(merge_grid(blocked)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_aux2.p,
-                           (const du64 *)(t->d_counters + kNumCounters + 5), (u64)blocked, view(t, npos), (int)k, t->d_counters);
-    }
-    HIP_TRY(hipGetLastError());
-    u64 c2[4], spilled2;
-    KCT_TRY(read_counters(t, c2, &spilled2));
     // n counts every window whose k-mer went into the shadow: the (2^-64 per k-mer) case of a MurmurHash3 value of 0,
     // which the reference leaves out of n, is only seen when the shadow is flushed.
     *n_out += counted + c2[kct::CTR_TOTAL_ADDED];
     t->n_keys += c2[kct::CTR_NEWKEYS];
-    if (spilled2) {
-        KCT_TRY(t->d_aux2.reserve(spilled2 * 16));
-        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled2 * 16, hipMemcpyDeviceToDevice, t->stream));
-        KCT_TRY(replay_spill(t, spilled2, n_out));
+    u64 new_in_table = c2[kct::CTR_NEWKEYS];
+    if (spilled) {
+        KCT_TRY(t->d_aux2.reserve(spilled * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(replay_spill(t, spilled, n_out));
+    }
+    if (nfailed) {  // shadow blocks that overflowed: their entries are hashed and counted into the real table
+        u64 tl[4] = {0, 0, 0, 0};
+        KCT_TRY(recount_failed(t, 1, aa.scratch, aa.seg_stride, aa.block_stride, aa.region_count, aa.nregions, nfailed, failed_entries, 0, tl));
+        *n_out += tl[kct::CTR_TOTAL_ADDED];
+        new_in_table += tl[kct::CTR_NEWKEYS];
     }
     DedupeOutcome o;
-    o.new_keys = new_shadow + c2[kct::CTR_NEWKEYS];
+    o.new_keys = new_shadow + new_in_table;
     o.blocked = blocked;
     KCT_TRY(after_dedupe_pass(t, false, npos, o, probe));
     // the shadow holds as many keys as the table would: grow both (the table's growth re-creates the shadow, flushed)
@@ -753,8 +878,8 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
     const u64 last_start = nbytes - k;  // last window start position
     const u64 cap_at_entry = t->cap;
     // Launch chunk.  The partitioned path on a large table re-reads and re-writes every table block
-    // once per pass, so it wants passes of several windows per slot; its scratch + spill lists cost
-    // ~26-36 B per window start, which bounds the pass by HBM (this is what 288 GB is for).  Decided
+    // once per pass, so it wants passes of several windows per slot; its scratch costs
+    // ~11-21 B per window start, which bounds the pass by HBM (this is what 288 GB is for).  Decided
     // once per call: buffers this table already holds are reused, so they count as available.
     u64 chunk_limit = kChunkPositions;
     if (t->force_path != 1 && partition_geometry_ok(t) && (t->cap >> t->block_bits) > 1024) {
@@ -763,13 +888,13 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
             const u64 held = t->d_scratch.cap + t->d_scratch2.cap + t->d_spill.cap + t->d_irr.cap + t->d_irr2.cap;
             double avail = (double)free_b + (double)held;
             // a shadow table this call may still have to allocate; per window: two levels of 4- or 8-byte entries with
-            // 20 % of slack, and a 16-byte spill-list slot
+            // ~20 % of slack, plus overflow regions
             const bool may_dedupe = t->k <= 32 && !t->dedupe_off && t->force_path != 2, may_compact = may_dedupe && t->k <= 21 && !t->compact_off;
             if (may_compact && !(t->shadow32 && t->s32_sbits == compact_sbits_for(t))) avail -= (double)(1ULL << (compact_sbits_for(t) + kct::kBlockBitsMax)) * 8.0;
             else if (may_dedupe && !may_compact && !(t->shadow && t->shadow_cap == t->cap)) avail -= (double)t->cap * 16.0;
-            const double per_window = may_compact ? 26.0 : 36.0;
+            const double per_window = may_compact ? 11.0 : 21.0;
             const u64 by_mem = avail > 0 ? (u64)(avail * 0.8 / per_window) : 0;
-            chunk_limit = std::max<u64>(kChunkPositions, std::min<u64>(8 * t->cap, by_mem));
+            chunk_limit = std::max<u64>(kChunkPositions, std::min<u64>(16 * t->cap, by_mem));
             chunk_limit &= ~(u64)0xFFFF;  // keeps `d_stream + done` 16-byte aligned
         }
     }

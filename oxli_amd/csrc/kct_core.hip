@@ -61,7 +61,7 @@ kct_status use_consume(kct_table *t) {
 
 kct_status use(kct_table *t) {
     KCT_TRY(use_consume(t));
-    if (t->shadow_dirty || t->s32_dirty) {   // reads must observe every earlier consume()
+    if (t->shadow_dirty || t->s32_dirty || t->pending_pairs) {   // reads must observe every earlier consume()
         KCT_DBG(t, "use(): converting pending counts (%llu / %llu shadow keys)\n", (unsigned long long)t->shadow_keys, (unsigned long long)t->s32_keys);
         KCT_TRY(flush_shadow(t));
         KCT_DBG(t, "use(): converted\n");
@@ -111,7 +111,7 @@ kct_status zero_counters(kct_table *t) {
 
 // copies the tallies back and folds the shards; waits for the stream
 kct_status read_counters(kct_table *t, u64 out[4], u64 *spill_n) {
-    HIP_TRY(hipMemcpyAsync(t->h_counters, t->d_counters, (kNumCounters + 8) * sizeof(u64), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->h_counters, t->d_counters, (kNumCounters + 9) * sizeof(u64), hipMemcpyDeviceToHost, t->stream));  // (+ the pending-list cursor)
     HIP_TRY(hipStreamSynchronize(t->stream));
     for (int c = 0; c < 4; ++c) out[c] = 0;
     for (int s = 0; s < kct::kCounterShards; ++s)
@@ -192,14 +192,6 @@ kct_status merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u
     return KCT_OK;
 }
 
-void launch_merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n_cap, const du64 *n_dev, int stride, kct::TableView tv) {
-    ProfScope ps(t, "merge_pairs_kernel");
-    hipLaunchKernelGGL(kct::merge_pairs_kernel, dim3(256), dim3(kct::kBlock), 0, t->stream, d_keys, d_counts, n_cap, n_dev, (const du64 *)nullptr, stride,
-                       tv, t->d_counters);
-}
-
-// Re-hash into a table of new_cap slots.  The new array is installed only once every key has been placed in it; on
-// failure the table is left as it was.
 kct_status rehash_into(kct_table *t, u64 new_cap);
 
 kct_status grow_to(kct_table *t, u64 new_cap) {
@@ -326,8 +318,9 @@ kct_status kct_create(uint8_t ksize, uint64_t capacity_hint, int device, kct_tab
     auto fail = [&](kct_status s) { kct_destroy(t); return s; };
     if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return fail(KCT_ERR_HIP); }
     t->own_stream = true;
-    if (hipMalloc((void **)&t->d_counters, (kNumCounters + 8) * sizeof(u64)) != hipSuccess) { set_err("hipMalloc(counters) failed"); return fail(KCT_ERR_NOMEM); }
-    if (hipHostMalloc((void **)&t->h_counters, (kNumCounters + 8) * sizeof(u64), hipHostMallocDefault) != hipSuccess) { set_err("hipHostMalloc failed"); return fail(KCT_ERR_NOMEM); }
+    if (hipMalloc((void **)&t->d_counters, (kNumCounters + 16) * sizeof(u64)) != hipSuccess) { set_err("hipMalloc(counters) failed"); return fail(KCT_ERR_NOMEM); }
+    if (hipMemset(t->d_counters, 0, (kNumCounters + 16) * sizeof(u64)) != hipSuccess) { set_err("hipMemset(counters) failed"); return fail(KCT_ERR_HIP); }
+    if (hipHostMalloc((void **)&t->h_counters, (kNumCounters + 16) * sizeof(u64), hipHostMallocDefault) != hipSuccess) { set_err("hipHostMalloc failed"); return fail(KCT_ERR_NOMEM); }
     u64 cap = capacity_hint ? next_pow2((u64)((double)capacity_hint / kMaxLoad) + 1) : kDefaultSlots;
     t->auto_sized = capacity_hint == 0;
     cap = std::max(cap, kMinSlots);
@@ -354,7 +347,7 @@ void kct_destroy(kct_table *t) {
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     t->d_stream.release(); t->d_spill.release(); t->d_aux.release(); t->d_aux2.release();
     t->d_scratch.release(); t->d_regions.release(); t->d_irr.release(); t->d_sort.release();
-    t->d_scratch2.release(); t->d_regions2.release(); t->d_irr2.release(); t->d_pairs_ovf.release(); t->d_prefix.release();
+    t->d_scratch2.release(); t->d_regions2.release(); t->d_irr2.release(); t->d_pairs_ovf.release(); t->d_prefix.release(); t->d_pending.release(); t->d_failed.release();
     t->h_stage.release(); t->h_pending.release();
     if (t->shadow) (void)hipFree(t->shadow);
     if (t->shadow32) (void)hipFree(t->shadow32);
@@ -372,6 +365,7 @@ kct_status kct_clear(kct_table *t) {
     t->shadow_empty = true; t->shadow_dirty = false; t->shadow_keys = 0; t->dedupe_off = false;  // pending counts are forgotten too
     t->s32_empty = true; t->s32_dirty = false; t->s32_keys = 0; t->s32_windows = 0; t->compact_off = false;
     t->n_keys = 0; t->consumed = 0; t->zero_present = false; t->zero_count = 0;
+    if (t->pending_pairs) { t->pending_pairs = 0; HIP_TRY(hipMemsetAsync(t->d_counters + kNumCounters + 8, 0, 8, t->stream)); }
     return KCT_OK;
 }
 
@@ -702,7 +696,7 @@ kct_status kct_release_scratch(kct_table *t) {
     KCT_TRY(use(t));  // nothing may be pending in a buffer that is about to go
     HIP_TRY(hipStreamSynchronize(t->stream));
     for (DevBuf *b : {&t->d_stream, &t->d_spill, &t->d_aux, &t->d_aux2, &t->d_scratch, &t->d_regions, &t->d_irr, &t->d_sort, &t->d_scratch2,
-                      &t->d_regions2, &t->d_irr2, &t->d_pairs_ovf, &t->d_prefix})
+                      &t->d_regions2, &t->d_irr2, &t->d_pairs_ovf, &t->d_prefix, &t->d_pending, &t->d_failed})
         b->release();
     if (t->shadow) { (void)hipFree(t->shadow); t->shadow = nullptr; t->shadow_cap = 0; t->shadow_empty = true; t->shadow_keys = 0; }
     if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; t->s32_empty = true; t->s32_keys = 0; t->s32_windows = 0; }

@@ -70,6 +70,18 @@ struct DevBuf {  // grow-only device buffer
         cap = want;
         return KCT_OK;
     }
+    // the same, keeping the first `keep` bytes (waits for `stream`)
+    kct_status reserve_keep(size_t n, size_t keep, hipStream_t stream) {
+        if (n <= cap) return KCT_OK;
+        size_t want = std::max(std::max(n, 2 * cap), (size_t)4096);
+        void *q = nullptr;
+        HIP_TRY(hipMalloc(&q, want));
+        if (p && keep) HIP_TRY(hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (p) HIP_TRY(hipFree(p));
+        p = q; cap = want;
+        return KCT_OK;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
@@ -132,6 +144,10 @@ struct kct_table {
     // the dedupe probe's own small shadows (kept between calls, swapped in for the probe pass only)
     du64 *probe_shadow = nullptr;
     unsigned int *probe_shadow32 = nullptr;
+    // {hash, count} pairs a dedupe-first pass set aside instead of inserting them into a lazily empty table (merge_overflow_kernel's
+    // PendingList): merged by the next conversion.  The device cursor is d_counters[kNumCounters + 8] (zero_counters leaves it).
+    kcth::DevBuf d_pending;
+    u64 pending_pairs = 0;
     u64 windows_since_read = 0; // window starts consumed since anything last read the table (use()): how long the caller's runs are
     u64 call_windows_left = 0;  // window starts the running consume call still has to count (no read can come before them)
     bool dedupe_hint = false;   // the last dedupe-first pass paid off: a cleared table starts with that path again
@@ -143,6 +159,7 @@ struct kct_table {
     du64 *d_counters = nullptr;  // kNumCounters tallies + 8 scratch words (device)
     u64 *h_counters = nullptr;   // pinned mirror
     kcth::DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort, d_scratch2, d_regions2, d_irr2, d_pairs_ovf,
+        d_failed,  // K2: the numbers of the blocks it abandoned (partition_kernels.h FailedBlocks)
         d_prefix;  // error mode: the offending record's valid prefix (its own buffer: consume_stream reuses d_aux2 / d_spill)
     kcth::PinnedBuf h_stage;
     std::vector<kcth::PinnedBuf> h_file;  // kct_consume_file's chunk buffers (two per parser thread), kept between calls
@@ -184,7 +201,7 @@ struct ProfScope {
 void prof_collect(kct_table *t);
 kct_status use(kct_table *t);         // select the device, count whatever deferred mode has buffered, convert the shadow table's pending counts
 kct_status use_consume(kct_table *t); // the same without the shadow flush: what consume entry points call
-kct_status flush_shadow(kct_table *t);
+kct_status flush_shadow(kct_table *t);   // both shadows' pending counts and the pending pair list -> the real table
 void parallel_memcpy(void *dst, const void *src, size_t nbytes);  // several threads above 8 MiB
 kct_status use_device(kct_table *t);  // select the device only
 kct_status flush_pending(kct_table *t);
@@ -197,10 +214,9 @@ kct_status zero_counters(kct_table *t);
 kct_status read_counters(kct_table *t, u64 out[4], u64 *spill_n);
 int merge_grid(u64 n);
 kct_status grow_to(kct_table *t, u64 new_cap);
+u64 spill_growth_target(const kct_table *t, u64 spilled);  // the capacity to grow to when `spilled` entries found no room
 kct_status maybe_grow(kct_table *t);
 kct_status merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n, int stride, u64 tallies[4]);
-// one launch of merge_pairs_kernel over at most n_cap pairs, their number read from *n_dev on the device; tallies go to d_counters
-void launch_merge_pairs(kct_table *t, const du64 *d_keys, const du64 *d_counts, u64 n_cap, const du64 *n_dev, int stride, kct::TableView tv);
 kct_status replay_spill(kct_table *t, u64 spilled, u64 *n_out);
 // kct_consume.hip: {hash, count} pairs through the LDS-ring partition + per-block LDS merge (tables of up to 1024 blocks)
 bool pairs_partition_pays(const kct_table *t, u64 n);

@@ -388,6 +388,17 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     }
 }
 
+// A block whose keys do not fit (the table, or the shadow, is too small for what a pass brings) is ABANDONED by its K2
+// workgroup: nothing of the pass is stored for it -- its HBM image stays as it was (zeros for a lazily empty table) -- and
+// its number goes on this list.  Its entries still sit in its scratch regions; after the pass the host makes room and
+// recount_failed_kernel counts them with the direct insert.  So K2 needs no per-window spill list: a list that had to
+// be sized for the worst case (16 B per window start of the pass) and was practically never used.
+struct FailedBlocks {
+    u32 *list = nullptr;   // block numbers, one per abandoned block
+    u64 *n = nullptr;      // how many
+    u64 *entries = nullptr;  // sum of their regions' entry counts
+};
+
 struct AggregateArgs {
     u64 *words;          // the table (block-SoA)
     int block_bits;
@@ -399,7 +410,7 @@ struct AggregateArgs {
     int fresh;           // table known empty: start every block from zeros instead of loading it
     const u64 *overflow; // K1's abandon flag
     int ablate;          // measurement only: bit 2 (4) = no count add, bit 4 (16) = loads only, bit 6 (64) = no streaming at all
-    u64 *spill; u64 spill_cap; u64 *spill_n;
+    FailedBlocks failed;
     u64 *counters;
 };
 
@@ -408,12 +419,13 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
     __shared__ u64 wq[(kPartThreads / 64) * kWaveQueue];                  // per-wave queues of deferred entries, 20 KiB
     __shared__ __attribute__((aligned(16))) unsigned char tags[1 << kBlockBitsMax];  // one fingerprint byte per slot, 8 KiB
     __shared__ u64 s_counted, s_new;
+    __shared__ u32 s_failed;
     if (*a.overflow) return;  // wave-uniform: K1 gave up, the host reruns the batch on the direct path
     const int b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
     u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u64 *keys = tab, *cnts = tab + S;
-    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
+    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; s_failed = 0; }
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
     // fingerprint of a key: a hash byte that neither the slot index (low bits) nor the multi-GPU
     // owner (top bits) uses; 0 is reserved for "empty slot"
@@ -459,10 +471,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
             g = (g + kGroup) & smask;
         }
         if (placed) ++counted;
-        else {  // block full: grow-and-replay list, tallied when replayed
-            u64 si = atomicAdd(a.spill_n, 1ULL);
-            if (si < a.spill_cap) { a.spill[2 * si] = h; a.spill[2 * si + 1] = 1; }
-        }
+        else s_failed = 1u;  // block full: the whole block is abandoned (FailedBlocks)
     };
     // Fast path: ~93 % of a block's entries are repeat sightings of a key that already sits in
     // its home group.  Those cost one 8-byte read of the group's fingerprints, a SWAR byte match,
@@ -575,6 +584,16 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
     u64 wc = wave_sum(counted), wn = wave_sum(newkeys);
     if (lane == 0) { atomicAdd(&s_counted, wc); atomicAdd(&s_new, wn); }
     __syncthreads();
+    if (s_failed) {  // (read after the barrier: uniform)
+        if (a.fresh) for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) {
+            u64 entries = 0;
+            for (int r = 0; r < a.nregions; ++r) entries += my_counts[r];
+            a.failed.list[atomicAdd(a.failed.n, 1ULL)] = (u32)b;
+            atomicAdd(a.failed.entries, entries);
+        }
+        return;
+    }
     for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
     if (threadIdx.x == 0) {
         u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
@@ -624,34 +643,6 @@ __global__ __launch_bounds__(kBlock) void shadow_flush_kernel(u64 *__restrict__ 
     }
 }
 
-// {mix64 value, count} pairs that found their shadow block full -> the real table (same tallies)
-template <int MODE = 1>
-__global__ __launch_bounds__(kBlock) void merge_mixed_pairs_kernel(const u64 *__restrict__ pairs, const u64 *n_dev, u64 n_cap, TableView main,
-                                                                   int k, u64 *counters) {
-    __shared__ u32 ascii4[256];
-    __shared__ u64 s_tot, s_new;
-    fill_ascii4_lut(ascii4, threadIdx.x, kBlock);
-    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; }
-    __syncthreads();
-    u64 n = *n_dev;
-    n = n < n_cap ? n : n_cap;
-    u64 tot = 0, nk = 0;
-    for (u64 i = (u64)blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64)gridDim.x * kBlock) {
-        const u64 h = hash_of_mixed<MODE>(pairs[2 * i], k, ascii4), c = pairs[2 * i + 1];
-        if (h == 0) continue;
-        const AddResult r = table_add<false>(main, h, c);
-        if (!r.spilled) { tot += c; nk += r.claimed; }
-    }
-    tot = wave_sum(tot); nk = wave_sum(nk);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
-        if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
-        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
-    }
-}
-
 // ---- compact dedupe-first path (k <= 21): 32-bit entries, a shadow table of u32 keys and u32 counts ----------------
 // A mix42 value is 10 bits of bin and 32 bits of entry; within a bin the entry identifies the k-mer.  K1 (MODE 2)
 // wrote the entries; this is K2 for them: same block ownership, fingerprint fast path and deferred queue as
@@ -668,7 +659,7 @@ struct Aggregate32Args {
     int nregions;
     int fresh;
     const u64 *overflow; // K1's abandon flag
-    u64 *spill; u64 spill_cap; u64 *spill_n;  // {mix42 value | bit 63, 1} pairs of entries that found their block full
+    FailedBlocks failed; // blocks that overflowed (abandoned whole; the host recounts their regions)
     u64 *counters;
     int ablate;          // measurement only: bit 4 (16) = loads only
     int sbits;           // log2(blocks of the shadow): a block index is the TOP sbits bits of the 42-bit value (>= 10)
@@ -681,16 +672,15 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
     __shared__ u32 wq[(kPartThreads / 64) * kWaveQueue32];
     __shared__ __attribute__((aligned(16))) unsigned char tags[1 << kBlockBitsMax];
     __shared__ u64 s_counted, s_new;
+    __shared__ u32 s_failed;
     if (*a.overflow) return;
     const int b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
     u32 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u32 *keys = tab, *cnts = tab + S;
-    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; }
+    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; s_failed = 0; }
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
     auto tag_of = [](u32 e) -> u32 { const u32 t = (e >> 13) & 0xFFu; return t ? t : 1u; };
-    // the 42-bit value of an entry of this block: its top 10 bits are the block index's top 10, the entry is its low 32
-    const u64 value_hi = ((u64)((u32)b >> (a.sbits - 10)) << 32) | (1ULL << 63);
     if (a.fresh) {
         for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
         for (u32 i = threadIdx.x; i < S / 16; i += kPartThreads) reinterpret_cast<uint4 *>(tags)[i] = make_uint4(0, 0, 0, 0);
@@ -724,10 +714,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
             g = (g + kGroup) & smask;
         }
         if (placed) ++counted;
-        else {
-            const u64 si = atomicAdd(a.spill_n, 1ULL);
-            if (si < a.spill_cap) { a.spill[2 * si] = value_hi | e; a.spill[2 * si + 1] = 1; }
-        }
+        else s_failed = 1u;  // block full: the whole block is abandoned (FailedBlocks)
     };
     u32 *myq = wq + wave * kWaveQueue32;
     u32 qn = 0;
@@ -848,6 +835,16 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
     u64 wc = wave_sum((u64)counted), wn = wave_sum((u64)newkeys);
     if (lane == 0) { atomicAdd(&s_counted, wc); atomicAdd(&s_new, wn); }
     __syncthreads();
+    if (s_failed) {
+        if (a.fresh) for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) {
+            u64 entries = 0;
+            for (int r = 0; r < a.nregions; ++r) entries += my_counts[r];
+            a.failed.list[atomicAdd(a.failed.n, 1ULL)] = (u32)b;
+            atomicAdd(a.failed.entries, entries);
+        }
+        return;
+    }
     for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
     if (threadIdx.x == 0) {
         u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
@@ -984,18 +981,19 @@ struct AggregatePairsArgs {
     const ulonglong2 *scratch; u64 seg_stride, block_stride;  // region (seg, b) at scratch + seg * seg_stride + b * block_stride
     const u32 *region_count; int nregions;
     int fresh;
-    u64 *spill; u64 spill_cap; u64 *spill_n;  // pairs that found their block full: grown-and-replayed by the host
+    FailedBlocks failed; // blocks that overflowed (abandoned whole; the host grows the table and recounts their regions)
     u64 *counters;       // CTR_TOTAL_ADDED (counts placed), CTR_NEWKEYS
 };
 
 __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(AggregatePairsArgs a) {
     __shared__ __attribute__((aligned(16))) u64 tab[2 << kBlockBitsMax];
     __shared__ u64 s_tot, s_new, s_nz;
+    __shared__ u32 s_failed;
     const int b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
     u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u64 *keys = tab, *cnts = tab + S;
-    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; s_nz = 0; }
+    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; s_nz = 0; s_failed = 0; }
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
     if (a.fresh) for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
     else for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
@@ -1028,10 +1026,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(Aggregate
             g = (g + kGroup) & smask;
         }
         if (placed) tot += c;
-        else {
-            const u64 si = atomicAdd(a.spill_n, 1ULL);
-            if (si < a.spill_cap) { a.spill[2 * si] = h; a.spill[2 * si + 1] = c; }
-        }
+        else s_failed = 1u;  // block full: the whole block is abandoned (FailedBlocks)
     };
     if (a.nregions >= 64) {
         // One level: a region holds only a handful of pairs (one workgroup's share of one block): FOUR lanes take a region,
@@ -1053,6 +1048,16 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(Aggregate
     tot = wave_sum(tot); nk = wave_sum(nk); nz = wave_sum(nz);
     if (lane == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); atomicAdd(&s_nz, nz); }
     __syncthreads();
+    if (s_failed) {
+        if (a.fresh) for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) {
+            u64 entries = 0;
+            for (int r = 0; r < a.nregions; ++r) entries += my_counts[r];
+            a.failed.list[atomicAdd(a.failed.n, 1ULL)] = (u32)b;
+            atomicAdd(a.failed.entries, entries);
+        }
+        return;
+    }
     for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
     if (threadIdx.x == 0) {
         u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
@@ -1067,10 +1072,19 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(Aggregate
 // equal (that is why they overflowed), so every wave first folds equal hashes: the lowest active
 // lane is the leader, all lanes holding the leader's hash retire into one add, repeat.
 // DEDUPE: the entries are mix64 values of packed k-mers (dedupe-first path); each group leader hashes its k-mer first.
+// pend (optional): instead of inserting, APPEND the folded {hash, count} pairs to a list that the next conversion of the
+// pending counts merges -- so that a dedupe-first pass need not touch a table that is still lazily empty (no memset, and
+// the conversion then starts every table block from zeros).  The entries are tallied as counted either way.
+struct PendingList {
+    u64 *pairs = nullptr;  // 2 * cap words
+    u64 cap = 0;
+    u64 *n = nullptr;      // cursor (device), never reset between passes
+};
+
 template <int DEDUPE = 0>  // 0: hashes; 1: mix64 values; 2: mix42 values (bit 63 set)
 __global__ __launch_bounds__(kBlock) void merge_overflow_kernel(const u64 *__restrict__ regions, const u32 *__restrict__ counts,
                                                                 int nregions, u32 region_cap, const u64 *abort, TableView table,
-                                                                u64 *counters, int k = 0, const u64 *total = nullptr) {
+                                                                u64 *counters, int k = 0, const u64 *total = nullptr, PendingList pend = PendingList()) {
     __shared__ u64 s_tot, s_new;
     __shared__ u32 ascii4[DEDUPE ? 256 : 1];
     if (abort && *abort) return;
@@ -1101,8 +1115,14 @@ __global__ __launch_bounds__(kBlock) void merge_overflow_kernel(const u64 *__res
             if (is_leader) {
                 const u64 hh = DEDUPE ? hash_of_mixed<(DEDUPE == 2 ? 2 : 1)>(h, k, ascii4) : h;
                 if (hh != 0) {
-                    const AddResult res = table_add<false>(table, hh, c);
-                    if (!res.spilled) { tot += c; nk += res.claimed; }
+                    if (pend.pairs) {
+                        const u64 pi = atomicAdd(pend.n, 1ULL);
+                        if (pi < pend.cap) { pend.pairs[2 * pi] = hh; pend.pairs[2 * pi + 1] = c; }  // (cap = every overflow entry: cannot be exceeded)
+                        tot += c;
+                    } else {
+                        const AddResult res = table_add<false>(table, hh, c);
+                        if (!res.spilled) { tot += c; nk += res.claimed; }
+                    }
                 }
             }
         }
@@ -1114,6 +1134,73 @@ __global__ __launch_bounds__(kBlock) void merge_overflow_kernel(const u64 *__res
         u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
         if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
         if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+    }
+}
+
+// ---- the abandoned blocks of a K2 launch -> the real table, with the direct insert ---------------------------------------
+// One 256-thread workgroup per abandoned block walks the block's scratch regions (same layout as K2 read them).
+// MODE 0: u64 MurmurHash3 values; 1: u64 mix64 values of packed k-mers (hashed here); 2: u32 compact entries (the block
+// number gives the 42-bit value's upper bits; hashed here); 3: {hash, count} pairs.  Equal neighbours are folded per wave
+// first (a block's entries repeat its k-mers many times over).  Tallies: CTR_TOTAL_ADDED, CTR_NEWKEYS, CTR_NEW_BY_ZERO.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void recount_failed_kernel(const void *scratch, u64 seg_stride, u64 block_stride, const u32 *region_count, int nregions,
+                                                                const u32 *failed_list, u64 nfailed, TableView table, u64 *counters, int k, int sbits) {
+    using T = typename std::conditional<MODE == 3, ulonglong2, typename std::conditional<MODE == 2, u32, u64>::type>::type;
+    __shared__ u64 s_tot, s_new, s_nz;
+    __shared__ u32 ascii4[(MODE == 1 || MODE == 2) ? 256 : 1];
+    if constexpr (MODE == 1 || MODE == 2) fill_ascii4_lut(ascii4, threadIdx.x, kBlock);
+    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; s_nz = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64 tot = 0, nk = 0, nz = 0;
+    for (u64 fi = blockIdx.x; fi < nfailed; fi += gridDim.x) {
+        const u32 b = failed_list[fi];
+        for (int seg = 0; seg < nregions; ++seg) {
+            const u32 cnt = region_count[(u64)b * nregions + seg];
+            const T *src = reinterpret_cast<const T *>(scratch) + (u64)seg * seg_stride + (u64)b * block_stride;
+            for (u32 base = 64u * wave; base < cnt; base += kBlock) {
+                const u32 i = base + lane;
+                u64 h = 0, c = 1;
+                if (i < cnt) {
+                    if constexpr (MODE == 3) { const ulonglong2 pr = src[i]; h = pr.x; c = pr.y; }
+                    else if constexpr (MODE == 2) { const u32 e = src[i]; h = e ? ((((u64)(b >> (sbits - 10))) << 32) | e | (1ULL << 63)) : 0ULL; }
+                    else h = src[i];
+                }
+                bool pending = h != 0, is_leader = false;
+                u64 csum = 0, act;
+                while ((act = __ballot(pending)) != 0) {  // fold equal values: one insert per distinct value of the wave
+                    const int leader = __ffsll((long long)act) - 1;
+                    const u64 hl = read_lane64(h, leader);
+                    const bool mine = pending && h == hl;
+                    const u64 same = __ballot(mine);
+                    u64 part = mine ? c : 0ULL;  // (pairs carry their own counts)
+                    if constexpr (MODE == 3) {
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+                    } else part = (u64)__popcll(same);
+                    if (lane == leader) { is_leader = true; csum = part; }
+                    if (mine) pending = false;
+                }
+                if (is_leader) {
+                    u64 hh = h;
+                    if constexpr (MODE == 1) hh = hash_of_mixed<1>(h, k, ascii4);
+                    if constexpr (MODE == 2) hh = hash_of_mixed<2>(h, k, ascii4);
+                    if (hh != 0) {
+                        const AddResult res = table_add<true>(table, hh, csum);
+                        if (!res.spilled) { tot += csum; nk += res.claimed; nz += res.old == 0; }
+                    }
+                }
+            }
+        }
+    }
+    tot = wave_sum(tot); nk = wave_sum(nk); nz = wave_sum(nz);
+    if (lane == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); atomicAdd(&s_nz, nz); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+        if (s_nz) atomicAdd(shard + CTR_NEW_BY_ZERO, s_nz);
     }
 }
 

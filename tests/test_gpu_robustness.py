@@ -159,3 +159,39 @@ def test_add_on_one_device_matches_oracle(KCT):
     assert a.add(b) == ra.add(rb)
     assert_same_table(a, ra)
     assert_same_table(b, rb)                          # the source is unchanged
+
+
+@pytest.mark.parametrize("k,path,cap_hint,G,R", [
+    (21, "partitioned", 300_000, 3_000_000, 200_000),     # 64 table blocks for 3 M k-mers: most blocks overflow, one level
+    (21, "dedupe", 300_000, 3_000_000, 200_000),          # ... the small compact shadow holds them; its conversion overflows the table
+    (31, "dedupe", 300_000, 3_000_000, 200_000),          # ... the table-sized 64-bit shadow overflows too
+    (25, "partitioned", 6_000_000, 20_000_000, 600_000),  # 2^24 slots for ~19 M k-mers: two levels, blocks overflow
+    (21, "dedupe", 6_000_000, 20_000_000, 600_000),       # ... the compact two-level shadow (2^29 slots) holds them; the table does not
+    (31, "dedupe", 6_000_000, 20_000_000, 600_000),       # ... the 2^24-slot 64-bit shadow does not
+])
+def test_undersized_tables_abandon_blocks_and_recount(KCT, k, path, cap_hint, G, R):
+    """A capacity hint far below what the input brings: K2 workgroups find their block full and abandon it, the host makes
+    room and recounts those blocks' entries with the direct insert (no per-window spill list exists any more).  Exactness must
+    not depend on the hint."""
+    import os
+
+    import torch
+    L = 150
+    genome = oracle.synth_genome(G, 77)
+    reads = oracle.synth_reads(genome, 0, R, L, 78)
+    ref, n_ref, _ = oracle.baseline_consume(reads, L, k, max(1, min(16, len(os.sched_getaffinity(0)))), native=False)
+    dev_reads = torch.from_numpy(reads.reshape(-1)).cuda()
+    t = KCT(k, capacity=cap_hint)
+    t.set_path(path)
+    t.profile(True)
+    assert t.consume_device(dev_reads.data_ptr(), dev_reads.numel(), R * L) == n_ref
+    dk, dc = t.dump_arrays(1)
+    prof = t.profile_read()
+    assert "recount_failed_kernel" in prof, prof   # blocks really were abandoned
+    rk, rc = ref.dump_arrays()
+    assert np.array_equal(dk, rk) and np.array_equal(dc, rc)
+    assert len(t) == len(ref) and t.sum_counts == n_ref
+    # once more into the (now large enough) table
+    assert t.consume_device(dev_reads.data_ptr(), dev_reads.numel(), R * L) == n_ref
+    dk, dc = t.dump_arrays(1)
+    assert np.array_equal(dk, rk) and np.array_equal(dc, 2 * rc)
