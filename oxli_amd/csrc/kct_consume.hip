@@ -123,11 +123,12 @@ Levels levels_for(int bbits, int nwg) {
 }
 
 // second partition level: lines of a bin that leave the ring together -- 2 or 4 when the ring is deep enough (its depth in
-// lines per bin >= 8x that), so that the scattered 64-byte stores become 128- or 256-byte ones
+// lines per bin >= 4x that), so that the scattered 64-byte stores become 128- or 256-byte ones (K1b: 1 -> 2 lines -13 %,
+// 2 -> 4 lines another -4 %)
 unsigned int repartition_min_lines(int ring_entries, int sub_bits, int entry_bytes) {
     if (const char *e = getenv("KCT_K1B_LINES")) return (unsigned int)std::max(1, std::min(4, atoi(e)));  // measurement only
     const int lines_per_bin = (ring_entries >> sub_bits) * entry_bytes / 64;
-    return lines_per_bin >= 32 ? 4u : lines_per_bin >= 16 ? 2u : 1u;
+    return lines_per_bin >= 16 ? 4u : lines_per_bin >= 8 ? 2u : 1u;
 }
 
 // overflow regions: an eighth of a workgroup's entries, but few enough that ring positions (21 bits in ring_flush's line
@@ -249,9 +250,12 @@ kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const
     fa.ovf = (du64 *)t->d_pairs_ovf.p; fa.ovf_cap = npairs; fa.ovf_n = d_ovf_n;
     {
         ProfScope ps(t, "flush_partition_kernel");
-        if (src == 0) hipLaunchKernelGGL(kct::flush_partition_kernel<0>, dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
-        else if (src == 1) hipLaunchKernelGGL(kct::flush_partition_kernel<1>, dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
-        else hipLaunchKernelGGL(kct::flush_partition_kernel<2>, dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
+        // (the popular k get the MurmurHash3 structure at compile time: the kernel is bound by hashing the pending k-mers)
+        if (src == 0 && t->k == 21) hipLaunchKernelGGL((kct::flush_partition_kernel<0, 21>), dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
+        else if (src == 0) hipLaunchKernelGGL((kct::flush_partition_kernel<0, 0>), dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
+        else if (src == 1 && t->k == 31) hipLaunchKernelGGL((kct::flush_partition_kernel<1, 31>), dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
+        else if (src == 1) hipLaunchKernelGGL((kct::flush_partition_kernel<1, 0>), dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
+        else hipLaunchKernelGGL((kct::flush_partition_kernel<2, 0>), dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, fa);
     }
     HIP_TRY(hipGetLastError());
     kct::AggregatePairsArgs pa;

@@ -902,9 +902,10 @@ struct FlushPartitionArgs {
 };
 
 // SRC 0: the compact shadow; 1: the 64-bit shadow; 2: a flat list of {hash, count} pairs (merges: add(), load(), the multi-GPU merge)
-template <int SRC>
+template <int SRC, int KC = 0>  // KC > 0: k at compile time
 __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPartitionArgs a) {
     constexpr bool COMPACT = SRC == 0;
+    const int k = KC > 0 ? KC : a.k;
     using W = typename std::conditional<COMPACT, u32, u64>::type;  // shadow word
     constexpr int kPairs = kRingEntries / 2;  // 8192 pairs = 128 KiB
     __shared__ __attribute__((aligned(16))) ulonglong2 ring[kPairs];
@@ -954,8 +955,8 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
             const W c = blk[S + i];
             if (c) {
                 blk[S + i] = 0;
-                const u64 h = COMPACT ? hash_of_mixed<2>(((u64)(sb >> (a.shadow_sbits - 10)) << 32) | blk[i], a.k, ascii4)
-                                      : hash_of_mixed<1>((u64)blk[i], a.k, ascii4);
+                const u64 h = COMPACT ? hash_of_mixed<2>(((u64)(sb >> (a.shadow_sbits - 10)) << 32) | blk[i], k, ascii4)
+                                      : hash_of_mixed<1>((u64)blk[i], k, ascii4);
                 if (h) {  // lib.rs:589: hash 0 is skipped
                     const u32 b = (u32)(h >> a.table_block_bits) & (u32)(P - 1);
                     const u64 cw = atomicAdd(&cur[b], 1ULL);
