@@ -113,7 +113,8 @@ def kernel_report(prof, kmers, b_alg, pmc_cfg):
     traffic = None
     if pmc_cfg:
         per_launch = pmc_cfg.get("kernels", {})
-        got = [(per_launch[n]["hbm_bytes_per_launch"] * v[0]) for n, v in prof.items() if n in per_launch and "hbm_bytes_per_launch" in per_launch[n]]
+        base = lambda n: n.replace("<shadow>", "")  # noqa: E731  (K2 on the shadow table is K2)
+        got = [(per_launch[base(n)]["hbm_bytes_per_launch"] * v[0]) for n, v in prof.items() if "hbm_bytes_per_launch" in per_launch.get(base(n), {})]
         if got:
             traffic = sum(got)
             out["hbm_bytes_measured"] = traffic

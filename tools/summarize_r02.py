@@ -41,7 +41,8 @@ def short(name):
         mode = targs.split(",")[-1].strip() if targs else "0"
         return base + {"0": "", "1": "<raw>", "true": "<raw>", "2": "<compact>"}.get(mode, "")
     if base == "repartition_kernel":
-        return base + {"unsigned int": "<compact>", "unsigned long long": "", "ulonglong2": "<pairs>", "HIP_vector_type<unsigned long long, 2u>": "<pairs>"}.get(targs, "<" + targs + ">")
+        targs = targs.strip()
+        return base + ("<pairs>" if "HIP_vector_type" in targs or "ulonglong2" in targs else "<compact>" if targs == "unsigned int" else "")
     return base
 
 
