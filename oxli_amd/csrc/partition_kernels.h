@@ -426,6 +426,36 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
     u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u64 *keys = tab, *cnts = tab + S;
     if (threadIdx.x == 0) { s_counted = 0; s_new = 0; s_failed = 0; }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int kInFlight = 12;
+    constexpr u32 kSlab = 64 * kInFlight;
+    constexpr int kWaves = kPartThreads / 64;
+    const u32 *my_counts = a.region_count + (u64)b * a.nregions;
+    // Two levels: a few long regions per block, their slabs dealt round-robin to the waves.  The wave's NEXT slab is loaded
+    // before the current one is counted, and its FIRST before the block itself is loaded, so that no HBM round trip of the
+    // entry stream is exposed (one workgroup per CU: nothing else would hide it).
+    int seg = 0;
+    u32 sbase = 0, g = (u32)wave, cnt = a.nregions > 0 ? my_counts[0] : 0u;  // sbase = global index of seg's first slab
+    auto load_slab = [&](u64 (&v)[kInFlight]) -> bool {
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) v[j] = 0ULL;
+        while (seg < a.nregions) {
+            const u32 nsl = (cnt + kSlab - 1) / kSlab;
+            if (g < sbase + nsl) break;
+            sbase += nsl; ++seg;
+            cnt = seg < a.nregions ? my_counts[seg] : 0u;
+        }
+        if (seg >= a.nregions) return false;
+        const u32 s0 = (g - sbase) * kSlab, left = cnt - s0;
+        const u64 *src = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride + s0;
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) { const u32 i = lane + 64 * j; if (i < left) v[j] = src[i]; }
+        g += kWaves;
+        return true;
+    };
+    const bool two_level = a.nregions < kWaves && !(a.ablate & 64);
+    u64 va[kInFlight], vb[kInFlight];
+    bool more = two_level ? load_slab(va) : false;
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
     // fingerprint of a key: a hash byte that neither the slot index (low bits) nor the multi-GPU
     // owner (top bits) uses; 0 is reserved for "empty slot"
@@ -439,7 +469,6 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
         for (u32 i = threadIdx.x; i < S; i += kPartThreads) { const u64 kk = keys[i]; tags[i] = (unsigned char)(kk ? tag_of(kk) : 0u); }
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32 counted = 0, newkeys = 0;
     // General insert.  One probe round = the 8 keys of a group = one 64-byte LDS line
     // (4 x ds_read_b128), examined in slot order so a new key lands in the first empty slot of
@@ -516,9 +545,6 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
     // The block's hashes arrive as `nregions` regions; they are cut into slabs of 64 x kInFlight
     // entries that the 16 waves take round-robin.  All of a lane's loads for a slab are issued before
     // the first insert, so ~12 x 512 B are in flight per wave instead of one dependent load.
-    constexpr int kInFlight = 12;
-    constexpr u32 kSlab = 64 * kInFlight;
-    const u32 *my_counts = a.region_count + (u64)b * a.nregions;
     auto do_slab = [&](const u64 *src, u32 left) {
         u64 v[kInFlight];
 #pragma unroll
@@ -531,7 +557,6 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
             for (int j = 0; j < kInFlight; ++j) fast(v[j]);
         }
     };
-    constexpr int kWaves = kPartThreads / 64;
     if (a.ablate & 64) {
     } else if (a.nregions >= kWaves) {  // one level: many short regions, one wave each
         for (int seg = wave; seg < a.nregions; seg += kWaves) {
@@ -539,28 +564,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
             const u64 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
             for (u32 s0 = 0; s0 < cnt; s0 += kSlab) do_slab(region + s0, cnt - s0);
         }
-    } else {  // two levels: a few long regions per block, their slabs dealt round-robin to the waves
-        // The wave's NEXT slab is loaded before the current one is counted: with one long stream per block the waves would
-        // otherwise all wait for HBM at the same moments.
-        int seg = 0;
-        u32 base = 0, g = (u32)wave, cnt = a.nregions > 0 ? my_counts[0] : 0u;  // base = global index of seg's first slab
-        auto load_slab = [&](u64 (&v)[kInFlight]) -> bool {
-#pragma unroll
-            for (int j = 0; j < kInFlight; ++j) v[j] = 0ULL;
-            while (seg < a.nregions) {
-                const u32 nsl = (cnt + kSlab - 1) / kSlab;
-                if (g < base + nsl) break;
-                base += nsl; ++seg;
-                cnt = seg < a.nregions ? my_counts[seg] : 0u;
-            }
-            if (seg >= a.nregions) return false;
-            const u32 s0 = (g - base) * kSlab, left = cnt - s0;
-            const u64 *src = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride + s0;
-#pragma unroll
-            for (int j = 0; j < kInFlight; ++j) { const u32 i = lane + 64 * j; if (i < left) v[j] = src[i]; }
-            g += kWaves;
-            return true;
-        };
+    } else {  // two levels (the first slab is already in registers)
         auto count_slab = [&](const u64 (&v)[kInFlight]) {
             if (a.ablate & 16) {
 #pragma unroll
@@ -570,8 +574,6 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
                 for (int j = 0; j < kInFlight; ++j) fast(v[j]);
             }
         };
-        u64 va[kInFlight], vb[kInFlight];
-        bool more = load_slab(va);
         while (more) {
             more = load_slab(vb);
             count_slab(va);
@@ -679,6 +681,65 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
     u32 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u32 *keys = tab, *cnts = tab + S;
     if (threadIdx.x == 0) { s_counted = 0; s_new = 0; s_failed = 0; }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int kInFlight = 12;
+    constexpr u32 kSlab = 64 * kInFlight;
+    constexpr int kWaves = kPartThreads / 64;
+    const u32 *my_counts = a.region_count + (u64)b * a.nregions;
+    // Two levels (large shadow): a few long regions per block (one per K1b writer); their slabs of 768 entries are dealt
+    // round-robin to the waves, the next slab in flight while the current one is counted -- and the FIRST requested before
+    // the block itself is loaded (one workgroup per CU: nothing else would hide that round trip).
+    int seg2 = 0;
+    u32 sbase = 0, g2 = (u32)wave, cnt2 = a.nregions > 0 ? my_counts[0] : 0u;
+    auto load_slab2 = [&](uint4 (&v)[kInFlight / 4]) -> bool {
+#pragma unroll
+        for (int j = 0; j < kInFlight / 4; ++j) v[j] = make_uint4(0, 0, 0, 0);
+        while (seg2 < a.nregions) {
+            const u32 nsl = (cnt2 + kSlab - 1) / kSlab;
+            if (g2 < sbase + nsl) break;
+            sbase += nsl; ++seg2;
+            cnt2 = seg2 < a.nregions ? my_counts[seg2] : 0u;
+        }
+        if (seg2 >= a.nregions) return false;
+        const u32 s0 = (g2 - sbase) * kSlab;
+        const u32 *region = a.scratch + (u64)seg2 * a.seg_stride + (u64)b * a.block_stride;
+#pragma unroll
+        for (int j = 0; j < kInFlight / 4; ++j) {  // regions are zero-padded to 16 entries
+            const u32 i = s0 + 4 * (lane + 64 * j);
+            if (i < cnt2) v[j] = *reinterpret_cast<const uint4 *>(region + i);
+        }
+        g2 += kWaves;
+        return true;
+    };
+    // One level: nregions short regions per block, wave w takes regions w, w + 16, ...  Their sizes are fetched
+    // with ONE load (lane l holds the size of the wave's l-th region), and the slabs are double-buffered across region
+    // boundaries: a region is only ~2 KB, so a wave that waited for each one separately would keep too few bytes in flight.
+    // Here too the first slab is requested before the block is loaded.
+    const bool two_level = a.nregions < kWaves;
+    const int my_nreg = two_level ? 0 : (a.nregions - wave + kWaves - 1) / kWaves;  // regions of this wave (64 per batch)
+    int r0 = 0, nr = my_nreg < 64 ? my_nreg : 64, ri = 0;  // ri: region index within the batch; off: offset inside the region
+    u32 off = 0, my_cnt = (!two_level && lane < nr) ? my_counts[wave + kWaves * lane] : 0u;
+    auto load_slab1 = [&](uint4 (&v)[kInFlight / 4]) -> bool {
+        u32 cnt = 0;
+        while (ri < nr) {
+            cnt = (u32)__builtin_amdgcn_readlane((int)my_cnt, ri);
+            if (off < cnt) break;
+            ++ri; off = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < kInFlight / 4; ++j) v[j] = make_uint4(0, 0, 0, 0);
+        if (ri >= nr) return false;
+        const u32 *region = a.scratch + (u64)(wave + kWaves * (r0 + ri)) * a.seg_stride + (u64)b * a.block_stride;
+#pragma unroll
+        for (int j = 0; j < kInFlight / 4; ++j) {  // 16-byte loads: a lane takes four consecutive entries (regions are zero-padded to 16)
+            const u32 i = off + 4 * (lane + 64 * j);
+            if (i < cnt) v[j] = *reinterpret_cast<const uint4 *>(region + i);
+        }
+        off += kSlab;
+        return true;
+    };
+    uint4 va2[kInFlight / 4], vb2[kInFlight / 4];
+    bool more2 = two_level ? load_slab2(va2) : (my_nreg > 0 ? load_slab1(va2) : false);
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
     auto tag_of = [](u32 e) -> u32 { const u32 t = (e >> 13) & 0xFFu; return t ? t : 1u; };
     if (a.fresh) {
@@ -690,7 +751,6 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
         for (u32 i = threadIdx.x; i < S; i += kPartThreads) { const u32 kk = keys[i]; tags[i] = (unsigned char)(kk ? tag_of(kk) : 0u); }
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32 counted = 0, newkeys = 0;
     auto insert = [&](u32 e) {
         u32 g = e & smask & ~(u32)(kGroup - 1);
@@ -745,10 +805,6 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
             if (qn > kWaveQueue32 - 64) drain(31);
         }
     };
-    constexpr int kInFlight = 12;
-    constexpr u32 kSlab = 64 * kInFlight;
-    const u32 *my_counts = a.region_count + (u64)b * a.nregions;
-    constexpr int kWaves = kPartThreads / 64;
     auto count_slab = [&](const uint4 (&v)[kInFlight / 4]) {
         if (a.ablate & 16) {
 #pragma unroll
@@ -758,77 +814,29 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
 #pragma unroll
         for (int j = 0; j < kInFlight / 4; ++j) { fast(v[j].x); fast(v[j].y); fast(v[j].z); fast(v[j].w); }
     };
-    if (a.nregions < kWaves) {
-        // Two levels (large shadow): a few long regions per block (one per K1b writer); their slabs of 768 entries are dealt
-        // round-robin to the waves, the next slab in flight while the current one is counted.
-        int seg = 0;
-        u32 base = 0, g = (u32)wave, cnt = a.nregions > 0 ? my_counts[0] : 0u;
-        auto load_slab = [&](uint4 (&v)[kInFlight / 4]) -> bool {
-#pragma unroll
-            for (int j = 0; j < kInFlight / 4; ++j) v[j] = make_uint4(0, 0, 0, 0);
-            while (seg < a.nregions) {
-                const u32 nsl = (cnt + kSlab - 1) / kSlab;
-                if (g < base + nsl) break;
-                base += nsl; ++seg;
-                cnt = seg < a.nregions ? my_counts[seg] : 0u;
-            }
-            if (seg >= a.nregions) return false;
-            const u32 s0 = (g - base) * kSlab;
-            const u32 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
-#pragma unroll
-            for (int j = 0; j < kInFlight / 4; ++j) {  // regions are zero-padded to 16 entries
-                const u32 i = s0 + 4 * (lane + 64 * j);
-                if (i < cnt) v[j] = *reinterpret_cast<const uint4 *>(region + i);
-            }
-            g += kWaves;
-            return true;
-        };
-        uint4 va[kInFlight / 4], vb[kInFlight / 4];
-        bool more = load_slab(va);
-        while (more) {
-            more = load_slab(vb);
-            count_slab(va);
-            if (!more) break;
-            more = load_slab(va);
-            count_slab(vb);
+    if (two_level) {  // (the first slab is already in registers)
+        while (more2) {
+            more2 = load_slab2(vb2);
+            count_slab(va2);
+            if (!more2) break;
+            more2 = load_slab2(va2);
+            count_slab(vb2);
         }
     }
-    // One level only: nregions short regions per block, wave w takes regions w, w + 16, ...  Their sizes are fetched
-    // with ONE load (lane l holds the size of the wave's l-th region), and the slabs are double-buffered across region
-    // boundaries: a region is only ~2 KB, so a wave that waited for each one separately would keep too few bytes in flight.
-    const int my_nreg = a.nregions < kWaves ? 0 : (a.nregions - wave + kWaves - 1) / kWaves;  // regions of this wave (<= 64 supported in one go)
-    for (int r0 = 0; r0 < my_nreg; r0 += 64) {
-        const int nr = my_nreg - r0 < 64 ? my_nreg - r0 : 64;
-        const u32 my_cnt = lane < nr ? my_counts[wave + kWaves * (r0 + lane)] : 0u;
-        int ri = 0;      // cursor: region index within this batch, offset inside it
-        u32 off = 0;
-        auto load_slab = [&](uint4 (&v)[kInFlight / 4]) -> bool {
-            u32 cnt = 0;
-            while (ri < nr) {
-                cnt = (u32)__builtin_amdgcn_readlane((int)my_cnt, ri);
-                if (off < cnt) break;
-                ++ri; off = 0;
-            }
-#pragma unroll
-            for (int j = 0; j < kInFlight / 4; ++j) v[j] = make_uint4(0, 0, 0, 0);
-            if (ri >= nr) return false;
-            const u32 *region = a.scratch + (u64)(wave + kWaves * (r0 + ri)) * a.seg_stride + (u64)b * a.block_stride;
-#pragma unroll
-            for (int j = 0; j < kInFlight / 4; ++j) {  // 16-byte loads: a lane takes four consecutive entries (regions are zero-padded to 16)
-                const u32 i = off + 4 * (lane + 64 * j);
-                if (i < cnt) v[j] = *reinterpret_cast<const uint4 *>(region + i);
-            }
-            off += kSlab;
-            return true;
-        };
-        uint4 va[kInFlight / 4], vb[kInFlight / 4];
-        bool more = load_slab(va);
-        while (more) {
-            more = load_slab(vb);
-            count_slab(va);
-            if (!more) break;
-            more = load_slab(va);
-            count_slab(vb);
+    // One level: nregions short regions per block (loop state and the first slab: see the top of the kernel).
+    for (; r0 < my_nreg; r0 += 64) {
+        if (r0 > 0) {  // (more than 64 regions per wave: the following batches)
+            nr = my_nreg - r0 < 64 ? my_nreg - r0 : 64;
+            my_cnt = lane < nr ? my_counts[wave + kWaves * (r0 + lane)] : 0u;
+            ri = 0; off = 0;
+            more2 = load_slab1(va2);
+        }
+        while (more2) {
+            more2 = load_slab1(vb2);
+            count_slab(va2);
+            if (!more2) break;
+            more2 = load_slab1(va2);
+            count_slab(vb2);
         }
     }
     drain(0);
@@ -947,16 +955,36 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
             flush_lines(false);  // a full row of pairs over up to 1024 bins of 8: every row
         }
     }
+    // The shadow is walked a row of 1024 slots at a time, FOUR rows' counts and keys in flight ahead of the row being
+    // hashed (one workgroup per CU and a dependent load per row made this kernel latency-bound: ~2 us of HBM round trip
+    // for ~1 us of work; lane compaction of the ~47 % occupied slots, tried first, bought nothing).
     const u32 nblocks = SRC == 2 ? 0u : a.shadow_blocks, per_wg = (nblocks + gridDim.x - 1) / gridDim.x;
-    for (u32 sb = blockIdx.x * per_wg; sb < nblocks && sb < (blockIdx.x + 1) * per_wg; ++sb) {
-        W *blk = reinterpret_cast<W *>(a.shadow) + ((u64)sb << (kBlockBitsMax + 1));
-        for (u32 row = 0; row < S / kPartThreads; ++row) {
-            const u32 i = row * kPartThreads + threadIdx.x;
-            const W c = blk[S + i];
+    constexpr u32 kRowsPerBlock = S / kPartThreads, kAhead = 4;  // (8 ahead: no better at k <= 21, worse with 64-bit words)
+    const u32 sb0 = blockIdx.x * per_wg, sb1 = sb0 + per_wg < nblocks ? sb0 + per_wg : nblocks;
+    const u32 nrows = sb1 > sb0 ? (sb1 - sb0) * kRowsPerBlock : 0u;
+    W *base = reinterpret_cast<W *>(a.shadow);
+    auto count_ptr = [&](u32 r) -> W * {  // the count of this thread's slot in row r of this workgroup's share
+        const u32 sb = sb0 + r / kRowsPerBlock, row = r % kRowsPerBlock;
+        return base + ((u64)sb << (kBlockBitsMax + 1)) + S + row * kPartThreads + threadIdx.x;
+    };
+    W cq[kAhead], kq[kAhead];
+#pragma unroll
+    for (u32 j = 0; j < kAhead; ++j) {
+        cq[j] = 0; kq[j] = 0;
+        if (j < nrows) { const W *cp = count_ptr(j); cq[j] = *cp; kq[j] = *(cp - S); }
+    }
+    for (u32 r0 = 0; r0 < nrows; r0 += kAhead) {
+#pragma unroll
+        for (u32 j = 0; j < kAhead; ++j) {
+            const u32 r = r0 + j;
+            if (r >= nrows) break;
+            const W c = cq[j], key = kq[j];
+            if (r + kAhead < nrows) { const W *cp = count_ptr(r + kAhead); cq[j] = *cp; kq[j] = *(cp - S); }  // the row four ahead
             if (c) {
-                blk[S + i] = 0;
-                const u64 h = COMPACT ? hash_of_mixed<2>(((u64)(sb >> (a.shadow_sbits - 10)) << 32) | blk[i], k, ascii4)
-                                      : hash_of_mixed<1>((u64)blk[i], k, ascii4);
+                *count_ptr(r) = 0;
+                const u32 sb = sb0 + r / kRowsPerBlock;
+                const u64 h = COMPACT ? hash_of_mixed<2>(((u64)(sb >> (a.shadow_sbits - 10)) << 32) | (u64)key, k, ascii4)
+                                      : hash_of_mixed<1>((u64)key, k, ascii4);
                 if (h) {  // lib.rs:589: hash 0 is skipped
                     const u32 b = (u32)(h >> a.table_block_bits) & (u32)(P - 1);
                     const u64 cw = atomicAdd(&cur[b], 1ULL);
@@ -965,7 +993,7 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
                     else overflow_pair(h, (u64)c);
                 }
             }
-            if ((row & 1) == 1) flush_lines(false);  // ~600 pairs per row over up to 1024 bins of 8: every second row
+            if ((r & 1) == 1) flush_lines(false);  // ~600 pairs per row over up to 1024 bins of 8: every second row
         }
     }
     while (flush_lines(true)) {}
@@ -996,12 +1024,24 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(Aggregate
     u64 *keys = tab, *cnts = tab + S;
     if (threadIdx.x == 0) { s_tot = 0; s_new = 0; s_nz = 0; s_failed = 0; }
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+    const u32 *my_counts = a.region_count + (u64)b * a.nregions;
+    // Two levels: the block's (few, long) regions.  The first rows of pairs are requested BEFORE the block itself, so that
+    // their HBM round trip runs under the block load instead of after it (one workgroup per CU: nothing else would hide it).
+    constexpr int kPre = 4;
+    ulonglong2 pre[kPre];
+    const bool few = a.nregions < 64;
+    const u32 cnt0 = few && a.nregions > 0 ? my_counts[0] : 0u;
+    const ulonglong2 *region0 = a.scratch + (u64)b * a.block_stride;
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+        const u32 i = threadIdx.x + (u32)j * kPartThreads;
+        pre[j] = i < cnt0 ? region0[i] : make_ulonglong2(0, 0);
+    }
     if (a.fresh) for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
     else for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     u64 tot = 0, nk = 0, nz = 0;
-    const u32 *my_counts = a.region_count + (u64)b * a.nregions;
     auto merge_pair = [&](const ulonglong2 pr) {
         const u64 h = pr.x, c = pr.y;
         if (h == 0) return;  // hole / padding
@@ -1039,11 +1079,14 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(Aggregate
             for (u32 i = q; i < cnt; i += 4) merge_pair(region[i]);
         }
     } else {
-        // Two levels: a few long regions per block (one per second-level writer), the whole workgroup strides over each.
+        // Two levels: a few long regions per block (one per second-level writer), the whole workgroup strides over each
+        // (the first kPre rows of region 0 are already in registers).
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) merge_pair(pre[j]);
         for (int seg = 0; seg < a.nregions; ++seg) {
             const u32 cnt = my_counts[seg];
             const ulonglong2 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
-            for (u32 i = threadIdx.x; i < cnt; i += kPartThreads) merge_pair(region[i]);
+            for (u32 i = threadIdx.x + (seg == 0 ? kPre * kPartThreads : 0); i < cnt; i += kPartThreads) merge_pair(region[i]);
         }
     }
     tot = wave_sum(tot); nk = wave_sum(nk); nz = wave_sum(nz);

@@ -167,3 +167,51 @@ def test_tables_of_more_than_1024_blocks_match_the_oracle(gpu, k, path, G, R):
     for h, c in zip(hk.tolist(), hc.tolist()):
         want[h] += c
     assert np.array_equal(dk, rk) and dc.tolist() == [want[h] for h in rk.tolist()]
+
+
+def test_heavy_hitters_and_bad_bases_at_scale(gpu):
+    """SURVEY 8d's robustness inputs at scale.  (1) `"ATGC" x 5x10^7` as one 200 Mbp record: a handful of k-mers, every lane
+    of every wave holds the same one -- the partition kernels' rings overflow, the pass is abandoned and the direct kernel's
+    wave combining takes over.  (2) the C2 stream with 1 % of its bases turned into N: n < reads x (L - k + 1), every window
+    over an N is skipped.  The automatic path must give the direct path's table bit for bit; an oracle slice checks (2)."""
+    torch, KCT, _ = gpu
+    k = 21
+    # (1)
+    unit = torch.tensor(list(b"ATGC"), dtype=torch.uint8, device="cuda")
+    rec = unit.repeat(50_000_000)
+    stream = torch.cat([rec, torch.tensor([10], dtype=torch.uint8, device="cuda")])
+    tables = {}
+    for path in ("auto", "direct"):
+        t = KCT(k, capacity=5_000_000)
+        t.set_path(path)
+        assert t.consume_device(stream.data_ptr(), stream.numel(), rec.numel()) == rec.numel() - k + 1
+        tables[path] = t.dump_arrays(1)
+        assert int(tables[path][1].sum()) == rec.numel() - k + 1
+    assert np.array_equal(tables["auto"][0], tables["direct"][0]) and np.array_equal(tables["auto"][1], tables["direct"][1])
+    small = OracleTable(k)
+    small.consume("ATGC" * 1000)
+    assert np.array_equal(small.dump_arrays()[0], tables["auto"][0])     # the same few k-mers
+    del stream, rec
+    # (2)
+    G, R, L = 5_000_000, 1_000_000, 150
+    g, r = synth(gpu, G, R, L)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    hit = (torch.rand(r.numel(), device="cuda", generator=gen) < 0.01) & (r != 10)
+    r[hit] = ord("N")
+    res = {}
+    for path in ("auto", "direct"):
+        t = KCT(k, capacity=G)
+        t.set_path(path)
+        res[path] = (t.consume_device(r.data_ptr(), r.numel(), R * L),) + t.dump_arrays(1)
+    assert res["auto"][0] == res["direct"][0] < R * (L - k + 1)
+    assert np.array_equal(res["auto"][1], res["direct"][1]) and np.array_equal(res["auto"][2], res["direct"][2])
+    ns = 20_000
+    sub = r[: ns * (L + 1)].cpu().numpy().reshape(ns, L + 1)
+    ref = OracleTable(k)
+    n_ref = sum(ref.consume(sub[i, :L]) for i in range(ns))
+    t = KCT(k, capacity=G)
+    assert t.consume_device(r.data_ptr(), ns * (L + 1), ns * L) == n_ref
+    dk, dc = t.dump_arrays(1)
+    rk, rc = ref.dump_arrays()
+    assert np.array_equal(dk, rk) and np.array_equal(dc, rc)
