@@ -83,11 +83,11 @@ def parse():
 
 
 def source_sha():
-    """Hash of the kernel sources: ties a committed PMC summary to the build it was measured on."""
+    """Hash of the DEVICE code (the kernel headers): ties a committed PMC summary to the kernels it was measured on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "oxli_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith(".h") and name != "kct_internal.h":
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]

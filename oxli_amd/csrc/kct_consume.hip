@@ -964,8 +964,10 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
                 const bool pays = per_key >= (double)windows_per_pending_key(t);
                 KCT_DBG(t, "dedupe probe%s: %llu k-mers, %llu first sightings -> ~%.3g k-mers per distinct k-mer over the call: %s\n", dry_run ? " (dry run)" : "",
                         (unsigned long long)valid, (unsigned long long)fresh_keys, per_key, pays ? "dedupe-first" : "hash every window");
+                // (a "no" is a verdict on THIS call: later calls are judged by what the table holds and how long the caller's
+                // runs between reads are -- dedupe_pays -- so nothing is switched off)
                 if (pays) t->dedupe_hint = true;
-                else { KCT_TRY(flush_shadow(t)); t->dedupe_off = true; }
+                else KCT_TRY(flush_shadow(t));
                 continue;
             }
         }
