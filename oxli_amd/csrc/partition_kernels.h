@@ -648,7 +648,7 @@ __global__ __launch_bounds__(kBlock) void shadow_flush_kernel(u64 *__restrict__ 
 // ---- compact dedupe-first path (k <= 21): 32-bit entries, a shadow table of u32 keys and u32 counts ----------------
 // A mix42 value is 10 bits of bin and 32 bits of entry; within a bin the entry identifies the k-mer.  K1 (MODE 2)
 // wrote the entries; this is K2 for them: same block ownership, fingerprint fast path and deferred queue as
-// aggregate_blocks_kernel, at half the LDS and HBM bytes.  Slot = entry bits 0-12, fingerprint = bits 13-20.
+// aggregate_blocks_kernel, at half the LDS and HBM bytes.  Slot = entry bits 0-12; no fingerprints (see the fast path).
 // Counts are u32.  No entry reaches this kernel without passing an LDS ring, and a ring bin lets at most D of the 8192 (K1)
 // or 8192 (K1b) appends of a flush interval through (the rest take the overflow route to the real table's u64 counts): a
 // k-mer's pending count grows by at most 1/256 of the window starts consumed.  The host converts before 2^39 of them.
@@ -672,7 +672,6 @@ constexpr int kWaveQueue32 = kWaveQueue;
 __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggregate32Args a) {
     __shared__ __attribute__((aligned(16))) u32 tab[2 << kBlockBitsMax];  // S keys then S counts = 64 KiB
     __shared__ u32 wq[(kPartThreads / 64) * kWaveQueue32];
-    __shared__ __attribute__((aligned(16))) unsigned char tags[1 << kBlockBitsMax];
     __shared__ u64 s_counted, s_new;
     __shared__ u32 s_failed;
     if (*a.overflow) return;
@@ -741,15 +740,8 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
     uint4 va2[kInFlight / 4], vb2[kInFlight / 4];
     bool more2 = two_level ? load_slab2(va2) : (my_nreg > 0 ? load_slab1(va2) : false);
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
-    auto tag_of = [](u32 e) -> u32 { const u32 t = (e >> 13) & 0xFFu; return t ? t : 1u; };
-    if (a.fresh) {
-        for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
-        for (u32 i = threadIdx.x; i < S / 16; i += kPartThreads) reinterpret_cast<uint4 *>(tags)[i] = make_uint4(0, 0, 0, 0);
-    } else {
-        for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
-        __syncthreads();
-        for (u32 i = threadIdx.x; i < S; i += kPartThreads) { const u32 kk = keys[i]; tags[i] = (unsigned char)(kk ? tag_of(kk) : 0u); }
-    }
+    if (a.fresh) for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
+    else for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
     __syncthreads();
     u32 counted = 0, newkeys = 0;
     auto insert = [&](u32 e) {
@@ -765,7 +757,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
                 u32 ks = keys[g + sel];
                 if (ks == 0) {
                     ks = atomicCAS(&keys[g + sel], 0u, e);
-                    if (ks == 0) { ++newkeys; ks = e; tags[g + sel] = (unsigned char)tag_of(e); }
+                    if (ks == 0) { ++newkeys; ks = e; }
                 }
                 if (ks == e) { atomicAdd(&cnts[g + sel], 1u); placed = true; break; }
                 ++sel;
@@ -789,13 +781,15 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
         bool miss = e != 0;
         if (e != 0) {
             const u32 g = e & smask & ~(u32)(kGroup - 1);
-            const u64 t8 = *reinterpret_cast<const u64 *>(tags + g);
-            const u64 x = t8 ^ ((u64)tag_of(e) * 0x0101010101010101ULL);
-            const u64 z = (x - 0x0101010101010101ULL) & ~x & 0x8080808080808080ULL;
-            if (z) {
-                const u32 idx = (u32)__builtin_ctzll(z) >> 3;
-                if (keys[g + idx] == e) { atomicAdd(&cnts[g + idx], 1u); ++counted; miss = false; }
-            }
+            // The home group's eight keys are only 32 bytes: they are read outright and compared -- ONE LDS round trip, where the
+            // 64-bit K2 reads the group's fingerprint bytes first and its candidate key second (K2-32 -9 %; no fingerprint
+            // array to build when the block is loaded, either).
+            const uint4 q0 = *reinterpret_cast<const uint4 *>(keys + g), q1 = *reinterpret_cast<const uint4 *>(keys + g + 4);
+            const u32 kk[kGroup] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            int idx = -1;
+#pragma unroll
+            for (int i = kGroup - 1; i >= 0; --i) if (kk[i] == e) idx = i;
+            if (idx >= 0) { atomicAdd(&cnts[g + idx], 1u); ++counted; miss = false; }
         }
         const u64 m = __ballot(miss);
         if (m) {
