@@ -275,7 +275,7 @@ kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const
         ra.min_lines = repartition_min_lines(kct::kRingEntries / 2, L.sub_bits, 16);
         {
             ProfScope ps(t, "repartition_kernel<pairs>");
-            hipLaunchKernelGGL(kct::repartition_kernel<ulonglong2>, dim3((unsigned)(P * L.W)), dim3(kct::kPartThreads), 0, t->stream, ra);
+            hipLaunchKernelGGL((kct::repartition_kernel<ulonglong2, false>), dim3((unsigned)(P * L.W)), dim3(kct::kPartThreads), 0, t->stream, ra);
         }
         HIP_TRY(hipGetLastError());
         pa.scratch = (const ulonglong2 *)t->d_scratch2.p; pa.seg_stride = out_cap; pa.block_stride = L.W * out_cap;
@@ -578,7 +578,8 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
         ra.min_lines = repartition_min_lines(kct::kRingEntries * 2, sub_bits, 4);
         {
             ProfScope ps(t, "repartition_kernel<compact>");
-            hipLaunchKernelGGL(kct::repartition_kernel<unsigned int>, dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, ra);
+            // (one flush per slab, as the 64-bit variant does, was measured: K1b -5 %, but more overflow entries: no gain overall)
+            hipLaunchKernelGGL((kct::repartition_kernel<unsigned int, false>), dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, ra);
         }
         HIP_TRY(hipGetLastError());
         aa.scratch = (const unsigned int *)t->d_scratch2.p; aa.seg_stride = out_cap; aa.block_stride = out_cap;
@@ -743,7 +744,13 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         ra.min_lines = repartition_min_lines(kct::kRingEntries, sub_bits, 8);
         {
             ProfScope ps(t, "repartition_kernel");
-            hipLaunchKernelGGL(kct::repartition_kernel<du64>, dim3((unsigned)(P * W)), dim3(kct::kPartThreads), 0, t->stream, ra);
+            // With >= 64 ring entries per bin the ring is flushed once per slab of eight entries per thread (half the ring per
+            // interval) instead of twice, a bin's lines leaving two at a time: the flush machinery is ~a third of K1b's
+            // instructions (K1b -6 %).
+            if ((kct::kRingEntries >> sub_bits) >= 64 && !getenv("KCT_K1B_HALF")) {
+                ra.min_lines = std::max(1u, ra.min_lines / 2);
+                hipLaunchKernelGGL((kct::repartition_kernel<du64, true>), dim3((unsigned)(P * W)), dim3(kct::kPartThreads), 0, t->stream, ra);
+            } else hipLaunchKernelGGL((kct::repartition_kernel<du64, false>), dim3((unsigned)(P * W)), dim3(kct::kPartThreads), 0, t->stream, ra);
         }
         HIP_TRY(hipGetLastError());
         aa.scratch = (const du64 *)t->d_scratch2.p; aa.seg_stride = out_cap; aa.block_stride = W * out_cap;

@@ -284,12 +284,12 @@ struct RepartitionArgs {
 // ({hash, count} pairs of a shadow flush / pair merge; sub-bin from the hash).
 // The NEXT slab's loads are issued before the current slab is appended (two register buffers): the flush barriers keep
 // the sixteen waves in step, so without the prefetch every HBM round trip was fully exposed.
-template <class T>
+template <class T, bool WHOLE_SLAB = false>  // WHOLE_SLAB: one flush per slab instead of two (half the ring per interval)
 __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionArgs a) {
     constexpr bool kPair = sizeof(T) == 16, kCompact = sizeof(T) == 4;
     constexpr int kEntries = kRingEntries * 8 / sizeof(T);  // 128 KiB of ring
     constexpr int kLoads = 64 / sizeof(T);                   // 64 bytes per lane per slab
-    constexpr int kFlushEvery = kLoads / 2;                  // appends per thread between flushes: a quarter of the ring
+    constexpr int kFlushEvery = WHOLE_SLAB ? kLoads : kLoads / 2;  // appends per thread between flushes: a quarter (half) of the ring
     constexpr u32 kSlab = 64 * kLoads;
     __shared__ __attribute__((aligned(16))) T ring[kEntries];
     __shared__ u64 cur[1024];  // per bin: fill (low half) | flushed (high half)
