@@ -215,3 +215,30 @@ def test_heavy_hitters_and_bad_bases_at_scale(gpu):
     dk, dc = t.dump_arrays(1)
     rk, rc = ref.dump_arrays()
     assert np.array_equal(dk, rk) and np.array_equal(dc, rc)
+
+
+@pytest.mark.parametrize("k,path", [(21, "dedupe"), (31, "dedupe"), (31, "partitioned"), (51, "partitioned")])
+def test_skewed_input_through_two_partition_levels(gpu, k, path):
+    """Homopolymers, tandem repeats and a repeated unit among random sequence, into a table of 2048 blocks: both partition
+    levels' rings overflow for the hot bins, the entries take the overflow regions and the direct insert.  Bit for bit
+    against the oracle."""
+    import random
+    torch, KCT, _ = gpu
+    rng = random.Random(31 + k)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))  # noqa: E731
+    unit = rnd(1000)
+    recs = [rnd(150) for _ in range(40000)] + ["A" * 300000, "T" * 50000, "AC" * 150000, "ACG" * 100000, unit * 200, rnd(3_000_000)]
+    rng.shuffle(recs)
+    ref = OracleTable(k)
+    n_ref = sum(ref.consume(r) for r in recs)
+    t = KCT(k, capacity=6_000_000)
+    assert t.capacity == 1 << 24
+    t.set_path(path)
+    t.profile(True)
+    assert t.consume_batch(recs) == n_ref
+    prof = t.profile_read()
+    assert any(name.startswith("repartition_kernel") for name in prof), prof
+    dk, dc = t.dump_arrays(1)
+    rk, rc = ref.dump_arrays()
+    assert np.array_equal(dk, rk) and np.array_equal(dc, rc)
+    assert t.consumed == ref.consumed
