@@ -15,7 +15,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 stream = torch.cuda.current_stream().cuda_stream
 t_start = time.time()
 for it in range(iters):
-    k = int(rng.choice([int(rng.integers(1, 33)), 21, 31, 32, 16, 17, 22]))
+    k = int(rng.choice([int(rng.integers(1, 33)), 21, 31, 32, 16, 17, 22, 33, 51, int(rng.integers(33, 65))]))
     L = int(rng.choice([50, 100, 150, 151, 250, 1000]))
     if L < k + 1:
         L = k + 30
@@ -41,6 +41,8 @@ for it in range(iters):
     sig = None
     for path in ("partitioned", "dedupe", "auto", "direct"):
         if path == "direct" and N * L > (100_000_000 if big else 30_000_000):
+            continue
+        if path == "dedupe" and k > 32:
             continue
         t = KmerCountTable(k, capacity=int(rng.choice([0, G, 4 * G])) or 0)
         t.set_path(path)
