@@ -237,6 +237,7 @@ kct_status rehash_into(kct_table *t, u64 new_cap) {
     }
     du64 *old = t->slots;
     t->slots = fresh;
+    t->slots_alloc = new_cap;
     t->cap = new_cap;
     set_geometry(t);
     t->n_keys = placed;
@@ -327,6 +328,7 @@ kct_status kct_create(uint8_t ksize, uint64_t capacity_hint, int device, kct_tab
     st = alloc_slots(device, cap, t->stream, &t->slots);
     if (st != KCT_OK) return fail(st);
     t->cap = cap;
+    t->slots_alloc = cap;
     set_geometry(t);
     t->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *e = getenv("KCT_ABLATE")) t->ablate = atoi(e);
@@ -382,22 +384,23 @@ kct_status kct_resize(kct_table *t, uint64_t distinct) {
     u64 want = std::max(next_pow2((u64)((double)std::max<u64>(distinct, t->n_keys) / kMaxLoad) + 1), kMinSlots);
     t->auto_sized = false;
     if (want == t->cap) return KCT_OK;
-    // shadows and scratch were sized for the old geometry (nothing is pending after use())
-    if (t->shadow) { (void)hipFree(t->shadow); t->shadow = nullptr; t->shadow_cap = 0; t->shadow_empty = true; t->shadow_keys = 0; }
-    if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; t->s32_empty = true; t->s32_keys = 0; t->s32_windows = 0; }
-    if (want > t->cap) return grow_to(t, want);
-    // smaller: a fresh array of the wanted size, the keys re-inserted (grow_to's re-hash works either way)
+    // (nothing is pending after use(); shadows of another geometry are re-made by the next pass that wants one)
     if (t->n_keys == 0 || t->lazy_empty) {
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        du64 *fresh = nullptr;
-        KCT_TRY(alloc_slots(t->device, want, t->stream, &fresh));
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        HIP_TRY(hipFree(t->slots));
-        t->slots = fresh; t->cap = want; set_geometry(t);
-        t->n_keys = 0; t->lazy_empty = false;
+        // an empty table changes its capacity IN PLACE when the allocation has room (no hipMalloc / hipFree: the multi-GPU
+        // merge resizes twice per job); its slots are cleared lazily
+        if (want > t->slots_alloc) {
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            du64 *fresh = nullptr;
+            HIP_TRY(hipMalloc((void **)&fresh, want * 16));
+            HIP_TRY(hipFree(t->slots));
+            t->slots = fresh; t->slots_alloc = want;
+        }
+        t->cap = want; set_geometry(t);
+        t->n_keys = 0; t->lazy_empty = true;
         return KCT_OK;
     }
-    return rehash_into(t, want);
+    if (want > t->cap) return grow_to(t, want);
+    return rehash_into(t, want);  // smaller, with keys: a fresh array of the wanted size, the keys re-inserted
 }
 
 kct_status kct_count_hash(kct_table *t, uint64_t hash, uint64_t *count_out) {

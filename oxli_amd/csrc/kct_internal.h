@@ -112,6 +112,7 @@ struct kct_table {
     bool own_stream = false;
 
     du64 *slots = nullptr;  // 2 * cap words (device)
+    u64 slots_alloc = 0;    // slots the allocation has room for (>= cap: kct_resize makes an EMPTY table smaller or larger in place)
     u64 cap = 0;
     int block_bits = 0;     // log2(slots per probing block) = min(13, log2 cap)
     bool lazy_empty = false;  // kct_clear() was called and the memset has not been issued yet

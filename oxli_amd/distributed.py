@@ -40,6 +40,9 @@ def partition_by_owner(hashes_i64, counts_i64, world):
     return torch.stack([hashes_i64[order], counts_i64[order]], dim=1).contiguous(), send_counts
 
 
+_ROUTES = {}
+
+
 def exchange_route(group=None):
     """Which collective moves the pairs: "all_to_all" (RCCL / gloo ``all_to_all_single`` with uneven splits) or
     "all_gather" (every rank publishes its whole bucketed list; world x the traffic, for back ends without an uneven
@@ -47,11 +50,14 @@ def exchange_route(group=None):
     tiny all-reduce, so that every rank issues the same collectives; an error in a collective is never caught (the
     communicator is unusable after one anyway, and a rank that switched routes alone would hang the others)."""
     import os
-    mine = 1 if os.environ.get("KCT_A2A_FALLBACK") == "1" else 0
-    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-    t = torch.tensor([mine], dtype=torch.int64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    return "all_gather" if int(t.item()) else "all_to_all"
+    key = id(group) if group is not None else 0
+    if key not in _ROUTES:  # agreed once per process group
+        mine = 1 if os.environ.get("KCT_A2A_FALLBACK") == "1" else 0
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor([mine], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        _ROUTES[key] = "all_gather" if int(t.item()) else "all_to_all"
+    return _ROUTES[key]
 
 
 def exchange_pairs(pairs, send_counts, zero_count=0, group=None, route=None):
