@@ -42,7 +42,7 @@ def short(name):
         return base + {"0": "", "1": "<raw>", "true": "<raw>", "2": "<compact>"}.get(mode, "")
     if base == "repartition_kernel":
         targs = targs.strip()
-        return base + ("<pairs>" if "HIP_vector_type" in targs or "ulonglong2" in targs else "<compact>" if targs == "unsigned int" else "")
+        return base + ("<pairs>" if "HIP_vector_type" in targs or "ulonglong2" in targs else "<compact>" if targs.startswith("unsigned int") else "")
     return base
 
 
