@@ -758,7 +758,9 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     }
     {
         ProfScope ps(t, raw ? "aggregate_blocks_kernel<shadow>" : "aggregate_blocks_kernel");
-        hipLaunchKernelGGL(kct::aggregate_blocks_kernel, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
+        // (a pass expected to bring mostly NEW k-mers into an empty table: the variant whose fast path claims slots itself)
+        if (!raw && fresh && t->expect_new_keys) hipLaunchKernelGGL(kct::aggregate_blocks_kernel<true>, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
+        else hipLaunchKernelGGL(kct::aggregate_blocks_kernel<false>, dim3((unsigned)B), dim3(kct::kPartThreads), 0, t->stream, aa);
     }
     HIP_TRY(hipGetLastError());
     // K1's (and K1b's) overflow regions go to the real table with the direct insert; so do -- after the pass -- the entries of
@@ -975,6 +977,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
                 // runs between reads are -- dedupe_pays -- so nothing is switched off)
                 if (pays) t->dedupe_hint = true;
                 else KCT_TRY(flush_shadow(t));
+                t->expect_new_keys = per_key < 6.0;  // fewer than six k-mers per distinct one: the first pass is mostly first sightings
                 continue;
             }
         }

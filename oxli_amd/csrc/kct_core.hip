@@ -367,6 +367,7 @@ kct_status kct_clear(kct_table *t) {
     t->shadow_empty = true; t->shadow_dirty = false; t->shadow_keys = 0; t->dedupe_off = false;  // pending counts are forgotten too
     t->s32_empty = true; t->s32_dirty = false; t->s32_keys = 0; t->s32_windows = 0; t->compact_off = false;
     t->n_keys = 0; t->consumed = 0; t->zero_present = false; t->zero_count = 0;
+    t->expect_new_keys = false;
     if (t->pending_pairs) { t->pending_pairs = 0; HIP_TRY(hipMemsetAsync(t->d_counters + kNumCounters + 8, 0, 8, t->stream)); }
     return KCT_OK;
 }

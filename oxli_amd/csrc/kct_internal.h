@@ -151,6 +151,7 @@ struct kct_table {
     u64 pending_pairs = 0;
     u64 windows_since_read = 0; // window starts consumed since anything last read the table (use()): how long the caller's runs are
     u64 call_windows_left = 0;  // window starts the running consume call still has to count (no read can come before them)
+    bool expect_new_keys = false;  // the dedupe probe found (nearly) every k-mer new: K2's fast path claims slots itself (AggregateArgs::claim)
     bool dedupe_hint = false;   // the last dedupe-first pass paid off: a cleared table starts with that path again
     u64 n_keys = 0;        // distinct non-zero hashes in `slots`
     u64 consumed = 0;      // lib.rs:36

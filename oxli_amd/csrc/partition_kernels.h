@@ -414,6 +414,7 @@ struct AggregateArgs {
     u64 *counters;
 };
 
+template <bool CLAIM = false>  // CLAIM: the fast path claims free home-group slots itself (passes of mostly new k-mers)
 __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(AggregateArgs a) {
     __shared__ __attribute__((aligned(16))) u64 tab[2 << kBlockBitsMax];  // S keys then S counts = 128 KiB
     __shared__ u64 wq[(kPartThreads / 64) * kWaveQueue];                  // per-wave queues of deferred entries, 20 KiB
@@ -531,6 +532,24 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
                     if (!(a.ablate & 4)) atomicAdd(&cnts[g + idx], 1ULL);
                     ++counted;
                     miss = false;
+                }
+            } else if constexpr (CLAIM) {
+                // No fingerprint matches and the home group has a free slot: a first sighting, claimed right here (the
+                // group's first free slot is where the general insert would put it) instead of taking the detour through the
+                // queue.  Only for passes the host expects to bring mostly NEW k-mers (low coverage into an empty table: K2
+                // -17 % on C4's shard): a branch one lane in ten takes is a branch nearly every wave takes, and where
+                // first sightings are rare it costs more than the queue (K2 +12 % in the steady state -- even behind a run-time
+                // flag that is off, hence the template parameter).
+                const u64 e8 = (t8 - 0x0101010101010101ULL) & ~t8 & 0x8080808080808080ULL;  // zero bytes: free slots
+                if (e8) {
+                    const u32 idx = (u32)__builtin_ctzll(e8) >> 3;
+                    const u64 old = atomicCAS(&keys[g + idx], 0ULL, h);
+                    if (old == 0 || old == h) {
+                        if (old == 0) { ++newkeys; tags[g + idx] = (unsigned char)tag_of(h); }
+                        if (!(a.ablate & 4)) atomicAdd(&cnts[g + idx], 1ULL);
+                        ++counted;
+                        miss = false;
+                    }
                 }
             }
         }
@@ -790,6 +809,9 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
 #pragma unroll
             for (int i = kGroup - 1; i >= 0; --i) if (kk[i] == e) idx = i;
             if (idx >= 0) { atomicAdd(&cnts[g + idx], 1u); ++counted; miss = false; }
+            // (Claiming a first sighting's slot right here, as the 64-bit K2 does, was measured and dropped: a path that one lane
+            // in ten takes is a path nearly every WAVE takes, and finding the group's first free slot among eight 32-bit keys
+            // costs every entry of the wave -- K2-32 +22 % in the steady state, +13 % even on a cold pass.)
         }
         const u64 m = __ballot(miss);
         if (m) {
