@@ -414,7 +414,7 @@ struct AggregateArgs {
     u64 *counters;
 };
 
-template <bool CLAIM = false>  // CLAIM: the fast path claims free home-group slots itself (passes of mostly new k-mers)
+template <bool CLAIM, bool TWO>  // CLAIM: the fast path claims free home-group slots itself (passes of mostly new k-mers); TWO: two partition levels
 __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(AggregateArgs a) {
     __shared__ __attribute__((aligned(16))) u64 tab[2 << kBlockBitsMax];  // S keys then S counts = 128 KiB
     __shared__ u64 wq[(kPartThreads / 64) * kWaveQueue];                  // per-wave queues of deferred entries, 20 KiB
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
         g += kWaves;
         return true;
     };
-    const bool two_level = a.nregions < kWaves && !(a.ablate & 64);
+    const bool two_level = TWO && !(a.ablate & 64);
     u64 va[kInFlight], vb[kInFlight];
     bool more = two_level ? load_slab(va) : false;
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
         }
     };
     if (a.ablate & 64) {
-    } else if (a.nregions >= kWaves) {  // one level: many short regions, one wave each
+    } else if constexpr (!TWO) {  // one level: many short regions, one wave each
         for (int seg = wave; seg < a.nregions; seg += kWaves) {
             const u32 cnt = my_counts[seg];
             const u64 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
@@ -688,6 +688,7 @@ struct Aggregate32Args {
 
 // (Two workgroups per CU -- 78 KiB of LDS and 60 VGPRs each, with a shorter queue -- were measured: 5 % slower.)
 constexpr int kWaveQueue32 = kWaveQueue;
+template <bool TWO>  // TWO: a few long regions per block (two partition levels); otherwise one short region per K1 workgroup
 __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggregate32Args a) {
     __shared__ __attribute__((aligned(16))) u32 tab[2 << kBlockBitsMax];  // S keys then S counts = 64 KiB
     __shared__ u32 wq[(kPartThreads / 64) * kWaveQueue32];
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
     // with ONE load (lane l holds the size of the wave's l-th region), and the slabs are double-buffered across region
     // boundaries: a region is only ~2 KB, so a wave that waited for each one separately would keep too few bytes in flight.
     // Here too the first slab is requested before the block is loaded.
-    const bool two_level = a.nregions < kWaves;
+    constexpr bool two_level = TWO;
     const int my_nreg = two_level ? 0 : (a.nregions - wave + kWaves - 1) / kWaves;  // regions of this wave (64 per batch)
     int r0 = 0, nr = my_nreg < 64 ? my_nreg : 64, ri = 0;  // ri: region index within the batch; off: offset inside the region
     u32 off = 0, my_cnt = (!two_level && lane < nr) ? my_counts[wave + kWaves * lane] : 0u;
