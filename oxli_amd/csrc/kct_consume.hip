@@ -282,11 +282,15 @@ kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const
         pa.region_count = (const unsigned int *)t->d_regions2.p; pa.nregions = (int)L.W;
     }
     pa.fresh = fresh ? 1 : 0;
+    pa.nblocks = (unsigned int)L.B;
     KCT_TRY(failed_blocks(t, L.B, &pa.failed));
     pa.counters = t->d_counters;
     {
         ProfScope ps(t, "aggregate_pairs_kernel");
-        hipLaunchKernelGGL(kct::aggregate_pairs_kernel, dim3((unsigned)L.B), dim3(kct::kPartThreads), 0, t->stream, pa);
+        // two levels: one workgroup per CU walks the blocks (a block's stores drain under the next block's merge)
+        unsigned grid = (unsigned)L.B;
+        if (L.two && !getenv("KCT_PAIRS_NOPERSIST")) grid = (unsigned)std::min<u64>(L.B, (u64)t->num_cus);
+        hipLaunchKernelGGL(kct::aggregate_pairs_kernel, dim3(grid), dim3(kct::kPartThreads), 0, t->stream, pa);
     }
     HIP_TRY(hipGetLastError());
     t->lazy_empty = false;

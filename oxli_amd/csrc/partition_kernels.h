@@ -1027,6 +1027,7 @@ struct AggregatePairsArgs {
     const ulonglong2 *scratch; u64 seg_stride, block_stride;  // region (seg, b) at scratch + seg * seg_stride + b * block_stride
     const u32 *region_count; int nregions;
     int fresh;
+    u32 nblocks;         // table blocks (the grid may be smaller: a workgroup then takes every grid-th block)
     FailedBlocks failed; // blocks that overflowed (abandoned whole; the host grows the table and recounts their regions)
     u64 *counters;       // CTR_TOTAL_ADDED (counts placed), CTR_NEWKEYS
 };
@@ -1035,96 +1036,107 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(Aggregate
     __shared__ __attribute__((aligned(16))) u64 tab[2 << kBlockBitsMax];
     __shared__ u64 s_tot, s_new, s_nz;
     __shared__ u32 s_failed;
-    const int b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
-    u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u64 *keys = tab, *cnts = tab + S;
-    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; s_nz = 0; s_failed = 0; }
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
-    const u32 *my_counts = a.region_count + (u64)b * a.nregions;
-    // Two levels: the block's (few, long) regions.  The first rows of pairs are requested BEFORE the block itself, so that
-    // their HBM round trip runs under the block load instead of after it (one workgroup per CU: nothing else would hide it).
+    const int lane = threadIdx.x & 63;
+    const bool few = a.nregions < 64;
+    u64 sum_tot = 0, sum_new = 0, sum_nz = 0;  // thread 0: the tallies of the blocks this workgroup has stored
+    // A workgroup takes blocks b, b + grid, ...: with two partition levels the grid is one workgroup per CU, and a block's
+    // 128 KiB of stores drain while the next block is zeroed and merged (a workgroup per block left the CU's share of HBM
+    // idle for half of every block's time: nothing overlaps the stores of a workgroup that is ending).
+    // Two levels: the block's (few, long) regions.  The first rows of a block's pairs are requested BEFORE the block itself
+    // is loaded, so that their HBM round trip runs under the block load instead of after it (one workgroup per CU: nothing
+    // else would hide it).  (Requesting them before the PREVIOUS block is stored was slower: 6.9 -> 7.2 ms.)
     constexpr int kPre = 4;
     ulonglong2 pre[kPre];
-    const bool few = a.nregions < 64;
-    const u32 cnt0 = few && a.nregions > 0 ? my_counts[0] : 0u;
-    const ulonglong2 *region0 = a.scratch + (u64)b * a.block_stride;
+    auto request_rows = [&](u32 b) {
+        const u32 cnt0 = few && a.nregions > 0 && b < a.nblocks ? a.region_count[(u64)b * a.nregions] : 0u;
+        const ulonglong2 *region0 = a.scratch + (u64)b * a.block_stride;
 #pragma unroll
-    for (int j = 0; j < kPre; ++j) {
-        const u32 i = threadIdx.x + (u32)j * kPartThreads;
-        pre[j] = i < cnt0 ? region0[i] : make_ulonglong2(0, 0);
-    }
-    if (a.fresh) for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
-    else for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    u64 tot = 0, nk = 0, nz = 0;
-    auto merge_pair = [&](const ulonglong2 pr) {
-        const u64 h = pr.x, c = pr.y;
-        if (h == 0) return;  // hole / padding
-        u32 g = (u32)h & smask & ~(u32)(kGroup - 1);
-        bool placed = false;
-        for (u32 round = 0; round < (S >> kGroupBits) && !placed; ++round) {
-            const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(keys + g);
-            const ulonglong2 q0 = kp[0], q1 = kp[1], q2 = kp[2], q3 = kp[3];
-            const u64 kk[kGroup] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
-            int sel = kGroup;  // first slot that holds h or is empty
-#pragma unroll
-            for (int sl = kGroup - 1; sl >= 0; --sl) if (kk[sl] == h || kk[sl] == 0) sel = sl;
-            while (sel < kGroup) {
-                u64 ks = keys[g + sel];
-                if (ks == 0) {
-                    ks = atomicCAS(&keys[g + sel], 0ULL, h);
-                    if (ks == 0) { ++nk; ks = h; }
-                }
-                if (ks == h) { nz += atomicAdd(&cnts[g + sel], c) == 0; placed = true; break; }  // (lib.rs:801-803: new = count was 0)
-                ++sel;  // another lane claimed that slot for a different key: try the following slots
-                while (sel < kGroup) { const u64 k2 = keys[g + sel]; if (k2 == h || k2 == 0) break; ++sel; }
-            }
-            g = (g + kGroup) & smask;
+        for (int j = 0; j < kPre; ++j) {
+            const u32 i = threadIdx.x + (u32)j * kPartThreads;
+            pre[j] = i < cnt0 ? region0[i] : make_ulonglong2(0, 0);
         }
-        if (placed) tot += c;
-        else s_failed = 1u;  // block full: the whole block is abandoned (FailedBlocks)
     };
-    if (a.nregions >= 64) {
-        // One level: a region holds only a handful of pairs (one workgroup's share of one block): FOUR lanes take a region,
-        // so all 256 regions are in flight at once and a group's loads are one 64-byte line.
-        const int q = threadIdx.x & 3;
-        for (int seg = threadIdx.x >> 2; seg < a.nregions; seg += kPartThreads / 4) {
-            const u32 cnt = my_counts[seg];
-            const ulonglong2 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
-            for (u32 i = q; i < cnt; i += 4) merge_pair(region[i]);
-        }
-    } else {
-        // Two levels: a few long regions per block (one per second-level writer), the whole workgroup strides over each
-        // (the first kPre rows of region 0 are already in registers).
+    for (u32 b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+        u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
+        if (threadIdx.x == 0) { s_tot = 0; s_new = 0; s_nz = 0; s_failed = 0; }
+        request_rows(b);
+        const u32 *my_counts = a.region_count + (u64)b * a.nregions;
+        if (a.fresh) for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = make_uint4(0, 0, 0, 0);
+        else for (u32 i = threadIdx.x; i < S; i += kPartThreads) t4[i] = reinterpret_cast<const uint4 *>(gblock)[i];
+        __syncthreads();
+        u64 tot = 0, nk = 0, nz = 0;
+        auto merge_pair = [&](const ulonglong2 pr) {
+            const u64 h = pr.x, c = pr.y;
+            if (h == 0) return;  // hole / padding
+            u32 g = (u32)h & smask & ~(u32)(kGroup - 1);
+            bool placed = false;
+            for (u32 round = 0; round < (S >> kGroupBits) && !placed; ++round) {
+                const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(keys + g);
+                const ulonglong2 q0 = kp[0], q1 = kp[1], q2 = kp[2], q3 = kp[3];
+                const u64 kk[kGroup] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+                int sel = kGroup;  // first slot that holds h or is empty
 #pragma unroll
-        for (int j = 0; j < kPre; ++j) merge_pair(pre[j]);
-        for (int seg = 0; seg < a.nregions; ++seg) {
-            const u32 cnt = my_counts[seg];
-            const ulonglong2 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
-            for (u32 i = threadIdx.x + (seg == 0 ? kPre * kPartThreads : 0); i < cnt; i += kPartThreads) merge_pair(region[i]);
+                for (int sl = kGroup - 1; sl >= 0; --sl) if (kk[sl] == h || kk[sl] == 0) sel = sl;
+                while (sel < kGroup) {
+                    u64 ks = keys[g + sel];
+                    if (ks == 0) {
+                        ks = atomicCAS(&keys[g + sel], 0ULL, h);
+                        if (ks == 0) { ++nk; ks = h; }
+                    }
+                    if (ks == h) { nz += atomicAdd(&cnts[g + sel], c) == 0; placed = true; break; }  // (lib.rs:801-803: new = count was 0)
+                    ++sel;  // another lane claimed that slot for a different key: try the following slots
+                    while (sel < kGroup) { const u64 k2 = keys[g + sel]; if (k2 == h || k2 == 0) break; ++sel; }
+                }
+                g = (g + kGroup) & smask;
+            }
+            if (placed) tot += c;
+            else s_failed = 1u;  // block full: the whole block is abandoned (FailedBlocks)
+        };
+        if (!few) {
+            // One level: a region holds only a handful of pairs (one workgroup's share of one block): FOUR lanes take a region,
+            // so all 256 regions are in flight at once and a group's loads are one 64-byte line.
+            const int q = threadIdx.x & 3;
+            for (int seg = threadIdx.x >> 2; seg < a.nregions; seg += kPartThreads / 4) {
+                const u32 cnt = my_counts[seg];
+                const ulonglong2 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
+                for (u32 i = q; i < cnt; i += 4) merge_pair(region[i]);
+            }
+        } else {
+            // Two levels: a few long regions per block (one per second-level writer), the whole workgroup strides over each
+            // (the first kPre rows of region 0 are already in registers).
+#pragma unroll
+            for (int j = 0; j < kPre; ++j) merge_pair(pre[j]);
+            for (int seg = 0; seg < a.nregions; ++seg) {
+                const u32 cnt = my_counts[seg];
+                const ulonglong2 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
+                for (u32 i = threadIdx.x + (seg == 0 ? kPre * kPartThreads : 0); i < cnt; i += kPartThreads) merge_pair(region[i]);
+            }
         }
-    }
-    tot = wave_sum(tot); nk = wave_sum(nk); nz = wave_sum(nz);
-    if (lane == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); atomicAdd(&s_nz, nz); }
-    __syncthreads();
-    if (s_failed) {
-        if (a.fresh) for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = make_uint4(0, 0, 0, 0);
-        if (threadIdx.x == 0) {
-            u64 entries = 0;
-            for (int r = 0; r < a.nregions; ++r) entries += my_counts[r];
-            a.failed.list[atomicAdd(a.failed.n, 1ULL)] = (u32)b;
-            atomicAdd(a.failed.entries, entries);
+        tot = wave_sum(tot); nk = wave_sum(nk); nz = wave_sum(nz);
+        if (lane == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); atomicAdd(&s_nz, nz); }
+        __syncthreads();
+        if (s_failed) {
+            if (a.fresh) for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = make_uint4(0, 0, 0, 0);
+            if (threadIdx.x == 0) {
+                u64 entries = 0;
+                for (int r = 0; r < a.nregions; ++r) entries += my_counts[r];
+                a.failed.list[atomicAdd(a.failed.n, 1ULL)] = b;
+                atomicAdd(a.failed.entries, entries);
+            }
+        } else {
+            for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
+            if (threadIdx.x == 0) { sum_tot += s_tot; sum_new += s_new; sum_nz += s_nz; }
         }
-        return;
+        __syncthreads();  // the block has left LDS (its stores may still be in flight) and the tallies are read
     }
-    for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
     if (threadIdx.x == 0) {
         u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
-        if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
-        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
-        if (s_nz) atomicAdd(shard + CTR_NEW_BY_ZERO, s_nz);
+        if (sum_tot) atomicAdd(shard + CTR_TOTAL_ADDED, sum_tot);
+        if (sum_new) atomicAdd(shard + CTR_NEWKEYS, sum_new);
+        if (sum_nz) atomicAdd(shard + CTR_NEW_BY_ZERO, sum_nz);
     }
 }
 
