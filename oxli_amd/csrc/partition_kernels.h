@@ -410,6 +410,7 @@ struct AggregateArgs {
     int fresh;           // table known empty: start every block from zeros instead of loading it
     const u64 *overflow; // K1's abandon flag
     int ablate;          // measurement only: bit 2 (4) = no count add, bit 4 (16) = loads only, bit 6 (64) = no streaming at all
+    u32 nblocks;         // table blocks (the grid may be smaller: a workgroup then takes every grid-th block)
     FailedBlocks failed;
     u64 *counters;
 };
@@ -422,15 +423,18 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
     __shared__ u64 s_counted, s_new;
     __shared__ u32 s_failed;
     if (*a.overflow) return;  // wave-uniform: K1 gave up, the host reruns the batch on the direct path
-    const int b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
-    u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u64 *keys = tab, *cnts = tab + S;
-    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; s_failed = 0; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int kInFlight = 12;
     constexpr u32 kSlab = 64 * kInFlight;
     constexpr int kWaves = kPartThreads / 64;
+    u64 sum_counted = 0, sum_new = 0;  // thread 0: the tallies of the blocks this workgroup has stored
+    // A workgroup takes blocks b, b + grid, ...: with two partition levels the grid is one workgroup per CU, so that a
+    // block's stores drain under the next block's load instead of in front of the next workgroup's start.
+    for (u32 b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+    u64 *gblock = a.words + ((u64)b << (a.block_bits + 1));
+    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; s_failed = 0; }
     const u32 *my_counts = a.region_count + (u64)b * a.nregions;
     // Two levels: a few long regions per block, their slabs dealt round-robin to the waves.  The wave's NEXT slab is loaded
     // before the current one is counted, and its FIRST before the block itself is loaded, so that no HBM round trip of the
@@ -610,16 +614,19 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
         if (threadIdx.x == 0) {
             u64 entries = 0;
             for (int r = 0; r < a.nregions; ++r) entries += my_counts[r];
-            a.failed.list[atomicAdd(a.failed.n, 1ULL)] = (u32)b;
+            a.failed.list[atomicAdd(a.failed.n, 1ULL)] = b;
             atomicAdd(a.failed.entries, entries);
         }
-        return;
+    } else {
+        for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
+        if (threadIdx.x == 0) { sum_counted += s_counted; sum_new += s_new; }
     }
-    for (u32 i = threadIdx.x; i < S; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
+    __syncthreads();  // the block has left LDS (its stores may still be in flight) and the tallies are read
+    }
     if (threadIdx.x == 0) {
         u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
-        if (s_counted) atomicAdd(shard + CTR_COUNTED, s_counted);
-        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+        if (sum_counted) atomicAdd(shard + CTR_COUNTED, sum_counted);
+        if (sum_new) atomicAdd(shard + CTR_NEWKEYS, sum_new);
     }
 }
 
@@ -684,6 +691,7 @@ struct Aggregate32Args {
     u64 *counters;
     int ablate;          // measurement only: bit 4 (16) = loads only
     int sbits;           // log2(blocks of the shadow): a block index is the TOP sbits bits of the 42-bit value (>= 10)
+    u32 nblocks;         // shadow blocks (the grid may be smaller: a workgroup then takes every grid-th block)
 };
 
 // (Two workgroups per CU -- 78 KiB of LDS and 60 VGPRs each, with a shorter queue -- were measured: 5 % slower.)
@@ -695,15 +703,17 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
     __shared__ u64 s_counted, s_new;
     __shared__ u32 s_failed;
     if (*a.overflow) return;
-    const int b = blockIdx.x;
     const u32 S = 1u << a.block_bits, smask = S - 1;
-    u32 *gblock = a.words + ((u64)b << (a.block_bits + 1));
     u32 *keys = tab, *cnts = tab + S;
-    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; s_failed = 0; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int kInFlight = 12;
     constexpr u32 kSlab = 64 * kInFlight;
     constexpr int kWaves = kPartThreads / 64;
+    u64 sum_counted = 0, sum_new = 0;  // thread 0: the tallies of the blocks this workgroup has stored
+    // (a workgroup takes blocks b, b + grid, ...: two levels run two workgroups per CU over all the blocks, as the 64-bit K2 does)
+    for (u32 b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+    u32 *gblock = a.words + ((u64)b << (a.block_bits + 1));
+    if (threadIdx.x == 0) { s_counted = 0; s_new = 0; s_failed = 0; }
     const u32 *my_counts = a.region_count + (u64)b * a.nregions;
     // Two levels (large shadow): a few long regions per block (one per K1b writer); their slabs of 768 entries are dealt
     // round-robin to the waves, the next slab in flight while the current one is counted -- and the FIRST requested before
@@ -865,16 +875,19 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
         if (threadIdx.x == 0) {
             u64 entries = 0;
             for (int r = 0; r < a.nregions; ++r) entries += my_counts[r];
-            a.failed.list[atomicAdd(a.failed.n, 1ULL)] = (u32)b;
+            a.failed.list[atomicAdd(a.failed.n, 1ULL)] = b;
             atomicAdd(a.failed.entries, entries);
         }
-        return;
+    } else {
+        for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
+        if (threadIdx.x == 0) { sum_counted += s_counted; sum_new += s_new; }
     }
-    for (u32 i = threadIdx.x; i < S / 2; i += kPartThreads) reinterpret_cast<uint4 *>(gblock)[i] = t4[i];
+    __syncthreads();  // the block has left LDS (its stores may still be in flight) and the tallies are read
+    }
     if (threadIdx.x == 0) {
         u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
-        if (s_counted) atomicAdd(shard + CTR_COUNTED, s_counted);
-        if (s_new) atomicAdd(shard + CTR_NEW_BY_ZERO, s_new);  // new SHADOW keys: kept apart from the merges' new table keys (CTR_NEWKEYS)
+        if (sum_counted) atomicAdd(shard + CTR_COUNTED, sum_counted);
+        if (sum_new) atomicAdd(shard + CTR_NEW_BY_ZERO, sum_new);  // new SHADOW keys: kept apart from the merges' new table keys (CTR_NEWKEYS)
     }
 }
 
