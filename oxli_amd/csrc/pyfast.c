@@ -1,0 +1,56 @@
+/* _kctfast -- CPython call glue for the one entry point a per-record loop hammers:
+ *
+ *     for rec in records: table.consume(rec)          (the reference's documented loop, README.md:96-98)
+ *
+ * ctypes spends ~0.6 us per call on argument conversion; pyo3, which the reference binds with (lib.rs:545-546), spends
+ * ~0.1 us.  This module is the pyo3-sized shim for Python callers of the C ABI: it is handed the ADDRESS of
+ * kct_consume (include/kct.h) by oxli_amd/table.py and forwards (handle, str | bytes, skip_bad) to it.  No k-mer
+ * arithmetic lives here; without it table.py uses ctypes, with identical results.
+ */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+
+typedef int (*kct_consume_fn)(void *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out);
+static kct_consume_fn g_consume = NULL;
+
+static PyObject *fast_bind(PyObject *self, PyObject *arg) {
+    (void)self;
+    const unsigned long long addr = PyLong_AsUnsignedLongLong(arg);
+    if (addr == (unsigned long long)-1 && PyErr_Occurred()) return NULL;
+    g_consume = (kct_consume_fn)(uintptr_t)addr;
+    Py_RETURN_NONE;
+}
+
+/* consume(handle: int, seq: str | bytes, skip_bad) -> n (int) on KCT_OK, (status, n) otherwise, None for other seq types */
+static PyObject *fast_consume(PyObject *self, PyObject *const *args, Py_ssize_t nargs) {
+    (void)self;
+    if (nargs != 3) { PyErr_SetString(PyExc_TypeError, "consume(handle, seq, skip_bad)"); return NULL; }
+    if (!g_consume) { PyErr_SetString(PyExc_RuntimeError, "_kctfast is not bound to libkct_hip.so"); return NULL; }
+    const unsigned long long h = PyLong_AsUnsignedLongLong(args[0]);
+    if (h == (unsigned long long)-1 && PyErr_Occurred()) return NULL;
+    const char *p;
+    Py_ssize_t len;
+    if (PyUnicode_Check(args[1])) {
+        p = PyUnicode_AsUTF8AndSize(args[1], &len);  /* the UTF-8 bytes of the str, as the reference sees them (lib.rs:548, 577) */
+        if (!p) return NULL;
+    } else if (PyBytes_Check(args[1])) {
+        if (PyBytes_AsStringAndSize(args[1], (char **)&p, &len) < 0) return NULL;
+    } else Py_RETURN_NONE;
+    const int skip = PyObject_IsTrue(args[2]);
+    if (skip < 0) return NULL;
+    uint64_t n = 0;
+    const int st = g_consume((void *)(uintptr_t)h, p, (size_t)len, skip, &n);
+    if (st == 0) return PyLong_FromUnsignedLongLong(n);
+    return Py_BuildValue("(iK)", st, (unsigned long long)n);
+}
+
+static PyMethodDef methods[] = {
+    {"bind", fast_bind, METH_O, "bind(address of kct_consume)"},
+    {"consume", (PyCFunction)(void (*)(void))fast_consume, METH_FASTCALL, "consume(handle, seq, skip_bad)"},
+    {NULL, NULL, 0, NULL},
+};
+
+static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_kctfast", "call glue for kct_consume", -1, methods, NULL, NULL, NULL, NULL};
+
+PyMODINIT_FUNC PyInit__kctfast(void) { return PyModule_Create(&moduledef); }

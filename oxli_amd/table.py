@@ -22,6 +22,14 @@ _COMP = str.maketrans("ACGT", "TGCA")
 VERSION = "0.3.0"
 
 
+try:  # CPython call glue for per-record loops (csrc/pyfast.c); without it the same call goes through ctypes
+    from . import _kctfast as _fast
+    _fast.bind(C.cast(L.load().kct_consume, C.c_void_p).value)
+    _fast_consume = _fast.consume
+except ImportError:
+    _fast_consume = None
+
+
 def _bytes(s):
     if isinstance(s, str):
         return s.encode("utf-8")  # the reference sees the UTF-8 bytes of the str (lib.rs:548, 577)
@@ -48,6 +56,7 @@ class KmerCountTable:
             self._h = None
             raise RuntimeError(f"kct_create failed ({st}): {L.last_error()}")
         self.ksize = int(ksize)
+        self._hv = self._h.value  # the handle as a plain int, for _kctfast
         self.version = VERSION
         if deferred is not None:
             self.set_deferred(bool(deferred))
@@ -196,6 +205,14 @@ class KmerCountTable:
         """lib.rs:545-607.  Returns the number of k-mers counted.  With ``skip_bad_kmers=False`` a
         window holding a non-ACGT byte raises ``ValueError("bad k-mer encountered at position n")``
         after the k-mers before it were counted, leaving ``consumed`` unchanged."""
+        if _fast_consume is not None and not self.store_kmers:
+            r = _fast_consume(self._hv, seq, skip_bad_kmers)  # n, or (status, n), or None for a seq that is neither str nor bytes
+            if r.__class__ is int:
+                return r
+            if r is not None:
+                if r[0] == L.KCT_ERR_BAD_KMER:
+                    raise ValueError(f"bad k-mer encountered at position {r[1]}")
+                self._check(r[0])
         b = _bytes(seq)
         if self.store_kmers:
             # lib.rs:552-573: this branch walks KmersAndHashesIter, which always skips bad windows

@@ -69,6 +69,17 @@ def test_no_cpu_fallback(lib):
 def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "oxli_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "kct_oracle" not in text, f
+
+
+def test_call_glue_is_built_and_bound():
+    """csrc/pyfast.c: the CPython shim per-record consume() loops go through (it only forwards to kct_consume)."""
+    import oxli_amd.table as T
+    assert T._fast_consume is not None, "oxli_amd/_kctfast.so missing: run `make -C oxli_amd/csrc`"
+    assert T._fast.consume(0, 12345, True) is None  # neither str nor bytes: left to the ctypes path (no call is made)
+    with pytest.raises(TypeError):
+        T._fast.consume(0, "ACGT")
+    text = open(os.path.join(ROOT, "oxli_amd", "csrc", "pyfast.c")).read()
+    assert "hip" not in text.replace("libkct_hip", "") and "murmur" not in text.lower()  # glue only
