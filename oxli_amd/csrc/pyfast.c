@@ -10,6 +10,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
+#include <string.h>
 
 typedef int (*kct_consume_fn)(void *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out);
 static kct_consume_fn g_consume = NULL;
@@ -45,7 +46,46 @@ static PyObject *fast_consume(PyObject *self, PyObject *const *args, Py_ssize_t 
     return Py_BuildValue("(iK)", st, (unsigned long long)n);
 }
 
+/* csr(seqs: list | tuple of str | bytes) -> (data: bytes, offsets: bytes of len(seqs) + 1 native u64), or None if an item is
+ * of another type.  The concatenation consume_batch() hands to kct_consume_batch, built without a Python-level pass per
+ * record (a list comprehension of .encode() calls, a cumsum of a list of lengths and a join were 0.25 s per million reads). */
+static PyObject *fast_csr(PyObject *self, PyObject *arg) {
+    (void)self;
+    PyObject *fastseq = PySequence_Fast(arg, "csr(seqs): a list or tuple");
+    if (!fastseq) return NULL;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(fastseq);
+    PyObject **items = PySequence_Fast_ITEMS(fastseq);
+    PyObject *offs = PyBytes_FromStringAndSize(NULL, (Py_ssize_t)((n + 1) * sizeof(uint64_t)));
+    if (!offs) { Py_DECREF(fastseq); return NULL; }
+    uint64_t *o = (uint64_t *)PyBytes_AS_STRING(offs);
+    uint64_t total = 0;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        Py_ssize_t len;
+        if (PyUnicode_Check(items[i])) {
+            if (!PyUnicode_AsUTF8AndSize(items[i], &len)) { Py_DECREF(offs); Py_DECREF(fastseq); return NULL; }
+        } else if (PyBytes_Check(items[i])) len = PyBytes_GET_SIZE(items[i]);
+        else { Py_DECREF(offs); Py_DECREF(fastseq); Py_RETURN_NONE; }
+        o[i] = total;
+        total += (uint64_t)len;
+    }
+    o[n] = total;
+    PyObject *data = PyBytes_FromStringAndSize(NULL, (Py_ssize_t)total);
+    if (!data) { Py_DECREF(offs); Py_DECREF(fastseq); return NULL; }
+    char *d = PyBytes_AS_STRING(data);
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        Py_ssize_t len;
+        const char *p = PyUnicode_Check(items[i]) ? PyUnicode_AsUTF8AndSize(items[i], &len) : (len = PyBytes_GET_SIZE(items[i]), PyBytes_AS_STRING(items[i]));
+        memcpy(d + o[i], p, (size_t)len);
+    }
+    Py_DECREF(fastseq);
+    PyObject *r = PyTuple_Pack(2, data, offs);
+    Py_DECREF(data);
+    Py_DECREF(offs);
+    return r;
+}
+
 static PyMethodDef methods[] = {
+    {"csr", fast_csr, METH_O, "csr(seqs) -> (data, offsets)"},
     {"bind", fast_bind, METH_O, "bind(address of kct_consume)"},
     {"consume", (PyCFunction)(void (*)(void))fast_consume, METH_FASTCALL, "consume(handle, seq, skip_bad)"},
     {NULL, NULL, 0, NULL},

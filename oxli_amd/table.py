@@ -27,7 +27,7 @@ try:  # CPython call glue for per-record loops (csrc/pyfast.c); without it the s
     _fast.bind(C.cast(L.load().kct_consume, C.c_void_p).value)
     _fast_consume = _fast.consume
 except ImportError:
-    _fast_consume = None
+    _fast = _fast_consume = None
 
 
 def _bytes(s):
@@ -238,11 +238,17 @@ class KmerCountTable:
             data = np.frombuffer(_bytes(seqs[0]), dtype=np.uint8) if not isinstance(seqs[0], np.ndarray) else seqs[0]
             offsets = np.ascontiguousarray(seqs[1], dtype=np.uint64)
         else:
-            parts = [_bytes(s) for s in seqs]
-            offsets = np.zeros(len(parts) + 1, dtype=np.uint64)
-            if parts:
-                offsets[1:] = np.cumsum([len(p) for p in parts], dtype=np.uint64)
-            data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+            if not isinstance(seqs, (list, tuple)):
+                seqs = list(seqs)
+            packed = _fast.csr(seqs) if _fast is not None else None  # (None: an item that is neither str nor bytes)
+            if packed is not None:
+                data, offsets = np.frombuffer(packed[0], dtype=np.uint8), np.frombuffer(packed[1], dtype=np.uint64)
+            else:
+                parts = [_bytes(s) for s in seqs]
+                offsets = np.zeros(len(parts) + 1, dtype=np.uint64)
+                if parts:
+                    offsets[1:] = np.cumsum([len(p) for p in parts], dtype=np.uint64)
+                data = np.frombuffer(b"".join(parts), dtype=np.uint8)
         data = np.ascontiguousarray(data)
         nrec = offsets.size - 1 if offsets.size else 0
         n, bad_rec, bad_pos = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -81,5 +81,13 @@ def test_call_glue_is_built_and_bound():
     assert T._fast.consume(0, 12345, True) is None  # neither str nor bytes: left to the ctypes path (no call is made)
     with pytest.raises(TypeError):
         T._fast.consume(0, "ACGT")
+    import numpy as np
+    seqs = ["ACGT" * 37 + "AC", b"GGGTTT", "", "\u00e9", "N" * 5]
+    data, offs = T._fast.csr(seqs)  # what consume_batch(list) hands to kct_consume_batch
+    parts = [T._bytes(x) for x in seqs]
+    assert data == b"".join(parts)
+    assert np.frombuffer(offs, dtype=np.uint64).tolist() == [0] + list(np.cumsum([len(x) for x in parts]))
+    assert T._fast.csr(tuple(seqs)) == (data, offs) and T._fast.csr([]) == (b"", bytes(8))
+    assert T._fast.csr(["A", bytearray(b"C")]) is None  # left to the Python path
     text = open(os.path.join(ROOT, "oxli_amd", "csrc", "pyfast.c")).read()
     assert "hip" not in text.replace("libkct_hip", "") and "murmur" not in text.lower()  # glue only

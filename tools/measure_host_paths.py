@@ -40,6 +40,20 @@ s = best(run_batch)
 out["consume_batch_host_csr"] = {"seconds": s, "kmers_per_s": kmers / s, "host_bytes": int(flat.size),
                                  "note": "pack into pinned staging + H2D + device passes, single-buffered"}
 
+strs = [reads[i, :L].tobytes().decode() for i in range(R)]   # what a screed loop would hold
+def run_list():
+    t.clear(); assert t.consume_batch(strs) == kmers
+s = best(run_list)
+out["consume_batch_list_of_str"] = {"seconds": s, "kmers_per_s": kmers / s, "note": "CSR built by csrc/pyfast.c, then as above"}
+def run_loop():
+    t.clear()
+    n = 0
+    for rec in strs:
+        n += t.consume(rec)
+    assert n == kmers and len(t) > 0
+s = best(run_loop)
+out["per_record_loop"] = {"seconds": s, "kmers_per_s": kmers / s, "us_per_call": s / R * 1e6}
+
 tmp = tempfile.mkdtemp()
 fa = os.path.join(tmp, "reads.fa")
 with open(fa, "wb") as f:
