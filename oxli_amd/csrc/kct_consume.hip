@@ -3,6 +3,7 @@
 #include "kct_internal.h"
 
 #include <type_traits>
+#include <emmintrin.h>
 #include "partition_kernels.h"
 
 namespace kcth {
@@ -1062,11 +1063,27 @@ constexpr size_t kPendingBytes = (size_t)64 << 20;
 // Valid k-windows of one record: the host-side twin of the device's window rule (all k bytes in ACGTacgt).
 // Used only for the number deferred consume() returns; the counting itself happens on the device at flush.
 u64 host_valid_windows(const unsigned char *s, size_t len, size_t k) {
-    static const struct Lut { bool ok[256]; Lut() { for (bool &b : ok) b = false; for (unsigned char c : {'A','C','G','T','a','c','g','t'}) ok[c] = true; } } lut;
+    // sixteen bytes at a time (SSE2, the x86-64 baseline): (c | 0x20) is one of a, c, g, t exactly for the eight valid bytes
+    const __m128i lower = _mm_set1_epi8(0x20), ca = _mm_set1_epi8('a'), cc = _mm_set1_epi8('c'), cg = _mm_set1_epi8('g'), ct = _mm_set1_epi8('t');
     u64 n = 0;
-    size_t run = 0;
-    for (size_t i = 0; i < len; ++i) {
-        run = lut.ok[s[i]] ? run + 1 : 0;
+    size_t run = 0, i = 0;  // run: valid bytes ending at the current position
+    for (; i + 16 <= len; i += 16) {
+        const __m128i v = _mm_or_si128(_mm_loadu_si128((const __m128i *)(s + i)), lower);
+        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, ca), _mm_cmpeq_epi8(v, cc)), _mm_or_si128(_mm_cmpeq_epi8(v, cg), _mm_cmpeq_epi8(v, ct)));
+        const unsigned m = (unsigned)_mm_movemask_epi8(ok);
+        if (m == 0xFFFFu) {  // windows END at each of the 16 positions whose run has reached k
+            run += 16;
+            if (run >= k) n += std::min<size_t>(16, run - k + 1);
+        } else {
+            for (int j = 0; j < 16; ++j) {
+                run = (m >> j) & 1u ? run + 1 : 0;
+                n += run >= k;
+            }
+        }
+    }
+    for (; i < len; ++i) {
+        const unsigned char c = s[i] | 0x20;
+        run = (c == 'a' || c == 'c' || c == 'g' || c == 't') ? run + 1 : 0;
         n += run >= k;
     }
     return n;
@@ -1158,12 +1175,14 @@ kct_status kct_get(kct_table *t, const char *kmer, size_t len, uint64_t *count_o
 kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out) {
     if (t && t->deferred && skip_bad && len + 64 < kPendingBytes / 2) {
         // deferred mode: buffer the record, answer from the host-side validity scan, count later
-        KCT_TRY(use_device(t));
         if ((!seq && len) || !n_out) { set_err("null argument"); return KCT_ERR_ARG; }
         *n_out = 0;
         if (len >= t->k) {
-            KCT_TRY(t->h_pending.reserve(kPendingBytes + 64));
-            if (t->pending_used + len + 1 > kPendingBytes) KCT_TRY(flush_pending(t));
+            if (!t->h_pending.p || t->pending_used + len + 1 > kPendingBytes) {  // (the common call touches no HIP API at all)
+                KCT_TRY(use_device(t));
+                KCT_TRY(t->h_pending.reserve(kPendingBytes + 64));
+                if (t->pending_used + len + 1 > kPendingBytes) KCT_TRY(flush_pending(t));
+            }
             char *dst = (char *)t->h_pending.p + t->pending_used;
             memcpy(dst, seq, len);
             dst[len] = '\n';
