@@ -1245,40 +1245,46 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
     };
     KCT_TRY(t->d_stream.reserve(padded + 16));
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t nthreads = stream_len >= (8u << 20) ? std::min<size_t>({(size_t)8, hw ? hw : 1, nrec}) : 1;
+    size_t max_threads = 16;
+    if (const char *e = getenv("KCT_PACK_THREADS")) max_threads = (size_t)std::max(1, atoi(e));
+    const size_t nthreads = stream_len >= (8u << 20) ? std::min<size_t>({max_threads, hw ? hw : 1, nrec}) : 1;
     if (nthreads <= 1) {
         pack_range(0, nrec);
         if (!skip_bad) rec_off[nrec] = stream_len;
         memset(dst + stream_len, '\n', padded + 16 - stream_len);
         HIP_TRY(hipMemcpyAsync(t->d_stream.p, dst, padded, hipMemcpyHostToDevice, t->stream));
     } else {
-        // The stream is cut into slices of records (by bytes: records may be ragged) that the packers take in
-        // order, round-robin; this thread uploads slice s as soon as it is packed, so the H2D copy runs under
-        // the packing of the slices behind it instead of after all of it.
-        // (slices of ~4 MiB: every copy costs ~15 us on top of its transfer -- 1 MiB slices were 20 % slower, 256 KiB 2x;
-        // more than 8 packers buy nothing, the copies are the longer leg: 2.6 ms of H2D at 57 GB/s against ~3 ms of packing)
-        const size_t nslices = std::min<size_t>(nrec, 4 * nthreads);
-        std::vector<size_t> cut(nslices + 1);
-        for (size_t i = 0; i <= nslices; ++i) {
-            const u64 lo = base0 + total * i / nslices;
-            cut[i] = i == nslices ? nrec : (size_t)(std::lower_bound(offsets, offsets + nrec, lo) - offsets);
+        // The stream is cut into slices (by bytes: records may be ragged) and every slice into parts; the packers take the
+        // parts in order, so ALL of them work on the slice that is uploaded next, and this thread starts a slice's H2D copy
+        // as soon as its last part is packed: the copy runs under the packing of the slices behind it and only one slice's
+        // copy is left when the packing ends.  (Slices of ~10 MB: every copy costs ~15 us on top of its transfer.)
+        const size_t nslices = std::min<size_t>(nrec, std::max<size_t>(4, std::min<size_t>(16, stream_len >> 22)));
+        const size_t parts = std::min<size_t>(nthreads, std::max<size_t>(1, nrec / nslices));
+        const size_t nitems = nslices * parts;
+        std::vector<size_t> cut(nitems + 1);
+        for (size_t i = 0; i <= nitems; ++i) {
+            const u64 lo = base0 + total * i / nitems;
+            cut[i] = i == nitems ? nrec : (size_t)(std::lower_bound(offsets, offsets + nrec, lo) - offsets);
         }
         cut[0] = 0;
-        std::vector<std::atomic<int>> ready(nslices);
-        for (auto &r : ready) r.store(0, std::memory_order_relaxed);
-        std::vector<std::thread> pool;
-        for (size_t i = 0; i < nthreads; ++i)
-            pool.emplace_back([&, i]() {
-                for (size_t sl = i; sl < nslices; sl += nthreads) {
-                    if (cut[sl + 1] > cut[sl]) pack_range(cut[sl], cut[sl + 1]);
-                    ready[sl].store(1, std::memory_order_release);
-                }
-            });
+        std::vector<std::atomic<int>> packed(nslices);
+        for (auto &r : packed) r.store(0, std::memory_order_relaxed);
+        std::atomic<size_t> next_item{0};
+        WorkerPool &pool = WorkerPool::instance();  // (threads that outlive the call: starting them cost more than the packing)
+        pool.start(nthreads, [&](size_t) {
+            for (;;) {
+                const size_t it = next_item.fetch_add(1, std::memory_order_relaxed);
+                if (it >= nitems) break;
+                if (cut[it + 1] > cut[it]) pack_range(cut[it], cut[it + 1]);
+                packed[it / parts].fetch_add(1, std::memory_order_release);
+            }
+        });
         hipError_t copy_err = hipSuccess;
         for (size_t sl = 0; sl < nslices; ++sl) {
-            while (!ready[sl].load(std::memory_order_acquire)) std::this_thread::yield();
-            const u64 b0 = cut[sl] < nrec ? (offsets[cut[sl]] - base0) + cut[sl] : stream_len;
-            u64 b1 = cut[sl + 1] < nrec ? (offsets[cut[sl + 1]] - base0) + cut[sl + 1] : stream_len;
+            while (packed[sl].load(std::memory_order_acquire) < (int)parts) std::this_thread::yield();
+            const size_t r0 = cut[sl * parts], r1 = cut[(sl + 1) * parts];
+            const u64 b0 = r0 < nrec ? (offsets[r0] - base0) + r0 : stream_len;
+            u64 b1 = r1 < nrec ? (offsets[r1] - base0) + r1 : stream_len;
             if (sl + 1 == nslices) {  // the tail slice carries the padding
                 if (!skip_bad) rec_off[nrec] = stream_len;
                 memset(dst + stream_len, '\n', padded + 16 - stream_len);
@@ -1288,7 +1294,7 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
                 copy_err = hipMemcpyAsync((char *)t->d_stream.p + b0, dst + b0, b1 - b0, hipMemcpyHostToDevice, t->stream);
         }
         KCT_DBG(t, "batch: last slice enqueued\n");
-        for (auto &th : pool) th.join();
+        pool.wait();
         HIP_TRY(copy_err);
         if (t->debug) { HIP_TRY(hipStreamSynchronize(t->stream)); KCT_DBG(t, "batch: upload done\n"); }
     }

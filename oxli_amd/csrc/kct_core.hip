@@ -2,6 +2,7 @@
 // point updates and lookups, dump / export / merge, stream and kernel-timing plumbing.
 // Bulk ingest lives in kct_consume.hip, file parsing in kct_ingest.hip.
 #include "kct_internal.h"
+#include <unistd.h>
 #include "table_kernels.h"
 
 extern "C" int kx_sort_pairs_u64(const unsigned long long *keys_in, unsigned long long *keys_out, const unsigned long long *vals_in,
@@ -45,6 +46,57 @@ void parallel_memcpy(void *dst, const void *src, size_t nbytes) {
         if (hi > lo) pool.emplace_back([=]() { memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
     }
     for (auto &th : pool) th.join();
+}
+
+WorkerPool &WorkerPool::instance() {
+    static WorkerPool *pool = new WorkerPool();  // never destroyed: its threads may outlive static destruction
+    return *pool;
+}
+
+void WorkerPool::worker(size_t id) {
+    size_t seen = 0;
+    std::unique_lock<std::mutex> lk(m_);
+    for (;;) {
+        cv_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (id >= want_) continue;  // this job uses fewer threads
+        auto fn = fn_;
+        lk.unlock();
+        fn(id);
+        lk.lock();
+        if (--running_ == 0) done_cv_.notify_all();
+    }
+}
+
+void WorkerPool::start(size_t n, std::function<void(size_t)> fn) {
+    job_lock_.lock();
+    std::unique_lock<std::mutex> lk(m_);
+    if (pid_ != (int)getpid()) {  // first use, or a forked child (threads do not survive a fork): a fresh set
+        auto *gone = new std::vector<std::thread>(std::move(threads_));  // (never joined or destroyed: they are not this process's)
+        (void)gone;
+        threads_.clear();
+        pid_ = (int)getpid();
+    }
+    fn_ = std::move(fn);
+    want_ = n;
+    running_ = n;
+    ++generation_;
+    // a worker born now starts with seen == 0 != generation_ and takes this job as soon as the lock is released
+    while (threads_.size() < n) {
+        const size_t id = threads_.size();
+        threads_.emplace_back([this, id]() { worker(id); });
+    }
+    lk.unlock();
+    cv_.notify_all();
+}
+
+void WorkerPool::wait() {
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        done_cv_.wait(lk, [&] { return running_ == 0; });
+        fn_ = nullptr;
+    }
+    job_lock_.unlock();
 }
 
 kct_status use_device(kct_table *t) {

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -29,6 +30,25 @@ namespace kcth {
 extern thread_local char g_err[512];
 void set_err(const char *fmt, ...);
 double now_ms();  // steady clock, for KCT_DEBUG lines
+
+// Host worker threads that outlive a call (starting eight threads costs more than packing a million reads does).
+// start(n, fn) runs fn(i), i = 0..n-1, on pool threads and returns at once; wait() blocks until they are done.  One job at
+// a time per process (callers serialise on the pool's own lock, released by wait()).
+class WorkerPool {
+public:
+    static WorkerPool &instance();
+    void start(size_t n, std::function<void(size_t)> fn);
+    void wait();
+private:
+    void worker(size_t id);
+    std::mutex job_lock_;               // held from start() to wait()
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> threads_;
+    std::function<void(size_t)> fn_;
+    size_t want_ = 0, generation_ = 0, running_ = 0;
+    int pid_ = 0;
+};
 #define KCT_DBG(t, ...) do { if ((t)->debug) { fprintf(stderr, "[kct %11.3f ms] ", kcth::now_ms()); fprintf(stderr, __VA_ARGS__); } } while (0)
 
 #define HIP_TRY(expr)                                                                       \
