@@ -167,7 +167,7 @@ def compact(res):
             g = c.get("gate", {})
             e = {"kmers_per_s": r(c["kmers_per_s"], 0), "seconds": r(c["seconds"], 5),
                  "gate": "ok" if all(v for kk, v in g.items() if kk != "sampled_keys") else [kk for kk, v in g.items() if not v]}
-            for k in ("alg_frac", "measured_frac", "hbm_bytes_per_kmer", "kmers_per_s_warm", "us_per_call"):
+            for k in ("alg_frac", "measured_frac", "hbm_bytes_per_kmer", "kmers_per_s_warm", "us_per_call", "us_per_call_loop_only"):
                 if k in c:
                     e[k] = r(c[k], 0 if k == "kmers_per_s_warm" else 4)
             if "kernels_ms" in c:
@@ -443,17 +443,25 @@ def main():
             assert ablate or ok
         if "per_record" in want:
             recs = [host[i, :L].tobytes() for i in range(R)]
-            t2 = KmerCountTable(k)          # default-constructed, as the README's loop would
-            t0 = time.perf_counter()
-            n = 0
-            consume = t2.consume
-            for rec in recs:
-                n += consume(rec)
-            total = t2.sum_counts           # (the first read of the table counts what the loop buffered)
-            dt = time.perf_counter() - t0
-            ok = n == kmers_per_step == total
-            configs["per_record"] = {"kmers_per_s": n / dt, "seconds": dt, "calls": R, "us_per_call": dt / R * 1e6,
-                                     "what": "for rec in reads: table.consume(rec) on KmerCountTable(21), Python loop and the final read included",
+            runs = []
+            for _ in range(3):
+                t2 = KmerCountTable(k)          # default-constructed, as the README's loop would
+                t0 = time.perf_counter()
+                n = 0
+                consume = t2.consume
+                for rec in recs:
+                    n += consume(rec)
+                t_loop = time.perf_counter() - t0
+                total = t2.sum_counts           # (the first read of the table counts what the loop buffered)
+                dt = time.perf_counter() - t0
+                runs.append((dt, t_loop, n == kmers_per_step == total))
+            dt, t_loop, _ = sorted(runs)[1]
+            n = kmers_per_step
+            ok = all(r[2] for r in runs)
+            configs["per_record"] = {"kmers_per_s": n / dt, "seconds": dt, "calls": R, "us_per_call": dt / R * 1e6, "us_per_call_loop_only": t_loop / R * 1e6,
+                                     "runs": len(runs),
+                                     "what": "for rec in reads: table.consume(rec) on KmerCountTable(21), Python loop and the final read (the device pass of "
+                                             "a table that starts tiny and finds its size) included; median of 3",
                                      "gate": {"n_and_sum_counts": bool(ok)}}
             assert ablate or ok
             del t2, recs
