@@ -970,9 +970,17 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
     // this workgroup's share of the shadow: whole blocks, kBlocksPerWg of them, one row of 1024 slots per step
     constexpr u32 S = 1u << kBlockBitsMax;
     if constexpr (SRC == 2) {
-        const u64 rows = (a.npairs + kPartThreads - 1) / kPartThreads, rows_per_wg = (rows + gridDim.x - 1) / gridDim.x;
+        // Pair lists are often sorted by the table slot they came from (an export of a table of the same geometry: add(),
+        // the multi-GPU merge): read in order, a row's 1024 pairs would all want the same few bins and nearly all of them
+        // would overflow the ring (5 M pairs: 1.0 ms here plus 0.5 ms of atomic inserts, against 0.1 ms).  The list is
+        // therefore read TRANSPOSED, as a matrix of 8192 columns walked down the columns: neighbouring lanes take pairs
+        // 8192 apart -- more than a block's worth of keys.
+        constexpr u64 kCols = 8192;
+        const u64 mrows = (a.npairs + kCols - 1) / kCols, cells = mrows * kCols;
+        const u64 rows = (cells + kPartThreads - 1) / kPartThreads, rows_per_wg = (rows + gridDim.x - 1) / gridDim.x;
         for (u64 r = 0; r < rows_per_wg; ++r) {
-            const u64 i = ((u64)blockIdx.x * rows_per_wg + r) * kPartThreads + threadIdx.x;
+            const u64 cell = ((u64)blockIdx.x * rows_per_wg + r) * kPartThreads + threadIdx.x;
+            const u64 i = cell < cells ? (cell % mrows) * kCols + cell / mrows : a.npairs;
             const u64 h = i < a.npairs ? a.pair_keys[i * a.pair_stride] : 0ULL;
             if (h) {
                 const u64 c = a.pair_counts[i * a.pair_stride];
