@@ -195,3 +195,42 @@ def test_undersized_tables_abandon_blocks_and_recount(KCT, k, path, cap_hint, G,
     assert t.consume_device(dev_reads.data_ptr(), dev_reads.numel(), R * L) == n_ref
     dk, dc = t.dump_arrays(1)
     assert np.array_equal(dk, rk) and np.array_equal(dc, 2 * rc)
+
+
+def test_batches_from_two_host_threads_share_the_packer_pool(KCT):
+    """kct_consume_batch packs with a process-wide pool of worker threads (one job at a time); ctypes releases the GIL, so
+    two Python threads ingesting into two tables do meet there.  Large batches (the pool is used from 8 MiB on), several
+    rounds, list and CSR inputs; both tables against the oracle."""
+    import threading
+    k, G, R, L = 21, 200_000, 70_000, 150
+    genome = oracle.synth_genome(G)
+    results, errors = {}, []
+
+    def work(tag, first):
+        try:
+            reads = oracle.synth_reads(genome, first, R, L)
+            recs = [bytes(r[:L]) for r in reads]
+            flat = np.ascontiguousarray(reads[:, :L]).reshape(-1)
+            offs = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
+            t = KCT(k, capacity=G)
+            n = 0
+            for rep in range(3):
+                n += t.consume_batch(recs) if rep % 2 == 0 else t.consume_batch((flat, offs))
+            results[tag] = (t, n, recs)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i, i * R)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for tag in (0, 1):
+        t, n, recs = results[tag]
+        ref = OracleTable(k)
+        n_ref = sum(ref.consume(r) for r in recs)
+        assert n == 3 * n_ref
+        dk, dc = t.dump_arrays(1)
+        rk, rc = ref.dump_arrays()
+        assert np.array_equal(dk, rk) and np.array_equal(dc, 3 * rc)
