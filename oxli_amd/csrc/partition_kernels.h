@@ -694,10 +694,12 @@ struct Aggregate32Args {
     u32 nblocks;         // shadow blocks (the grid may be smaller: a workgroup then takes every grid-th block)
 };
 
-// (Two workgroups per CU -- 78 KiB of LDS and 60 VGPRs each, with a shorter queue -- were measured: 5 % slower.)
+// TWO workgroups share a CU: 74 KiB of LDS each, and __launch_bounds__(1024, 8) holds the kernel to 64 VGPRs (it compiled to
+// 87, which silently left every CU with one workgroup; at 64 a few values spill, and K2-32 is still 13 % faster -- the fast
+// path waits on LDS round trips, which a second workgroup's waves fill).
 constexpr int kWaveQueue32 = kWaveQueue;
 template <bool TWO>  // TWO: a few long regions per block (two partition levels); otherwise one short region per K1 workgroup
-__global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggregate32Args a) {
+__global__ __launch_bounds__(kPartThreads, 8) void aggregate_blocks32_kernel(Aggregate32Args a) {
     __shared__ __attribute__((aligned(16))) u32 tab[2 << kBlockBitsMax];  // S keys then S counts = 64 KiB
     __shared__ u32 wq[(kPartThreads / 64) * kWaveQueue32];
     __shared__ u64 s_counted, s_new;
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks32_kernel(Aggreg
     const u32 S = 1u << a.block_bits, smask = S - 1;
     u32 *keys = tab, *cnts = tab + S;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int kInFlight = 12;
+        constexpr int kInFlight = 8;  // (12 and 16 spill more at 64 VGPRs: K2-32 +2 % / +6 %; 4: +2 %)
     constexpr u32 kSlab = 64 * kInFlight;
     constexpr int kWaves = kPartThreads / 64;
     u64 sum_counted = 0, sum_new = 0;  // thread 0: the tallies of the blocks this workgroup has stored
