@@ -335,7 +335,9 @@ class KmerCountTable:
         """lib.rs:330-381."""
         if sortcounts and sortkeys:
             raise ValueError("Cannot sort by both counts and keys at the same time.")
-        keys, counts = self.dump_arrays(1 if sortkeys else 2 if sortcounts else 0)
+        # (no sort option: the reference returns its map's iteration order, the same order `list(table)` has --
+        # test_dump.py:38-49; here that order is by hash)
+        keys, counts = self.dump_arrays(2 if sortcounts else 1)
         if file is not None:
             with open(file, "w") as f:  # OSError on a bad path, as File::create (lib.rs:362)
                 f.write("".join(f"{h}\t{c}\n" for h, c in zip(keys.tolist(), counts.tolist())))
