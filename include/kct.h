@@ -176,6 +176,12 @@ KCT_API kct_status kct_merge_pairs_device(kct_table *t, const void *d_pairs, siz
  * magnitude term of cosine() (lib.rs:747-760).  Any output pointer may be NULL. */
 KCT_API kct_status kct_count_stats(kct_table *t, uint64_t *min_out, uint64_t *max_out, double *sum_squares_out);
 
+/* An order-free digest of the table's contents, computed by one scan on the device: sum and xor over all keys of
+ * hash * count, and the sum of count^2 (all wrapping u64).  Not in the reference; it lets a table of 10^8 .. 10^9 keys be
+ * compared EXACTLY with the CPU oracle's (tests/test_gpu_scale.py) where comparing dumps would not be practical
+ * (cf. the digests SURVEY.md 8c records for doc/example.fa). */
+KCT_API kct_status kct_digest(kct_table *t, uint64_t *sum_hc_out, uint64_t *xor_hc_out, uint64_t *sum_sq_out);
+
 /* histo(zero=False) (lib.rs:464-488): the distinct count values in ascending order and how many keys have
  * each.  *n_out = number of distinct values; at most `cap` are written. */
 KCT_API kct_status kct_histogram(kct_table *t, uint64_t *values_out, uint64_t *freq_out, size_t cap, uint64_t *n_out);

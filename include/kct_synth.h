@@ -33,6 +33,15 @@ KCT_API int kct_synth_genome_device(void *d_genome, uint64_t G, uint64_t seed_g,
 KCT_API int kct_synth_reads_device(void *d_reads, const void *d_genome, uint64_t G, uint64_t first, uint64_t count, uint32_t L,
                            uint64_t seed_r, void *stream);
 
+/* The same stream with a sequencing-error model (SURVEY.md 8d's secondary inputs), byte-identical to
+ * oracle/kct_oracle.c orc_synth_reads_ex:
+ *   e = mix64(seed_e + i * L + j) for base j of read i;  u = e mod 10^6
+ *   u < n_ppm            -> 'N'
+ *   u < n_ppm + sub_ppm  -> "ACGT"[(code + 1 + (e >> 32) mod 3) & 3]      (a substitution: never the true base)
+ *   sorted_total > 0     -> start = (i mod sorted_total) * (G - L + 1) / sorted_total   (position-sorted reads) */
+KCT_API int kct_synth_reads_device_ex(void *d_reads, const void *d_genome, uint64_t G, uint64_t first, uint64_t count, uint32_t L,
+                              uint64_t seed_r, uint32_t sub_ppm, uint32_t n_ppm, uint64_t sorted_total, uint64_t seed_e, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -426,6 +426,37 @@ void orc_synth_reads(uint8_t *out, const uint8_t *genome, uint64_t G, uint64_t f
     }
 }
 
+/* The same stream with a sequencing-error model (SURVEY.md 8d's secondary inputs; include/kct_synth.h):
+ *   e = mix64(seed_e + i * L + j) for base j of read i;  u = e mod 10^6;
+ *   u < n_ppm            -> 'N'
+ *   u < n_ppm + sub_ppm  -> "ACGT"[(code + 1 + (e >> 32) mod 3) & 3]   (a base that differs from the true one)
+ *   sorted_total > 0     -> start = i * (G - L + 1) / sorted_total     (position-sorted reads; the strand stays random) */
+static inline uint8_t synth_base(uint8_t c, uint64_t i, uint32_t L, uint32_t j, uint32_t sub_ppm, uint32_t n_ppm, uint64_t seed_e) {
+    if (!(sub_ppm | n_ppm)) return c;
+    const uint64_t e = mix64(seed_e + i * (uint64_t)L + j), u = e % 1000000u;
+    if (u < n_ppm) return (uint8_t)'N';
+    if (u < (uint64_t)n_ppm + sub_ppm) {
+        const unsigned code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u;
+        return (uint8_t)"ACGT"[(code + 1u + (unsigned)((e >> 32) % 3u)) & 3u];
+    }
+    return c;
+}
+
+void orc_synth_reads_ex(uint8_t *out, const uint8_t *genome, uint64_t G, uint64_t first, uint64_t count, uint32_t L, uint64_t seed_r,
+                        uint32_t sub_ppm, uint32_t n_ppm, uint64_t sorted_total, uint64_t seed_e) {
+    for (uint64_t r = 0; r < count; ++r) {
+        const uint64_t i = first + r;
+        const uint64_t start = sorted_total ? (i % sorted_total) * (G - L + 1) / sorted_total : mix64(seed_r + 2 * i) % (G - L + 1);
+        const int strand = (int)(mix64(seed_r + 2 * i + 1) & 1);
+        uint8_t *dst = out + r * (uint64_t)(L + 1);
+        for (uint32_t j = 0; j < L; ++j) {
+            const uint8_t c = strand ? complement(genome[start + L - 1 - j]) : genome[start + j];
+            dst[j] = synth_base(c, i, L, j, sub_ppm, n_ppm, seed_e);
+        }
+        dst[L] = '\n';
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * CPU baseline ("port" of the reference CPU path): one orc_consume per record, exactly as the
  * README loop does (README.md:96-98); with T threads each thread owns a private table over a
@@ -599,4 +630,150 @@ orc_table *orc_sharded_consume(const uint8_t *reads, uint64_t nreads, uint32_t L
     pthread_barrier_destroy(&bar);
     free(out); free(tables); free(jobs); free(tid);
     return dst;
+}
+
+
+/* ------------------------------------------------------------------------------------------
+ * Full-size parity: a SHARD SET is orc_sharded_consume's T owner tables kept apart (owner = top bits of the hash), built
+ * from reads in memory or -- reads == NULL -- from the synthetic stream generated on the fly (100 M reads need no 15 GB
+ * buffer), so that the tables of the 10^8 .. 10^10-k-mer configurations can be checked EXACTLY:
+ *   orc_shardset_digest      len, sum_counts, sum(hash * count) mod 2^64, xor(hash * count), min / max count,
+ *                            sum(count^2) mod 2^64, n (k-mers counted), consumed
+ *   orc_shardset_mismatches  how many of the caller's (key, count) pairs differ from the set's (with len equal: 0 <=> equal maps)
+ * Per record this is orc_consume's work (iter_init / iter_next: lib.rs:576-600, count_hash: lib.rs:100-104).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int threads;
+    orc_table **tables;
+    uint64_t n;
+} orc_shardset;
+
+typedef struct {
+    const uint8_t *reads; const uint8_t *genome; uint64_t G, first, nreads, batch; uint32_t L; uint8_t k;
+    uint64_t seed_r, sorted_total, seed_e; uint32_t sub_ppm, n_ppm;
+    int id, threads;
+    hbuf *out; orc_table **tables; pthread_barrier_t *bar;
+    uint64_t n;
+} shardset_job;
+
+static void *shardset_run(void *p) {
+    shardset_job *j = (shardset_job *)p;
+    const int T = j->threads;
+    orc_table *mine = j->tables[j->id];
+    uint8_t *buf = (uint8_t *)malloc((size_t)j->L + 1);
+    uint64_t n = 0;
+    for (uint64_t b0 = 0; b0 < j->nreads; b0 += j->batch) {
+        const uint64_t bn = j->nreads - b0 < j->batch ? j->nreads - b0 : j->batch;
+        const uint64_t lo = b0 + bn * (uint64_t)j->id / (uint64_t)T, hi = b0 + bn * (uint64_t)(j->id + 1) / (uint64_t)T;
+        for (int o = 0; o < T; ++o) j->out[(size_t)j->id * T + o].n = 0;
+        for (uint64_t r = lo; r < hi; ++r) {
+            const uint8_t *rec;
+            if (j->reads) rec = j->reads + r * (uint64_t)(j->L + 1);
+            else { orc_synth_reads_ex(buf, j->genome, j->G, j->first + r, 1, j->L, j->seed_r, j->sub_ppm, j->n_ppm, j->sorted_total, j->seed_e); rec = buf; }
+            seq_iter it;
+            uint64_t h;
+            int rc;
+            mine->consumed += j->L;
+            if (iter_init(&it, rec, j->L, j->k, 1, 42) != ORC_OK) continue;
+            while ((rc = iter_next(&it, &h)) != 0) {
+                if (rc == 2 || h == 0) continue;
+                hbuf_push(&j->out[(size_t)j->id * T + (int)(((h >> 32) * (uint64_t)T) >> 32)], h);
+                ++n;
+            }
+            iter_free(&it);
+        }
+        pthread_barrier_wait(j->bar);
+        for (int src = 0; src < T; ++src) {
+            const hbuf *b = &j->out[(size_t)src * T + j->id];
+            for (size_t i = 0; i < b->n; ++i) orc_count_hash(mine, b->v[i]);
+        }
+        pthread_barrier_wait(j->bar);
+    }
+    free(buf);
+    j->n = n;
+    return NULL;
+}
+
+/* reads != NULL: nreads records of stride L + 1 in memory; reads == NULL: records [first, first + nreads) of the synthetic
+ * stream over `genome` (G bytes) with the given error model */
+orc_shardset *orc_shardset_build(const uint8_t *reads, const uint8_t *genome, uint64_t G, uint64_t first, uint64_t nreads, uint32_t L,
+                                 uint8_t k, uint64_t seed_r, uint32_t sub_ppm, uint32_t n_ppm, uint64_t sorted_total, uint64_t seed_e,
+                                 int threads, uint64_t batch) {
+    if (threads < 1) threads = 1;
+    if (batch < (uint64_t)threads) batch = (uint64_t)threads;
+    const int T = threads;
+    orc_shardset *s = (orc_shardset *)calloc(1, sizeof *s);
+    shardset_job *jobs = (shardset_job *)calloc((size_t)T, sizeof *jobs);
+    pthread_t *tid = (pthread_t *)calloc((size_t)T, sizeof *tid);
+    hbuf *out = (hbuf *)calloc((size_t)T * T, sizeof *out);
+    s->threads = T;
+    s->tables = (orc_table **)calloc((size_t)T, sizeof *s->tables);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)T);
+    for (int i = 0; i < T; ++i) s->tables[i] = orc_new(k);
+    for (int i = 0; i < T; ++i) {
+        shardset_job *j = &jobs[i];
+        j->reads = reads; j->genome = genome; j->G = G; j->first = first; j->nreads = nreads; j->batch = batch; j->L = L; j->k = k;
+        j->seed_r = seed_r; j->sub_ppm = sub_ppm; j->n_ppm = n_ppm; j->sorted_total = sorted_total; j->seed_e = seed_e;
+        j->id = i; j->threads = T; j->out = out; j->tables = s->tables; j->bar = &bar;
+        pthread_create(&tid[i], NULL, shardset_run, j);
+    }
+    for (int i = 0; i < T; ++i) { pthread_join(tid[i], NULL); s->n += jobs[i].n; }
+    for (size_t i = 0; i < (size_t)T * T; ++i) free(out[i].v);
+    pthread_barrier_destroy(&bar);
+    free(out); free(jobs); free(tid);
+    return s;
+}
+
+void orc_shardset_free(orc_shardset *s) {
+    if (!s) return;
+    for (int i = 0; i < s->threads; ++i) orc_free(s->tables[i]);
+    free(s->tables); free(s);
+}
+
+/* out[9] = len, sum_counts, sum(hash * count), xor(hash * count), min count, max count, sum(count^2), n, consumed (all mod 2^64) */
+void orc_shardset_digest(const orc_shardset *s, uint64_t out[9]) {
+    uint64_t len = 0, sum = 0, shc = 0, xhc = 0, lo = ~0ULL, hi = 0, sq = 0, consumed = 0;
+    for (int t = 0; t < s->threads; ++t) {
+        const u64map *m = &s->tables[t]->counts;
+        consumed += s->tables[t]->consumed;
+        for (size_t i = 0; i < m->cap; ++i)
+            if (m->used[i]) {
+                const uint64_t h = m->keys[i], c = m->vals[i];
+                ++len; sum += c; shc += h * c; xhc ^= h * c; sq += c * c;
+                if (c < lo) lo = c;
+                if (c > hi) hi = c;
+            }
+    }
+    out[0] = len; out[1] = sum; out[2] = shc; out[3] = xhc; out[4] = len ? lo : 0; out[5] = hi; out[6] = sq; out[7] = s->n; out[8] = consumed;
+}
+
+uint64_t orc_shardset_get(const orc_shardset *s, uint64_t h) {
+    return map_get(&s->tables[(int)(((h >> 32) * (uint64_t)s->threads) >> 32)]->counts, h);
+}
+
+typedef struct { const orc_shardset *s; const uint64_t *keys, *counts; uint64_t lo, hi, bad; } mismatch_job;
+
+static void *mismatch_run(void *p) {
+    mismatch_job *j = (mismatch_job *)p;
+    uint64_t bad = 0;
+    for (uint64_t i = j->lo; i < j->hi; ++i) bad += orc_shardset_get(j->s, j->keys[i]) != j->counts[i];
+    j->bad = bad;
+    return NULL;
+}
+
+/* pairs (keys[i], counts[i]) whose count differs from the set's (an absent key reads as 0) */
+uint64_t orc_shardset_mismatches(const orc_shardset *s, const uint64_t *keys, const uint64_t *counts, uint64_t n, int threads) {
+    if (threads < 1) threads = 1;
+    mismatch_job *jobs = (mismatch_job *)calloc((size_t)threads, sizeof *jobs);
+    pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof *tid);
+    uint64_t bad = 0;
+    for (int i = 0; i < threads; ++i) {
+        jobs[i].s = s; jobs[i].keys = keys; jobs[i].counts = counts;
+        jobs[i].lo = n * (uint64_t)i / (uint64_t)threads; jobs[i].hi = n * (uint64_t)(i + 1) / (uint64_t)threads;
+        pthread_create(&tid[i], NULL, mismatch_run, &jobs[i]);
+    }
+    for (int i = 0; i < threads; ++i) { pthread_join(tid[i], NULL); bad += jobs[i].bad; }
+    free(jobs); free(tid);
+    return bad;
 }

@@ -14,7 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 ORC_OK, ORC_ERR_WRONG_KSIZE, ORC_ERR_INVALID_DNA, ORC_ERR_BAD_KMER, ORC_ERR_KSIZE_MISMATCH = 0, 1, 2, 3, 4
 
-__all__ = ["OracleTable", "murmur64", "hash_kmer", "seq_to_hashes", "synth_genome", "synth_reads",
+SEED_E = 7331  # default seed of the synthetic error model
+
+__all__ = ["ShardSet", "SEED_E", "synth_reads_ex", "OracleTable", "murmur64", "hash_kmer", "seq_to_hashes", "synth_genome", "synth_reads",
            "baseline_consume", "sharded_consume", "build", "lib", "mix64"]
 
 
@@ -72,6 +74,15 @@ def lib(native=False):
         L.orc_baseline_consume.argtypes = [vp, u64, C.c_uint32, C.c_uint8, C.c_int, u64p, C.POINTER(C.c_double)]
         L.orc_sharded_consume.restype = vp
         L.orc_sharded_consume.argtypes = [vp, u64, C.c_uint32, C.c_uint8, C.c_int, u64, u64p, C.POINTER(C.c_double)]
+        L.orc_synth_reads_ex.argtypes = [vp, vp, u64, u64, u64, C.c_uint32, u64, C.c_uint32, C.c_uint32, u64, u64]
+        L.orc_shardset_build.restype = vp
+        L.orc_shardset_build.argtypes = [vp, vp, u64, u64, u64, C.c_uint32, C.c_uint8, u64, C.c_uint32, C.c_uint32, u64, u64, C.c_int, u64]
+        L.orc_shardset_free.argtypes = [vp]
+        L.orc_shardset_digest.argtypes = [vp, vp]
+        L.orc_shardset_get.restype = u64
+        L.orc_shardset_get.argtypes = [vp, u64]
+        L.orc_shardset_mismatches.restype = u64
+        L.orc_shardset_mismatches.argtypes = [vp, vp, vp, u64, C.c_int]
         _libs[native] = L
     return _libs[native]
 
@@ -121,6 +132,56 @@ def synth_reads(genome, first, count, L, seed_r=1337):
     out = np.empty((count, L + 1), dtype=np.uint8)
     lib().orc_synth_reads(out.ctypes.data, genome.ctypes.data, len(genome), first, count, L, seed_r)
     return out
+
+
+def synth_reads_ex(genome, first, count, L, seed_r=1337, sub_ppm=0, n_ppm=0, sorted_total=0, seed_e=SEED_E):
+    """synth_reads with the error model of include/kct_synth.h (substitutions / N per million bases, position-sorted starts)."""
+    out = np.empty((count, L + 1), dtype=np.uint8)
+    lib().orc_synth_reads_ex(out.ctypes.data, genome.ctypes.data, len(genome), first, count, L, seed_r, sub_ppm, n_ppm, sorted_total, seed_e)
+    return out
+
+
+class ShardSet:
+    """The CPU table of a whole configuration, key space sharded over ``threads`` owner tables (orc_shardset_*): exact
+    digests and exact pair comparison for inputs of 10^8 .. 10^10 k-mers.  ``reads`` = uint8 [n, L+1] in memory, or None
+    to generate reads [first, first + nreads) of the synthetic stream over ``genome`` on the fly."""
+
+    FIELDS = ("len", "sum_counts", "sum_hc", "xor_hc", "min", "max", "sum_sq", "n", "consumed")
+
+    def __init__(self, k, L, reads=None, genome=None, first=0, nreads=0, seed_r=1337, sub_ppm=0, n_ppm=0, sorted_total=0, seed_e=SEED_E,
+                 threads=None, batch=262144, native=False):
+        self._L = lib(native)
+        threads = threads or min(64, len(os.sched_getaffinity(0)))
+        self.threads = threads
+        if reads is not None:
+            reads = np.ascontiguousarray(reads)
+            assert reads.ndim == 2 and reads.shape[1] == L + 1
+            nreads, rp = reads.shape[0], reads.ctypes.data
+        else:
+            rp = None
+        gp = genome.ctypes.data if genome is not None else None
+        self._keep = (reads, genome)
+        self._h = self._L.orc_shardset_build(rp, gp, 0 if genome is None else len(genome), first, nreads, L, k, seed_r, sub_ppm, n_ppm,
+                                             sorted_total, seed_e, threads, batch)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_shardset_free(self._h)
+            self._h = None
+
+    def digest(self):
+        out = np.zeros(9, dtype=np.uint64)
+        self._L.orc_shardset_digest(self._h, out.ctypes.data)
+        return dict(zip(self.FIELDS, (int(v) for v in out)))
+
+    def get_hash(self, h):
+        return self._L.orc_shardset_get(self._h, h)
+
+    def mismatches(self, keys, counts):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint64)
+        assert keys.size == counts.size
+        return self._L.orc_shardset_mismatches(self._h, keys.ctypes.data, counts.ctypes.data, keys.size, self.threads)
 
 
 class OracleTable:

@@ -63,6 +63,7 @@ SIGNATURES = {
     "kct_load_rest_json": (cp, []),
     "kct_set_deferred": (ci, [vp, ci]),
     "kct_count_stats": (ci, [vp, u64p, u64p, C.POINTER(C.c_double)]),
+    "kct_digest": (ci, [vp, u64p, u64p, u64p]),
     "kct_histogram": (ci, [vp, vp, vp, sz, u64p]),
     "kct_retain_counts": (ci, [vp, u64, u64, u64p]),
     "kct_remove_hash": (ci, [vp, u64, u64p]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     # include/kct_synth.h (measurement infrastructure)
     "kct_synth_genome_device": (ci, [vp, u64, u64, vp]),
     "kct_synth_reads_device": (ci, [vp, vp, u64, u64, u64, C.c_uint32, u64, vp]),
+    "kct_synth_reads_device_ex": (ci, [vp, vp, u64, u64, u64, C.c_uint32, u64, C.c_uint32, C.c_uint32, u64, u64, vp]),
 }
 
 _lib = None

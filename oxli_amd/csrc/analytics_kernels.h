@@ -44,6 +44,31 @@ __global__ __launch_bounds__(kBlock) void count_stats_kernel(const u64 *__restri
     }
 }
 
+// out[0] += sum over keys of hash * count, out[1] ^= xor over keys of hash * count, out[2] += sum of count^2 (all wrapping u64):
+// an order-free digest of the table's contents (tests compare it with the CPU oracle's at sizes no dump would be compared at)
+__device__ __forceinline__ u64 wave_xor(u64 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v ^= __shfl_down(v, off);
+    return v;
+}
+__global__ __launch_bounds__(kBlock) void digest_kernel(const u64 *__restrict__ words, TableGeom g, u64 *out) {
+    const u64 cap = g.mask + 1, S = block_slots(g);
+    u64 shc = 0, xhc = 0, sq = 0;
+    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (u64)gridDim.x * kBlock) {
+        const u64 kw = key_word(g, s), h = words[kw];
+        if (h != 0) {
+            const u64 c = words[kw + S];
+            shc += h * c; xhc ^= h * c; sq += c * c;
+        }
+    }
+    shc = wave_sum(shc); xhc = wave_xor(xhc); sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) {
+        if (shc) atomicAdd(out, shc);
+        if (xhc) atomicXor(out + 1, xhc);
+        if (sq) atomicAdd(out + 2, sq);
+    }
+}
+
 // the counts of all occupied slots, in no particular order; *out_n must be zero on entry
 __global__ __launch_bounds__(kBlock) void compact_counts_kernel(const u64 *__restrict__ words, TableGeom g, u64 *__restrict__ out,
                                                                 u64 out_cap, u64 *out_n) {

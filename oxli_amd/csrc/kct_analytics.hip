@@ -98,6 +98,28 @@ kct_status kct_count_stats(kct_table *t, uint64_t *min_out, uint64_t *max_out, d
     return KCT_OK;
 }
 
+kct_status kct_digest(kct_table *t, uint64_t *sum_hc_out, uint64_t *xor_hc_out, uint64_t *sum_sq_out) {
+    KCT_TRY(use(t));
+    u64 d[3] = {0, 0, 0};
+    if (live_words(t)) {
+        du64 *d_d = t->d_counters + kNumCounters + 4;
+        HIP_TRY(hipMemsetAsync(d_d, 0, 24, t->stream));
+        {
+            ProfScope ps(t, "digest_kernel");
+            hipLaunchKernelGGL(kct::digest_kernel, dim3(merge_grid(t->cap)), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->slots, geom(t), d_d);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(t->h_counters, d_d, 24, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        for (int i = 0; i < 3; ++i) d[i] = t->h_counters[i];
+    }
+    if (t->zero_present) d[2] += t->zero_count * t->zero_count;  // (key 0 adds nothing to hash * count)
+    if (sum_hc_out) *sum_hc_out = d[0];
+    if (xor_hc_out) *xor_hc_out = d[1];
+    if (sum_sq_out) *sum_sq_out = d[2];
+    return KCT_OK;
+}
+
 kct_status kct_histogram(kct_table *t, uint64_t *values_out, uint64_t *freq_out, size_t cap, uint64_t *n_out) {
     KCT_TRY(use(t));
     if (!n_out || (cap && (!values_out || !freq_out))) { set_err("null argument"); return KCT_ERR_ARG; }

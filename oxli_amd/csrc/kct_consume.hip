@@ -109,13 +109,13 @@ struct Levels {
     u64 P, B, W;
 };
 
-Levels levels_for(int bbits, int nwg) {
+Levels levels_for(int bbits, int nwg, int forced_pbits = -1) {
     Levels L;
     L.bbits = bbits;
     L.two = bbits > 10;
     L.pbits = bbits;
     if (L.two) L.pbits = bbits <= 14 ? bbits - 6 : std::min(10, bbits - 7);
-    if (const char *e = getenv("KCT_PBITS")) if (L.two) L.pbits = std::max(bbits - 10, std::min(10, atoi(e)));  // measurement only
+    if (forced_pbits >= 0 && L.two) L.pbits = std::max(bbits - 10, std::min(10, forced_pbits));  // (Tuning::pbits: measurement only)
     L.sub_bits = bbits - L.pbits;
     L.P = 1ULL << L.pbits;
     L.B = 1ULL << bbits;
@@ -126,8 +126,8 @@ Levels levels_for(int bbits, int nwg) {
 // second partition level: lines of a bin that leave the ring together -- 2 or 4 when the ring is deep enough (its depth in
 // lines per bin >= 4x that), so that the scattered 64-byte stores become 128- or 256-byte ones (K1b: 1 -> 2 lines -13 %,
 // 2 -> 4 lines another -4 %)
-unsigned int repartition_min_lines(int ring_entries, int sub_bits, int entry_bytes) {
-    if (const char *e = getenv("KCT_K1B_LINES")) return (unsigned int)std::max(1, std::min(4, atoi(e)));  // measurement only
+unsigned int repartition_min_lines(const kct_table *t, int ring_entries, int sub_bits, int entry_bytes) {
+    if (t->tune.k1b_lines) return (unsigned int)t->tune.k1b_lines;  // (measurement only)
     const int lines_per_bin = (ring_entries >> sub_bits) * entry_bytes / 64;
     return lines_per_bin >= 16 ? 4u : lines_per_bin >= 8 ? 2u : 1u;
 }
@@ -228,7 +228,7 @@ kct_status ensure_shadow32(kct_table *t, int want, bool *ok) {
 // counts[i * stride]) -- add(), load(), the multi-GPU merge.  tallies (may be null) += CTR_* of the pass.
 kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const du64 *counts, u64 n, int stride, u64 *tallies) {
     const bool compact = src == 0;
-    const Levels L = levels_for(log2_u64(t->cap >> t->block_bits), t->num_cus);
+    const Levels L = levels_for(log2_u64(t->cap >> t->block_bits), t->num_cus, t->tune.pbits);
     const u64 P = L.P;
     const u64 sslots = src == 2 ? n : compact ? compact_slots(t) : t->shadow_cap;
     const u64 npairs = std::max<u64>(1, src == 2 ? n : compact ? t->s32_keys : t->shadow_keys);  // at most this many pairs exist
@@ -273,7 +273,7 @@ kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const
         ra.nseg = nwg; ra.nbins = (int)P; ra.writers = (int)L.W;
         ra.out = t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
         ra.ovf = (du64 *)t->d_pairs_ovf.p; ra.ovf_cap = (unsigned int)std::min<u64>(npairs, 0xFFFFFFFFu); ra.ovf_count = nullptr; ra.overflow = nullptr; ra.ovf_n = d_ovf_n;
-        ra.min_lines = repartition_min_lines(kct::kRingEntries / 2, L.sub_bits, 16);
+        ra.min_lines = repartition_min_lines(t, kct::kRingEntries / 2, L.sub_bits, 16);
         {
             ProfScope ps(t, "repartition_kernel<pairs>");
             hipLaunchKernelGGL((kct::repartition_kernel<ulonglong2, false>), dim3((unsigned)(P * L.W)), dim3(kct::kPartThreads), 0, t->stream, ra);
@@ -290,7 +290,7 @@ kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const
         ProfScope ps(t, "aggregate_pairs_kernel");
         // two levels: one workgroup per CU walks the blocks (a block's stores drain under the next block's merge)
         unsigned grid = (unsigned)L.B;
-        if (L.two && !getenv("KCT_PAIRS_NOPERSIST")) grid = (unsigned)std::min<u64>(L.B, (u64)t->num_cus);
+        if (L.two && !t->tune.pairs_nopersist) grid = (unsigned)std::min<u64>(L.B, (u64)t->num_cus);
         hipLaunchKernelGGL(kct::aggregate_pairs_kernel, dim3(grid), dim3(kct::kPartThreads), 0, t->stream, pa);
     }
     HIP_TRY(hipGetLastError());
@@ -322,7 +322,7 @@ kct_status flush_partitioned(kct_table *t, bool compact) { return partitioned_pa
 // streaming a slot ~7 ps).
 bool pairs_partition_pays(const kct_table *t, u64 n) {
     const u64 blocks = t->cap >> t->block_bits;
-    if (!partition_geometry_ok(t) || t->block_bits != kct::kBlockBitsMax || getenv("KCT_FLUSH_ATOMIC")) return false;
+    if (!partition_geometry_ok(t) || t->block_bits != kct::kBlockBitsMax || t->tune.flush_atomic || t->force_path == 1) return false;
     return blocks <= 1024 ? n >= (1ULL << 18) : n >= t->cap / 16;
 }
 
@@ -580,7 +580,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
         ra.nseg = nwg; ra.nbins = (int)P; ra.writers = 1;
         ra.out = t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
         ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow; ra.ovf_n = nullptr;
-        ra.min_lines = repartition_min_lines(kct::kRingEntries * 2, sub_bits, 4);
+        ra.min_lines = repartition_min_lines(t, kct::kRingEntries * 2, sub_bits, 4);
         {
             ProfScope ps(t, "repartition_kernel<compact>");
             // (one flush per slab, as the 64-bit variant does, was measured: K1b -5 %, but more overflow entries: no gain overall)
@@ -598,7 +598,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
         // two workgroups per CU walk the blocks: a block's stores drain under the next block's load instead of in front of
         // the next workgroup's start (K2-32 -1.3 %)
         aa.nblocks = (unsigned int)B;
-        const unsigned grid2 = getenv("KCT_K2_NOPERSIST") ? (unsigned)B : (unsigned)std::min<u64>(B, 2 * (u64)t->num_cus);
+        const unsigned grid2 = t->tune.k2_nopersist ? (unsigned)B : (unsigned)std::min<u64>(B, 2 * (u64)t->num_cus);
         if (two_level) hipLaunchKernelGGL(kct::aggregate_blocks32_kernel<true>, dim3(grid2), dim3(kct::kPartThreads), 0, t->stream, aa);
         else hipLaunchKernelGGL(kct::aggregate_blocks32_kernel<false>, dim3(grid2), dim3(kct::kPartThreads), 0, t->stream, aa);
     }
@@ -697,7 +697,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     const u64 gcap = raw ? t->shadow_cap : t->cap;
     const int gbb = raw ? t->shadow_block_bits : t->block_bits;
     const int nwg = t->num_cus;
-    const Levels L = levels_for(log2_u64(gcap >> gbb), nwg);
+    const Levels L = levels_for(log2_u64(gcap >> gbb), nwg, t->tune.pbits);
     const bool two_level = L.two;
     const int bbits = L.bbits, pbits = L.pbits, sub_bits = L.sub_bits;
     const u64 P = L.P, B = L.B, W = L.W;
@@ -751,13 +751,13 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         ra.nseg = nwg; ra.nbins = (int)P; ra.writers = (int)W;
         ra.out = t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
         ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow; ra.ovf_n = nullptr;
-        ra.min_lines = repartition_min_lines(kct::kRingEntries, sub_bits, 8);
+        ra.min_lines = repartition_min_lines(t, kct::kRingEntries, sub_bits, 8);
         {
             ProfScope ps(t, "repartition_kernel");
             // With >= 64 ring entries per bin the ring is flushed once per slab of eight entries per thread (half the ring per
             // interval) instead of twice, a bin's lines leaving two at a time: the flush machinery is ~a third of K1b's
             // instructions (K1b -6 %).
-            if ((kct::kRingEntries >> sub_bits) >= 64 && !getenv("KCT_K1B_HALF")) {
+            if ((kct::kRingEntries >> sub_bits) >= 64 && !t->tune.k1b_half) {
                 ra.min_lines = std::max(1u, ra.min_lines / 2);
                 hipLaunchKernelGGL((kct::repartition_kernel<du64, true>), dim3((unsigned)(P * W)), dim3(kct::kPartThreads), 0, t->stream, ra);
             } else hipLaunchKernelGGL((kct::repartition_kernel<du64, false>), dim3((unsigned)(P * W)), dim3(kct::kPartThreads), 0, t->stream, ra);
@@ -772,7 +772,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         const bool claim = !raw && fresh && t->expect_new_keys, two = aa.nregions < kct::kPartThreads / 64;
         aa.nblocks = (unsigned int)B;
         // one workgroup per CU walks the blocks: a block's stores drain under the next block's load (K2 -3 % on C3 / C5, -7 % on C4's shard)
-        const unsigned grid2 = getenv("KCT_K2_NOPERSIST") ? (unsigned)B : (unsigned)std::min<u64>(B, (u64)t->num_cus);
+        const unsigned grid2 = t->tune.k2_nopersist ? (unsigned)B : (unsigned)std::min<u64>(B, (u64)t->num_cus);
         if (claim && two) hipLaunchKernelGGL((kct::aggregate_blocks_kernel<true, true>), dim3(grid2), dim3(kct::kPartThreads), 0, t->stream, aa);
         else if (claim) hipLaunchKernelGGL((kct::aggregate_blocks_kernel<true, false>), dim3(grid2), dim3(kct::kPartThreads), 0, t->stream, aa);
         else if (two) hipLaunchKernelGGL((kct::aggregate_blocks_kernel<false, true>), dim3(grid2), dim3(kct::kPartThreads), 0, t->stream, aa);
@@ -1092,14 +1092,24 @@ u64 host_valid_windows(const unsigned char *s, size_t len, size_t k) {
 kct_status flush_pending(kct_table *t) {
     const size_t used = t->pending_used;
     if (!used) return KCT_OK;
+    const u64 records = t->pending_records;
     t->pending_used = 0;  // consume_stream -> ... -> use() must not re-enter
     t->pending_records = 0;
     const size_t padded = (used + 15) & ~(size_t)15;
     memset((char *)t->h_pending.p + used, '\n', padded + 16 - used);
-    KCT_TRY(t->d_stream.reserve(padded + 16));
-    HIP_TRY(hipMemcpyAsync(t->d_stream.p, t->h_pending.p, padded + 16, hipMemcpyHostToDevice, t->stream));
+    // Nothing has been counted yet if the upload cannot be made: the records stay buffered and the call can be retried
+    // (after kct_release_scratch, say).  Once the device pass has started, a failure leaves the table short of counts that
+    // earlier consume() calls have already reported: it is poisoned, and every later call fails until kct_clear.
+    kct_status st = t->d_stream.reserve(padded + 16);
+    if (st == KCT_OK && hipMemcpyAsync(t->d_stream.p, t->h_pending.p, padded + 16, hipMemcpyHostToDevice, t->stream) != hipSuccess) {
+        set_err("hipMemcpyAsync of the buffered records failed");
+        st = KCT_ERR_HIP;
+    }
+    if (st != KCT_OK) { t->pending_used = used; t->pending_records = records; return st; }
     u64 n = 0;
-    return consume_stream(t, (const unsigned char *)t->d_stream.p, used, &n);
+    st = consume_stream(t, (const unsigned char *)t->d_stream.p, used, &n);
+    if (st != KCT_OK) t->poisoned = true;
+    return st;
 }
 
 // hashes of all windows of the staged stream [0, nbytes) into d_aux; returns first bad window index
@@ -1178,10 +1188,13 @@ kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, 
         if ((!seq && len) || !n_out) { set_err("null argument"); return KCT_ERR_ARG; }
         *n_out = 0;
         if (len >= t->k) {
-            if (!t->h_pending.p || t->pending_used + len + 1 > kPendingBytes) {  // (the common call touches no HIP API at all)
+            if (t->pending_used + len + 1 + 64 > t->h_pending.cap) {  // (the common call touches no HIP API at all)
                 KCT_TRY(use_device(t));
-                KCT_TRY(t->h_pending.reserve(kPendingBytes + 64));
+                // the pinned buffer grows geometrically from 1 MiB to its full 64 MiB: a table that sees a few records pins little
                 if (t->pending_used + len + 1 > kPendingBytes) KCT_TRY(flush_pending(t));
+                size_t want = std::max<size_t>(t->h_pending.cap, (size_t)1 << 20);
+                while (want < kPendingBytes + 64 && t->pending_used + len + 1 + 64 > want) want *= 2;
+                KCT_TRY(t->h_pending.reserve_keep(std::min(want, kPendingBytes + 64), t->pending_used));
             }
             char *dst = (char *)t->h_pending.p + t->pending_used;
             memcpy(dst, seq, len);
@@ -1245,8 +1258,7 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
     };
     KCT_TRY(t->d_stream.reserve(padded + 16));
     const unsigned hw = std::thread::hardware_concurrency();
-    size_t max_threads = 16;
-    if (const char *e = getenv("KCT_PACK_THREADS")) max_threads = (size_t)std::max(1, atoi(e));
+    const size_t max_threads = (size_t)t->tune.pack_threads;
     const size_t nthreads = stream_len >= (8u << 20) ? std::min<size_t>({max_threads, hw ? hw : 1, nrec}) : 1;
     if (nthreads <= 1) {
         pack_range(0, nrec);

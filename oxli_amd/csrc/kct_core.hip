@@ -101,6 +101,7 @@ void WorkerPool::wait() {
 
 kct_status use_device(kct_table *t) {
     if (!t) { set_err("null table handle"); return KCT_ERR_ARG; }
+    if (t->poisoned) { set_err("an earlier device pass over buffered records failed: the table is missing counts it has reported (kct_clear resets it)"); return KCT_ERR_HIP; }
     HIP_TRY(hipSetDevice(t->device));
     return KCT_OK;
 }
@@ -383,7 +384,17 @@ kct_status kct_create(uint8_t ksize, uint64_t capacity_hint, int device, kct_tab
     t->slots_alloc = cap;
     set_geometry(t);
     t->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char *e = getenv("KCT_ABLATE")) t->ablate = atoi(e);
+#ifdef KCT_DEBUG_ENV
+    if (const char *e = getenv("KCT_ABLATE")) t->tune.ablate = atoi(e);
+    if (const char *e = getenv("KCT_PBITS")) t->tune.pbits = atoi(e);
+    if (const char *e = getenv("KCT_K1B_LINES")) t->tune.k1b_lines = std::max(1, std::min(4, atoi(e)));
+    t->tune.pairs_nopersist = getenv("KCT_PAIRS_NOPERSIST") != nullptr;
+    t->tune.k2_nopersist = getenv("KCT_K2_NOPERSIST") != nullptr;
+    t->tune.flush_atomic = getenv("KCT_FLUSH_ATOMIC") != nullptr;
+    t->tune.k1b_half = getenv("KCT_K1B_HALF") != nullptr;
+#endif
+    if (const char *e = getenv("KCT_PACK_THREADS")) t->tune.pack_threads = std::max(1, atoi(e));
+    t->ablate = t->tune.ablate;
     t->debug = getenv("KCT_DEBUG") != nullptr;
     if (hipStreamSynchronize(t->stream) != hipSuccess) { set_err("stream sync failed"); return fail(KCT_ERR_HIP); }
     *out = t;
@@ -415,6 +426,7 @@ void kct_destroy(kct_table *t) {
 kct_status kct_clear(kct_table *t) {
     KCT_TRY(use_device(t));
     t->pending_used = 0; t->pending_records = 0;  // buffered records are forgotten with everything else
+    t->poisoned = false;
     t->lazy_empty = true;  // the memset is issued by materialize() only if something needs it
     t->shadow_empty = true; t->shadow_dirty = false; t->shadow_keys = 0; t->dedupe_off = false;  // pending counts are forgotten too
     t->s32_empty = true; t->s32_dirty = false; t->s32_keys = 0; t->s32_windows = 0; t->compact_off = false;

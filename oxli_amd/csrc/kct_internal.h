@@ -117,7 +117,29 @@ struct PinnedBuf {  // grow-only pinned host buffer
         cap = want;
         return KCT_OK;
     }
+    // the same, keeping the first `keep` bytes
+    kct_status reserve_keep(size_t n, size_t keep) {
+        if (n <= cap) return KCT_OK;
+        void *q = nullptr;
+        HIP_TRY(hipHostMalloc(&q, n, hipHostMallocDefault));
+        if (p && keep) memcpy(q, p, keep);
+        if (p) (void)hipHostFree(p);
+        p = q; cap = n;
+        return KCT_OK;
+    }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// Measurement-only switches (A/B experiments of tools/*.sh).  Read from the environment ONCE, by kct_create, and only in a
+// library built with -DKCT_DEBUG_ENV (`make variant V=dbg EXTRA=-DKCT_DEBUG_ENV`); the shipped build compiles the defaults in.
+struct Tuning {
+    int pbits = -1;            // KCT_PBITS: first-level bins of a two-level pass
+    int k1b_lines = 0;         // KCT_K1B_LINES: 64-byte lines a second-level bin flushes together
+    bool pairs_nopersist = false, k2_nopersist = false;  // KCT_PAIRS_NOPERSIST / KCT_K2_NOPERSIST: one workgroup per block
+    bool flush_atomic = false; // KCT_FLUSH_ATOMIC: conversions by random table access instead of the partitioned pair route
+    bool k1b_half = false;     // KCT_K1B_HALF: two ring flushes per slab in the 64-bit second level
+    int ablate = 0;            // KCT_ABLATE: skip work (results INVALID)
+    int pack_threads = 16;     // KCT_PACK_THREADS (operational, read in every build): host threads packing a batch
 };
 
 struct ProfEntry { std::string name; u64 launches = 0; double ms = 0; };
@@ -144,8 +166,11 @@ struct kct_table {
     kcth::PinnedBuf h_pending;
     size_t pending_used = 0;
     u64 pending_records = 0;
+    bool poisoned = false;  // a device pass over buffered records failed half-way: counts already reported are missing for good,
+                            // so every later call on this table fails too (kct_clear resets it)
     bool auto_sized = true; // no capacity hint / reserve yet: bulk ingest ramps its launch size up with the table
-    int ablate = 0;         // KCT_ABLATE at create time: measurement-only switches that skip work (results invalid)
+    kcth::Tuning tune;      // measurement switches, fixed at create time
+    int ablate = 0;         // = tune.ablate
     bool debug = false;     // KCT_DEBUG at create time: one stderr line per partitioned pass
     int force_path = 0;     // 0 = choose per pass, 1 = direct atomic kernel only, 2 = partitioned whenever the geometry allows, 3 = dedupe-first
     bool dedupe_off = false;  // a dedupe-first pass found too many distinct k-mers: this table goes back to hashing every window

@@ -41,7 +41,13 @@ static PyObject *fast_consume(PyObject *self, PyObject *const *args, Py_ssize_t 
     const int skip = PyObject_IsTrue(args[2]);
     if (skip < 0) return NULL;
     uint64_t n = 0;
-    const int st = g_consume((void *)(uintptr_t)h, p, (size_t)len, skip, &n);
+    int st;
+    /* The GIL is released around the call, as ctypes does: when deferred mode's buffer fills the call runs a whole device
+     * pass, and other Python threads (a second feeder, torch.distributed's watchdog) must not stall behind it.  The
+     * str / bytes object stays alive through args[1]; its buffer is immutable. */
+    Py_BEGIN_ALLOW_THREADS
+    st = g_consume((void *)(uintptr_t)h, p, (size_t)len, skip, &n);
+    Py_END_ALLOW_THREADS
     if (st == 0) return PyLong_FromUnsignedLongLong(n);
     return Py_BuildValue("(iK)", st, (unsigned long long)n);
 }

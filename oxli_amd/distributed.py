@@ -40,7 +40,9 @@ def partition_by_owner(hashes_i64, counts_i64, world):
     return torch.stack([hashes_i64[order], counts_i64[order]], dim=1).contiguous(), send_counts
 
 
-_ROUTES = {}
+import weakref
+
+_ROUTES = weakref.WeakKeyDictionary()  # process group object -> route (a destroyed group takes its entry along)
 
 
 def exchange_route(group=None):
@@ -50,7 +52,7 @@ def exchange_route(group=None):
     tiny all-reduce, so that every rank issues the same collectives; an error in a collective is never caught (the
     communicator is unusable after one anyway, and a rank that switched routes alone would hang the others)."""
     import os
-    key = id(group) if group is not None else 0
+    key = group if group is not None else dist.group.WORLD  # (the default group's object changes with every init_process_group)
     if key not in _ROUTES:  # agreed once per process group
         mine = 1 if os.environ.get("KCT_A2A_FALLBACK") == "1" else 0
         dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"

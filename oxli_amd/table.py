@@ -56,7 +56,6 @@ class KmerCountTable:
             self._h = None
             raise RuntimeError(f"kct_create failed ({st}): {L.last_error()}")
         self.ksize = int(ksize)
-        self._hv = self._h.value  # the handle as a plain int, for _kctfast
         self.version = VERSION
         if deferred is not None:
             self.set_deferred(bool(deferred))
@@ -65,6 +64,12 @@ class KmerCountTable:
         # key it still come from the device.
         self.store_kmers = bool(store_kmers)
         self._hash_to_kmer = {} if store_kmers else None
+
+    @property
+    def _hv(self):
+        """The handle as a plain int, for _kctfast (derived from ``_h`` so that every construction path -- ``__init__``,
+        ``load`` -- has it)."""
+        return self._h.value
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -381,6 +386,12 @@ class KmerCountTable:
         lo, hi, sq = C.c_uint64(), C.c_uint64(), C.c_double()
         self._check(self._lib.kct_count_stats(self._h, C.byref(lo), C.byref(hi), C.byref(sq)))
         return lo.value, hi.value, sq.value
+
+    def digest(self):
+        """(sum of hash * count, xor of hash * count, sum of count^2), all mod 2^64, from one device scan (``kct_digest``)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._lib.kct_digest(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     @property
     def min(self):

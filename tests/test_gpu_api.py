@@ -383,9 +383,9 @@ def test_large_pair_merges_take_the_partitioned_route_and_tally_like_add(KCT, mo
     rng = np.random.default_rng(21)
     base_keys = rng.integers(1, 1 << 63, size=600_000, dtype=np.uint64)
     for route in ("partitioned", "atomic"):
-        if route == "atomic":
-            monkeypatch.setenv("KCT_FLUSH_ATOMIC", "1")
         t = KCT(21, capacity=3_000_000)
+        if route == "atomic":
+            t.set_path("direct")  # atomic inserts only: merges too
         d = {}
         t.profile(True)
         for rnd in range(3):

@@ -1,14 +1,19 @@
 """BASELINE.json's configurations at FULL size on one MI355X (``-m gpu``), and the device paths that only large tables
 take (two partition levels, table-sized shadows, the two-level pair flush, the dedupe probe).
 
-What is checked without an oracle run over 10^10 k-mers (the oracle does ~6x10^6 k-mers/s):
+EXACT checks against the CPU oracle at full size (``oracle.ShardSet``: the key space sharded over the host's cores, reads
+generated on the fly -- ~5x10^8 k-mers/s on the GPU box's host): C2 and the C4 shard are compared pair by pair (every
+(hash, count) of the device's dump looked up in the oracle's tables, ``len`` equal: the maps are equal); the 10^10-k-mer
+configurations by ``len``, ``sum_counts``, min / max count and the order-free digests sum(hash x count), xor(hash x count),
+sum(count^2) mod 2^64 (``kct_digest``), plus every key of an oracle slice and as many absent keys, counts EQUAL.
+
+Cheaper invariants beside them:
 
 * ``n == reads x (L - k + 1) == sum_counts``, ``consumed == reads x L``, ``len`` inside the bounds the genome gives;
 * consuming the same stream again doubles ``sum_counts`` and ``max``, quadruples the sum of squared counts, adds no key;
 * the automatic path and the DIRECT path (one HBM atomic per k-mer -- the simplest kernel, oracle-checked on every
   small case in test_gpu_parity.py) agree on ``len``, ``sum_counts``, ``min``, ``max``, the sum of squared counts, and
   on the count of every key of a sample of 10^5-10^6 keys;
-* a slice of a few thousand reads through the ORACLE: every key the oracle finds is present with at least its count.
 
 Smaller inputs into tables of more than 1024 blocks are compared with the oracle's table bit for bit.
 """
@@ -58,6 +63,31 @@ def stats(t):
     return len(t), t.sum_counts, lo, hi, sq
 
 
+def host_mem_gib():
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable:"):
+            return int(line.split()[1]) / (1 << 20)
+    return 0.0
+
+
+def oracle_shardset(gpu, g, r, R, L, k, **model):
+    """The oracle's table of reads [0, R) of the stream over the device-made genome ``g`` -- generated again on the host,
+    after checking that the host generator reproduces the device's bytes on the first and the last 2000 reads."""
+    genome = g.cpu().numpy()
+    ns = min(2000, R)
+    for first in (0, R - ns):
+        dev = r[first * (L + 1): (first + ns) * (L + 1)].cpu().numpy().reshape(ns, L + 1)
+        assert np.array_equal(dev, oracle.synth_reads_ex(genome, first, ns, L, SEED_R, **model)), "host and device generators differ"
+    return oracle.ShardSet(k, L, genome=genome, nreads=R, seed_r=SEED_R, **model)
+
+
+def assert_digest_equal(t, ss, n):
+    d = ss.digest()
+    lo, hi, _ = t._count_stats()
+    got = dict(zip(("sum_hc", "xor_hc", "sum_sq"), t.digest()), len=len(t), sum_counts=t.sum_counts, min=lo, max=hi, n=n, consumed=t.consumed)
+    assert got == {k_: d[k_] for k_ in got}, (got, d)
+
+
 @pytest.mark.parametrize("name", list(FULL))
 def test_full_size_config(gpu, name):
     torch, KCT, _ = gpu
@@ -67,7 +97,6 @@ def test_full_size_config(gpu, name):
     if free < 250 * (1 << 30):
         pytest.skip("needs a whole MI355X (250 GiB of free HBM)")
     g, r = synth(gpu, G, R, L)
-    del g
     n_expect = R * (L - k + 1)
     t = KCT(k, capacity=G)
     t.profile(True)
@@ -88,11 +117,21 @@ def test_full_size_config(gpu, name):
     for i in range(ns):
         ref.consume(sub[i, :L])
     rk, rc = ref.dump_arrays()
-    got = np.array(t.get_hash_array(rk), dtype=np.uint64)
-    assert np.all(got >= rc)
-    # a sample of keys for the path comparison: the slice's keys plus keys that are absent
+    # a sample of keys: the slice's keys plus keys that are absent
     sample = np.concatenate([rk, rk ^ np.uint64(0x5555555555555555)])
     sample_counts = np.array(t.get_hash_array(sample), dtype=np.uint64)
+    # THE ORACLE'S TABLE OF THE WHOLE INPUT: digests equal, and every sampled key's count equal
+    if host_mem_gib() < 40:
+        pytest.fail("the full-size oracle table needs ~20 GiB of host memory")
+    ss = oracle_shardset(gpu, g, r, R, L, k)
+    del g
+    assert_digest_equal(t, ss, n)
+    assert sample_counts.tolist() == [ss.get_hash(int(h)) for h in sample.tolist()]
+    if name == "C4-shard":  # 4.8x10^8 pairs: the whole dump, pair by pair
+        dk, dc = t.dump_arrays(0)
+        assert dk.size == ss.digest()["len"] and ss.mismatches(dk, dc) == 0
+        del dk, dc
+    del ss
     # the same stream again: every count doubles, no key is new
     assert t.consume_device(r.data_ptr(), r.numel(), R * L) == n_expect
     d2, total2, lo2, hi2, sq2 = stats(t)
@@ -110,6 +149,59 @@ def test_full_size_config(gpu, name):
     assert (dd, dtotal, dlo, dhi) == (distinct, n_expect, lo, hi)
     assert dsq == pytest.approx(sq, rel=1e-12)
     assert np.array_equal(np.array(d.get_hash_array(sample), dtype=np.uint64), sample_counts)
+
+
+def test_full_C2_table_equals_the_oracle_table(gpu):
+    """BASELINE.json configs[1] at full size (1 M x 150 bp, k=21, genome 5 Mbp): the device's dump against the oracle's table
+    of the same 1.3x10^8 k-mers, pair by pair, on the automatic path (cold: probe, compact dedupe-first, conversion), again
+    after a second pass into the live table (steady state), and on the hashing path."""
+    torch, KCT, _ = gpu
+    G, R, L, k = 5_000_000, 1_000_000, 150, 21
+    g, r = synth(gpu, G, R, L)
+    ss = oracle_shardset(gpu, g, r, R, L, k)
+    d = ss.digest()
+    assert d["n"] == R * (L - k + 1) == d["sum_counts"]
+    for path in ("auto", "partitioned", "direct"):
+        t = KCT(k, capacity=G)
+        t.set_path(path)
+        n = t.consume_device(r.data_ptr(), r.numel(), R * L)
+        dk, dc = t.dump_arrays(1)
+        assert dk.size == d["len"] and ss.mismatches(dk, dc) == 0, path
+        assert_digest_equal(t, ss, n)
+        if path == "auto":   # the same reads again into the live table: every count doubles (the steady state's second step)
+            assert t.consume_device(r.data_ptr(), r.numel(), R * L) == n
+            dk2, dc2 = t.dump_arrays(1)
+            assert np.array_equal(dk2, dk) and np.array_equal(dc2, 2 * dc)
+
+
+@pytest.mark.parametrize("model", [dict(sub_ppm=10_000), dict(n_ppm=10_000), dict(sub_ppm=5_000, n_ppm=2_000), dict(sorted_total=1_000_000)],
+                         ids=["1pct_substitutions", "1pct_N", "mixed_errors", "position_sorted"])
+def test_C2_with_sequencing_errors_equals_the_oracle_table(gpu, model):
+    """SURVEY 8d's secondary inputs at C2 size, from the device generator's error model (include/kct_synth.h): 1 % substitution
+    errors (a quarter of the k-mers become singletons: the dedupe probe's estimate is off), 1 % N (windows skipped),
+    both, and position-sorted reads.  Whatever path the table chooses: the oracle's table, pair by pair, and n."""
+    torch, KCT, lib = gpu
+    G, R, L, k = 5_000_000, 1_000_000, 150, 21
+    g = torch.empty(G, dtype=torch.uint8, device="cuda")
+    r = torch.empty(R * (L + 1), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    m = dict(sub_ppm=0, n_ppm=0, sorted_total=0)
+    m.update(model)
+    assert lib.kct_synth_genome_device(g.data_ptr(), G, SEED_G, stream) == 0
+    assert lib.kct_synth_reads_device_ex(r.data_ptr(), g.data_ptr(), G, 0, R, L, SEED_R, m["sub_ppm"], m["n_ppm"], m["sorted_total"],
+                                         oracle.SEED_E, stream) == 0
+    torch.cuda.synchronize()
+    ss = oracle_shardset(gpu, g, r, R, L, k, **m)
+    d = ss.digest()
+    if m["n_ppm"]:
+        assert d["n"] < R * (L - k + 1)
+    for path in ("auto", "dedupe", "partitioned"):
+        t = KCT(k, capacity=int(d["len"]))
+        t.set_path(path)
+        n = t.consume_device(r.data_ptr(), r.numel(), R * L)
+        dk, dc = t.dump_arrays(1)
+        assert dk.size == d["len"] and ss.mismatches(dk, dc) == 0, path
+        assert_digest_equal(t, ss, n)
 
 
 def _oracle_table(reads, L, k):

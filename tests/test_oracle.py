@@ -214,3 +214,58 @@ def test_baseline_port_equals_single_table():
         k0, c0 = ref.dump_arrays()
         assert np.array_equal(k0, k1) and np.array_equal(c0, c1)
         assert t.consumed == ref.consumed
+
+
+def test_shardset_equals_the_single_table_oracle():
+    """oracle.ShardSet (the full-size checker of tests/test_gpu_scale.py): its digest and its pair comparison against
+    OracleTable over the same reads -- in memory and generated on the fly, with and without the error model."""
+    import oracle
+    G, R, L = 20_000, 3_000, 150
+    genome = oracle.synth_genome(G, 42)
+    for k, model in ((21, {}), (31, dict(sub_ppm=10_000, n_ppm=5_000)), (51, dict(sorted_total=R)), (5, dict(n_ppm=100_000))):
+        reads = oracle.synth_reads_ex(genome, 7, R, L, 1337, **model)
+        ref = oracle.OracleTable(k)
+        n = sum(ref.consume(reads[i, :L]) for i in range(R))
+        rk, rc = ref.dump_arrays()
+        want = {"len": len(ref), "sum_counts": ref.sum_counts, "n": n, "consumed": R * L, "min": int(rc.min()), "max": int(rc.max()),
+                "sum_hc": int(np.sum(rk * rc, dtype=np.uint64)), "xor_hc": int(np.bitwise_xor.reduce(rk * rc)),
+                "sum_sq": int(np.sum(rc * rc, dtype=np.uint64))}
+        for ss in (oracle.ShardSet(k, L, reads=reads, threads=3, batch=500),
+                   oracle.ShardSet(k, L, genome=genome, first=7, nreads=R, threads=4, batch=1000, **model)):
+            assert ss.digest() == want
+            assert ss.mismatches(rk, rc) == 0
+            bad = rc.copy()
+            bad[5] += 1
+            assert ss.mismatches(rk, bad) == 1 and ss.mismatches(rk ^ np.uint64(1), rc) == rk.size
+            assert ss.get_hash(int(rk[0])) == int(rc[0]) and ss.get_hash(12345) == 0
+
+
+def test_error_model_of_the_synthetic_stream():
+    """include/kct_synth.h: substitutions never restore the true base, N and substitution rates, position-sorted starts; all
+    rates zero = the plain stream."""
+    import oracle
+    G, R, L = 50_000, 4_000, 150
+    genome = oracle.synth_genome(G, 42)
+    plain = oracle.synth_reads(genome, 3, R, L)
+    assert np.array_equal(oracle.synth_reads_ex(genome, 3, R, L), plain)
+    sub = oracle.synth_reads_ex(genome, 3, R, L, sub_ppm=10_000)
+    diff = sub != plain
+    assert 0.008 < diff[:, :L].mean() < 0.012 and not diff[:, L].any()
+    assert set(np.unique(sub[:, :L]).tolist()) <= set(b"ACGT")
+    both = oracle.synth_reads_ex(genome, 3, R, L, sub_ppm=5_000, n_ppm=20_000)
+    isn = both[:, :L] == ord("N")
+    assert 0.018 < isn.mean() < 0.022
+    changed = (both[:, :L] != plain[:, :L]) & ~isn
+    assert 0.004 < changed.mean() < 0.006
+    srt = oracle.synth_reads_ex(genome, 0, R, L, sorted_total=R)
+    text = genome.tobytes()
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    starts = []
+    for i in range(0, R, 97):
+        rec = srt[i, :L].tobytes()
+        pos = text.find(rec)
+        if pos < 0:
+            pos = text.find(rec.translate(comp)[::-1])
+        starts.append(pos)
+        assert pos == i * (G - L + 1) // R
+    assert starts == sorted(starts)
