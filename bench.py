@@ -57,7 +57,20 @@ BIG = {  # name -> reads, read length, k, genome
     "C4_shard": (12_500_000, 150, 21, 500_000_000),
     "C5_shard": (1_250_000, 10_000, 51, 387_500_000),
 }
-ALL_CONFIGS = ["cold_C2", "e2e_C2", "per_record"] + list(BIG)
+# SURVEY 8d's secondary inputs, timed (the heuristics -- probe, dedupe hint, windows_since_read -- were tuned on error-free
+# reads): name -> (reads, read length, k, genome, error model of include/kct_synth.h)
+ERR = {
+    "C2_sub1pct": (1_000_000, 150, 21, 5_000_000, dict(sub_ppm=10_000)),
+    "C2_N1pct": (1_000_000, 150, 21, 5_000_000, dict(n_ppm=10_000)),
+    "C2_sorted": (1_000_000, 150, 21, 5_000_000, dict(sorted_total=1_000_000)),
+    "NS25_sub1pct": (25_000_000, 150, 21, 500_000_000, dict(sub_ppm=10_000)),
+}
+# N > 1 ranks only: BASELINE.json configs[3] / [4] as ONE job over all ranks (strong scaling: the reads are split N ways)
+MULTI = {
+    "C4": (100_000_000, 150, 21, 500_000_000),
+    "C5": (10_000_000, 10_000, 51, 3_100_000_000),
+}
+ALL_CONFIGS = ["cold_C2", "e2e_C2", "per_record"] + list(BIG) + list(ERR) + list(MULTI)
 
 
 def parse():
@@ -167,9 +180,18 @@ def compact(res):
             g = c.get("gate", {})
             e = {"kmers_per_s": r(c["kmers_per_s"], 0), "seconds": r(c["seconds"], 5),
                  "gate": "ok" if all(v for kk, v in g.items() if kk != "sampled_keys") else [kk for kk, v in g.items() if not v]}
-            for k in ("alg_frac", "measured_frac", "hbm_bytes_per_kmer", "kmers_per_s_warm", "us_per_call", "us_per_call_loop_only"):
+            for k in ("alg_frac", "measured_frac", "hbm_bytes_per_kmer", "kmers_per_s_warm", "us_per_call", "us_per_call_loop_only", "vs_partitioned"):
                 if k in c:
                     e[k] = r(c[k], 0 if k == "kmers_per_s_warm" else 4)
+            for k in ("path_chosen", "world", "best_route", "note", "reads_total"):
+                if k in c:
+                    e[k] = c[k]
+            if "partitioned_path_kmers_per_s" in c:
+                e["partitioned_path_kmers_per_s"] = r(c["partitioned_path_kmers_per_s"], 0)
+            if "routes" in c:
+                e["routes"] = {rn: {"kmers_per_s": r(rv["kmers_per_s"], 0), "seconds": r(rv["seconds"], 5), "mode": rv["mode"],
+                                    "rank0": {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in (rv["per_rank"][0] or {}).items()}}
+                               for rn, rv in c["routes"].items()}
             if "kernels_ms" in c:
                 e["kernels_ms"] = {k: round(v, 2 if v >= 1 else 3) for k, v in c["kernels_ms"].items() if v >= 0.02}
             out["configs"][name] = e
@@ -224,8 +246,24 @@ def cpu_baseline(args, log):
     return out, (readsT[:n1], tab1)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process -- before
+    anything in this process has touched the GPU -- and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -237,8 +275,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
@@ -532,6 +568,159 @@ def main():
             assert ablate or all(v for kk, v in gate.items() if kk != "sampled_keys"), (name, gate)
             del r
             torch.cuda.empty_cache()
+    # ------------------------------------------------------------------------------------------ inputs with sequencing errors
+    if rank == 0 and world == 1:
+        for name in [c for c in want if c in ERR]:
+            Rb, Lb, kb, Gb, model = ERR[name]
+            free, _tot = torch.cuda.mem_get_info()
+            if Rb > 5_000_000 and free < 230 * (1 << 30):
+                configs[name] = {"skipped": f"needs a whole MI355X: {free >> 30} GiB free"}
+                continue
+            m = dict(sub_ppm=0, n_ppm=0, sorted_total=0)
+            m.update(model)
+            g = torch.empty(Gb, dtype=torch.uint8, device="cuda")
+            r = torch.empty(Rb * (Lb + 1), dtype=torch.uint8, device="cuda")
+            assert lib.kct_synth_genome_device(g.data_ptr(), Gb, SEED_G, stream) == 0
+            assert lib.kct_synth_reads_device_ex(r.data_ptr(), g.data_ptr(), Gb, 0, Rb, Lb, SEED_R, m["sub_ppm"], m["n_ppm"], m["sorted_total"], 7331, stream) == 0
+            torch.cuda.synchronize()
+            # distinct k-mers: the genome's plus ~ (k - 1) / 2 .. k new ones per substituted base
+            distinct_hint = int(min(Gb, Rb * (Lb - kb + 1)) + Rb * Lb * m["sub_ppm"] / 1e6 * kb)
+            balg = Lb / (Lb - kb + 1) + 24.0
+            entry, tables = {"model": model}, {}
+            for path in ("auto", "partitioned", "direct"):
+                t = KmerCountTable(kb, capacity=distinct_hint)
+                t.set_path(path)
+                call = lambda: t.consume_device(r.data_ptr(), r.numel(), Rb * Lb)  # noqa: E731
+                call(); t.sync()                                  # allocations
+                runs = [timed_call(t, call, True) for _ in range(3 if path != "direct" else 1)]
+                dt, n, prof = sorted(runs, key=lambda x: x[0])[len(runs) // 2]
+                tables[path] = (n, len(t), t.sum_counts) + t.digest()
+                if path == "auto":
+                    rep, _ = kernel_report(prof, n, balg, None)
+                    k1 = [kn for kn in prof if kn.startswith("partition_windows_kernel")]
+                    entry.update({"kmers": n, "kmers_per_s": n / dt, "seconds": dt, "table_slots": t.capacity, "distinct": len(t),
+                                  "path_chosen": ("compact dedupe-first" if any("compact" in kn for kn in k1) else "64-bit dedupe-first" if any("raw" in kn for kn in k1)
+                                                  else "hash every window") + (" after a probe" if len(k1) > 1 else "") if k1 else "direct", **rep})
+                    if checker and Rb <= 5_000_000:   # the oracle's table of the same reads, pair by pair
+                        ss = oracle.ShardSet(kb, Lb, genome=g.cpu().numpy(), nreads=Rb, seed_r=SEED_R, **m)
+                        dk, dc = t.dump_arrays(0)
+                        entry["oracle_mismatches"] = int(ss.mismatches(dk, dc)) + abs(int(dk.size) - ss.digest()["len"])
+                        del ss, dk, dc
+                elif path == "partitioned":
+                    entry["partitioned_path_kmers_per_s"] = n / dt
+                else:
+                    entry["direct_path_kmers_per_s"] = n / dt
+                t.release_scratch()
+                del t
+                torch.cuda.empty_cache()
+            gate = {"equals_partitioned_and_direct_path": bool(tables["auto"] == tables["partitioned"] == tables["direct"]),
+                    "sum_counts_is_n": bool(tables["auto"][0] == tables["auto"][2])}
+            if "oracle_mismatches" in entry:
+                gate["equals_oracle_table"] = entry["oracle_mismatches"] == 0
+            # a wrong guess of the path may cost speed, not a factor: never more than 10 % slower than hashing every window
+            entry["vs_partitioned"] = entry["kmers_per_s"] / entry["partitioned_path_kmers_per_s"]
+            entry["gate"] = gate
+            configs[name] = entry
+            log(f"{name}: {entry['kmers_per_s']:.3g} k-mers/s ({entry['path_chosen']}; partitioned {entry['partitioned_path_kmers_per_s']:.3g}), gate {gate}")
+            assert ablate or all(gate.values()), (name, gate)
+            del g, r
+            torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------------------------------ N ranks: C4 / C5 as one job
+    if world > 1:
+        from oxli_amd.distributed import consume_device_early
+        shared = world > torch.cuda.device_count()       # (debugging: several ranks on one GPU over gloo -- reduced sizes)
+        cdev = "cuda" if args.backend == "nccl" else "cpu"
+
+        def gmax(x):
+            t_ = torch.tensor([x], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+
+        for name in [c for c in want if c in MULTI]:
+            Rt, Lb, kb, Gb = MULTI[name]
+            note = None
+            if shared:
+                Rt, Gb, note = Rt // 16 if Lb < 1000 else Rt // 64, Gb // 16, "REDUCED: ranks share one GPU (reads and genome / 16)"
+            per = Rt // world
+            n_exp_total = per * world * (Lb - kb + 1)
+            free, _tot = torch.cuda.mem_get_info()
+            need = per * (Lb + 1) * 4 + Gb + (64 << 30)
+            ok_mem = torch.tensor([1 if free > need else 0], dtype=torch.int64, device=cdev)
+            dist.all_reduce(ok_mem, op=dist.ReduceOp.MIN)
+            if not int(ok_mem.item()):
+                configs[name] = {"skipped": f"rank needs ~{need >> 30} GiB of HBM, {free >> 30} free"}
+                continue
+            g = torch.empty(Gb, dtype=torch.uint8, device="cuda")
+            r = torch.empty(per * (Lb + 1), dtype=torch.uint8, device="cuda")
+            assert lib.kct_synth_genome_device(g.data_ptr(), Gb, SEED_G, stream) == 0
+            assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), Gb, rank * per, per, Lb, SEED_R, stream) == 0
+            torch.cuda.synchronize()
+            del g
+            distinct_global = min(Gb, n_exp_total)
+            # windows per distinct k-mer over the WHOLE job decide the early route's mode (an owner sees the full coverage)
+            deep = n_exp_total / distinct_global >= 16
+            routes = {"late": None, "early": ("compact" if kb <= 21 else "dedupe64" if kb <= 32 else "hash") if deep else "hash"}
+            entry = {"world": world, "reads_total": per * world, "reads_per_rank": per, "read_len": Lb, "k": kb, "genome": Gb, "kmers": n_exp_total,
+                     "scaling": "strong", "routes": {}}
+            if note:
+                entry["note"] = note
+            digests = {}
+            for route, mode in routes.items():
+                # late: a rank's private table meets k-mers from all over the genome; early: an owner holds 1 / world of the key space
+                distinct_rank = min(Gb, per * (Lb - kb + 1)) if route == "late" else distinct_global // world + (1 << 16)
+                t = KmerCountTable(kb, capacity=max(distinct_rank, 400_000))
+                stats = {}
+
+                def job():
+                    t.clear()
+                    if route == "late":
+                        t.resize(max(distinct_rank, 400_000))
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    if route == "late":
+                        n = t.consume_device(r.data_ptr(), r.numel(), per * Lb)
+                        t_x = time.perf_counter()
+                        stats["pairs_received"] = merge_across_ranks(t)
+                        stats["merge_ms"] = (time.perf_counter() - t_x) * 1e3
+                    else:
+                        n, st_ = consume_device_early(t, r.data_ptr(), r.numel(), per * Lb, mode=mode)
+                        stats.update(st_)
+                    t.sync()        # the dedupe-first modes' conversion is part of the job
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    return gmax(time.perf_counter() - t0), n
+
+                job()   # allocations, communicator warm-up
+                runs = sorted(job() for _ in range(3))
+                dt, n = runs[1]
+                n_all = global_scalar_sum(n, "cuda")
+                per_rank_stats = [None] * world
+                dist.all_gather_object(per_rank_stats, {k_: v for k_, v in stats.items() if isinstance(v, (int, float, str))})
+                dg = [None] * world
+                dist.all_gather_object(dg, (len(t), t.sum_counts) + t.digest())
+                glen, gsum = sum(d[0] for d in dg), sum(d[1] for d in dg)
+                gshc = sum(d[2] for d in dg) & ((1 << 64) - 1)
+                gx = 0
+                for d in dg:
+                    gx ^= d[3]
+                digests[route] = (glen, gsum, gshc, gx)
+                entry["routes"][route] = {"kmers_per_s": n_exp_total / dt, "seconds": dt, "seconds_min_max": [runs[0][0], runs[-1][0]], "mode": mode,
+                                          "n": n_all, "distinct_global": glen, "per_rank": per_rank_stats}
+                t.release_scratch()
+                del t
+                torch.cuda.empty_cache()
+            gate = {"n": all(v["n"] == n_exp_total for v in entry["routes"].values()), "sum_counts": all(d[1] == n_exp_total for d in digests.values()),
+                    "routes_agree_on_len_and_digests": len(set(digests.values())) == 1}
+            best = max(entry["routes"], key=lambda k_: entry["routes"][k_]["kmers_per_s"])
+            entry.update({"kmers_per_s": entry["routes"][best]["kmers_per_s"], "seconds": entry["routes"][best]["seconds"], "best_route": best, "gate": gate})
+            configs[name] = entry
+            log(f"{name} on {world} ranks: " + ", ".join(f"{k_} {v['kmers_per_s']:.3g}" for k_, v in entry["routes"].items()) + f" k-mers/s, gate {gate}")
+            assert ablate or all(gate.values()), (name, gate, digests)
+            del r
+            torch.cuda.empty_cache()
+
     if configs:
         result["configs"] = configs
 

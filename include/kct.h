@@ -176,6 +176,26 @@ KCT_API kct_status kct_merge_pairs_device(kct_table *t, const void *d_pairs, siz
  * magnitude term of cosine() (lib.rs:747-760).  Any output pointer may be NULL. */
 KCT_API kct_status kct_count_stats(kct_table *t, uint64_t *min_out, uint64_t *max_out, double *sum_squares_out);
 
+/* ---- multi-GPU "early" route: entries travel to the GPU that owns their slice of the key space -----------
+ * One call = one pass: K1 over THIS rank's records with its bins grouped by owner, three all-to-alls through the caller's
+ * callbacks (region sizes, entries of 4 or 8 bytes, the few entries that overflowed K1's LDS ring), then K1b / K2 on the
+ * entries this rank OWNS (oxli_amd/csrc/kct_route.hip).  Every rank of the job must make the same calls with the same world,
+ * mode and table capacity.  mode: 0 = MurmurHash3 values (any k <= 64) counted into the table; 1 = mix64 values of packed
+ * k-mers (k <= 32) and 2 = compact 32-bit entries (k <= 21) counted into the shadow tables (dedupe-first: converted when the
+ * table is read).  The ranks' tables end up a disjoint partition of the key space: add() semantics (lib.rs:778-837) hold for
+ * their union.  *n_owned = k-mers counted by this rank as an owner (summed over ranks: the job's n); stats8 (optional):
+ * entries sent to / received from other ranks, bytes per entry, overflow entries sent / received, microseconds in the
+ * exchange callbacks, K2 blocks abandoned, 1 if this rank's input was too skewed (its share then was NOT counted: error).
+ *   alloc(user, bytes)    -> a device buffer the exchange can send from (valid until the routed call returns)
+ *   exchange(user, d_send, send_elems[world], elem_bytes, &d_recv, recv_elems[world]) -> 0 on success: an all-to-all with
+ *                            uneven splits; d_send came from alloc; rank r's part is send_elems[r] elements, parts in rank
+ *                            order; *d_recv (valid until the routed call returns) holds the parts received, in rank order.
+ * world == 1 with null callbacks is a loop-back (tests).  A future Rust caller implements the callbacks with ncclSend/ncclRecv. */
+typedef void *(*kct_alloc_fn)(void *user, uint64_t bytes);
+typedef int (*kct_exchange_fn)(void *user, const void *d_send, const uint64_t *send_elems, uint32_t elem_bytes, void **d_recv, uint64_t *recv_elems);
+KCT_API kct_status kct_consume_device_routed(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes, uint32_t world, uint32_t rank,
+                                             int mode, kct_alloc_fn alloc, kct_exchange_fn exchange, void *user, uint64_t *n_owned, uint64_t *stats8);
+
 /* An order-free digest of the table's contents, computed by one scan on the device: sum and xor over all keys of
  * hash * count, and the sum of count^2 (all wrapping u64).  Not in the reference; it lets a table of 10^8 .. 10^9 keys be
  * compared EXACTLY with the CPU oracle's (tests/test_gpu_scale.py) where comparing dumps would not be practical

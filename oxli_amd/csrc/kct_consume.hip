@@ -80,6 +80,40 @@ struct PartitionByK<0> {
     }
 };
 
+void launch_partition(kct_table *t, int mode, const unsigned char *d_stream, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa) {
+    const int k = t->k, nwg = t->num_cus;
+    ProfScope ps(t, mode == 2 ? "partition_windows_kernel<compact>" : mode == 1 ? "partition_windows_kernel<raw>" : "partition_windows_kernel");
+    if (mode == 2) PartitionCompactByK<21>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
+    else if (mode == 1) PartitionRawByK<32>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
+    else PartitionByK<64>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
+}
+
+void launch_repartition(kct_table *t, int mode, unsigned grid, const kct::RepartitionArgs &ra, bool whole_slab) {
+    ProfScope ps(t, mode == 2 ? "repartition_kernel<compact>" : "repartition_kernel");
+    if (mode == 2) hipLaunchKernelGGL((kct::repartition_kernel<unsigned int, false>), dim3(grid), dim3(kct::kPartThreads), 0, t->stream, ra);
+    else if (whole_slab) hipLaunchKernelGGL((kct::repartition_kernel<du64, true>), dim3(grid), dim3(kct::kPartThreads), 0, t->stream, ra);
+    else hipLaunchKernelGGL((kct::repartition_kernel<du64, false>), dim3(grid), dim3(kct::kPartThreads), 0, t->stream, ra);
+}
+
+void launch_aggregate32(kct_table *t, unsigned grid, const kct::Aggregate32Args &aa) {
+    ProfScope ps(t, "aggregate_blocks32_kernel");
+    hipLaunchKernelGGL(kct::aggregate_blocks32_kernel<true>, dim3(grid), dim3(kct::kPartThreads), 0, t->stream, aa);
+}
+
+void launch_aggregate64(kct_table *t, unsigned grid, const kct::AggregateArgs &aa, bool shadow) {
+    ProfScope ps(t, shadow ? "aggregate_blocks_kernel<shadow>" : "aggregate_blocks_kernel");
+    hipLaunchKernelGGL((kct::aggregate_blocks_kernel<false, true>), dim3(grid), dim3(kct::kPartThreads), 0, t->stream, aa);
+}
+
+void launch_merge_overflow(kct_table *t, int mode, const du64 *regions, const unsigned int *counts, int nregions, unsigned int region_cap,
+                           const du64 *abort, const kct::TableView &tv, const du64 *total) {
+    ProfScope ps(t, "merge_overflow_kernel");
+    const kct::PendingList none;
+    if (mode == 2) hipLaunchKernelGGL(kct::merge_overflow_kernel<2>, dim3(256), dim3(kct::kBlock), 0, t->stream, regions, counts, nregions, region_cap, abort, tv, t->d_counters, (int)t->k, total, none);
+    else if (mode == 1) hipLaunchKernelGGL(kct::merge_overflow_kernel<1>, dim3(256), dim3(kct::kBlock), 0, t->stream, regions, counts, nregions, region_cap, abort, tv, t->d_counters, (int)t->k, total, none);
+    else hipLaunchKernelGGL(kct::merge_overflow_kernel<0>, dim3(256), dim3(kct::kBlock), 0, t->stream, regions, counts, nregions, region_cap, abort, tv, t->d_counters, (int)t->k, total, none);
+}
+
 // The partitioned path pays 16 B (one level) or 32 B (two levels) of streaming scratch traffic per
 // k-mer plus 32 B per table slot per pass; the direct path pays one memory-side atomic per k-mer.
 // It wins once a pass brings a fair fraction as many windows as the table has slots.
@@ -135,10 +169,6 @@ unsigned int repartition_min_lines(const kct_table *t, int ring_entries, int sub
 // overflow regions: an eighth of a workgroup's entries, but few enough that ring positions (21 bits in ring_flush's line
 // list) cannot wrap before a hopelessly skewed pass is abandoned
 unsigned int overflow_capacity(u64 entries_per_wg) { return (unsigned int)std::min<u64>(1ULL << 20, std::max<u64>(4096, entries_per_wg / 8)); }
-
-kct_status failed_blocks(kct_table *t, u64 nblocks, kct::FailedBlocks *fb);
-kct_status recount_failed(kct_table *t, int mode, const void *scratch, u64 seg_stride, u64 block_stride, const unsigned int *region_count, int nregions,
-                          u64 nfailed, u64 entries, int sbits, u64 tallies[4]);
 
 // Dedupe-first pass (k <= 32).  Reads that cover a small genome deeply repeat every k-mer tens of times per pass, and
 // ~55 % of K1's instructions are MurmurHash3 plus the ASCII re-expansion.  So the pass counts PACKED k-mers: K1 (RAW)
@@ -204,18 +234,19 @@ int compact_sbits_for(const kct_table *t) {
     const int bbits = log2_u64(t->cap >> t->block_bits);
     return bbits <= 10 ? kCompactBlockBits : std::max(16, bbits);
 }
-u64 compact_slots(const kct_table *t) { return 1ULL << (t->s32_sbits + kct::kBlockBitsMax); }
+u64 compact_slots(const kct_table *t) { return ((u64)t->s32_nbins << (t->s32_sbits - kCompactBlockBits)) << kct::kBlockBitsMax; }
 
-kct_status ensure_shadow32(kct_table *t, int want, bool *ok) {
+kct_status ensure_shadow32(kct_table *t, int want, bool *ok, unsigned int nbins, unsigned int bin0) {
     *ok = true;
-    if (t->shadow32 && t->s32_sbits == want) return KCT_OK;
+    if (t->shadow32 && t->s32_sbits == want && t->s32_nbins == nbins && t->s32_bin0 == bin0) return KCT_OK;
     KCT_TRY(flush_compact(t));
     if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; }
-    const u64 bytes = (1ULL << (want + kct::kBlockBitsMax)) * 8;
+    t->s32_nbins = 1024; t->s32_bin0 = 0; t->s32_sbits = kCompactBlockBits;
+    const u64 bytes = (((u64)nbins << (want - kCompactBlockBits)) << kct::kBlockBitsMax) * 8;
     size_t free_b = 0, total_b = 0;
     if (want > kCompactBlockBits && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 3.0 * (double)bytes)) { *ok = false; return KCT_OK; }
     if (hipMalloc((void **)&t->shadow32, bytes) != hipSuccess) { (void)hipGetLastError(); t->shadow32 = nullptr; *ok = false; return KCT_OK; }  // no room: this table does without
-    t->s32_sbits = want;
+    t->s32_sbits = want; t->s32_nbins = nbins; t->s32_bin0 = bin0;
     t->s32_empty = true;
     t->s32_keys = 0;
     return KCT_OK;
@@ -244,7 +275,7 @@ kct_status partitioned_pairs_pass(kct_table *t, int src, const du64 *keys, const
     const bool fresh = t->lazy_empty;
     kct::FlushPartitionArgs fa;
     fa.shadow = compact ? (void *)t->shadow32 : (void *)t->shadow; fa.shadow_blocks = src == 2 ? 0u : (unsigned int)(sslots >> kct::kBlockBitsMax); fa.k = t->k;
-    fa.shadow_sbits = t->s32_sbits;
+    fa.shadow_sbits = t->s32_sbits; fa.shadow_bin0 = t->s32_bin0;
     fa.pair_keys = keys; fa.pair_counts = counts; fa.pair_stride = stride; fa.npairs = n;
     fa.table_block_bits = t->block_bits + L.sub_bits; fa.pbits = L.pbits;  // (two levels: the first-level bins are super-bins)
     fa.scratch = (ulonglong2 *)t->d_scratch.p; fa.region_cap = region_cap; fa.region_count = (unsigned int *)t->d_regions.p;
@@ -343,7 +374,7 @@ kct_status flush_compact(kct_table *t) {
     {
         ProfScope ps(t, "shadow32_flush_kernel");
         hipLaunchKernelGGL(kct::shadow32_flush_kernel, dim3(merge_grid(slots)), dim3(kct::kBlock), 0, t->stream, t->shadow32,
-                           (int)kct::kBlockBitsMax, slots, view(t, std::max<u64>(t->s32_keys, 1)), (int)t->k, t->d_counters, t->s32_sbits);
+                           (int)kct::kBlockBitsMax, slots, view(t, std::max<u64>(t->s32_keys, 1)), (int)t->k, t->d_counters, t->s32_sbits, t->s32_bin0);
     }
     HIP_TRY(hipGetLastError());
     u64 c[4], spilled;
@@ -442,7 +473,7 @@ kct_status recount_failed(kct_table *t, int mode, const void *scratch, u64 seg_s
         ProfScope ps(t, "recount_failed_kernel");
         if (mode == 0) hipLaunchKernelGGL(kct::recount_failed_kernel<0>, dim3(grid), dim3(kct::kBlock), 0, t->stream, scratch, seg_stride, block_stride, region_count, nregions, fl, nfailed, tv, t->d_counters, (int)t->k, sbits);
         else if (mode == 1) hipLaunchKernelGGL(kct::recount_failed_kernel<1>, dim3(grid), dim3(kct::kBlock), 0, t->stream, scratch, seg_stride, block_stride, region_count, nregions, fl, nfailed, tv, t->d_counters, (int)t->k, sbits);
-        else if (mode == 2) hipLaunchKernelGGL(kct::recount_failed_kernel<2>, dim3(grid), dim3(kct::kBlock), 0, t->stream, scratch, seg_stride, block_stride, region_count, nregions, fl, nfailed, tv, t->d_counters, (int)t->k, sbits);
+        else if (mode == 2) hipLaunchKernelGGL(kct::recount_failed_kernel<2>, dim3(grid), dim3(kct::kBlock), 0, t->stream, scratch, seg_stride, block_stride, region_count, nregions, fl, nfailed, tv, t->d_counters, (int)t->k, sbits, t->s32_bin0);
         else hipLaunchKernelGGL(kct::recount_failed_kernel<3>, dim3(grid), dim3(kct::kBlock), 0, t->stream, scratch, seg_stride, block_stride, region_count, nregions, fl, nfailed, tv, t->d_counters, (int)t->k, sbits);
     }
     HIP_TRY(hipGetLastError());
@@ -962,9 +993,9 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
             const bool use_compact = t->k <= 21 && !t->compact_off;
             const bool swap32 = use_compact && compact_sbits_for(t) != kCompactBlockBits, swap64 = !use_compact && t->cap > kProbeShadowSlots;
             const bool dry_run = swap32 || swap64;
-            unsigned int *big32 = t->shadow32; const int big_sbits = t->s32_sbits;
+            unsigned int *big32 = t->shadow32; const int big_sbits = t->s32_sbits; const unsigned int big_nbins = t->s32_nbins, big_bin0 = t->s32_bin0;
             du64 *big64 = t->shadow; const u64 big_cap = t->shadow_cap; const int big_bb = t->shadow_block_bits;
-            if (swap32) { t->shadow32 = t->probe_shadow32; t->s32_sbits = kCompactBlockBits; t->s32_empty = true; }
+            if (swap32) { t->shadow32 = t->probe_shadow32; t->s32_sbits = kCompactBlockBits; t->s32_nbins = 1024; t->s32_bin0 = 0; t->s32_empty = true; }
             if (swap64) { t->shadow = t->probe_shadow; t->shadow_cap = t->shadow ? kProbeShadowSlots : 0; t->shadow_block_bits = kct::kBlockBitsMax; t->shadow_empty = true; }
             const u64 table_before = t->n_keys, n_before = *n_out;
             DedupeOutcome seen;
@@ -973,7 +1004,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
             if (use_compact) st = consume_compact(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true, dry_run ? &seen : nullptr);
             if (st == KCT_OK && !handled && !t->dedupe_off && (!dry_run || swap64))
                 st = consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true, true, dry_run ? &seen : nullptr);
-            if (swap32) { t->probe_shadow32 = t->shadow32; t->shadow32 = big32; t->s32_sbits = big_sbits; t->s32_empty = true; }
+            if (swap32) { t->probe_shadow32 = t->shadow32; t->shadow32 = big32; t->s32_sbits = big_sbits; t->s32_nbins = big_nbins; t->s32_bin0 = big_bin0; t->s32_empty = true; }
             if (swap64) { t->probe_shadow = t->shadow; t->shadow = big64; t->shadow_cap = big_cap; t->shadow_block_bits = big_bb; t->shadow_empty = true; }
             KCT_TRY(st);
             if (handled) {

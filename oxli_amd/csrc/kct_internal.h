@@ -20,7 +20,7 @@
 #include <vector>
 
 #include "../../include/kct.h"
-#include "device_common.h"
+#include "partition_args.h"
 
 typedef uint64_t u64;     // host-side 64-bit values (matches the ABI's uint64_t)
 typedef kct::u64 du64;    // words that live in device memory (unsigned long long, what HIP atomics take)
@@ -185,6 +185,9 @@ struct kct_table {
     // of up to 1024 blocks, otherwise as many blocks as the table has (at least 2^16): two partition levels
     unsigned int *shadow32 = nullptr;
     int s32_sbits = 10;
+    // ... of which this table holds the blocks of first-level bins [s32_bin0, s32_bin0 + s32_nbins): all 1024 on one GPU, an
+    // owner's range of them in the multi-GPU early route (kct_route.hip); blocks = s32_nbins << (s32_sbits - 10)
+    unsigned int s32_bin0 = 0, s32_nbins = 1024;
     bool s32_empty = true, s32_dirty = false, compact_off = false;
     u64 s32_keys = 0, s32_windows = 0;  // keys it holds; window starts counted into it since its last flush (u32 counts!)
     // the dedupe probe's own small shadows (kept between calls, swapped in for the probe pass only)
@@ -271,5 +274,23 @@ kct_status merge_pairs_partitioned(kct_table *t, const du64 *d_keys, const du64 
 kct_status point_add(kct_table *t, u64 h, u64 *count_out);
 // kct_consume.hip
 kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 *n_out);
+// ... its kernels' launchers and sizing rules, for kct_route.hip (which does not instantiate the kernels itself)
+void launch_partition(kct_table *t, int mode /* 0 hashes, 1 mix64 values, 2 compact */, const unsigned char *d_stream, u64 chunk_bytes, u64 ntiles,
+                      const kct::PartitionArgs &pa);
+void launch_repartition(kct_table *t, int mode, unsigned grid, const kct::RepartitionArgs &ra, bool whole_slab);
+void launch_aggregate32(kct_table *t, unsigned grid, const kct::Aggregate32Args &aa);                 // two-level variant
+void launch_aggregate64(kct_table *t, unsigned grid, const kct::AggregateArgs &aa, bool shadow);      // two-level variant
+void launch_merge_overflow(kct_table *t, int mode, const du64 *regions, const unsigned int *counts, int nregions, unsigned int region_cap,
+                           const du64 *abort, const kct::TableView &tv, const du64 *total);
+unsigned int region_capacity(double avg);
+unsigned int overflow_capacity(u64 entries_per_wg);
+unsigned int repartition_min_lines(const kct_table *t, int ring_entries, int sub_bits, int entry_bytes);
+kct_status failed_blocks(kct_table *t, u64 nblocks, kct::FailedBlocks *fb);
+kct_status recount_failed(kct_table *t, int mode, const void *scratch, u64 seg_stride, u64 block_stride, const unsigned int *region_count, int nregions,
+                          u64 nfailed, u64 entries, int sbits, u64 tallies[4]);
+kct_status overflow_total(kct_table *t, const unsigned int *d_counts_a, size_t na, const unsigned int *d_counts_b, size_t nb, u64 *total);
+kct_status ensure_shadow(kct_table *t, u64 want_cap, bool *ok);
+kct_status ensure_shadow32(kct_table *t, int want_sbits, bool *ok, unsigned int nbins = 1024, unsigned int bin0 = 0);
+u64 compact_slots(const kct_table *t);
 
 }  // namespace kcth

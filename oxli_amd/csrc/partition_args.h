@@ -1,0 +1,119 @@
+// partition_args.h -- argument blocks of the partitioned path's kernels (partition_kernels.h), kept apart from the kernels so
+// that host translation units which only LAUNCH them through kct_consume.hip's launchers (kct_route.hip) need not
+// instantiate them.
+#pragma once
+#include "device_common.h"
+
+namespace kct {
+
+struct PartitionArgs {
+    u64 mask;            // table capacity - 1
+    int block_bits;      // log2(slots per block)
+    int pbits;           // log2(number of blocks P); P * D = kRingEntries, D >= 16
+    u64 *scratch;        // [nwg][P][region_cap] hashes
+    u32 region_cap;      // entries per (workgroup, block) region, multiple of kChunk
+    u32 *region_count;   // [P][nwg] entries written (multiple of kChunk, zero-padded)
+    u64 *ovf;            // [nwg][ovf_cap] hashes that found their ring (or region) full
+    u32 ovf_cap;
+    u32 *ovf_count;      // [nwg]
+    u64 *overflow;       // set to 1 if an overflow region itself overflowed: the pass is abandoned
+    int ablate;          // measurement only: bit 0 = skip the ring append, bit 1 = skip the flush phases
+    // owner-first binning (the multi-GPU "early" route, kct_route.hip; u64 entries only -- compact entries' bins are the value's
+    // top 10 bits either way): bin = owner * 2^pl_bits + local super-bin, owner = floor(hi32(value) * world / 2^32)
+    u32 world = 0;       // 0 = off
+    int pl_bits = 0;
+};
+
+struct RepartitionArgs {
+    u64 mask;            // table capacity - 1
+    int block_bits;      // log2(slots per block) (u64 / pair entries: the sub-bin is hash bits block_bits ...)
+    int sub_bits;        // log2(blocks per super-bin); ring depth D = ring entries >> sub_bits >= 16
+    const void *in;      // K1's regions: region (seg, s) at in + (seg * nbins + s) * in_cap entries
+    u32 in_cap;
+    const u32 *in_count; // [nbins][nseg]
+    int nseg, nbins;
+    int writers;         // workgroups per super-bin (W): each takes every W-th group of 16 input regions, so that
+                         // W x nbins workgroups fill the chip even when there are few super-bins
+    void *out;           // region of (block b, writer w) at out + (b * W + w) * out_cap entries
+    u32 out_cap;         // multiple of a 64-byte line of entries
+    u32 *out_count;      // [blocks][W]
+    u64 *ovf; u32 ovf_cap; u32 *ovf_count;  // per workgroup overflow regions (u64 values; pairs: two words each)
+    u64 *overflow;       // abandon flag (shared with K1)
+    u64 *ovf_n;          // pairs only: ONE shared overflow list instead of per-workgroup regions (ovf_cap = its capacity)
+    u32 min_lines;       // 64-byte lines of a bin that leave the ring together (1, 2 or 4; needs a ring depth of >= 4x that)
+    const u64 *in_off = nullptr;  // optional [nbins][nseg]: region (seg, s) starts at in + in_off[s * nseg + seg] entries instead (packed
+                                  // regions received from other GPUs, kct_route.hip)
+    u32 bin0 = 0;        // compact entries: the first-level bin of super-bin 0 (an owner GPU holds a RANGE of the 1024 bins)
+};
+
+struct FailedBlocks {
+    u32 *list = nullptr;   // block numbers, one per abandoned block
+    u64 *n = nullptr;      // how many
+    u64 *entries = nullptr;  // sum of their regions' entry counts
+};
+
+struct AggregateArgs {
+    u64 *words;          // the table (block-SoA)
+    int block_bits;
+    int pbits;
+    const u64 *scratch;  // region (seg, b) starts at scratch + seg * seg_stride + b * block_stride (u64 words)
+    u64 seg_stride, block_stride;
+    const u32 *region_count;  // [P][nregions] entries in each region
+    int nregions;        // source regions per block: K1's workgroups (one level) or 1 (two levels)
+    int fresh;           // table known empty: start every block from zeros instead of loading it
+    const u64 *overflow; // K1's abandon flag
+    int ablate;          // measurement only: bit 2 (4) = no count add, bit 4 (16) = loads only, bit 6 (64) = no streaming at all
+    u32 nblocks;         // table blocks (the grid may be smaller: a workgroup then takes every grid-th block)
+    FailedBlocks failed;
+    u64 *counters;
+};
+
+struct Aggregate32Args {
+    u32 *words;          // [blocks][S keys][S counts]
+    int block_bits;
+    const u32 *scratch;  // region (seg, b) at scratch + seg * seg_stride + b * block_stride (entries)
+    u64 seg_stride, block_stride;
+    const u32 *region_count;  // [blocks][nregions]
+    int nregions;
+    int fresh;
+    const u64 *overflow; // K1's abandon flag
+    FailedBlocks failed; // blocks that overflowed (abandoned whole; the host recounts their regions)
+    u64 *counters;
+    int ablate;          // measurement only: bit 4 (16) = loads only
+    int sbits;           // log2(blocks of the shadow): a block index is the TOP sbits bits of the 42-bit value (>= 10)
+    u32 nblocks;         // shadow blocks (the grid may be smaller: a workgroup then takes every grid-th block)
+};
+
+// A compact shadow block's place in the 42-bit value space: block b holds the values whose top 10 bits are bin0 + (b >> (sbits - 10))
+// (bin0 = 0 and 2^sbits blocks on one GPU; an owner GPU of the early route holds the blocks of ITS range of bins).
+struct FlushPartitionArgs {
+    void *shadow;        // compact shadow: [1024 blocks][8192 u32 keys][8192 u32 counts]; 64-bit shadow: u64 keys and counts
+    u32 shadow_blocks;   // 1024 for the one-level compact shadow
+    int shadow_sbits;    // compact shadow: log2(shadow_blocks) (a block index is the top sbits bits of the 42-bit value)
+    u32 shadow_bin0 = 0; // compact shadow: first-level bin of block 0
+    const u64 *pair_keys, *pair_counts; int pair_stride; u64 npairs;  // SRC 2: a flat list of {hash, count} pairs instead of a shadow
+    int k;
+    int table_block_bits, pbits;  // the REAL table: slots per block, log2(blocks) (<= 10)
+    ulonglong2 *scratch; // [nwg][P][region_cap] pairs
+    u32 region_cap;      // pairs, multiple of 4
+    u32 *region_count;   // [P][nwg]
+    u64 *ovf; u64 ovf_cap; u64 *ovf_n;  // one shared list of pairs that found ring or region full (merge_pairs_kernel takes it)
+};
+
+struct AggregatePairsArgs {
+    u64 *words; int block_bits;
+    const ulonglong2 *scratch; u64 seg_stride, block_stride;  // region (seg, b) at scratch + seg * seg_stride + b * block_stride
+    const u32 *region_count; int nregions;
+    int fresh;
+    u32 nblocks;         // table blocks (the grid may be smaller: a workgroup then takes every grid-th block)
+    FailedBlocks failed; // blocks that overflowed (abandoned whole; the host grows the table and recounts their regions)
+    u64 *counters;       // CTR_TOTAL_ADDED (counts placed), CTR_NEWKEYS
+};
+
+struct PendingList {
+    u64 *pairs = nullptr;  // 2 * cap words
+    u64 cap = 0;
+    u64 *n = nullptr;      // cursor (device), never reset between passes
+};
+
+}  // namespace kct

@@ -4,6 +4,7 @@
 #include <type_traits>
 
 #include "window_kernels.h"
+#include "partition_args.h"
 
 namespace kct {
 
@@ -103,19 +104,6 @@ __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *f
     return listed > LISTCAP;
 }
 
-struct PartitionArgs {
-    u64 mask;            // table capacity - 1
-    int block_bits;      // log2(slots per block)
-    int pbits;           // log2(number of blocks P); P * D = kRingEntries, D >= 16
-    u64 *scratch;        // [nwg][P][region_cap] hashes
-    u32 region_cap;      // entries per (workgroup, block) region, multiple of kChunk
-    u32 *region_count;   // [P][nwg] entries written (multiple of kChunk, zero-padded)
-    u64 *ovf;            // [nwg][ovf_cap] hashes that found their ring (or region) full
-    u32 ovf_cap;
-    u32 *ovf_count;      // [nwg]
-    u64 *overflow;       // set to 1 if an overflow region itself overflowed: the pass is abandoned
-    int ablate;          // measurement only: bit 0 = skip the ring append, bit 1 = skip the flush phases
-};
 
 // MODE 0: MurmurHash3 values (u64 entries).  MODE 1 (dedupe-first, k <= 32): mix64(packed k-mer + 1) values (u64).
 // MODE 2 (compact dedupe-first, k <= 21): mix42(packed k-mer) values, of which the bin is the top 10 bits and the ring /
@@ -230,7 +218,10 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
                 if (MODE == 2 && (u32)h == 0) overflow_hash(h);  // (one value in 2^32: its low half is the hole marker)
                 else {
                     // bin = the pbits hash bits above the block (or super-bin) offset; the top bits in compact mode
-                    pend_b = MODE == 2 ? (u32)(h >> 32) & 1023u : (u32)(h >> a.block_bits) & (u32)(P - 1);
+                    if constexpr (MODE == 2) pend_b = (u32)(h >> 32) & 1023u;
+                    else if (a.world)  // (wave-uniform) owner-first bins of the multi-GPU early route
+                        pend_b = (__umulhi((u32)(h >> 32), a.world) << a.pl_bits) | ((u32)(h >> a.block_bits) & ((1u << a.pl_bits) - 1u));
+                    else pend_b = (u32)(h >> a.block_bits) & (u32)(P - 1);
                     const u64 cw = atomicAdd(&cur[pend_b], 1ULL);
                     pend_pos = (u32)cw;
                     pend_mark = (u32)(cw >> 32);
@@ -260,24 +251,6 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
 // 2^sub_bits consecutive table blocks, and this kernel -- one 1024-thread workgroup per super-bin --
 // re-partitions a super-bin's hashes by block with the same LDS write-combining ring.  Exactly one
 // workgroup writes a given block's region, so K2 then reads a single region per block.
-struct RepartitionArgs {
-    u64 mask;            // table capacity - 1
-    int block_bits;      // log2(slots per block) (u64 / pair entries: the sub-bin is hash bits block_bits ...)
-    int sub_bits;        // log2(blocks per super-bin); ring depth D = ring entries >> sub_bits >= 16
-    const void *in;      // K1's regions: region (seg, s) at in + (seg * nbins + s) * in_cap entries
-    u32 in_cap;
-    const u32 *in_count; // [nbins][nseg]
-    int nseg, nbins;
-    int writers;         // workgroups per super-bin (W): each takes every W-th group of 16 input regions, so that
-                         // W x nbins workgroups fill the chip even when there are few super-bins
-    void *out;           // region of (block b, writer w) at out + (b * W + w) * out_cap entries
-    u32 out_cap;         // multiple of a 64-byte line of entries
-    u32 *out_count;      // [blocks][W]
-    u64 *ovf; u32 ovf_cap; u32 *ovf_count;  // per workgroup overflow regions (u64 values; pairs: two words each)
-    u64 *overflow;       // abandon flag (shared with K1)
-    u64 *ovf_n;          // pairs only: ONE shared overflow list instead of per-workgroup regions (ovf_cap = its capacity)
-    u32 min_lines;       // 64-byte lines of a bin that leave the ring together (1, 2 or 4; needs a ring depth of >= 4x that)
-};
 
 // T = u64 (MurmurHash3 / mix64 values; sub-bin = value bits block_bits...), u32 (compact dedupe-first entries: the low 32
 // bits of a mix42 value whose top 10 bits chose the super-bin; sub-bin = the entry's top sub_bits bits) or ulonglong2
@@ -311,7 +284,7 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     T *my_out = reinterpret_cast<T *>(a.out) + (((u64)s << a.sub_bits) * W + w) * a.out_cap;
     const u64 bin_stride = (u64)W * a.out_cap;
     u64 *my_ovf = a.ovf + (u64)blockIdx.x * a.ovf_cap;
-    const u64 ovf_hi = kCompact ? (((u64)s << 32) | (1ULL << 63)) : 0ULL;
+    const u64 ovf_hi = kCompact ? (((u64)(s + a.bin0) << 32) | (1ULL << 63)) : 0ULL;
     auto overflow_one = [&](u64 h) {
         const u32 i = atomicAdd(&ovf_n, 1u);
         if (i < a.ovf_cap) my_ovf[i] = h;
@@ -346,7 +319,7 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
         while (seg < a.nseg && off >= counts[seg]) { seg += seg_step; off = 0; }  // next non-empty region
         if (seg < a.nseg) {
             const u32 cnt = counts[seg];
-            const T *src = reinterpret_cast<const T *>(a.in) + ((u64)seg * a.nbins + s) * a.in_cap + off;
+            const T *src = reinterpret_cast<const T *>(a.in) + (a.in_off ? a.in_off[(u64)s * a.nseg + seg] : ((u64)seg * a.nbins + s) * a.in_cap) + off;
             const u32 left = cnt - off;
 #pragma unroll
             for (int j = 0; j < kLoads; ++j) { const u32 i = lane + 64 * j; if (i < left) v[j] = src[i]; }
@@ -393,27 +366,7 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
 // its number goes on this list.  Its entries still sit in its scratch regions; after the pass the host makes room and
 // recount_failed_kernel counts them with the direct insert.  So K2 needs no per-window spill list: a list that had to
 // be sized for the worst case (16 B per window start of the pass) and was practically never used.
-struct FailedBlocks {
-    u32 *list = nullptr;   // block numbers, one per abandoned block
-    u64 *n = nullptr;      // how many
-    u64 *entries = nullptr;  // sum of their regions' entry counts
-};
 
-struct AggregateArgs {
-    u64 *words;          // the table (block-SoA)
-    int block_bits;
-    int pbits;
-    const u64 *scratch;  // region (seg, b) starts at scratch + seg * seg_stride + b * block_stride (u64 words)
-    u64 seg_stride, block_stride;
-    const u32 *region_count;  // [P][nregions] entries in each region
-    int nregions;        // source regions per block: K1's workgroups (one level) or 1 (two levels)
-    int fresh;           // table known empty: start every block from zeros instead of loading it
-    const u64 *overflow; // K1's abandon flag
-    int ablate;          // measurement only: bit 2 (4) = no count add, bit 4 (16) = loads only, bit 6 (64) = no streaming at all
-    u32 nblocks;         // table blocks (the grid may be smaller: a workgroup then takes every grid-th block)
-    FailedBlocks failed;
-    u64 *counters;
-};
 
 template <bool CLAIM, bool TWO>  // CLAIM: the fast path claims free home-group slots itself (passes of mostly new k-mers); TWO: two partition levels
 __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(AggregateArgs a) {
@@ -678,21 +631,6 @@ __global__ __launch_bounds__(kBlock) void shadow_flush_kernel(u64 *__restrict__ 
 // Counts are u32.  No entry reaches this kernel without passing an LDS ring, and a ring bin lets at most D of the 8192 (K1)
 // or 8192 (K1b) appends of a flush interval through (the rest take the overflow route to the real table's u64 counts): a
 // k-mer's pending count grows by at most 1/256 of the window starts consumed.  The host converts before 2^39 of them.
-struct Aggregate32Args {
-    u32 *words;          // [blocks][S keys][S counts]
-    int block_bits;
-    const u32 *scratch;  // region (seg, b) at scratch + seg * seg_stride + b * block_stride (entries)
-    u64 seg_stride, block_stride;
-    const u32 *region_count;  // [blocks][nregions]
-    int nregions;
-    int fresh;
-    const u64 *overflow; // K1's abandon flag
-    FailedBlocks failed; // blocks that overflowed (abandoned whole; the host recounts their regions)
-    u64 *counters;
-    int ablate;          // measurement only: bit 4 (16) = loads only
-    int sbits;           // log2(blocks of the shadow): a block index is the TOP sbits bits of the 42-bit value (>= 10)
-    u32 nblocks;         // shadow blocks (the grid may be smaller: a workgroup then takes every grid-th block)
-};
 
 // TWO workgroups share a CU: 74 KiB of LDS each, and __launch_bounds__(1024, 8) holds the kernel to 64 VGPRs (it compiled to
 // 87, which silently left every CU with one workgroup; at 64 a few values spill, and K2-32 is still 13 % faster -- the fast
@@ -895,7 +833,7 @@ __global__ __launch_bounds__(kPartThreads, 8) void aggregate_blocks32_kernel(Agg
 
 // the compact shadow table's pending counts -> the real table (cf. shadow_flush_kernel)
 __global__ __launch_bounds__(kBlock) void shadow32_flush_kernel(u32 *__restrict__ shadow, int block_bits, u64 slots, TableView main, int k,
-                                                                u64 *counters, int sbits) {
+                                                                u64 *counters, int sbits, u32 bin0) {
     __shared__ u32 ascii4[256];
     __shared__ u64 s_tot, s_new;
     fill_ascii4_lut(ascii4, threadIdx.x, kBlock);
@@ -908,7 +846,7 @@ __global__ __launch_bounds__(kBlock) void shadow32_flush_kernel(u32 *__restrict_
         const u32 c = shadow[kw + S];
         if (c == 0) continue;
         shadow[kw + S] = 0;
-        const u64 h = hash_of_mixed<2>(((blk >> (sbits - 10)) << 32) | shadow[kw], k, ascii4);
+        const u64 h = hash_of_mixed<2>(((bin0 + (blk >> (sbits - 10))) << 32) | shadow[kw], k, ascii4);
         if (h == 0) continue;  // lib.rs:589: hash 0 is skipped
         const AddResult r = table_add<false>(main, h, (u64)c);
         if (!r.spilled) { tot += c; nk += r.claimed; }
@@ -928,18 +866,6 @@ __global__ __launch_bounds__(kBlock) void shadow32_flush_kernel(u32 *__restrict_
 // Here the {hash, count} pairs take the k-mers' own route instead: this kernel hashes every pending k-mer and
 // radix-partitions the PAIRS by table block through the LDS ring (16-byte entries, four per line), and
 // aggregate_pairs_kernel merges each block's pairs in LDS.  The table is read and written once, sequentially.
-struct FlushPartitionArgs {
-    void *shadow;        // compact shadow: [1024 blocks][8192 u32 keys][8192 u32 counts]; 64-bit shadow: u64 keys and counts
-    u32 shadow_blocks;   // 1024 for the one-level compact shadow
-    int shadow_sbits;    // compact shadow: log2(shadow_blocks) (a block index is the top sbits bits of the 42-bit value)
-    const u64 *pair_keys, *pair_counts; int pair_stride; u64 npairs;  // SRC 2: a flat list of {hash, count} pairs instead of a shadow
-    int k;
-    int table_block_bits, pbits;  // the REAL table: slots per block, log2(blocks) (<= 10)
-    ulonglong2 *scratch; // [nwg][P][region_cap] pairs
-    u32 region_cap;      // pairs, multiple of 4
-    u32 *region_count;   // [P][nwg]
-    u64 *ovf; u64 ovf_cap; u64 *ovf_n;  // one shared list of pairs that found ring or region full (merge_pairs_kernel takes it)
-};
 
 // SRC 0: the compact shadow; 1: the 64-bit shadow; 2: a flat list of {hash, count} pairs (merges: add(), load(), the multi-GPU merge)
 template <int SRC, int KC = 0>  // KC > 0: k at compile time
@@ -1023,7 +949,7 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
             if (c) {
                 *count_ptr(r) = 0;
                 const u32 sb = sb0 + r / kRowsPerBlock;
-                const u64 h = COMPACT ? hash_of_mixed<2>(((u64)(sb >> (a.shadow_sbits - 10)) << 32) | (u64)key, k, ascii4)
+                const u64 h = COMPACT ? hash_of_mixed<2>(((u64)(a.shadow_bin0 + (sb >> (a.shadow_sbits - 10))) << 32) | (u64)key, k, ascii4)
                                       : hash_of_mixed<1>((u64)key, k, ascii4);
                 if (h) {  // lib.rs:589: hash 0 is skipped
                     const u32 b = (u32)(h >> a.table_block_bits) & (u32)(P - 1);
@@ -1045,15 +971,6 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
 
 // One workgroup per table block: the block in LDS, its pairs merged with LDS atomics, the block stored back.
 // Few pairs per block (thousands, against 10^5 k-mers in a counting pass): the general insert alone will do.
-struct AggregatePairsArgs {
-    u64 *words; int block_bits;
-    const ulonglong2 *scratch; u64 seg_stride, block_stride;  // region (seg, b) at scratch + seg * seg_stride + b * block_stride
-    const u32 *region_count; int nregions;
-    int fresh;
-    u32 nblocks;         // table blocks (the grid may be smaller: a workgroup then takes every grid-th block)
-    FailedBlocks failed; // blocks that overflowed (abandoned whole; the host grows the table and recounts their regions)
-    u64 *counters;       // CTR_TOTAL_ADDED (counts placed), CTR_NEWKEYS
-};
 
 __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(AggregatePairsArgs a) {
     __shared__ __attribute__((aligned(16))) u64 tab[2 << kBlockBitsMax];
@@ -1171,11 +1088,6 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(Aggregate
 // pend (optional): instead of inserting, APPEND the folded {hash, count} pairs to a list that the next conversion of the
 // pending counts merges -- so that a dedupe-first pass need not touch a table that is still lazily empty (no memset, and
 // the conversion then starts every table block from zeros).  The entries are tallied as counted either way.
-struct PendingList {
-    u64 *pairs = nullptr;  // 2 * cap words
-    u64 cap = 0;
-    u64 *n = nullptr;      // cursor (device), never reset between passes
-};
 
 template <int DEDUPE = 0>  // 0: hashes; 1: mix64 values; 2: mix42 values (bit 63 set)
 __global__ __launch_bounds__(kBlock) void merge_overflow_kernel(const u64 *__restrict__ regions, const u32 *__restrict__ counts,
@@ -1240,7 +1152,7 @@ __global__ __launch_bounds__(kBlock) void merge_overflow_kernel(const u64 *__res
 // first (a block's entries repeat its k-mers many times over).  Tallies: CTR_TOTAL_ADDED, CTR_NEWKEYS, CTR_NEW_BY_ZERO.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void recount_failed_kernel(const void *scratch, u64 seg_stride, u64 block_stride, const u32 *region_count, int nregions,
-                                                                const u32 *failed_list, u64 nfailed, TableView table, u64 *counters, int k, int sbits) {
+                                                                const u32 *failed_list, u64 nfailed, TableView table, u64 *counters, int k, int sbits, u32 bin0 = 0) {
     using T = typename std::conditional<MODE == 3, ulonglong2, typename std::conditional<MODE == 2, u32, u64>::type>::type;
     __shared__ u64 s_tot, s_new, s_nz;
     __shared__ u32 ascii4[(MODE == 1 || MODE == 2) ? 256 : 1];
@@ -1259,7 +1171,7 @@ __global__ __launch_bounds__(kBlock) void recount_failed_kernel(const void *scra
                 u64 h = 0, c = 1;
                 if (i < cnt) {
                     if constexpr (MODE == 3) { const ulonglong2 pr = src[i]; h = pr.x; c = pr.y; }
-                    else if constexpr (MODE == 2) { const u32 e = src[i]; h = e ? ((((u64)(b >> (sbits - 10))) << 32) | e | (1ULL << 63)) : 0ULL; }
+                    else if constexpr (MODE == 2) { const u32 e = src[i]; h = e ? ((((u64)(bin0 + (b >> (sbits - 10)))) << 32) | e | (1ULL << 63)) : 0ULL; }
                     else h = src[i];
                 }
                 bool pending = h != 0, is_leader = false;

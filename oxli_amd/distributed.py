@@ -21,7 +21,8 @@ in the HIP library.
 import torch
 import torch.distributed as dist
 
-__all__ = ["owner_of", "partition_by_owner", "exchange_route", "exchange_pairs", "merge_across_ranks", "global_scalar_sum"]
+__all__ = ["owner_of", "partition_by_owner", "exchange_route", "exchange_pairs", "merge_across_ranks", "global_scalar_sum",
+           "consume_device_early", "EARLY_MODES"]
 
 
 def owner_of(hashes_i64: torch.Tensor, world: int) -> torch.Tensor:
@@ -174,3 +175,106 @@ def merge_across_ranks(table, group=None):
     table._check(table._lib.kct_merge_pairs_device(table._h, C.c_void_p(recv.data_ptr()), recv.shape[0], C.byref(a), C.byref(b)))
     table._check(table._lib.kct_add_consumed(table._h, consumed))
     return recv.shape[0]
+
+
+# ---- the EARLY route: entries travel to their owner while they are counted (csrc/kct_route.hip) -----------------------------
+EARLY_MODES = {"hash": 0, "dedupe64": 1, "compact": 2}
+
+
+class _Exchanger:
+    """The two callbacks ``kct_consume_device_routed`` needs, over ``torch.distributed``: device buffers come from torch
+    (so that the collective can take them as tensors), the all-to-all is ``all_to_all_single`` on bytes with uneven splits
+    (RCCL over xGMI with the nccl backend; staged through host memory when ranks share a GPU under gloo)."""
+
+    def __init__(self, group, dev):
+        import ctypes as C
+        self.group, self.dev = group, dev
+        self.world = dist.get_world_size(group)
+        self.host = dist.get_backend(group) != "nccl"
+        self.keep = {}      # device address -> tensor (send buffers handed to the library)
+        self.recv = []      # received buffers, alive until the routed call returns
+        self.error = None
+        self.bytes_sent = 0
+        self._alloc = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)(self.alloc)
+        self._xchg = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p),
+                                 C.POINTER(C.c_uint64))(self.exchange)
+        self.alloc_ptr = C.cast(self._alloc, C.c_void_p)
+        self.xchg_ptr = C.cast(self._xchg, C.c_void_p)
+
+    def alloc(self, _user, nbytes):
+        try:
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
+            self.keep[t.data_ptr()] = t
+            return t.data_ptr()
+        except Exception as e:  # noqa: BLE001 -- reported through the library's status
+            self.error = e
+            return None
+
+    def exchange(self, _user, d_send, send_elems, elem_bytes, d_recv, recv_elems):
+        try:
+            world, eb = self.world, int(elem_bytes)
+            send = [int(send_elems[i]) for i in range(world)]
+            buf = self.keep[int(d_send)][: sum(send) * eb]
+            meta = torch.tensor(send, dtype=torch.int64, device="cpu" if self.host else self.dev)
+            got = torch.empty_like(meta)
+            dist.all_to_all_single(got, meta, group=self.group)
+            recv = [int(v) for v in got.cpu().tolist()]
+            src = buf.cpu() if self.host else buf
+            out = torch.empty(sum(recv) * eb, dtype=torch.uint8, device=src.device)
+            dist.all_to_all_single(out, src, output_split_sizes=[r * eb for r in recv], input_split_sizes=[s_ * eb for s_ in send],
+                                   group=self.group)
+            if self.host:
+                out = out.to(self.dev)
+            torch.cuda.synchronize()
+            if out.numel() == 0:
+                out = torch.empty(256, dtype=torch.uint8, device=self.dev)
+            self.recv.append(out)
+            self.bytes_sent += (sum(send) - send[dist.get_rank(self.group)]) * eb
+            d_recv[0] = out.data_ptr()
+            for i in range(world):
+                recv_elems[i] = recv[i]
+            return 0
+        except Exception as e:  # noqa: BLE001
+            self.error = e
+            return 1
+
+
+def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, mode="auto"):
+    """Counts this rank's device-resident record stream by the EARLY route: K1 here, entries to their owner GPUs with three
+    all-to-alls, K1b / K2 on the owners (``kct_consume_device_routed``).  Every rank must call it, with tables of one
+    capacity.  ``mode``: "compact" (k <= 21) and "dedupe64" (k <= 32) count packed k-mers first and hash each distinct one
+    when the table is read -- right for deep coverage, where an owner meets every k-mer many times; "hash" hashes every window
+    (any k <= 64; low coverage); "auto" picks by k.  Returns (k-mers this rank counted as an owner, stats dict).
+
+    Afterwards the ranks' tables are a disjoint partition of the key space (by k-mer slice for the dedupe-first modes, by
+    hash slice -- the late route's owner rule -- for "hash"): ``global_scalar_sum`` of ``len`` / ``sum_counts`` gives the
+    global table's, and no ``merge_across_ranks`` is needed."""
+    import ctypes as C
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if getattr(table, "store_kmers", False):
+        raise ValueError("the early route moves packed k-mers / hashes only: a store_kmers table would lose its hash -> k-mer map")
+    if mode == "auto":
+        mode = "compact" if table.ksize <= 21 else "dedupe64" if table.ksize <= 32 else "hash"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    host = dist.get_backend(group) != "nccl"
+    # one capacity on every rank (the senders' bins follow the owners' table geometry)
+    cap = torch.tensor([table.capacity, -table.capacity], dtype=torch.int64, device="cpu" if host else dev)
+    dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
+    if int(cap[0]) != -int(cap[1]):
+        raise ValueError(f"the early route needs tables of one capacity on every rank (have {-int(cap[1])} .. {int(cap[0])} slots)")
+    ex = _Exchanger(group, dev)
+    n, stats = C.c_uint64(), (C.c_uint64 * 8)()
+    st = table._lib.kct_consume_device_routed(table._h, C.c_void_p(int(data_ptr)), int(nbytes), int(consumed_bytes), world, rank,
+                                              EARLY_MODES[mode], ex.alloc_ptr, ex.xchg_ptr, None, C.byref(n), stats)
+    # a failure on ANY rank is every rank's failure (tables are then inconsistent across the job)
+    bad = torch.tensor([1 if st != 0 else 0], dtype=torch.int64, device="cpu" if host else dev)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    if ex.error is not None:
+        raise ex.error
+    table._check(st)
+    if int(bad.item()):
+        raise RuntimeError("the early route failed on another rank: clear the tables and use the late route (merge_across_ranks)")
+    keys = ("entries_sent", "entries_received", "entry_bytes", "overflow_sent", "overflow_received", "exchange_us", "blocks_abandoned", "skewed")
+    return n.value, dict(zip(keys, (int(v) for v in stats)), mode=mode, bytes_sent=ex.bytes_sent)

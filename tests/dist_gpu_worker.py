@@ -2,7 +2,11 @@
 own device table.  Every rank counts its shard of one read stream, merge_across_ranks() makes the tables the owner
 partitions of the global table, and rank 0 checks their union against the oracle's count of the whole stream.
 
-    python -m torch.distributed.run --nproc-per-node W tests/dist_gpu_worker.py <k> <reads per rank> <genome>
+    python -m torch.distributed.run --nproc-per-node W tests/dist_gpu_worker.py <k> <reads per rank> <genome> [route]
+
+route: "late" (default: private tables, then merge_across_ranks) or "early:compact" / "early:dedupe64" / "early:hash"
+(consume_device_early: entries travel to their owners while they are counted; two passes, so that the second one meets live
+tables and shadows).
 """
 import os
 import sys
@@ -17,17 +21,21 @@ sys.path.insert(0, ROOT)
 
 def main():
     k, per_rank, G = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    route = sys.argv[4] if len(sys.argv) > 4 else "late"
     L = 150
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle
     from oxli_amd import KmerCountTable
-    from oxli_amd.distributed import global_scalar_sum, merge_across_ranks, owner_of
+    from oxli_amd.distributed import consume_device_early, global_scalar_sum, merge_across_ranks, owner_of
 
     genome = oracle.synth_genome(G, 42)
     reads = oracle.synth_reads(genome, rank * per_rank, per_rank, L, 1337)
     dev_reads = torch.from_numpy(reads.reshape(-1)).cuda()
+    if route.startswith("early"):
+        early(route.split(":")[1], k, per_rank, G, L, rank, world, genome, reads, dev_reads)
+        return
     t = KmerCountTable(k, capacity=G)
     n = t.consume_device(dev_reads.data_ptr(), dev_reads.numel(), per_rank * L)
     assert n == per_rank * (L - k + 1)
@@ -60,6 +68,43 @@ def main():
         assert np.array_equal(gk[order], rk) and np.array_equal(gc[order], rc), "union of the owner tables differs from the oracle"
         del ref
         print(f"DIST_GPU_OK world={world} distinct={rk.size}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def early(mode, k, per_rank, G, L, rank, world, genome, reads, dev_reads):
+    """Two early-route passes (the rank's reads in two halves) into owner-sized tables; union of the ranks' tables == oracle."""
+    import oracle
+    from oxli_amd import KmerCountTable
+    from oxli_amd.distributed import consume_device_early, global_scalar_sum, owner_of
+
+    t = KmerCountTable(k, capacity=max(G // world, 400_000))
+    half = (per_rank // 2) * (L + 1)
+    n1, s1 = consume_device_early(t, dev_reads.data_ptr(), half, (per_rank // 2) * L, mode=mode)
+    n2, s2 = consume_device_early(t, dev_reads.data_ptr() + half, dev_reads.numel() - half, (per_rank - per_rank // 2) * L, mode=mode)
+    assert s1["mode"] == mode and s1["entry_bytes"] == (4 if mode == "compact" else 8) and not s1["skewed"]
+    assert s1["entries_sent"] > 0 and s1["entries_received"] > 0
+    total_n = global_scalar_sum(n1 + n2, "cpu")
+    assert total_n == world * per_rank * (L - k + 1), total_n
+    keys, counts = t.dump_arrays(1)          # (reading the table converts what the dedupe-first modes left pending)
+    if mode == "hash":                       # hashing mode partitions by the late route's owner rule
+        assert np.all(owner_of(torch.from_numpy(keys.view(np.int64).copy()), world).numpy() == rank)
+    assert global_scalar_sum(t.sum_counts, "cpu") == world * per_rank * (L - k + 1)
+    assert global_scalar_sum(t.consumed, "cpu") == world * per_rank * L
+    parts = [None] * world
+    dist.all_gather_object(parts, (keys, counts))
+    if rank == 0:
+        allreads = oracle.synth_reads(genome, 0, world * per_rank, L, 1337)
+        tab, _, _ = oracle.baseline_consume(allreads, L, k, min(8, len(os.sched_getaffinity(0))), native=False)
+        rk, rc = tab.dump_arrays()
+        gk = np.concatenate([p[0] for p in parts])
+        gc = np.concatenate([p[1] for p in parts])
+        order = np.argsort(gk, kind="stable")
+        assert gk.size == np.unique(gk).size, "owner partitions overlap"
+        assert np.array_equal(gk[order], rk) and np.array_equal(gc[order], rc), "union of the owner tables differs from the oracle"
+        sizes = [int(p[0].size) for p in parts]
+        assert min(sizes) > 0.5 * rk.size / world, sizes     # every owner holds about its share
+        print(f"DIST_GPU_OK world={world} distinct={rk.size} route=early:{mode} sent={s1['entries_sent'] + s2['entries_sent']}")
     dist.barrier()
     dist.destroy_process_group()
 

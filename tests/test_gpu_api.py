@@ -151,6 +151,32 @@ def test_serialize_save_load(KCT, tmp_path, capfd):
 
 
 # ---- dunders / attributes (test_dunders.py, test_attr.py) ------------------------------------------------------
+def test_consume_into_a_loaded_table(KCT, tmp_path):
+    """load() then consume(): a loaded table takes every consume route (the per-record call glue included) and counts on
+    top of what the file held -- against the oracle counting both inputs."""
+    from oracle import OracleTable
+    rng = random.Random(77)
+    a, b = "".join(rng.choice("ACGT") for _ in range(30000)), "".join(rng.choice("ACGTN") for _ in range(30000))
+    t = KCT(21)
+    t.consume(a)
+    f = str(tmp_path / "t.json.gz")
+    t.save(f)
+    u = KCT.load(f)
+    ref = OracleTable(21)
+    ref.consume(a)
+    recs = [b[i:i + 150] for i in range(0, len(b), 150)]
+    assert [u.consume(r) for r in recs] == [ref.consume(r) for r in recs]       # per-record (deferred + call glue)
+    assert u.consume_batch(recs) == sum(ref.consume(r) for r in recs)           # batch
+    with pytest.raises(ValueError):
+        u.consume("ACGTN" * 10, skip_bad_kmers=False)
+    with pytest.raises(ValueError):
+        ref.consume("ACGTN" * 10, skip_bad_kmers=False)
+    dk, dc = u.dump_arrays(1)
+    rk, rc = ref.dump_arrays()
+    assert np.array_equal(dk, rk) and np.array_equal(dc, rc)
+    assert u.consumed == ref.consumed and u.sum_counts == ref.sum_counts
+
+
 def test_dunders_and_attrs(KCT):
     from oxli_amd import VERSION
     t = KCT(ksize=16)
