@@ -176,6 +176,20 @@ KCT_API kct_status kct_merge_pairs_device(kct_table *t, const void *d_pairs, siz
  * magnitude term of cosine() (lib.rs:747-760).  Any output pointer may be NULL. */
 KCT_API kct_status kct_count_stats(kct_table *t, uint64_t *min_out, uint64_t *max_out, double *sum_squares_out);
 
+/* ---- PACKED base arrays (BASELINE north star: "over packed base arrays") ------------------------------------------------
+ * A record stream as 2 bits per base + 1 validity bit per base, sixteen bases per group: codes[g] (uint32, first base in bits
+ * 31:30, A C G T = 0 1 2 3) and valid[g] (uint16, first base in bit 15; 0 = not ACGT / separator / padding).  Records are
+ * separated by at least one invalid base, exactly as the ASCII stream separates them by a non-ACGT byte -- so the validity
+ * rule of lib.rs:586-600 ("a window is good iff its k bytes are all ACGT after upper-casing") is the AND of k bits.  0.375 B
+ * per base instead of 1: what kct_consume_batch uploads for large skip-bad batches (kct_set_packed_upload, on by default),
+ * and what the partition kernels read directly.
+ *   kct_consume_device_packed  counts nbases bases of a device-resident packed stream (kct_consume_device's twin)
+ *   kct_pack_stream_device     ASCII record stream -> packed arrays, on the device (ceil(nbytes / 16) groups)              */
+KCT_API kct_status kct_consume_device_packed(kct_table *t, const void *d_codes, const void *d_valid, size_t nbases, uint64_t consumed_bytes,
+                                             uint64_t *n_total);
+KCT_API kct_status kct_pack_stream_device(const void *d_stream, size_t nbytes, void *d_codes, void *d_valid, void *stream);
+KCT_API kct_status kct_set_packed_upload(kct_table *t, int on);
+
 /* ---- multi-GPU "early" route: entries travel to the GPU that owns their slice of the key space -----------
  * One call = one pass: K1 over THIS rank's records with its bins grouped by owner, three all-to-alls through the caller's
  * callbacks (region sizes, entries of 4 or 8 bytes, the few entries that overflowed K1's LDS ring), then K1b / K2 on the

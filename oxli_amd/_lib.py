@@ -42,6 +42,9 @@ SIGNATURES = {
     "kct_consume": (ci, [vp, vp, sz, ci, u64p]),
     "kct_consume_batch": (ci, [vp, vp, vp, sz, ci, u64p, u64p, u64p]),
     "kct_consume_device": (ci, [vp, vp, sz, u64, u64p]),
+    "kct_consume_device_packed": (ci, [vp, vp, vp, sz, u64, u64p]),
+    "kct_pack_stream_device": (ci, [vp, sz, vp, vp, vp]),
+    "kct_set_packed_upload": (ci, [vp, ci]),
     "kct_consume_device_routed": (ci, [vp, vp, sz, u64, C.c_uint32, C.c_uint32, ci, vp, vp, vp, u64p, u64p]),
     "kct_consume_file": (ci, [vp, cp, ci, u64p, u64p, u64p]),
     "kct_len": (ci, [vp, u64p]),

@@ -114,6 +114,15 @@ void launch_merge_overflow(kct_table *t, int mode, const du64 *regions, const un
     else hipLaunchKernelGGL(kct::merge_overflow_kernel<0>, dim3(256), dim3(kct::kBlock), 0, t->stream, regions, counts, nregions, region_cap, abort, tv, t->d_counters, (int)t->k, total, none);
 }
 
+
+// packed input: the K1 launch reads groups instead of bytes (PartitionArgs::pcodes)
+static void packed_args(const kct_table *t, const unsigned char *d_stream, kct::PartitionArgs *pa) {
+    if (!t->packed_codes) return;
+    const u64 g0 = (u64)(d_stream - t->packed_base) >> 4;
+    pa->pcodes = t->packed_codes + g0;
+    pa->pvalid = t->packed_valid + g0;
+}
+
 // The partitioned path pays 16 B (one level) or 32 B (two levels) of streaming scratch traffic per
 // k-mer plus 32 B per table slot per pass; the direct path pays one memory-side atomic per k-mer.
 // It wins once a pass brings a fair fraction as many windows as the table has slots.
@@ -587,6 +596,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
     pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
     pa.ablate = t->ablate;
+    packed_args(t, d_stream, &pa);
     {
         ProfScope ps(t, "partition_windows_kernel<compact>");
         PartitionCompactByK<21>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
@@ -752,6 +762,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
     pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
     pa.ablate = t->ablate;  // measurement only; wrong counts when set
+    packed_args(t, d_stream, &pa);
     {
         ProfScope ps(t, raw ? "partition_windows_kernel<raw>" : "partition_windows_kernel");
         if (raw) PartitionRawByK<32>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
@@ -1046,12 +1057,21 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         KCT_TRY(materialize(t));
         KCT_TRY(t->d_spill.reserve(npos * 16));
         KCT_TRY(zero_counters(t));
+        const unsigned char *chunk = d_stream + done;
+        if (t->packed_codes) {  // the direct kernel reads bytes: the chunk's ASCII image
+            const u64 g0 = done >> 4, ng = (chunk_bytes + 15) >> 4;
+            KCT_TRY(t->d_unpack.reserve(ng * 16 + 16));
+            ProfScope ps(t, "unpack_stream_kernel");
+            hipLaunchKernelGGL(kct::unpack_stream_kernel, dim3((unsigned)std::min<u64>((ng + kct::kBlock - 1) / kct::kBlock, 1u << 16)), dim3(kct::kBlock), 0, t->stream,
+                               t->packed_codes + g0, t->packed_valid + g0, ng, (unsigned char *)t->d_unpack.p);
+            chunk = (const unsigned char *)t->d_unpack.p;
+        }
         const int grid = (int)((npos + kct::kTile - 1) / kct::kTile);
         // the kernel derives window ownership from tile positions, so hand it a stream that ends
         // where this chunk's last window ends
         {
             ProfScope ps(t, "count_windows_kernel");
-            dispatch_k<CountLauncher>(k, t->stream, grid, d_stream + done, chunk_bytes, k, view(t, npos), t->d_counters);
+            dispatch_k<CountLauncher>(k, t->stream, grid, chunk, chunk_bytes, k, view(t, npos), t->d_counters);
         }
         HIP_TRY(hipGetLastError());
         u64 c[4], spilled;
@@ -1070,6 +1090,60 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
     KCT_DBG(t, "consume_stream: done\n");
     if (t->auto_sized && t->cap == cap_at_entry && nbytes >= (1u << 20)) t->auto_sized = false;  // the table has found its size
     return KCT_OK;
+}
+
+// Counts a PACKED record stream (window_kernels.h pack_stream_kernel's format): the partition kernels read the groups directly;
+// whatever reads bytes (the direct kernel; every kernel at k > 64) gets an unpacked image.
+kct_status consume_stream_packed(kct_table *t, const unsigned int *d_codes, const unsigned short *d_valid, u64 nbases, u64 *n_out) {
+    *n_out = 0;
+    if (nbases < t->k) return KCT_OK;
+    const u64 ng = (nbases + 15) >> 4;
+    if (t->k > 64) {  // bytewise kernels only
+        KCT_TRY(t->d_unpack.reserve(ng * 16 + 16));
+        hipLaunchKernelGGL(kct::unpack_stream_kernel, dim3((unsigned)std::min<u64>((ng + kct::kBlock - 1) / kct::kBlock, 1u << 16)), dim3(kct::kBlock), 0, t->stream,
+                           d_codes, d_valid, ng, (unsigned char *)t->d_unpack.p);
+        HIP_TRY(hipGetLastError());
+        return consume_stream(t, (const unsigned char *)t->d_unpack.p, nbases, n_out);
+    }
+    t->packed_codes = d_codes; t->packed_valid = d_valid;
+    t->packed_base = (const unsigned char *)(uintptr_t)0x100000000000ULL;  // a 16-byte aligned origin for offsets; never dereferenced
+    const kct_status st = consume_stream(t, t->packed_base, nbases, n_out);
+    t->packed_codes = nullptr; t->packed_valid = nullptr; t->packed_base = nullptr;
+    return st;
+}
+
+
+// ---- host packer: ASCII -> 2-bit codes + validity bits (the host twin of kmer_device.h encode16) -----------------------
+#include <tmmintrin.h>
+static inline void encode16_scalar(const unsigned char *p, unsigned int *codes, unsigned short *valid) {
+    unsigned int c = 0, v = 0;
+    for (int i = 0; i < 16; ++i) {
+        const unsigned b = p[i] | 0x20u;
+        const bool ok = b == 'a' || b == 'c' || b == 'g' || b == 't';
+        unsigned int x = (p[i] >> 1) & 3u;
+        x ^= x >> 1;  // A0 C1 G2 T3
+        c = (c << 2) | (ok ? x : 0u);
+        v = (v << 1) | (ok ? 1u : 0u);
+    }
+    *codes = c; *valid = (unsigned short)v;
+}
+__attribute__((target("ssse3"))) static inline void encode16_ssse3(const unsigned char *p, unsigned int *codes, unsigned short *valid) {
+    const __m128i v = _mm_loadu_si128((const __m128i *)p), up = _mm_or_si128(v, _mm_set1_epi8(0x20));
+    const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(up, _mm_set1_epi8('a')), _mm_cmpeq_epi8(up, _mm_set1_epi8('c'))),
+                                    _mm_or_si128(_mm_cmpeq_epi8(up, _mm_set1_epi8('g')), _mm_cmpeq_epi8(up, _mm_set1_epi8('t'))));
+    __m128i x = _mm_and_si128(_mm_srli_epi16(v, 1), _mm_set1_epi8(3));
+    x = _mm_xor_si128(x, _mm_and_si128(_mm_srli_epi16(x, 1), _mm_set1_epi8(1)));
+    x = _mm_and_si128(x, ok);
+    const __m128i p2 = _mm_maddubs_epi16(x, _mm_set1_epi16(0x0104));      // base 2i * 4 + base 2i+1
+    const __m128i p4 = _mm_madd_epi16(p2, _mm_set1_epi32(0x00010010));    // pair 2j * 16 + pair 2j+1: four bases per 32-bit lane
+    const __m128i sh = _mm_shuffle_epi8(p4, _mm_set_epi8(-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12));
+    *codes = (unsigned int)_mm_cvtsi128_si32(sh);                         // bases 0-3 in the top byte
+    *valid = (unsigned short)(__builtin_bitreverse16((unsigned short)_mm_movemask_epi8(ok)));
+}
+static void encode_groups(const unsigned char *p, size_t ngroups, unsigned int *codes, unsigned short *valid) {
+    static const bool ssse3 = __builtin_cpu_supports("ssse3");
+    if (ssse3) for (size_t g = 0; g < ngroups; ++g) encode16_ssse3(p + 16 * g, codes + g, valid + g);
+    else for (size_t g = 0; g < ngroups; ++g) encode16_scalar(p + 16 * g, codes + g, valid + g);
 }
 
 // host bytes -> pinned staging -> device stream buffer (padded with '\n' to a multiple of 16)
@@ -1291,6 +1365,81 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
     const unsigned hw = std::thread::hardware_concurrency();
     const size_t max_threads = (size_t)t->tune.pack_threads;
     const size_t nthreads = stream_len >= (8u << 20) ? std::min<size_t>({max_threads, hw ? hw : 1, nrec}) : 1;
+    if (skip_bad && t->packed_upload && t->k <= 64 && nthreads > 1) {
+        // PACKED upload: every part of the batch starts on a 16-base boundary of the stream (extra separator bytes in front of
+        // it -- any number of invalid bases may sit between two records), so the packers can encode their parts independently:
+        // each streams its records (+ one separator each) through a small buffer and writes one code word + one validity word
+        // per 16 bases -- 0.375 B per base cross the PCIe link instead of 1.
+        const size_t nslices = std::min<size_t>(nrec, std::max<size_t>(4, std::min<size_t>(16, stream_len >> 22)));
+        const size_t parts = std::min<size_t>(nthreads, std::max<size_t>(1, nrec / nslices));
+        const size_t nitems = nslices * parts;
+        std::vector<size_t> cut(nitems + 1);
+        for (size_t i = 0; i <= nitems; ++i) {
+            const u64 lo = base0 + total * i / nitems;
+            cut[i] = i == nitems ? nrec : (size_t)(std::lower_bound(offsets, offsets + nrec, lo) - offsets);
+        }
+        cut[0] = 0;
+        std::vector<u64> pos(nitems + 1);
+        pos[0] = 0;
+        for (size_t i = 0; i < nitems; ++i) pos[i + 1] = (pos[i] + (offsets[cut[i + 1]] - offsets[cut[i]]) + (cut[i + 1] - cut[i]) + 15) & ~(u64)15;
+        const u64 nbases = pos[nitems], ng = nbases >> 4;
+        const u64 valid_off = (ng * 4 + 255) & ~(u64)255;
+        KCT_TRY(t->h_stage.reserve(valid_off + ng * 2 + 64));
+        KCT_TRY(t->d_stream.reserve(valid_off + ng * 2 + 64));
+        unsigned int *h_codes = (unsigned int *)t->h_stage.p;
+        unsigned short *h_valid = (unsigned short *)((char *)t->h_stage.p + valid_off);
+        std::vector<std::atomic<int>> packed(nslices);
+        for (auto &r : packed) r.store(0, std::memory_order_relaxed);
+        std::atomic<size_t> next_item{0};
+        WorkerPool &pool = WorkerPool::instance();
+        pool.start(nthreads, [&](size_t) {
+            constexpr size_t kBuf = 4096;
+            unsigned char buf[kBuf + 16];
+            for (;;) {
+                const size_t it = next_item.fetch_add(1, std::memory_order_relaxed);
+                if (it >= nitems) break;
+                size_t g = pos[it] >> 4, fill = 0;
+                auto drain = [&](bool all) {  // encode the buffer's whole groups (all: pad the rest with separators first)
+                    if (all) while (fill & 15) buf[fill++] = '\n';
+                    const size_t n = fill >> 4;
+                    encode_groups(buf, n, h_codes + g, h_valid + g);
+                    g += n;
+                    const size_t rest = fill - 16 * n;
+                    if (rest) memmove(buf, buf + 16 * n, rest);
+                    fill = rest;
+                };
+                for (size_t r = cut[it]; r < cut[it + 1]; ++r) {
+                    const unsigned char *src = (const unsigned char *)bytes + offsets[r];
+                    size_t n = (size_t)(offsets[r + 1] - offsets[r]);
+                    while (n) {
+                        const size_t take = std::min(n, kBuf - fill);
+                        memcpy(buf + fill, src, take);
+                        fill += take; src += take; n -= take;
+                        if (fill == kBuf) drain(false);
+                    }
+                    buf[fill++] = '\n';
+                    if (fill == kBuf) drain(false);
+                }
+                drain(true);
+                for (; g < (pos[it + 1] >> 4); ++g) { h_codes[g] = 0; h_valid[g] = 0; }  // (never: a part's groups are exactly its bytes, padded)
+                packed[it / parts].fetch_add(1, std::memory_order_release);
+            }
+        });
+        hipError_t copy_err = hipSuccess;
+        char *d_base = (char *)t->d_stream.p;
+        for (size_t sl = 0; sl < nslices; ++sl) {
+            while (packed[sl].load(std::memory_order_acquire) < (int)parts) std::this_thread::yield();
+            const u64 g0 = pos[sl * parts] >> 4, g1 = pos[(sl + 1) * parts] >> 4;
+            if (g1 > g0 && copy_err == hipSuccess) copy_err = hipMemcpyAsync(d_base + g0 * 4, h_codes + g0, (g1 - g0) * 4, hipMemcpyHostToDevice, t->stream);
+            if (g1 > g0 && copy_err == hipSuccess) copy_err = hipMemcpyAsync(d_base + valid_off + g0 * 2, h_valid + g0, (g1 - g0) * 2, hipMemcpyHostToDevice, t->stream);
+        }
+        pool.wait();
+        HIP_TRY(copy_err);
+        KCT_DBG(t, "batch: packed upload of %llu bases enqueued\n", (unsigned long long)nbases);
+        KCT_TRY(consume_stream_packed(t, (const unsigned int *)d_base, (const unsigned short *)(d_base + valid_off), nbases, n_total));
+        t->consumed += total;
+        return KCT_OK;
+    }
     if (nthreads <= 1) {
         pack_range(0, nrec);
         if (!skip_bad) rec_off[nrec] = stream_len;
@@ -1384,6 +1533,31 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
     KCT_TRY(consume_stream(t, (const unsigned char *)t->d_stream.p, stream_len, n_total));
     KCT_DBG(t, "batch: counted\n");
     t->consumed += total;
+    return KCT_OK;
+}
+
+kct_status kct_consume_device_packed(kct_table *t, const void *d_codes, const void *d_valid, size_t nbases, uint64_t consumed_bytes, uint64_t *n_total) {
+    KCT_TRY(use_consume(t));
+    if (!n_total || ((!d_codes || !d_valid) && nbases)) { set_err("null argument"); return KCT_ERR_ARG; }
+    if (((uintptr_t)d_codes & 3) != 0 || ((uintptr_t)d_valid & 1) != 0) { set_err("d_codes / d_valid must be 4- / 2-byte aligned"); return KCT_ERR_ARG; }
+    KCT_TRY(consume_stream_packed(t, (const unsigned int *)d_codes, (const unsigned short *)d_valid, nbases, n_total));
+    t->consumed += consumed_bytes;
+    return KCT_OK;
+}
+
+kct_status kct_pack_stream_device(const void *d_stream, size_t nbytes, void *d_codes, void *d_valid, void *stream) {
+    const u64 ng = ((u64)nbytes + 15) >> 4;
+    if (!ng) return KCT_OK;
+    if (!d_stream || !d_codes || !d_valid || ((uintptr_t)d_stream & 15)) { set_err("null or misaligned argument"); return KCT_ERR_ARG; }
+    hipLaunchKernelGGL(kct::pack_stream_kernel, dim3((unsigned)std::min<u64>((ng + kct::kBlock - 1) / kct::kBlock, 1u << 16)), dim3(kct::kBlock), 0, (hipStream_t)stream,
+                       (const unsigned char *)d_stream, (u64)nbytes, (unsigned int *)d_codes, (unsigned short *)d_valid, ng);
+    HIP_TRY(hipGetLastError());
+    return KCT_OK;
+}
+
+kct_status kct_set_packed_upload(kct_table *t, int on) {
+    if (!t) { set_err("null table handle"); return KCT_ERR_ARG; }
+    t->packed_upload = on != 0;
     return KCT_OK;
 }
 

@@ -168,6 +168,12 @@ struct kct_table {
     u64 pending_records = 0;
     bool poisoned = false;  // a device pass over buffered records failed half-way: counts already reported are missing for good,
                             // so every later call on this table fails too (kct_clear resets it)
+    // packed input (2-bit codes + validity bits, 16 bases per group): set while a packed stream is being counted; the `d_stream`
+    // pointers handed around inside kct_consume.hip are then offsets from packed_base (never dereferenced)
+    const unsigned int *packed_codes = nullptr;
+    const unsigned short *packed_valid = nullptr;
+    const unsigned char *packed_base = nullptr;
+    bool packed_upload = true;  // kct_consume_batch packs large skip-bad batches on the host and uploads 0.375 B per base
     bool auto_sized = true; // no capacity hint / reserve yet: bulk ingest ramps its launch size up with the table
     kcth::Tuning tune;      // measurement switches, fixed at create time
     int ablate = 0;         // = tune.ablate
@@ -209,6 +215,7 @@ struct kct_table {
     du64 *d_counters = nullptr;  // kNumCounters tallies + 8 scratch words (device)
     u64 *h_counters = nullptr;   // pinned mirror
     kcth::DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort, d_scratch2, d_regions2, d_irr2, d_pairs_ovf,
+        d_unpack,  // the ASCII image of a packed chunk, for the kernels that read bytes
         d_failed,  // K2: the numbers of the blocks it abandoned (partition_kernels.h FailedBlocks)
         d_prefix;  // error mode: the offending record's valid prefix (its own buffer: consume_stream reuses d_aux2 / d_spill)
     kcth::PinnedBuf h_stage;
@@ -274,6 +281,7 @@ kct_status merge_pairs_partitioned(kct_table *t, const du64 *d_keys, const du64 
 kct_status point_add(kct_table *t, u64 h, u64 *count_out);
 // kct_consume.hip
 kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 *n_out);
+kct_status consume_stream_packed(kct_table *t, const unsigned int *d_codes, const unsigned short *d_valid, u64 nbases, u64 *n_out);
 // ... its kernels' launchers and sizing rules, for kct_route.hip (which does not instantiate the kernels itself)
 void launch_partition(kct_table *t, int mode /* 0 hashes, 1 mix64 values, 2 compact */, const unsigned char *d_stream, u64 chunk_bytes, u64 ntiles,
                       const kct::PartitionArgs &pa);

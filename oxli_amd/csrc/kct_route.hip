@@ -22,14 +22,14 @@
 
 namespace kct {
 
-// region rho = bin * nwg + wg of K1's output ([wg][1024 bins][region_cap]) -> dst + off[rho]; cnt[rho] entries (whole 64-byte lines)
+// region rho = bin * nwg + wg of K1's output ([wg][P bins][region_cap]) -> dst + off[rho]; cnt[rho] entries (whole 64-byte lines)
 template <class T>
 __global__ __launch_bounds__(kBlock) void pack_regions_kernel(const T *__restrict__ scratch, u32 region_cap, const u32 *__restrict__ cnt,
-                                                              const u64 *__restrict__ off, u32 nregions, u32 nwg, T *__restrict__ dst) {
+                                                              const u64 *__restrict__ off, u32 nregions, u32 nwg, u32 P, T *__restrict__ dst) {
     constexpr u32 kVec = 16 / sizeof(T);
     for (u32 rho = blockIdx.x; rho < nregions; rho += gridDim.x) {
         const u32 bin = rho / nwg, wg = rho - bin * nwg, n = cnt[rho];
-        const uint4 *src = reinterpret_cast<const uint4 *>(scratch + ((u64)wg * 1024u + bin) * region_cap);
+        const uint4 *src = reinterpret_cast<const uint4 *>(scratch + ((u64)wg * P + bin) * region_cap);
         uint4 *out = reinterpret_cast<uint4 *>(dst + off[rho]);
         for (u32 i = threadIdx.x; i < n / kVec; i += kBlock) out[i] = src[i];
     }
@@ -134,6 +134,9 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     }
     const unsigned nb_me = lo[rank + 1] - lo[rank], bins_used = lo[world];
     const unsigned esz = mode == 2 ? 4 : 8;
+    // K1's ring is split over 2^pbits bins: as few as hold the bins in use, so that a bin is as deep as it can be
+    const int pbits = mode == 2 ? 10 : std::max(1, ceil_log2(bins_used));
+    const u64 P = 1ULL << pbits;
     Exchange ex{t, world, rank, alloc, xfn, user, {}};
     // the shadow the entries will be counted into (dedupe-first modes) -- first of all: making it may convert what an older
     // shadow holds, which uses the scratch buffers below
@@ -155,15 +158,14 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     unsigned int region_cap = region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)bins_used);
     region_cap = (region_cap + 15u) & ~15u;
     const unsigned int ovf_cap = overflow_capacity(tiles_per_wg * kct::kPartTile);
-    KCT_TRY(t->d_scratch.reserve((u64)nwg * 1024 * region_cap * esz));
-    KCT_TRY(t->d_regions.reserve((u64)nwg * 1024 * 4));
+    KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * esz));
+    KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
     KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
     KCT_TRY(zero_counters(t));
-    HIP_TRY(hipMemsetAsync(t->d_regions.p, 0, (u64)nwg * 1024 * 4, t->stream));  // (bins K1 does not use stay at zero)
     du64 *d_overflow = t->d_counters + kNumCounters + 6;
     unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
     kct::PartitionArgs pa;
-    pa.mask = t->cap - 1; pa.block_bits = kct::kBlockBitsMax + sub_bits; pa.pbits = 10;
+    pa.mask = t->cap - 1; pa.block_bits = kct::kBlockBitsMax + sub_bits; pa.pbits = pbits;
     pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
     pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
     pa.ablate = 0;
@@ -200,9 +202,9 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
         ProfScope ps(t, "pack_regions_kernel");
         const unsigned grid = (unsigned)std::min<u64>(nreg, 1u << 16);
         if (mode == 2) hipLaunchKernelGGL(kct::pack_regions_kernel<unsigned int>, dim3(grid), dim3(kct::kBlock), 0, t->stream, (const unsigned int *)t->d_scratch.p,
-                                          region_cap, (const unsigned int *)t->d_regions.p, (const du64 *)t->d_aux.p, (unsigned)nreg, (unsigned)nwg, (unsigned int *)d_send);
+                                          region_cap, (const unsigned int *)t->d_regions.p, (const du64 *)t->d_aux.p, (unsigned)nreg, (unsigned)nwg, (unsigned)P, (unsigned int *)d_send);
         else hipLaunchKernelGGL(kct::pack_regions_kernel<du64>, dim3(grid), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_scratch.p, region_cap,
-                                (const unsigned int *)t->d_regions.p, (const du64 *)t->d_aux.p, (unsigned)nreg, (unsigned)nwg, (du64 *)d_send);
+                                (const unsigned int *)t->d_regions.p, (const du64 *)t->d_aux.p, (unsigned)nreg, (unsigned)nwg, (unsigned)P, (du64 *)d_send);
         HIP_TRY(hipGetLastError());
     }
     // ---- K1's overflow entries, bucketed by owner ----------------------------------------------------------------------------
@@ -259,7 +261,7 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     }
     u64 recv_ovf_total = 0;
     for (u64 v : recv_ovf) recv_ovf_total += v;
-    KCT_TRY(t->d_regions.reserve(std::max<u64>((u64)nwg * 1024 * 4, nidx * 4)));
+    KCT_TRY(t->d_regions.reserve(std::max<u64>((u64)nwg * P * 4, nidx * 4)));
     KCT_TRY(t->d_aux.reserve(nidx * 8 + 64));
     HIP_TRY(hipMemcpyAsync(t->d_regions.p, h_c2.data(), nidx * 4, hipMemcpyHostToDevice, t->stream));
     HIP_TRY(hipMemcpyAsync(t->d_aux.p, h_o2.data(), nidx * 8, hipMemcpyHostToDevice, t->stream));

@@ -22,6 +22,11 @@ struct PartitionArgs {
     // top 10 bits either way): bin = owner * 2^pl_bits + local super-bin, owner = floor(hi32(value) * world / 2^32)
     u32 world = 0;       // 0 = off
     int pl_bits = 0;
+    // PACKED input ("packed base arrays", BASELINE north star): the record stream as 2-bit codes + validity bits, sixteen bases
+    // per group -- codes[g] (first base in bits 31:30) and valid[g] (first base in bit 15), exactly what encode16 makes of the
+    // ASCII stream.  When pcodes is set, `stream` is ignored and group g of this launch is pcodes[g] / pvalid[g].  (k <= 64.)
+    const u32 *pcodes = nullptr;
+    const unsigned short *pvalid = nullptr;
 };
 
 struct RepartitionArgs {

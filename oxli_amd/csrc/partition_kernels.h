@@ -174,10 +174,24 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         }
         return v;
     };
+    // packed input: a group's code word and validity bits travel in .x / .y of the same prefetch registers
+    const bool packed = KW != 0 && a.pcodes != nullptr;  // (workgroup-uniform)
+    auto load_group = [&](u64 tile_base, int c) -> uint4 {
+        const u64 g = (tile_base >> 4) + (u64)c, off = g << 4;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (off < nbytes) {
+            v.x = a.pcodes[g];
+            u32 vb = a.pvalid[g];
+            if (off + 16 > nbytes) vb &= ~((1u << (16 - (u32)(nbytes - off))) - 1u);  // bases at or beyond nbytes do not exist
+            v.y = vb;
+        }
+        return v;
+    };
+    auto load_any = [&](u64 tile_base, int c) -> uint4 { return packed ? load_group(tile_base, c) : load_chunk(tile_base, c); };
     uint4 pre_main = make_uint4(0, 0, 0, 0), pre_halo = make_uint4(0, 0, 0, 0);
     if (blockIdx.x < ntiles) {
-        pre_main = load_chunk((u64)blockIdx.x * kPartTile, threadIdx.x);
-        if (threadIdx.x < 16) pre_halo = load_chunk((u64)blockIdx.x * kPartTile, kPartThreads + threadIdx.x);
+        pre_main = load_any((u64)blockIdx.x * kPartTile, threadIdx.x);
+        if (threadIdx.x < 16) pre_halo = load_any((u64)blockIdx.x * kPartTile, kPartThreads + threadIdx.x);
     }
     for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();  // the previous tile's readers are done with `lds`; ring/fill init is visible
@@ -186,18 +200,20 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
             if (threadIdx.x < 16) reinterpret_cast<uint4 *>(lds)[kPartThreads + threadIdx.x] = pre_halo;
         } else {
             u32 c, v;
-            encode16(pre_main, c, v);
+            if (packed) { c = pre_main.x; v = pre_main.y; }
+            else encode16(pre_main, c, v);
             tcodes[threadIdx.x] = c; tvalid[threadIdx.x] = (unsigned short)v;
             if (threadIdx.x < 16) {
-                encode16(pre_halo, c, v);
+                if (packed) { c = pre_halo.x; v = pre_halo.y; }
+                else encode16(pre_halo, c, v);
                 tcodes[kPartThreads + threadIdx.x] = c; tvalid[kPartThreads + threadIdx.x] = (unsigned short)v;
             }
         }
         __syncthreads();
         const u64 next = tile + gridDim.x;
         if (next < ntiles) {
-            pre_main = load_chunk(next * kPartTile, threadIdx.x);
-            if (threadIdx.x < 16) pre_halo = load_chunk(next * kPartTile, kPartThreads + threadIdx.x);
+            pre_main = load_any(next * kPartTile, threadIdx.x);
+            if (threadIdx.x < 16) pre_halo = load_any(next * kPartTile, kPartThreads + threadIdx.x);
         }
         // The append is software-pipelined: window j's ring cursor is bumped (ds_add_rtn_u32) and the
         // block's flush mark is read as soon as its hash exists, but the returned position is only

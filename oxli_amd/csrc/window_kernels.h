@@ -195,6 +195,38 @@ __device__ __forceinline__ void walk_windows(const unsigned char *lds, int k, Si
     else walk_windows_packed<KW, KC, WPT>(lds, k, sink);
 }
 
+// ---- packed base arrays <-> ASCII record stream -----------------------------------------------------------------
+// pack: group g = bytes [16g, 16g + 16) of the stream through encode16 (bytes past nbytes are invalid).
+__global__ __launch_bounds__(kBlock) void pack_stream_kernel(const unsigned char *__restrict__ stream, u64 nbytes, u32 *__restrict__ codes,
+                                                             unsigned short *__restrict__ valid, u64 ngroups) {
+    for (u64 g = (u64)blockIdx.x * kBlock + threadIdx.x; g < ngroups; g += (u64)gridDim.x * kBlock) {
+        const u64 off = g << 4;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (off + 16 <= nbytes) v = *reinterpret_cast<const uint4 *>(stream + off);
+        else {
+            unsigned char tmp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tmp[i] = (off + i < nbytes) ? stream[off + i] : (unsigned char)0;
+            v = *reinterpret_cast<uint4 *>(tmp);
+        }
+        u32 c, vb;
+        encode16(v, c, vb);
+        codes[g] = c; valid[g] = (unsigned short)vb;
+    }
+}
+// unpack: 'A' 'C' 'G' 'T' for valid bases, 'N' for the others (case and the identity of an invalid byte are not kept -- neither
+// matters to any count: a window is good iff its k bytes are all ACGT after upper-casing).  For the kernels that read bytes.
+__global__ __launch_bounds__(kBlock) void unpack_stream_kernel(const u32 *__restrict__ codes, const unsigned short *__restrict__ valid, u64 ngroups,
+                                                               unsigned char *__restrict__ out) {
+    for (u64 g = (u64)blockIdx.x * kBlock + threadIdx.x; g < ngroups; g += (u64)gridDim.x * kBlock) {
+        const u32 c = codes[g], vb = valid[g];
+        unsigned char b[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b[i] = (vb >> (15 - i)) & 1u ? (unsigned char)((0x54474341u >> (8 * ((c >> (30 - 2 * i)) & 3u))) & 0xFFu) : (unsigned char)'N';
+        *reinterpret_cast<uint4 *>(out + (g << 4)) = *reinterpret_cast<uint4 *>(b);
+    }
+}
+
 // ---- hash-only kernel: SeqToHashes as consume drives it (lib.rs:576-600) ------------------------
 // out[p] = hash of the window starting at p (0 if bad), p in [0, nwindows);
 // *first_bad = min index of a bad window (left untouched if none).

@@ -297,6 +297,19 @@ class KmerCountTable:
         self._check(self._lib.kct_consume_device(self._h, C.c_void_p(int(data_ptr)), int(nbytes), int(consumed_bytes), C.byref(n)))
         return n.value
 
+    def consume_device_packed(self, codes_ptr, valid_ptr, nbases, consumed_bytes):
+        """Counts a PACKED record stream in HBM: ``codes`` (uint32 per 16 bases) and ``valid`` (uint16 per 16 bases), see
+        include/kct.h.  Raw device addresses."""
+        n = C.c_uint64()
+        self._check(self._lib.kct_consume_device_packed(self._h, C.c_void_p(int(codes_ptr)), C.c_void_p(int(valid_ptr)), int(nbases),
+                                                        int(consumed_bytes), C.byref(n)))
+        return n.value
+
+    def set_packed_upload(self, on=True):
+        """Large skip-bad batches of ``consume_batch`` are packed to 2 bits + 1 validity bit per base on the host before the
+        upload (``kct_set_packed_upload``; on by default).  Results do not depend on it."""
+        self._check(self._lib.kct_set_packed_upload(self._h, 1 if on else 0))
+
     # ---- attributes ---------------------------------------------------------------------------------
     def __len__(self):
         out = C.c_uint64()

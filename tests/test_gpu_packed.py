@@ -1,0 +1,121 @@
+"""Packed base arrays (include/kct.h: 2-bit codes + validity bits, sixteen bases per group) as the input format: the device
+packer against a plain numpy encoding, ``kct_consume_device_packed`` against the ASCII stream and the oracle on every path,
+and ``kct_consume_batch``'s packed upload (host SIMD packer, 0.375 B per base over PCIe) against its ASCII upload and the
+oracle -- lower case, N, non-ASCII bytes, records shorter than k, empty records (lib.rs:548 byte semantics, 576-600)."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import OracleTable  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from oxli_amd import KmerCountTable, _lib
+    return torch, KmerCountTable, _lib.load()
+
+
+def messy_records(rng, n, lo=0, hi=400):
+    alphabet = "ACGT" * 30 + "acgt" * 4 + "N" + "n" + "R" + "é" + "-"
+    recs = []
+    for _ in range(n):
+        L = rng.randint(lo, hi)
+        recs.append("".join(rng.choice(alphabet) for _ in range(L)) if rng.random() < 0.3 else "".join(rng.choice("ACGT") for _ in range(L)))
+    return recs
+
+
+def np_pack(stream):
+    """Reference encoding of a byte stream: codes (first base in bits 31:30) and validity (first base in bit 15) per 16 bytes."""
+    b = np.frombuffer(stream + b"\n" * ((-len(stream)) % 16), dtype=np.uint8).reshape(-1, 16)
+    low = b | 0x20
+    ok = (low == ord("a")) | (low == ord("c")) | (low == ord("g")) | (low == ord("t"))
+    x = (b >> 1) & 3
+    x = x ^ (x >> 1)
+    x = np.where(ok, x, 0).astype(np.uint32)
+    shifts = np.arange(30, -2, -2, dtype=np.uint32)
+    codes = (x << shifts).sum(axis=1).astype(np.uint32)
+    valid = (ok.astype(np.uint32) << np.arange(15, -1, -1, dtype=np.uint32)).sum(axis=1).astype(np.uint16)
+    return codes, valid
+
+
+def test_device_packer_matches_numpy(gpu):
+    torch, _, lib = gpu
+    rng = random.Random(3)
+    stream = ("\n".join(messy_records(rng, 3000)) + "\n").encode("utf-8")
+    dev = torch.frombuffer(bytearray(stream + b"\n" * ((-len(stream)) % 16)), dtype=torch.uint8).cuda()
+    ng = (len(stream) + 15) // 16
+    codes = torch.zeros(ng, dtype=torch.int32, device="cuda")
+    valid = torch.zeros(ng, dtype=torch.int16, device="cuda")
+    assert lib.kct_pack_stream_device(dev.data_ptr(), len(stream), codes.data_ptr(), valid.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    rc, rv = np_pack(stream)
+    got_v = valid.cpu().numpy().view(np.uint16)
+    assert np.array_equal(got_v, rv)
+    # (codes under invalid bases are unspecified on the device: compare the valid ones)
+    mask = np.repeat(((rv[:, None] >> np.arange(15, -1, -1, dtype=np.uint16)) & 1).astype(np.uint32), 1, axis=1)
+    keep = (mask * np.uint32(3) << np.arange(30, -2, -2, dtype=np.uint32)).sum(axis=1).astype(np.uint32)
+    assert np.array_equal(codes.cpu().numpy().view(np.uint32) & keep, rc & keep)
+
+
+@pytest.mark.parametrize("k,path", [(21, "auto"), (21, "dedupe"), (21, "partitioned"), (21, "direct"), (31, "dedupe"), (31, "partitioned"),
+                                    (51, "partitioned"), (64, "auto"), (1, "auto"), (5, "direct"), (90, "partitioned")])
+def test_packed_device_stream_equals_ascii_and_oracle(gpu, k, path):
+    torch, KCT, lib = gpu
+    rng = random.Random(100 + k)
+    recs = messy_records(rng, 20000, 0, 300) + ["".join(rng.choice("ACGT") for _ in range(600_000))] + messy_records(rng, 20000, 100, 200)
+    ref = OracleTable(k)
+    n_ref = sum(ref.consume(r) for r in recs)
+    stream = ("\n".join(recs) + "\n").encode("utf-8")
+    dev = torch.frombuffer(bytearray(stream + b"\n" * ((-len(stream)) % 16)), dtype=torch.uint8).cuda()
+    ng = (len(stream) + 15) // 16
+    codes = torch.zeros(ng, dtype=torch.int32, device="cuda")
+    valid = torch.zeros(ng, dtype=torch.int16, device="cuda")
+    assert lib.kct_pack_stream_device(dev.data_ptr(), len(stream), codes.data_ptr(), valid.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    consumed = sum(len(r.encode("utf-8")) for r in recs)
+    rk, rc = ref.dump_arrays()
+    for packed in (True, False):
+        t = KCT(k, capacity=3_000_000)
+        t.set_path(path)
+        n = t.consume_device_packed(codes.data_ptr(), valid.data_ptr(), len(stream), consumed) if packed else \
+            t.consume_device(dev.data_ptr(), len(stream), consumed)
+        assert n == n_ref, (packed, n, n_ref)
+        dk, dc = t.dump_arrays(1)
+        assert np.array_equal(dk, rk) and np.array_equal(dc, rc), packed
+        assert t.consumed == ref.consumed
+
+
+@pytest.mark.parametrize("k", [21, 31, 51])
+def test_batch_packed_upload_equals_ascii_upload_and_oracle(gpu, k):
+    """kct_consume_batch with >= 8 MiB of records: the host packers (16 pool threads, SSSE3) + packed H2D, against the ASCII
+    upload and the oracle.  Ragged records, empty ones, lower case, N, multi-byte UTF-8."""
+    torch, KCT, _ = gpu
+    rng = random.Random(7 + k)
+    recs = messy_records(rng, 60000, 0, 400) + [""] * 50 + ["".join(rng.choice("ACGT") for _ in range(150)) for _ in range(30000)] + \
+        ["".join(rng.choice("ACGTacgtN") for _ in range(2_000_003))]
+    rng.shuffle(recs)
+    assert sum(len(r) for r in recs) > (9 << 20)
+    ref = OracleTable(k)
+    n_ref = sum(ref.consume(r) for r in recs)
+    rk, rc = ref.dump_arrays()
+    for packed in (True, False):
+        t = KCT(k, capacity=8_000_000)
+        t.set_packed_upload(packed)
+        t.profile(True)
+        assert t.consume_batch(recs) == n_ref
+        dk, dc = t.dump_arrays(1)
+        assert np.array_equal(dk, rk) and np.array_equal(dc, rc), packed
+        assert t.consumed == ref.consumed
+        # error mode never packs (the first bad byte is found on the ASCII stream): same answer either way
+        with pytest.raises(ValueError) as e1:
+            t.consume_batch(recs, skip_bad_kmers=False)
+        r2 = OracleTable(k)
+        with pytest.raises(ValueError) as e2:
+            for r in recs:
+                r2.consume(r, skip_bad_kmers=False)
+        assert str(e1.value) == str(e2.value)
