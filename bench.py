@@ -431,11 +431,11 @@ def main():
     # ------------------------------------------------------------------------------------------ the other configs
     configs = {}
 
-    def timed_call(t, fn, cold):
+    def timed_call(t, fn, cold, path=None):
         """One call on an existing table: cleared, and (cold) made to forget what it learnt about its input."""
         t.clear()
         if cold:
-            t.set_path(args.path)  # (resets the dedupe hint)
+            t.set_path(path or args.path)  # (resets the dedupe hint)
         t.profile(True)
         t.profile_reset()
         torch.cuda.synchronize()
@@ -615,7 +615,7 @@ def main():
                 t.set_path(path)
                 call = lambda: t.consume_device(r.data_ptr(), r.numel(), Rb * Lb)  # noqa: E731
                 call(); t.sync()                                  # allocations
-                runs = [timed_call(t, call, True) for _ in range(3 if path != "direct" else 1)]
+                runs = [timed_call(t, call, True, path) for _ in range(3 if path != "direct" else 1)]
                 dt, n, prof = sorted(runs, key=lambda x: x[0])[len(runs) // 2]
                 tables[path] = (n, len(t), t.sum_counts) + t.digest()
                 if path == "auto":

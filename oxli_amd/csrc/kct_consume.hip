@@ -205,7 +205,17 @@ constexpr u64 kProbeWindows = 1ULL << 22;
 constexpr u64 kProbeShadowSlots = 1ULL << (10 + kct::kBlockBitsMax);
 kct_status flush_compact(kct_table *t);
 
-bool dedupe_pays(const kct_table *t, u64 npos) {
+// A dedupe-first run also pays for its SHADOW, whatever the input: the first K2 pass stores every shadow block and the
+// conversion reads (and re-zeroes) every slot -- ~2.5 bytes of streaming per shadow byte at ~4.5 TB/s -- while a dedupe-first
+// pass saves ~3.75 ps per window over hashing it (K1 0.92 -> 0.35 ms per 1.5x10^8 windows): ~0.15 windows per shadow byte must
+// be consumed between two reads of the table.  Negligible for a table of up to 1024 blocks (64 MiB of compact shadow: 10^7
+// windows); decisive for a small two-level table, whose compact shadow is 4 GiB at least (C2-sized reads with 1 % substitution
+// errors into a 2^26-slot table: 7.2 ms dedupe-first against 2.4 ms hashing every window, tools/err_probe.py).
+u64 shadow_bytes_for(const kct_table *t, bool compact);
+bool shadow_amortises(const kct_table *t, bool compact, u64 windows) { return (double)windows >= 0.15 * (double)shadow_bytes_for(t, compact); }
+
+// (everything but the shadow's own cost, which differs between the variants)
+bool dedupe_pays_but_for_the_shadow(const kct_table *t, u64 npos) {
     if (t->k > 32 || t->dedupe_off || npos < (1ULL << 22) || !partition_geometry_ok(t)) return false;
     if (t->force_path == 3) return true;
     if (t->force_path != 0 || !partition_pays(t, npos)) return false;  // the shadow mirrors the table's geometry
@@ -215,6 +225,11 @@ bool dedupe_pays(const kct_table *t, u64 npos) {
     // Converting pays once ~16 (32) windows have been counted per distinct k-mer between two reads of the table.  The
     // caller's run so far is the evidence that reads are that rare -- and nothing can read before the running call ends.
     return known * windows_per_pending_key(t) <= t->windows_since_read + std::max(npos, t->call_windows_left);
+}
+
+bool dedupe_pays(const kct_table *t, u64 npos) {  // the 64-bit variant: a table-sized shadow
+    if (!dedupe_pays_but_for_the_shadow(t, npos)) return false;
+    return t->force_path == 3 || t->shadow_dirty || shadow_amortises(t, false, t->windows_since_read + std::max(npos, t->call_windows_left));
 }
 
 // The shadow mirrors the real table's capacity (the same k-mers live in both) -- except for the dedupe probe's, which is
@@ -242,6 +257,10 @@ constexpr int kCompactBlockBits = 10;
 int compact_sbits_for(const kct_table *t) {
     const int bbits = log2_u64(t->cap >> t->block_bits);
     return bbits <= 10 ? kCompactBlockBits : std::max(16, bbits);
+}
+// the shadow a dedupe-first run of this table would use
+u64 shadow_bytes_for(const kct_table *t, bool compact) {
+    return compact ? (1ULL << (compact_sbits_for(t) + kct::kBlockBitsMax)) * 8 : t->cap * 16;
 }
 u64 compact_slots(const kct_table *t) { return ((u64)t->s32_nbins << (t->s32_sbits - kCompactBlockBits)) << kct::kBlockBitsMax; }
 
@@ -552,7 +571,8 @@ kct_status after_dedupe_pass(kct_table *t, bool compact, u64 npos, const DedupeO
 // ring flushes.  With a shadow of more than 1024 blocks a second partition level (repartition_kernel<u32>) sits between.
 // Same contract as consume_partitioned(raw = true).
 bool compact_pays(const kct_table *t, u64 npos) {
-    if (t->k > 21 || t->compact_off || !dedupe_pays(t, npos)) return false;
+    if (t->k > 21 || t->compact_off || !dedupe_pays_but_for_the_shadow(t, npos)) return false;
+    if (t->force_path != 3 && !t->s32_dirty && !shadow_amortises(t, true, t->windows_since_read + std::max(npos, t->call_windows_left))) return false;
     if (compact_sbits_for(t) > kCompactBlockBits) return true;  // a shadow as large as the table
     const u64 known = std::max(t->n_keys, t->s32_keys);
     return known <= (u64)((double)(1ULL << (kCompactBlockBits + kct::kBlockBitsMax)) * 0.6);
@@ -979,7 +999,9 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
             (unsigned long long)t->cap);
     bool probe = t->force_path == 0 && t->k <= 32 && !t->dedupe_off && !t->dedupe_hint && !t->auto_sized &&
                  std::max({t->n_keys, t->shadow_keys, t->s32_keys}) == 0 && call_windows >= 8 * kProbeWindows &&
-                 t->cap >= kProbeShadowSlots && partition_geometry_ok(t) && partition_pays(t, call_windows);
+                 t->cap >= kProbeShadowSlots && partition_geometry_ok(t) && partition_pays(t, call_windows) &&
+                 ((t->k <= 21 && !t->compact_off && shadow_amortises(t, true, t->windows_since_read + call_windows)) ||
+                  shadow_amortises(t, false, t->windows_since_read + call_windows));  // (no shadow this call could pay for: no probe)
     if (call_windows > chunk_limit) {  // passes of equal size
         const u64 passes = (call_windows + chunk_limit - 1) / chunk_limit;
         chunk_limit = std::min(chunk_limit, (((call_windows + passes - 1) / passes) + 0xFFFF) & ~(u64)0xFFFF);
@@ -1028,7 +1050,8 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
                 }
                 const double x = draws_per_distinct((double)fresh_keys / (double)valid);         // the probe's k-mers per distinct k-mer
                 const double per_key = x * (double)call_windows / (double)npos;                  // ... the whole call's
-                const bool pays = per_key >= (double)windows_per_pending_key(t);
+                const bool pays = per_key >= (double)windows_per_pending_key(t) &&
+                                  (shadow_amortises(t, use_compact, t->windows_since_read + call_windows) || shadow_amortises(t, false, t->windows_since_read + call_windows));
                 KCT_DBG(t, "dedupe probe%s: %llu k-mers, %llu first sightings -> ~%.3g k-mers per distinct k-mer over the call: %s\n", dry_run ? " (dry run)" : "",
                         (unsigned long long)valid, (unsigned long long)fresh_keys, per_key, pays ? "dedupe-first" : "hash every window");
                 // (a "no" is a verdict on THIS call: later calls are judged by what the table holds and how long the caller's

@@ -157,7 +157,9 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
     unsigned int region_cap = region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)bins_used);
     region_cap = (region_cap + 15u) & ~15u;
-    const unsigned int ovf_cap = overflow_capacity(tiles_per_wg * kct::kPartTile);
+    // (an abandoned pass cannot fall back to the direct kernel here: room for EVERY entry of a workgroup, up to the 2^20 the ring's
+    // position arithmetic allows -- only a workgroup with more than a million overflowing entries makes the call fail)
+    const unsigned int ovf_cap = (unsigned int)std::min<u64>(1ULL << 20, std::max<u64>(4096, tiles_per_wg * kct::kPartTile));
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * esz));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
     KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
@@ -269,7 +271,8 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     HIP_TRY(hipMemcpyAsync(d_ovf_total, &recv_ovf_total, 8, hipMemcpyHostToDevice, t->stream));
 
     // ---- K1b: every super-bin of mine over its 2^sub_bits blocks ---------------------------------------------------------------
-    const u64 B = (u64)nb_me << sub_bits, W = std::max<u64>(1, (u64)nwg / nb_me);
+    // (a writer's sixteen waves take one input segment each: more than nseg / 16 writers would find nothing to read)
+    const u64 B = (u64)nb_me << sub_bits, W = std::max<u64>(1, std::min<u64>((u64)nwg / nb_me, nseg / 16));
     unsigned int out_cap = region_capacity((double)total_recv / (double)B / (double)W);
     out_cap = (out_cap + 63u) & ~63u;
     const unsigned int ovf2_cap = overflow_capacity(total_recv / nb_me / W);

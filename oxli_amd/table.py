@@ -13,7 +13,12 @@ import numpy as np
 
 from . import _lib as L
 
-__all__ = ["KmerCountTable", "VERSION"]
+__all__ = ["KmerCountTable", "VERSION", "PanicException"]
+
+
+class PanicException(BaseException):
+    """What a Rust panic surfaces as under pyo3 (``pyo3_runtime.PanicException``, a ``BaseException``): the reference's
+    ``get`` panics on invalid DNA of the right length (lib.rs:176 ``.expect("error hashing this k-mer")``)."""
 
 _COMP = str.maketrans("ACGT", "TGCA")
 
@@ -180,7 +185,7 @@ class KmerCountTable:
             raise ValueError("kmer size does not match count table ksize")
         if st == L.KCT_ERR_INVALID_DNA:
             # the reference panics here (lib.rs:176 `.expect`), surfacing pyo3's PanicException
-            raise RuntimeError("error hashing this k-mer")
+            raise PanicException(f"error hashing this k-mer: invalid DNA character in input k-mer: {kmer}")
         self._check(st)
         return out.value
 
@@ -545,7 +550,8 @@ class KmerCountTable:
         import sys
         lib = L.load()
         if not os.path.exists(filepath):
-            raise OSError(f"cannot open {filepath}")
+            # File::open fails inside a function returning anyhow::Result (lib.rs:296-299): pyo3 turns that into RuntimeError
+            raise RuntimeError("No such file or directory (os error 2)")
         h = C.c_void_p()
         st = lib.kct_load(str(filepath).encode(), int(device), C.byref(h))
         if st != L.KCT_OK:

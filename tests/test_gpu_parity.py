@@ -84,6 +84,23 @@ def test_hash_windows_equal_oracle_every_k(KCT):
             assert np.array_equal(got, want), f"k={k}"
 
 
+def test_exception_types_at_the_two_panic_and_anyhow_edges(KCT, tmp_path):
+    """get() on invalid DNA of the right length: the reference PANICS (lib.rs:176 `.expect`), which pyo3 surfaces as
+    PanicException -- a BaseException, not caught by `except Exception`.  load() of a missing path: File::open fails inside an
+    anyhow::Result function (lib.rs:296-299), which pyo3 turns into RuntimeError (save() to a bad path is a PyIOError)."""
+    from oxli_amd.table import PanicException
+    t = KCT(4)
+    with pytest.raises(PanicException, match="error hashing this k-mer"):
+        t.get("ACGN")
+    assert not issubclass(PanicException, Exception)
+    with pytest.raises(ValueError):
+        t.get("ACG")
+    with pytest.raises(RuntimeError, match="No such file or directory"):
+        KCT.load(str(tmp_path / "missing.json.gz"))
+    with pytest.raises(OSError, match="No such file or directory"):
+        t.save(str(tmp_path / "noexist" / "t.json.gz"))
+
+
 def test_hash_kmer_errors(KCT):
     t = KCT(4)
     with pytest.raises(RuntimeError, match="wrong ksize"):
