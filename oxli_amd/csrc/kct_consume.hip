@@ -5,8 +5,12 @@
 #include <type_traits>
 #include <emmintrin.h>
 #include "partition_kernels.h"
+#include "path_policy.h"
 
 namespace kcth {
+
+static_assert(kPolicyBlockBitsMax == kct::kBlockBitsMax && kPolicyPartTile == kct::kPartTile && kPolicyRingEntries == kct::kRingEntries,
+              "path_policy.h restates these constants");
 
 template <template <int, int> class Launcher, class... Args>
 void dispatch_k(int k, Args &&...args) {
@@ -123,61 +127,6 @@ static void packed_args(const kct_table *t, const unsigned char *d_stream, kct::
     pa->pvalid = t->packed_valid + g0;
 }
 
-// The partitioned path pays 16 B (one level) or 32 B (two levels) of streaming scratch traffic per
-// k-mer plus 32 B per table slot per pass; the direct path pays one memory-side atomic per k-mer.
-// It wins once a pass brings a fair fraction as many windows as the table has slots.
-bool partition_geometry_ok(const kct_table *t) {
-    const u64 nblocks = t->cap >> t->block_bits;
-    return nblocks >= 16 && t->cap <= (1ULL << 33);  // two levels of 1024 bins x 8192 slots: 128 GiB of table
-}
-
-bool partition_pays(const kct_table *t, u64 npos) {
-    const u64 nblocks = t->cap >> t->block_bits;
-    if (!partition_geometry_ok(t) || npos < (1ULL << 20)) return false;
-    return nblocks <= 1024 ? npos >= t->cap / 4 : npos >= t->cap / 2;
-}
-
-unsigned int region_capacity(double avg) {
-    return (unsigned int)((((u64)(avg * 1.15 + 8.0 * __builtin_sqrt(avg) + 64.0)) + 7) & ~7ULL);
-}
-
-// How a table of 2^bbits blocks is reached: K1 (or the first level of a pair flush) fans out to 2^pbits bins through its
-// LDS ring -- at most 1024 --, each holding 2^sub_bits table blocks that the second level (repartition_kernel) separates.
-// The second level wants >= 64 bins per super-bin: with 16 its lanes fight over a handful of LDS cursors (2.5x slower per
-// entry), so small two-level tables give the first level FEWER bins, and W workgroups share a super-bin so that the second
-// level still fills the chip.
-struct Levels {
-    int bbits, pbits, sub_bits;
-    bool two;
-    u64 P, B, W;
-};
-
-Levels levels_for(int bbits, int nwg, int forced_pbits = -1) {
-    Levels L;
-    L.bbits = bbits;
-    L.two = bbits > 10;
-    L.pbits = bbits;
-    if (L.two) L.pbits = bbits <= 14 ? bbits - 6 : std::min(10, bbits - 7);
-    if (forced_pbits >= 0 && L.two) L.pbits = std::max(bbits - 10, std::min(10, forced_pbits));  // (Tuning::pbits: measurement only)
-    L.sub_bits = bbits - L.pbits;
-    L.P = 1ULL << L.pbits;
-    L.B = 1ULL << bbits;
-    L.W = L.two ? std::max<u64>(1, (u64)nwg / L.P) : 1;
-    return L;
-}
-
-// second partition level: lines of a bin that leave the ring together -- 2 or 4 when the ring is deep enough (its depth in
-// lines per bin >= 4x that), so that the scattered 64-byte stores become 128- or 256-byte ones (K1b: 1 -> 2 lines -13 %,
-// 2 -> 4 lines another -4 %)
-unsigned int repartition_min_lines(const kct_table *t, int ring_entries, int sub_bits, int entry_bytes) {
-    if (t->tune.k1b_lines) return (unsigned int)t->tune.k1b_lines;  // (measurement only)
-    const int lines_per_bin = (ring_entries >> sub_bits) * entry_bytes / 64;
-    return lines_per_bin >= 16 ? 4u : lines_per_bin >= 8 ? 2u : 1u;
-}
-
-// overflow regions: an eighth of a workgroup's entries, but few enough that ring positions (21 bits in ring_flush's line
-// list) cannot wrap before a hopelessly skewed pass is abandoned
-unsigned int overflow_capacity(u64 entries_per_wg) { return (unsigned int)std::min<u64>(1ULL << 20, std::max<u64>(4096, entries_per_wg / 8)); }
 
 // Dedupe-first pass (k <= 32).  Reads that cover a small genome deeply repeat every k-mer tens of times per pass, and
 // ~55 % of K1's instructions are MurmurHash3 plus the ASCII re-expansion.  So the pass counts PACKED k-mers: K1 (RAW)
@@ -194,43 +143,7 @@ kct::TableGeom shadow_geom(const kct_table *t) {
     return g;
 }
 
-// windows a dedupe-first pass must amortise per k-mer it leaves pending: a flush costs ~0.04-0.05 ns per pending k-mer when
-// the pairs are partitioned (~0.11 ns with one random table access each), a dedupe-first pass saves ~3-5 ps per window
-u64 windows_per_pending_key(const kct_table *t) { return partition_geometry_ok(t) && t->block_bits == kct::kBlockBitsMax ? 16 : 32; }
-
-// The dedupe probe of a large call into a table that knows nothing yet: 2^22 window starts counted into a SMALL shadow
-// (1024 blocks: one partition level, whatever the table's size) that could hold every one of their k-mers, were they all
-// distinct.  ~0.5 ms, and 4 million draws fix the number of distinct k-mers behind the input to about a percent.
-constexpr u64 kProbeWindows = 1ULL << 22;
-constexpr u64 kProbeShadowSlots = 1ULL << (10 + kct::kBlockBitsMax);
 kct_status flush_compact(kct_table *t);
-
-// A dedupe-first run also pays for its SHADOW, whatever the input: the first K2 pass stores every shadow block and the
-// conversion reads (and re-zeroes) every slot -- ~2.5 bytes of streaming per shadow byte at ~4.5 TB/s -- while a dedupe-first
-// pass saves ~3.75 ps per window over hashing it (K1 0.92 -> 0.35 ms per 1.5x10^8 windows): ~0.15 windows per shadow byte must
-// be consumed between two reads of the table.  Negligible for a table of up to 1024 blocks (64 MiB of compact shadow: 10^7
-// windows); decisive for a small two-level table, whose compact shadow is 4 GiB at least (C2-sized reads with 1 % substitution
-// errors into a 2^26-slot table: 7.2 ms dedupe-first against 2.4 ms hashing every window, tools/err_probe.py).
-u64 shadow_bytes_for(const kct_table *t, bool compact);
-bool shadow_amortises(const kct_table *t, bool compact, u64 windows) { return (double)windows >= 0.15 * (double)shadow_bytes_for(t, compact); }
-
-// (everything but the shadow's own cost, which differs between the variants)
-bool dedupe_pays_but_for_the_shadow(const kct_table *t, u64 npos) {
-    if (t->k > 32 || t->dedupe_off || npos < (1ULL << 22) || !partition_geometry_ok(t)) return false;
-    if (t->force_path == 3) return true;
-    if (t->force_path != 0 || !partition_pays(t, npos)) return false;  // the shadow mirrors the table's geometry
-    // few distinct k-mers, each many times?  What the table (or the shadow) holds so far is the best guess.
-    const u64 known = std::max({t->n_keys, t->shadow_keys, t->s32_keys});
-    if (known == 0) return t->dedupe_hint;  // nothing counted yet (new or cleared table): go by how the last pass went
-    // Converting pays once ~16 (32) windows have been counted per distinct k-mer between two reads of the table.  The
-    // caller's run so far is the evidence that reads are that rare -- and nothing can read before the running call ends.
-    return known * windows_per_pending_key(t) <= t->windows_since_read + std::max(npos, t->call_windows_left);
-}
-
-bool dedupe_pays(const kct_table *t, u64 npos) {  // the 64-bit variant: a table-sized shadow
-    if (!dedupe_pays_but_for_the_shadow(t, npos)) return false;
-    return t->force_path == 3 || t->shadow_dirty || shadow_amortises(t, false, t->windows_since_read + std::max(npos, t->call_windows_left));
-}
 
 // The shadow mirrors the real table's capacity (the same k-mers live in both) -- except for the dedupe probe's, which is
 // small.  (Re)allocated empty, after converting what is pending, when the wanted capacity changes.
@@ -249,19 +162,6 @@ kct_status ensure_shadow(kct_table *t, u64 want_cap, bool *ok) {
     return KCT_OK;
 }
 
-// The compact shadow (k <= 21): 2^sbits blocks x 8192 slots of u32 key + u32 count.  A block index is the TOP sbits bits
-// of the 42-bit mix42 value, an entry its low 32 bits, so sbits >= 10.  Beside a table of up to 1024 blocks it is the
-// fixed 1024-block (64 MiB) one and K1's bins are its blocks; beside a larger table it has as many blocks as the table
-// (at least 2^16, so that the second partition level has >= 64 bins per super-bin) and K1's 1024 bins are super-bins.
-constexpr int kCompactBlockBits = 10;
-int compact_sbits_for(const kct_table *t) {
-    const int bbits = log2_u64(t->cap >> t->block_bits);
-    return bbits <= 10 ? kCompactBlockBits : std::max(16, bbits);
-}
-// the shadow a dedupe-first run of this table would use
-u64 shadow_bytes_for(const kct_table *t, bool compact) {
-    return compact ? (1ULL << (compact_sbits_for(t) + kct::kBlockBitsMax)) * 8 : t->cap * 16;
-}
 u64 compact_slots(const kct_table *t) { return ((u64)t->s32_nbins << (t->s32_sbits - kCompactBlockBits)) << kct::kBlockBitsMax; }
 
 kct_status ensure_shadow32(kct_table *t, int want, bool *ok, unsigned int nbins, unsigned int bin0) {
@@ -566,18 +466,7 @@ kct_status after_dedupe_pass(kct_table *t, bool compact, u64 npos, const DedupeO
     return KCT_OK;
 }
 
-// Compact dedupe-first pass (k <= 21): K1 MODE 2 writes 32-bit entries, aggregate_blocks32_kernel counts them
-// into the compact shadow (u32 keys, u32 counts).  Half the partition traffic of the 64-bit variant and half as many
-// ring flushes.  With a shadow of more than 1024 blocks a second partition level (repartition_kernel<u32>) sits between.
-// Same contract as consume_partitioned(raw = true).
-bool compact_pays(const kct_table *t, u64 npos) {
-    if (t->k > 21 || t->compact_off || !dedupe_pays_but_for_the_shadow(t, npos)) return false;
-    if (t->force_path != 3 && !t->s32_dirty && !shadow_amortises(t, true, t->windows_since_read + std::max(npos, t->call_windows_left))) return false;
-    if (compact_sbits_for(t) > kCompactBlockBits) return true;  // a shadow as large as the table
-    const u64 known = std::max(t->n_keys, t->s32_keys);
-    return known <= (u64)((double)(1ULL << (kCompactBlockBits + kct::kBlockBitsMax)) * 0.6);
-}
-
+// (compact_pays: path_policy.h.)  Same contract as consume_partitioned(raw = true).
 // dry (the probe of a large table, counting into its own small shadow): K1 and K2 only -- nothing reaches the real table,
 // no state changes, *n_out stays; what the pass saw comes back in *dry.
 kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled, bool probe,
@@ -948,18 +837,6 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     return KCT_OK;
 }
 
-// From the share r of a uniform sample's n draws that were first sightings: x = n / D solves r = (1 - e^-x) / x.
-double draws_per_distinct(double r) {
-    if (r >= 0.9995) return 0.0;   // (nearly) every draw new: D is beyond what the sample can see
-    if (r <= 0.0) return 1e9;
-    double lo = 1e-6, hi = 1e6;    // (1 - e^-x) / x falls monotonically from 1 to 0
-    for (int i = 0; i < 80; ++i) {
-        const double mid = __builtin_sqrt(lo * hi);
-        if ((1.0 - __builtin_exp(-mid)) / mid > r) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
 // Counts every good window of a device-resident record stream.  *n_out = k-mers counted.
 kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 *n_out) {
     *n_out = 0;
@@ -997,11 +874,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
     const u64 call_windows = last_start + 1;
     KCT_DBG(t, "consume_stream: %llu window starts, chunk limit %llu, table %llu slots\n", (unsigned long long)call_windows, (unsigned long long)chunk_limit,
             (unsigned long long)t->cap);
-    bool probe = t->force_path == 0 && t->k <= 32 && !t->dedupe_off && !t->dedupe_hint && !t->auto_sized &&
-                 std::max({t->n_keys, t->shadow_keys, t->s32_keys}) == 0 && call_windows >= 8 * kProbeWindows &&
-                 t->cap >= kProbeShadowSlots && partition_geometry_ok(t) && partition_pays(t, call_windows) &&
-                 ((t->k <= 21 && !t->compact_off && shadow_amortises(t, true, t->windows_since_read + call_windows)) ||
-                  shadow_amortises(t, false, t->windows_since_read + call_windows));  // (no shadow this call could pay for: no probe)
+    bool probe = probe_wanted(t, call_windows);
     if (call_windows > chunk_limit) {  // passes of equal size
         const u64 passes = (call_windows + chunk_limit - 1) / chunk_limit;
         chunk_limit = std::min(chunk_limit, (((call_windows + passes - 1) / passes) + 0xFFFF) & ~(u64)0xFFFF);
@@ -1050,8 +923,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
                 }
                 const double x = draws_per_distinct((double)fresh_keys / (double)valid);         // the probe's k-mers per distinct k-mer
                 const double per_key = x * (double)call_windows / (double)npos;                  // ... the whole call's
-                const bool pays = per_key >= (double)windows_per_pending_key(t) &&
-                                  (shadow_amortises(t, use_compact, t->windows_since_read + call_windows) || shadow_amortises(t, false, t->windows_since_read + call_windows));
+                const bool pays = probe_verdict(t, per_key, call_windows);
                 KCT_DBG(t, "dedupe probe%s: %llu k-mers, %llu first sightings -> ~%.3g k-mers per distinct k-mer over the call: %s\n", dry_run ? " (dry run)" : "",
                         (unsigned long long)valid, (unsigned long long)fresh_keys, per_key, pays ? "dedupe-first" : "hash every window");
                 // (a "no" is a verdict on THIS call: later calls are judged by what the table holds and how long the caller's

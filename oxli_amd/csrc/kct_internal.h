@@ -290,9 +290,7 @@ void launch_aggregate32(kct_table *t, unsigned grid, const kct::Aggregate32Args 
 void launch_aggregate64(kct_table *t, unsigned grid, const kct::AggregateArgs &aa, bool shadow);      // two-level variant
 void launch_merge_overflow(kct_table *t, int mode, const du64 *regions, const unsigned int *counts, int nregions, unsigned int region_cap,
                            const du64 *abort, const kct::TableView &tv, const du64 *total);
-unsigned int region_capacity(double avg);
-unsigned int overflow_capacity(u64 entries_per_wg);
-unsigned int repartition_min_lines(const kct_table *t, int ring_entries, int sub_bits, int entry_bytes);
+// (region_capacity / overflow_capacity / repartition_min_lines and the path choices: path_policy.h)
 kct_status failed_blocks(kct_table *t, u64 nblocks, kct::FailedBlocks *fb);
 kct_status recount_failed(kct_table *t, int mode, const void *scratch, u64 seg_stride, u64 block_stride, const unsigned int *region_count, int nregions,
                           u64 nfailed, u64 entries, int sbits, u64 tallies[4]);

@@ -17,6 +17,7 @@
 // DISJOINT partition of the key space (by k-mer slice in the dedupe-first modes, by hash slice in hashing mode), so len /
 // sum_counts of the global table are sums over ranks, exactly as after the late route (merge_across_ranks).
 #include "kct_internal.h"
+#include "path_policy.h"
 
 #include <numeric>
 

@@ -5,6 +5,7 @@ build.  Usage: python tools/stress_paths.py [iterations] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import ctypes as C
 import numpy as np
 import torch
 from oxli_amd import KmerCountTable, _lib
@@ -39,17 +40,37 @@ for it in range(iters):
     ncalls = int(rng.choice([1, 2, 3]))
     cut = [0] + sorted(int(x) - int(x) % 16 for x in rng.integers(1, N, ncalls - 1)) + [N]
     sig = None
-    for path in ("partitioned", "dedupe", "auto", "direct"):
+    # the same stream as packed base arrays (cuts are multiples of 16 reads: group-aligned)
+    ng = (r.numel() + 15) // 16
+    pc = torch.empty(ng, dtype=torch.int32, device="cuda")
+    pv = torch.empty(ng, dtype=torch.int16, device="cuda")
+    assert lib.kct_pack_stream_device(r.data_ptr(), r.numel(), pc.data_ptr(), pv.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    for path in ("partitioned", "dedupe", "auto", "direct", "packed", "routed"):
         if path == "direct" and N * L > (100_000_000 if big else 30_000_000):
             continue
         if path == "dedupe" and k > 32:
             continue
-        t = KmerCountTable(k, capacity=int(rng.choice([0, G, 4 * G])) or 0)
-        t.set_path(path)
+        cap = int(rng.choice([0, G, 4 * G])) or 0
+        if path == "routed":   # the early route's loop-back (world = 1): needs a table of >= 2^19 slots
+            cap = max(cap, 400_000)
+        t = KmerCountTable(k, capacity=cap)
+        t.set_path("auto" if path in ("packed", "routed") else path)
+        mode = int(rng.choice([0, 1, 2] if k <= 21 else [0, 1] if k <= 32 else [0]))
         tot = 0
         for rep in range(2):
             for a, b in zip(cut[:-1], cut[1:]):
-                if b > a:
+                if b <= a:
+                    continue
+                if path == "packed":
+                    g0 = a * (L + 1) // 16
+                    tot += t.consume_device_packed(pc.data_ptr() + 4 * g0, pv.data_ptr() + 2 * g0, (b - a) * (L + 1), (b - a) * L)
+                elif path == "routed":
+                    n_, st_ = C.c_uint64(), (C.c_uint64 * 8)()
+                    t._check(lib.kct_consume_device_routed(t._h, C.c_void_p(r.data_ptr() + a * (L + 1)), (b - a) * (L + 1), (b - a) * L, 1, 0, mode,
+                                                           None, None, None, C.byref(n_), st_))
+                    tot += n_.value
+                else:
                     tot += t.consume_device(r.data_ptr() + a * (L + 1), (b - a) * (L + 1), (b - a) * L)
             if rep == 0 and rng.random() < 0.5:
                 t.get_hash(12345)          # a read between the two rounds
