@@ -151,7 +151,7 @@ class ShardSet:
     def __init__(self, k, L, reads=None, genome=None, first=0, nreads=0, seed_r=1337, sub_ppm=0, n_ppm=0, sorted_total=0, seed_e=SEED_E,
                  threads=None, batch=262144, native=False):
         self._L = lib(native)
-        threads = threads or max(1, min(192, len(os.sched_getaffinity(0)) * 3 // 4))
+        threads = threads or max(1, min(64, len(os.sched_getaffinity(0))))  # (64 of 256 threads is the fastest on the GPU box's host)
         self.threads = threads
         if reads is not None:
             reads = np.ascontiguousarray(reads)

@@ -634,7 +634,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
 //        (same geometry); what does not fit (overflow regions, pairs that found their block full) is hashed and goes
 //        to the real table at once.
 kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled, bool raw, bool probe = false,
-                               DedupeOutcome *dry = nullptr) {
+                               DedupeOutcome *dry = nullptr, int chunks = 1) {
     *handled = false;
     const int k = t->k;
     if (raw) {
@@ -652,56 +652,64 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
     const int bbits = L.bbits, pbits = L.pbits, sub_bits = L.sub_bits;
     const u64 P = L.P, B = L.B, W = L.W;
     const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
-    const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
+    // Two levels: the pass may be cut into SUB-CHUNKS -- K1 and K1b run once per sub-chunk, K1's scratch regions are reused, and
+    // every sub-chunk's K1b writes its own region slots of the blocks (RepartitionArgs::writer0 / wtot) -- so that ONE K2 pass
+    // counts them all: 9.6 / C + 9.6 B of scratch per window start instead of 19.2, and the 100 M-read k = 31 / k = 51
+    // configurations load and store their 16 GiB table (or shadow) once instead of twice.
+    const u64 C = two_level ? (u64)std::max(1, std::min<int>(chunks, (int)((ntiles + 255) / 256))) : 1;
+    const u64 tiles_per_chunk = (ntiles + C - 1) / C;
+    const u64 tiles_per_wg = (tiles_per_chunk + nwg - 1) / nwg;
     const unsigned int region_cap = region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P);
     const unsigned int ovf_cap = overflow_capacity(tiles_per_wg * kct::kPartTile);
     KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 8));
     KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
-    KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
+    KCT_TRY(t->d_irr.reserve(C * nwg * ovf_cap * 8 + C * nwg * 4));
     // the overflow merges' own spill list (entries the real table has no room for): one level -- everything is one
     // submission -- sized for every overflow region being full; two levels: sized after the fact, below
     if (!two_level) KCT_TRY(t->d_spill.reserve((u64)nwg * ovf_cap * 16));
     KCT_TRY(zero_counters(t));
     du64 *d_overflow = t->d_counters + kNumCounters + 6;
-    unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
+    unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + C * nwg * ovf_cap);  // [C][nwg]
     const bool fresh = raw ? t->shadow_empty : t->lazy_empty;
-
-    kct::PartitionArgs pa;
-    pa.mask = gcap - 1; pa.block_bits = gbb + sub_bits; pa.pbits = pbits;
-    pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
-    pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
-    pa.ablate = t->ablate;  // measurement only; wrong counts when set
-    packed_args(t, d_stream, &pa);
-    {
-        ProfScope ps(t, raw ? "partition_windows_kernel<raw>" : "partition_windows_kernel");
-        if (raw) PartitionRawByK<32>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
-        else PartitionByK<64>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
-    }
-    HIP_TRY(hipGetLastError());
 
     kct::AggregateArgs aa;
     aa.words = words; aa.block_bits = gbb; aa.pbits = bbits;
-    aa.fresh = fresh ? 1 : 0; aa.overflow = d_overflow; aa.ablate = pa.ablate;
+    aa.fresh = fresh ? 1 : 0; aa.overflow = d_overflow; aa.ablate = t->ablate;
     KCT_TRY(failed_blocks(t, B, &aa.failed));
     aa.counters = t->d_counters;
-    unsigned int ovf2_cap = 0, *d_ovf2_count = nullptr;
-    if (!two_level) {
-        aa.scratch = (const du64 *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
-        aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
-    } else {
-        // second level: one workgroup per super-bin spreads its hashes over the super-bin's blocks
-        const unsigned int out_cap = (region_capacity((double)npos / (double)B / (double)W) + 31u) & ~31u;  // 256-byte multiples
-        ovf2_cap = overflow_capacity(npos / P / W);
-        KCT_TRY(t->d_scratch2.reserve(B * W * out_cap * 8));
-        KCT_TRY(t->d_regions2.reserve(B * W * 4));
-        KCT_TRY(t->d_irr2.reserve(P * W * ovf2_cap * 8 + P * W * 4));
-        d_ovf2_count = (unsigned int *)((du64 *)t->d_irr2.p + P * W * ovf2_cap);
+    unsigned int ovf2_cap = 0, *d_ovf2_count = nullptr, out_cap = 0;
+    if (two_level) {
+        // second level: one workgroup per super-bin (and writer) spreads its hashes over the super-bin's blocks
+        out_cap = (region_capacity((double)(tiles_per_chunk * kct::kPartTile) / (double)B / (double)W) + 31u) & ~31u;  // 256-byte multiples
+        ovf2_cap = overflow_capacity(tiles_per_chunk * kct::kPartTile / P / W);
+        KCT_TRY(t->d_scratch2.reserve(B * C * W * out_cap * 8));
+        KCT_TRY(t->d_regions2.reserve(B * C * W * 4));
+        KCT_TRY(t->d_irr2.reserve(C * P * W * ovf2_cap * 8 + C * P * W * 4));
+        d_ovf2_count = (unsigned int *)((du64 *)t->d_irr2.p + C * P * W * ovf2_cap);  // [C][P * W]
+    }
+    for (u64 c = 0; c < C; ++c) {
+        const u64 tile0 = c * tiles_per_chunk, ntiles_c = std::min(tiles_per_chunk, ntiles > tile0 ? ntiles - tile0 : 0);
+        const u64 off = tile0 * kct::kPartTile;
+        const u64 bytes_c = off < chunk_bytes ? std::min<u64>(chunk_bytes - off, ntiles_c * kct::kPartTile + k - 1) : 0;
+        kct::PartitionArgs pa;
+        pa.mask = gcap - 1; pa.block_bits = gbb + sub_bits; pa.pbits = pbits;
+        pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
+        pa.ovf = (du64 *)t->d_irr.p + c * nwg * ovf_cap; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count + c * nwg; pa.overflow = d_overflow;
+        pa.ablate = t->ablate;  // measurement only; wrong counts when set
+        packed_args(t, d_stream + off, &pa);
+        {
+            ProfScope ps(t, raw ? "partition_windows_kernel<raw>" : "partition_windows_kernel");
+            if (raw) PartitionRawByK<32>::run(k, t->stream, nwg, d_stream + off, bytes_c, ntiles_c, pa);
+            else PartitionByK<64>::run(k, t->stream, nwg, d_stream + off, bytes_c, ntiles_c, pa);
+        }
+        HIP_TRY(hipGetLastError());
+        if (!two_level) break;
         kct::RepartitionArgs ra;
         ra.mask = gcap - 1; ra.block_bits = gbb; ra.sub_bits = sub_bits;
         ra.in = t->d_scratch.p; ra.in_cap = region_cap; ra.in_count = (const unsigned int *)t->d_regions.p;
-        ra.nseg = nwg; ra.nbins = (int)P; ra.writers = (int)W;
+        ra.nseg = nwg; ra.nbins = (int)P; ra.writers = (int)W; ra.writer0 = (int)(c * W); ra.wtot = (int)(C * W);
         ra.out = t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
-        ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow; ra.ovf_n = nullptr;
+        ra.ovf = (du64 *)t->d_irr2.p + c * P * W * ovf2_cap; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count + c * P * W; ra.overflow = d_overflow; ra.ovf_n = nullptr;
         ra.min_lines = repartition_min_lines(t, kct::kRingEntries, sub_bits, 8);
         {
             ProfScope ps(t, "repartition_kernel");
@@ -714,9 +722,15 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
             } else hipLaunchKernelGGL((kct::repartition_kernel<du64, false>), dim3((unsigned)(P * W)), dim3(kct::kPartThreads), 0, t->stream, ra);
         }
         HIP_TRY(hipGetLastError());
-        aa.scratch = (const du64 *)t->d_scratch2.p; aa.seg_stride = out_cap; aa.block_stride = W * out_cap;
-        aa.region_count = (const unsigned int *)t->d_regions2.p; aa.nregions = (int)W;
     }
+    if (!two_level) {
+        aa.scratch = (const du64 *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
+        aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
+    } else {
+        aa.scratch = (const du64 *)t->d_scratch2.p; aa.seg_stride = out_cap; aa.block_stride = C * W * out_cap;
+        aa.region_count = (const unsigned int *)t->d_regions2.p; aa.nregions = (int)(C * W);
+    }
+    const u64 n_ovf1 = C * nwg, n_ovf2 = C * P * W;  // overflow regions of the first / second level (all sub-chunks)
     {
         ProfScope ps(t, raw ? "aggregate_blocks_kernel<shadow>" : "aggregate_blocks_kernel");
         // (a pass expected to bring mostly NEW k-mers into an empty table: the variant whose fast path claims slots itself)
@@ -747,12 +761,12 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
             return KCT_OK;
         }
         if (raw) HIP_TRY(hipMemsetAsync(t->d_counters, 0, (kNumCounters + 1) * sizeof(u64), t->stream));  // the tallies (and the unused spill cursor) only
-        if (raw && two_level && t->lazy_empty && t->h_counters[kNumCounters + 7] == 0) KCT_TRY(reserve_pending(t, d_ovf_count, nwg, d_ovf2_count, P * W, &pend));
+        if (raw && two_level && t->lazy_empty && t->h_counters[kNumCounters + 7] == 0) KCT_TRY(reserve_pending(t, d_ovf_count, n_ovf1, d_ovf2_count, n_ovf2, &pend));
         else {
             if (raw) KCT_TRY(materialize(t));
             if (two_level) {
                 u64 total = 0;
-                KCT_TRY(overflow_total(t, d_ovf_count, nwg, d_ovf2_count, P * W, &total));
+                KCT_TRY(overflow_total(t, d_ovf_count, n_ovf1, d_ovf2_count, n_ovf2, &total));
                 KCT_TRY(t->d_spill.reserve(std::max<u64>(total, 1) * 16));
                 mv = view(t, std::max<u64>(total, 1));
             }
@@ -764,16 +778,16 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         ProfScope ps(t, "merge_overflow_kernel");
         if (raw) {
             hipLaunchKernelGGL(kct::merge_overflow_kernel<1>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
-                               (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, mv, t->d_counters, k, (const du64 *)nullptr, pend);
+                               (const unsigned int *)d_ovf_count, (int)n_ovf1, ovf_cap, (const du64 *)d_overflow, mv, t->d_counters, k, (const du64 *)nullptr, pend);
             if (two_level)
                 hipLaunchKernelGGL(kct::merge_overflow_kernel<1>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
-                                   (const unsigned int *)d_ovf2_count, (int)(P * W), ovf2_cap, (const du64 *)d_overflow, mv, t->d_counters, k, (const du64 *)nullptr, pend);
+                                   (const unsigned int *)d_ovf2_count, (int)n_ovf2, ovf2_cap, (const du64 *)d_overflow, mv, t->d_counters, k, (const du64 *)nullptr, pend);
         } else {
             hipLaunchKernelGGL(kct::merge_overflow_kernel<0>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p,
-                               (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, mv, t->d_counters, k);
+                               (const unsigned int *)d_ovf_count, (int)n_ovf1, ovf_cap, (const du64 *)d_overflow, mv, t->d_counters, k);
             if (two_level)
                 hipLaunchKernelGGL(kct::merge_overflow_kernel<0>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
-                                   (const unsigned int *)d_ovf2_count, (int)(P * W), ovf2_cap, (const du64 *)d_overflow, mv, t->d_counters, k);
+                                   (const unsigned int *)d_ovf2_count, (int)n_ovf2, ovf2_cap, (const du64 *)d_overflow, mv, t->d_counters, k);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -850,6 +864,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
     // ~11-21 B per window start, which bounds the pass by HBM (this is what 288 GB is for).  Decided
     // once per call: buffers this table already holds are reused, so they count as available.
     u64 chunk_limit = kChunkPositions;
+    int sub_chunks = 1;
     if (t->force_path != 1 && partition_geometry_ok(t) && (t->cap >> t->block_bits) > 1024) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -864,6 +879,13 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
             const u64 by_mem = avail > 0 ? (u64)(avail * 0.8 / per_window) : 0;
             chunk_limit = std::max<u64>(kChunkPositions, std::min<u64>(16 * t->cap, by_mem));
             chunk_limit &= ~(u64)0xFFFF;  // keeps `d_stream + done` 16-byte aligned
+            // The 64-bit paths can cut a pass into four sub-chunks that share K1's scratch (consume_partitioned): 12.5 B per
+            // window start instead of 21 -- taken when that saves whole passes over the table.
+            if (!may_compact && nbytes - k + 1 > chunk_limit) {
+                u64 limit4 = std::max<u64>(kChunkPositions, std::min<u64>(16 * t->cap, avail > 0 ? (u64)(avail * 0.8 / 12.5) : 0)) & ~(u64)0xFFFF;
+                const u64 w = nbytes - k + 1;
+                if ((w + limit4 - 1) / limit4 < (w + chunk_limit - 1) / chunk_limit) { chunk_limit = limit4; sub_chunks = 4; }
+            }
         }
     }
     // A large call into a table that knows nothing about its input (no keys, no hint from earlier passes): is this deep
@@ -941,12 +963,12 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         }
         if (dedupe_pays(t, npos)) {
             bool handled = false;
-            KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true));
+            KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true, false, nullptr, sub_chunks));
             if (handled) { done += npos; t->windows_since_read += npos; continue; }
         }
         if (partition_geometry_ok(t) && t->force_path != 1 && (t->force_path == 2 || partition_pays(t, npos))) {
             bool handled = false;
-            KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, false));
+            KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, false, false, nullptr, sub_chunks));
             if (handled) { done += npos; t->windows_since_read += npos; continue; }
         }
         KCT_TRY(materialize(t));

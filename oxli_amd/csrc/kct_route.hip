@@ -276,7 +276,17 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     const u64 B = (u64)nb_me << sub_bits, W = std::max<u64>(1, std::min<u64>((u64)nwg / nb_me, nseg / 16));
     unsigned int out_cap = region_capacity((double)total_recv / (double)B / (double)W);
     out_cap = (out_cap + 63u) & ~63u;
-    const unsigned int ovf2_cap = overflow_capacity(total_recv / nb_me / W);
+    // K1b's overflow regions: room for EVERY entry of the busiest workgroup (an abandoned pass cannot fall back to the direct kernel
+    // here), up to the 2^20 the ring's position arithmetic allows.  Workgroup (s, w) reads segments 16 w + wave, + 16 W, ...
+    u64 busiest = 0;
+    for (unsigned sb = 0; sb < nb_me; ++sb)
+        for (u64 w = 0; w < W; ++w) {
+            u64 sum = 0;
+            for (u64 seg0 = w * 16; seg0 < nseg; seg0 += W * 16)
+                for (u64 seg = seg0; seg < std::min<u64>(seg0 + 16, nseg); ++seg) sum += h_c2[(u64)sb * nseg + seg];
+            busiest = std::max(busiest, sum);
+        }
+    const unsigned int ovf2_cap = (unsigned int)std::min<u64>(1ULL << 20, std::max<u64>(4096, busiest));
     KCT_TRY(t->d_scratch2.reserve(B * W * out_cap * esz));
     KCT_TRY(t->d_regions2.reserve(B * W * 4));
     KCT_TRY(t->d_irr2.reserve((u64)nb_me * W * ovf2_cap * 8 + (u64)nb_me * W * 4));

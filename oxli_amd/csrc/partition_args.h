@@ -49,6 +49,9 @@ struct RepartitionArgs {
     const u64 *in_off = nullptr;  // optional [nbins][nseg]: region (seg, s) starts at in + in_off[s * nseg + seg] entries instead (packed
                                   // regions received from other GPUs, kct_route.hip)
     u32 bin0 = 0;        // compact entries: the first-level bin of super-bin 0 (an owner GPU holds a RANGE of the 1024 bins)
+    // several launches feeding ONE K2 pass (a pass cut into sub-chunks so that K1's scratch is reused, kct_consume.hip): this
+    // launch's writers are slots writer0 .. writer0 + writers - 1 of the wtot regions every block has (0 = writers)
+    int writer0 = 0, wtot = 0;
 };
 
 struct FailedBlocks {

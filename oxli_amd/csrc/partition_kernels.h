@@ -297,8 +297,9 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     __syncthreads();
     if (rounds == ~0u) return;  // read through LDS so that the whole workgroup takes the same branch
     __syncthreads();
-    T *my_out = reinterpret_cast<T *>(a.out) + (((u64)s << a.sub_bits) * W + w) * a.out_cap;
-    const u64 bin_stride = (u64)W * a.out_cap;
+    const int Wt = a.wtot ? a.wtot : W, wslot = a.writer0 + w;  // (a block's regions: wtot of them, this workgroup writes slot wslot)
+    T *my_out = reinterpret_cast<T *>(a.out) + (((u64)s << a.sub_bits) * Wt + wslot) * a.out_cap;
+    const u64 bin_stride = (u64)Wt * a.out_cap;
     u64 *my_ovf = a.ovf + (u64)blockIdx.x * a.ovf_cap;
     const u64 ovf_hi = kCompact ? (((u64)(s + a.bin0) << 32) | (1ULL << 63)) : 0ULL;
     auto overflow_one = [&](u64 h) {
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     while (flush_lines(true)) {}
     for (int b = threadIdx.x; b < P2; b += kPartThreads) {
         const u32 f = (u32)(cur[b] >> 32);
-        a.out_count[(((u64)s << a.sub_bits) + b) * W + w] = f < a.out_cap ? f : a.out_cap;
+        a.out_count[(((u64)s << a.sub_bits) + b) * Wt + wslot] = f < a.out_cap ? f : a.out_cap;
     }
     if constexpr (!kPair) {
         __syncthreads();

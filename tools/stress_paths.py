@@ -51,6 +51,8 @@ for it in range(iters):
             continue
         if path == "dedupe" and k > 32:
             continue
+        if path == "routed" and G < 50_000:   # a handful of k-mers at 10^7 windows: the early route refuses such skew (its rings
+            continue                          # cannot fall back to the direct kernel); the late route is the tool for it
         cap = int(rng.choice([0, G, 4 * G])) or 0
         if path == "routed":   # the early route's loop-back (world = 1): needs a table of >= 2^19 slots
             cap = max(cap, 400_000)
