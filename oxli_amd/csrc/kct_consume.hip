@@ -881,10 +881,12 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
             chunk_limit &= ~(u64)0xFFFF;  // keeps `d_stream + done` 16-byte aligned
             // The 64-bit paths can cut a pass into four sub-chunks that share K1's scratch (consume_partitioned): 12.5 B per
             // window start instead of 21 -- taken when that saves whole passes over the table.
-            if (!may_compact && nbytes - k + 1 > chunk_limit) {
-                u64 limit4 = std::max<u64>(kChunkPositions, std::min<u64>(16 * t->cap, avail > 0 ? (u64)(avail * 0.8 / 12.5) : 0)) & ~(u64)0xFFFF;
+            const int want_chunks = t->tune.sub_chunks ? t->tune.sub_chunks : 4;
+            if (!may_compact && want_chunks > 1 && nbytes - k + 1 > chunk_limit) {
+                const double per4 = 9.6 / want_chunks + 9.6 + 0.5;
+                u64 limit4 = std::max<u64>(kChunkPositions, std::min<u64>(16 * t->cap, avail > 0 ? (u64)(avail * 0.8 / per4) : 0)) & ~(u64)0xFFFF;
                 const u64 w = nbytes - k + 1;
-                if ((w + limit4 - 1) / limit4 < (w + chunk_limit - 1) / chunk_limit) { chunk_limit = limit4; sub_chunks = 4; }
+                if ((w + limit4 - 1) / limit4 < (w + chunk_limit - 1) / chunk_limit) { chunk_limit = limit4; sub_chunks = want_chunks; }
             }
         }
     }

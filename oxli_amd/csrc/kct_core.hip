@@ -392,6 +392,7 @@ kct_status kct_create(uint8_t ksize, uint64_t capacity_hint, int device, kct_tab
     t->tune.k2_nopersist = getenv("KCT_K2_NOPERSIST") != nullptr;
     t->tune.flush_atomic = getenv("KCT_FLUSH_ATOMIC") != nullptr;
     t->tune.k1b_half = getenv("KCT_K1B_HALF") != nullptr;
+    if (const char *e = getenv("KCT_SUB_CHUNKS")) t->tune.sub_chunks = std::max(1, std::min(15, atoi(e)));
 #endif
     if (const char *e = getenv("KCT_PACK_THREADS")) t->tune.pack_threads = std::max(1, atoi(e));
     t->ablate = t->tune.ablate;

@@ -138,6 +138,7 @@ struct Tuning {
     bool pairs_nopersist = false, k2_nopersist = false;  // KCT_PAIRS_NOPERSIST / KCT_K2_NOPERSIST: one workgroup per block
     bool flush_atomic = false; // KCT_FLUSH_ATOMIC: conversions by random table access instead of the partitioned pair route
     bool k1b_half = false;     // KCT_K1B_HALF: two ring flushes per slab in the 64-bit second level
+    int sub_chunks = 0;        // KCT_SUB_CHUNKS: sub-chunks of a 64-bit two-level pass that does not fit in one (0 = the default, 4)
     int ablate = 0;            // KCT_ABLATE: skip work (results INVALID)
     int pack_threads = 16;     // KCT_PACK_THREADS (operational, read in every build): host threads packing a batch
 };
