@@ -1,10 +1,10 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of bench.py, per workload.
-# Usage: tools/collect_r02.sh [tag]   -> writes gpurun_out/prof_<tag>/<workload>/{stats,pmc_fetch,pmc_write,pmc_sq[,pmc_tcc]}
+# Usage: tools/collect_r03.sh [tag]   -> writes gpurun_out/prof_<tag>/<workload>/{stats,pmc_fetch,pmc_write,pmc_sq[,pmc_tcc]}
 # Every rocprofv3 line profiles `python3 bench.py` directly (no shell/env hop after `--`); --pmc passes never share a
 # run with a trace.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
@@ -25,6 +25,7 @@ run north_star_k21 --configs north_star_k21 --no-headline
 run C3 --configs C3 --no-headline
 run C5_shard --configs C5_shard --no-headline
 run C4_shard --configs C4_shard --no-headline
+run C2_sub1pct --configs C2_sub1pct --no-headline
 # the direct path's L2-atomic counters (north_star: "L2-atomic counters")
 mkdir -p $O/C2_direct
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/C2_direct/stats -- $B --configs none --steps 5 --warmup 2 --max-repeats 3 --path direct > $O/C2_direct/stats.log 2>&1
@@ -34,5 +35,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/C2_direct/pmc_write -- $B -
 # the bench line of the same build, un-profiled
 python3 /root/repo/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 # keep what travels back small: the raw per-dispatch CSVs are summarised here
-python3 /root/repo/tools/summarize_r02.py $TAG --on-box
+python3 /root/repo/tools/summarize_prof.py $TAG --on-box
 du -sh $O; ls $O

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/prof_<tag>/ (made by tools/collect_r02.sh on the GPU box) into the small, committed files under profiles/:
+"""Turns gpurun_out/prof_<tag>/ (made by tools/collect_r03.sh on the GPU box) into the small, committed files under profiles/:
 
   profiles/<tag>_<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of that workload
   profiles/<tag>_pmc_full.json                 per workload, per kernel: launches, mean of every PMC counter, derived figures
-  profiles/pmc_r02.json                        what bench.py reads: {source_sha, <workload>: {kernels: {name: {hbm_bytes_per_launch}}, valu, atomics}}
+  profiles/pmc_<tag>.json                      what bench.py reads: {source_sha, <workload>: {kernels: {name: {hbm_bytes_per_launch}}, valu, atomics}}
   profiles/<tag>_bench.json                    the un-profiled bench.py line of the same build
 
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are collected in
@@ -24,7 +24,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 on_box = "--on-box" in sys.argv
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
@@ -116,9 +116,9 @@ def main():
         json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
     except Exception as e:  # noqa: BLE001
         print("no bench.json:", e)
-    json.dump({"_how": "tools/collect_r02.sh + tools/summarize_r02.py; FETCH_SIZE/WRITE_SIZE in KiB, separate passes; x2 on streaming reads",
+    json.dump({"_how": "tools/collect_r03.sh + tools/summarize_prof.py; FETCH_SIZE/WRITE_SIZE in KiB, separate passes; x2 on streaming reads",
                "source_sha": source_sha(), "workloads": full}, open(os.path.join(dst, f"{tag}_pmc_full.json"), "w"), indent=1)
-    windows = {"C2": 1.3e8, "C2_hashing": 1.3e8, "cold_C2": 1.3e8}
+    windows = {"C2": 1.3e8, "C2_hashing": 1.3e8, "cold_C2": 1.3e8}  # k-mers of a launch
     small = {"source_sha": source_sha(), "_how": f"profiles/{tag}_pmc_full.json condensed for bench.py"}
     for w, kernels in full.items():
         e = {"kernels": {k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in kernels.items() if "hbm_bytes_per_launch" in v}}
@@ -138,7 +138,7 @@ def main():
         small[w] = e
     if "C2_direct" in small and "atomics" in small["C2_direct"] and "C2" in small:
         small["C2"]["atomics"] = dict(small["C2_direct"]["atomics"], note="the DIRECT path (one HBM atomic per k-mer), measured beside the partitioned paths, which issue none per k-mer")
-    json.dump(small, open(os.path.join(dst, "pmc_r02.json"), "w"), indent=1)
+    json.dump(small, open(os.path.join(dst, f"pmc_{tag}.json"), "w"), indent=1)
     for w, kernels in full.items():
         for k, v in kernels.items():
             if "hbm_bytes_per_launch" in v and v.get("avg_launch_ns", 0) > 50000:
