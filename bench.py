@@ -19,12 +19,26 @@ each with per-kernel device times, the algorithmic HBM fraction and a correctnes
 ones -- len / min / max / sum of squared counts and ~10^6 sampled keys equal to the DIRECT path's table, plus an oracle
 slice when the CPU checker is enabled):
   cold_C2        one 1 M-read pass into an empty, hint-free table + conversion
-  e2e_C2         the same batch from HOST memory through kct_consume_batch (pack + H2D + count; PCIe-inclusive)
+  packed_C2      the headline's steps with the batch resident as PACKED base arrays (2 bits + 1 validity bit per base)
+  e2e_C2         the same batch from HOST memory through kct_consume_batch (SIMD pack to 0.375 B/base + H2D + count; PCIe-inclusive)
   per_record     the reference's own loop, `for rec: table.consume(rec)` (README.md:96-98), on a default table
   north_star_k21 100 M x 150 bp, k=21, genome 500 Mbp, one GPU (the north-star sentence)
   C3             100 M x 150 bp, k=31, genome 500 Mbp        (BASELINE.json configs[2])
   C4_shard       one GPU's eighth of configs[3]: 12.5 M x 150 bp, k=21, same genome
   C5_shard       one GPU's eighth of configs[4]: 1.25 M x 10 kbp, k=51
+  C2_sub1pct / C2_N1pct / C2_sorted / NS25_sub1pct   inputs the path heuristics were NOT tuned on (the device generator's error
+                 model, include/kct_synth.h): 1 % substitution errors, 1 % N, position-sorted reads at C2 size; 25 M reads of the
+                 500 Mbp genome with 1 % substitutions.  Each reports the path the table chose, the rate, the rate of
+                 `--path partitioned` on the same input (`vs_partitioned`) and is gated against the partitioned and direct paths'
+                 tables (n, len, sum_counts, sum / xor / square digests) and -- C2-sized -- the oracle's table pair by pair.
+With N > 1 ranks (`python bench.py --gpus N` launches itself under torch.distributed.run, or the driver does) the headline is the
+same weak-scaled C2 job per rank + the late merge, and
+  C4 / C5        BASELINE.json configs[3] / [4] as ONE strong-scaled job over the N ranks (100 M x 150 bp k=21 / 10 M x 10 kbp k=51,
+                 reads split N ways), on both multi-GPU routes: "late" (private tables, then the owner all-to-all of
+                 {hash, count} pairs) and "early" (entries travel to their owner while they are counted); exchange and conversion
+                 inside the timed region; per rank: entries / pairs sent and received, exchange and merge ms; gated on n,
+                 sum_counts and on the routes agreeing on the global len and digests.  Ranks that SHARE a GPU (--backend gloo on a
+                 one-GPU box) run a reduced size and say so.
 
 `roofline`: bound "hbm"; `achieved` = ALGORITHMIC bytes per step (k-mers x (L/(L-k+1) + 24) B) / the summed
 device time of every kernel of the step (HIP events on the table's stream, in an instrumented repetition of the job;
@@ -620,9 +634,9 @@ def main():
                 tables[path] = (n, len(t), t.sum_counts) + t.digest()
                 if path == "auto":
                     rep, _ = kernel_report(prof, n, balg, None)
-                    k1 = [kn for kn in prof if kn.startswith("partition_windows_kernel")]
+                    k1 = sorted((kn for kn in prof if kn.startswith("partition_windows_kernel")), key=lambda kn: -prof[kn][1])  # the pass's K1 first, a probe's after
                     entry.update({"kmers": n, "kmers_per_s": n / dt, "seconds": dt, "table_slots": t.capacity, "distinct": len(t),
-                                  "path_chosen": ("compact dedupe-first" if any("compact" in kn for kn in k1) else "64-bit dedupe-first" if any("raw" in kn for kn in k1)
+                                  "path_chosen": ("compact dedupe-first" if "compact" in k1[0] else "64-bit dedupe-first" if "raw" in k1[0]
                                                   else "hash every window") + (" after a probe" if len(k1) > 1 else "") if k1 else "direct", **rep})
                     if checker and Rb <= 5_000_000:   # the oracle's table of the same reads, pair by pair
                         ss = oracle.ShardSet(kb, Lb, genome=g.cpu().numpy(), nreads=Rb, seed_r=SEED_R, **m)

@@ -106,6 +106,11 @@ KCT_API kct_status kct_set_hash(kct_table *t, uint64_t hash, uint64_t count);
  * counted), `consumed` unchanged -- the message is "bad k-mer encountered at position {n}". */
 KCT_API kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out);
 
+/* 1 if kct_consume(t, seq of `len` bytes, skip_bad) would only APPEND to deferred mode's buffer (no device work, ~60 ns), 0 if it
+ * would run a device pass (buffer full, error mode, deferred mode off, long record).  For call glue that holds a lock it would
+ * rather not hold across a device pass (csrc/pyfast.c and the GIL; a pyo3 shim's `allow_threads`). */
+KCT_API int kct_consume_will_defer(const kct_table *t, size_t len, int skip_bad);
+
 /* The reference is called once per FASTA/FASTQ record (README.md:96-98).  This is the same
  * loop in one call: record r is bytes[offsets[r] .. offsets[r+1]); k-mers never span records.
  * *n_total = sum of the per-record n.  With skip_bad == 0 the call stops at the first record

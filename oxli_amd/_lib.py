@@ -40,6 +40,7 @@ SIGNATURES = {
     "kct_get_hash_array": (ci, [vp, vp, sz, vp]),
     "kct_set_hash": (ci, [vp, u64, u64]),
     "kct_consume": (ci, [vp, vp, sz, ci, u64p]),
+    "kct_consume_will_defer": (ci, [vp, sz, ci]),
     "kct_consume_batch": (ci, [vp, vp, vp, sz, ci, u64p, u64p, u64p]),
     "kct_consume_device": (ci, [vp, vp, sz, u64, u64p]),
     "kct_consume_device_packed": (ci, [vp, vp, vp, sz, u64, u64p]),

@@ -1206,6 +1206,10 @@ kct_status kct_get(kct_table *t, const char *kmer, size_t len, uint64_t *count_o
     return kct_get_hash(t, h, count_out);
 }
 
+int kct_consume_will_defer(const kct_table *t, size_t len, int skip_bad) {
+    return t && !t->poisoned && t->deferred && skip_bad && len + 64 < kPendingBytes / 2 && (len < t->k || t->pending_used + len + 1 + 64 <= t->h_pending.cap) ? 1 : 0;
+}
+
 kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out) {
     if (t && t->deferred && skip_bad && len + 64 < kPendingBytes / 2) {
         // deferred mode: buffer the record, answer from the host-side validity scan, count later

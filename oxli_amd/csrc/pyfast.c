@@ -13,13 +13,18 @@
 #include <string.h>
 
 typedef int (*kct_consume_fn)(void *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out);
+typedef int (*kct_will_defer_fn)(const void *t, size_t len, int skip_bad);
 static kct_consume_fn g_consume = NULL;
+static kct_will_defer_fn g_will_defer = NULL;
 
-static PyObject *fast_bind(PyObject *self, PyObject *arg) {
+/* bind(address of kct_consume, address of kct_consume_will_defer) */
+static PyObject *fast_bind(PyObject *self, PyObject *const *args, Py_ssize_t nargs) {
     (void)self;
-    const unsigned long long addr = PyLong_AsUnsignedLongLong(arg);
-    if (addr == (unsigned long long)-1 && PyErr_Occurred()) return NULL;
-    g_consume = (kct_consume_fn)(uintptr_t)addr;
+    if (nargs != 2) { PyErr_SetString(PyExc_TypeError, "bind(consume_address, will_defer_address)"); return NULL; }
+    const unsigned long long a = PyLong_AsUnsignedLongLong(args[0]), b = PyLong_AsUnsignedLongLong(args[1]);
+    if ((a == (unsigned long long)-1 || b == (unsigned long long)-1) && PyErr_Occurred()) return NULL;
+    g_consume = (kct_consume_fn)(uintptr_t)a;
+    g_will_defer = (kct_will_defer_fn)(uintptr_t)b;
     Py_RETURN_NONE;
 }
 
@@ -42,12 +47,16 @@ static PyObject *fast_consume(PyObject *self, PyObject *const *args, Py_ssize_t 
     if (skip < 0) return NULL;
     uint64_t n = 0;
     int st;
-    /* The GIL is released around the call, as ctypes does: when deferred mode's buffer fills the call runs a whole device
-     * pass, and other Python threads (a second feeder, torch.distributed's watchdog) must not stall behind it.  The
-     * str / bytes object stays alive through args[1]; its buffer is immutable. */
-    Py_BEGIN_ALLOW_THREADS
-    st = g_consume((void *)(uintptr_t)h, p, (size_t)len, skip, &n);
-    Py_END_ALLOW_THREADS
+    /* A call that only appends to deferred mode's buffer (~60 ns) keeps the GIL: releasing and re-taking it would cost as much
+     * again.  A call that will run a device pass -- the buffer is full, error mode, deferred mode off -- releases it, as ctypes
+     * does: other Python threads (a second feeder, torch.distributed's watchdog) must not stall behind the pass.  The str /
+     * bytes object stays alive through args[1]; its buffer is immutable. */
+    if (g_will_defer && g_will_defer((const void *)(uintptr_t)h, (size_t)len, skip)) st = g_consume((void *)(uintptr_t)h, p, (size_t)len, skip, &n);
+    else {
+        Py_BEGIN_ALLOW_THREADS
+        st = g_consume((void *)(uintptr_t)h, p, (size_t)len, skip, &n);
+        Py_END_ALLOW_THREADS
+    }
     if (st == 0) return PyLong_FromUnsignedLongLong(n);
     return Py_BuildValue("(iK)", st, (unsigned long long)n);
 }
@@ -92,7 +101,7 @@ static PyObject *fast_csr(PyObject *self, PyObject *arg) {
 
 static PyMethodDef methods[] = {
     {"csr", fast_csr, METH_O, "csr(seqs) -> (data, offsets)"},
-    {"bind", fast_bind, METH_O, "bind(address of kct_consume)"},
+    {"bind", (PyCFunction)(void (*)(void))fast_bind, METH_FASTCALL, "bind(address of kct_consume, address of kct_consume_will_defer)"},
     {"consume", (PyCFunction)(void (*)(void))fast_consume, METH_FASTCALL, "consume(handle, seq, skip_bad)"},
     {NULL, NULL, 0, NULL},
 };

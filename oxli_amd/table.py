@@ -29,7 +29,7 @@ VERSION = "0.3.0"
 
 try:  # CPython call glue for per-record loops (csrc/pyfast.c); without it the same call goes through ctypes
     from . import _kctfast as _fast
-    _fast.bind(C.cast(L.load().kct_consume, C.c_void_p).value)
+    _fast.bind(C.cast(L.load().kct_consume, C.c_void_p).value, C.cast(L.load().kct_consume_will_defer, C.c_void_p).value)
     _fast_consume = _fast.consume
 except ImportError:
     _fast = _fast_consume = None
