@@ -132,6 +132,18 @@ static int iter_init(seq_iter *it, const uint8_t *s, size_t len, size_t k, int f
 
 static void iter_free(seq_iter *it) { free(it->seq); free(it->rc); }
 
+/* the same iterator over caller-owned buffers of >= len bytes each (the full-size checker walks 10^8 records per thread:
+ * no malloc per record); nothing to free */
+static void iter_attach(seq_iter *it, const uint8_t *s, size_t len, size_t k, int force, uint64_t seed, uint8_t *seq_buf, uint8_t *rc_buf) {
+    it->seq = seq_buf;
+    for (size_t i = 0; i < len; ++i) it->seq[i] = ascii_upper(s[i]);
+    it->rc = rc_buf;
+    for (size_t i = 0; i < len; ++i) it->rc[i] = complement(it->seq[len - 1 - i]);
+    it->len = len; it->k = k; it->kmer_index = 0; it->last_check = 0;
+    it->max_index = len >= k ? len - k + 1 : 0;
+    it->force = force; it->seed = seed;
+}
+
 /* returns 0 = end, 1 = Ok(*out), 2 = Err(InvalidDNA) */
 static int iter_next(seq_iter *it, uint64_t *out) {
     if (it->kmer_index >= it->max_index) return 0;
@@ -244,6 +256,19 @@ static int map_grow(u64map *m) {
     free(m->keys); free(m->vals); free(m->used);
     *m = n;
     return ORC_OK;
+}
+
+/* room for n keys without further growth (an EMPTY map only; the checker's shard sets know how many keys to expect) */
+static void map_reserve(u64map *m, size_t n) {
+    if (m->len || !n) return;
+    size_t cap = 4;
+    while (cap * 7 < (n + 1) * 8) cap *= 2;
+    if (cap <= m->cap) return;
+    free(m->keys); free(m->vals); free(m->used);
+    m->cap = cap;
+    m->keys = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    m->vals = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    m->used = (uint8_t *)calloc(cap, 1);
 }
 
 /* find-or-insert (value initialised to 0 when fresh) */
@@ -660,7 +685,7 @@ static void *shardset_run(void *p) {
     shardset_job *j = (shardset_job *)p;
     const int T = j->threads;
     orc_table *mine = j->tables[j->id];
-    uint8_t *buf = (uint8_t *)malloc((size_t)j->L + 1);
+    uint8_t *buf = (uint8_t *)malloc((size_t)j->L + 1), *seq_buf = (uint8_t *)malloc((size_t)j->L + 1), *rc_buf = (uint8_t *)malloc((size_t)j->L + 1);
     uint64_t n = 0;
     for (uint64_t b0 = 0; b0 < j->nreads; b0 += j->batch) {
         const uint64_t bn = j->nreads - b0 < j->batch ? j->nreads - b0 : j->batch;
@@ -674,22 +699,31 @@ static void *shardset_run(void *p) {
             uint64_t h;
             int rc;
             mine->consumed += j->L;
-            if (iter_init(&it, rec, j->L, j->k, 1, 42) != ORC_OK) continue;
+            iter_attach(&it, rec, j->L, j->k, 1, 42, seq_buf, rc_buf);
             while ((rc = iter_next(&it, &h)) != 0) {
                 if (rc == 2 || h == 0) continue;
                 hbuf_push(&j->out[(size_t)j->id * T + (int)(((h >> 32) * (uint64_t)T) >> 32)], h);
                 ++n;
             }
-            iter_free(&it);
         }
         pthread_barrier_wait(j->bar);
         for (int src = 0; src < T; ++src) {
             const hbuf *b = &j->out[(size_t)src * T + j->id];
-            for (size_t i = 0; i < b->n; ++i) orc_count_hash(mine, b->v[i]);
+            /* (tables of 10^7 keys per owner do not fit any cache: the slot of the hash sixteen ahead is prefetched -- the
+             * count_hash calls themselves are unchanged) */
+            for (size_t i = 0; i < b->n; ++i) {
+                if (i + 16 < b->n && mine->counts.cap) {
+                    const size_t at = (size_t)siphash13_u64(mine->counts.k0, mine->counts.k1, b->v[i + 16]) & (mine->counts.cap - 1);
+                    __builtin_prefetch(&mine->counts.used[at]);
+                    __builtin_prefetch(&mine->counts.keys[at]);
+                    __builtin_prefetch(&mine->counts.vals[at], 1);
+                }
+                orc_count_hash(mine, b->v[i]);
+            }
         }
         pthread_barrier_wait(j->bar);
     }
-    free(buf);
+    free(buf); free(seq_buf); free(rc_buf);
     j->n = n;
     return NULL;
 }
@@ -698,7 +732,7 @@ static void *shardset_run(void *p) {
  * stream over `genome` (G bytes) with the given error model */
 orc_shardset *orc_shardset_build(const uint8_t *reads, const uint8_t *genome, uint64_t G, uint64_t first, uint64_t nreads, uint32_t L,
                                  uint8_t k, uint64_t seed_r, uint32_t sub_ppm, uint32_t n_ppm, uint64_t sorted_total, uint64_t seed_e,
-                                 int threads, uint64_t batch) {
+                                 int threads, uint64_t batch, uint64_t expect_keys) {
     if (threads < 1) threads = 1;
     if (batch < (uint64_t)threads) batch = (uint64_t)threads;
     const int T = threads;
@@ -710,7 +744,7 @@ orc_shardset *orc_shardset_build(const uint8_t *reads, const uint8_t *genome, ui
     s->tables = (orc_table **)calloc((size_t)T, sizeof *s->tables);
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, NULL, (unsigned)T);
-    for (int i = 0; i < T; ++i) s->tables[i] = orc_new(k);
+    for (int i = 0; i < T; ++i) { s->tables[i] = orc_new(k); map_reserve(&s->tables[i]->counts, (size_t)(expect_keys / (uint64_t)T + expect_keys / (uint64_t)T / 16)); }
     for (int i = 0; i < T; ++i) {
         shardset_job *j = &jobs[i];
         j->reads = reads; j->genome = genome; j->G = G; j->first = first; j->nreads = nreads; j->batch = batch; j->L = L; j->k = k;

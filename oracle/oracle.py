@@ -76,7 +76,7 @@ def lib(native=False):
         L.orc_sharded_consume.argtypes = [vp, u64, C.c_uint32, C.c_uint8, C.c_int, u64, u64p, C.POINTER(C.c_double)]
         L.orc_synth_reads_ex.argtypes = [vp, vp, u64, u64, u64, C.c_uint32, u64, C.c_uint32, C.c_uint32, u64, u64]
         L.orc_shardset_build.restype = vp
-        L.orc_shardset_build.argtypes = [vp, vp, u64, u64, u64, C.c_uint32, C.c_uint8, u64, C.c_uint32, C.c_uint32, u64, u64, C.c_int, u64]
+        L.orc_shardset_build.argtypes = [vp, vp, u64, u64, u64, C.c_uint32, C.c_uint8, u64, C.c_uint32, C.c_uint32, u64, u64, C.c_int, u64, u64]
         L.orc_shardset_free.argtypes = [vp]
         L.orc_shardset_digest.argtypes = [vp, vp]
         L.orc_shardset_get.restype = u64
@@ -144,12 +144,13 @@ def synth_reads_ex(genome, first, count, L, seed_r=1337, sub_ppm=0, n_ppm=0, sor
 class ShardSet:
     """The CPU table of a whole configuration, key space sharded over ``threads`` owner tables (orc_shardset_*): exact
     digests and exact pair comparison for inputs of 10^8 .. 10^10 k-mers.  ``reads`` = uint8 [n, L+1] in memory, or None
-    to generate reads [first, first + nreads) of the synthetic stream over ``genome`` on the fly."""
+    to generate reads [first, first + nreads) of the synthetic stream over ``genome`` on the fly.  ``expect_keys`` (optional)
+    pre-sizes the owner tables: no re-hash while they grow."""
 
     FIELDS = ("len", "sum_counts", "sum_hc", "xor_hc", "min", "max", "sum_sq", "n", "consumed")
 
     def __init__(self, k, L, reads=None, genome=None, first=0, nreads=0, seed_r=1337, sub_ppm=0, n_ppm=0, sorted_total=0, seed_e=SEED_E,
-                 threads=None, batch=262144, native=False):
+                 threads=None, batch=262144, native=False, expect_keys=0):
         self._L = lib(native)
         threads = threads or max(1, min(64, len(os.sched_getaffinity(0))))  # (64 of 256 threads is the fastest on the GPU box's host)
         self.threads = threads
@@ -162,7 +163,7 @@ class ShardSet:
         gp = genome.ctypes.data if genome is not None else None
         self._keep = (reads, genome)
         self._h = self._L.orc_shardset_build(rp, gp, 0 if genome is None else len(genome), first, nreads, L, k, seed_r, sub_ppm, n_ppm,
-                                             sorted_total, seed_e, threads, batch)
+                                             sorted_total, seed_e, threads, batch, int(expect_keys))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -78,31 +78,7 @@ def oracle_shardset(gpu, g, r, R, L, k, **model):
     for first in (0, R - ns):
         dev = r[first * (L + 1): (first + ns) * (L + 1)].cpu().numpy().reshape(ns, L + 1)
         assert np.array_equal(dev, oracle.synth_reads_ex(genome, first, ns, L, SEED_R, **model)), "host and device generators differ"
-    return oracle.ShardSet(k, L, genome=genome, nreads=R, seed_r=SEED_R, **model)
-
-
-# The oracle's tables of the four full-size configurations are built CONCURRENTLY (64 host threads each, ~100 s apiece on the GPU
-# box's 256-thread host) from the first test that needs one on, beside the GPU work of the tests in front of it.
-_FULL_ORACLES = {}
-
-
-def full_oracle_future(name):
-    import concurrent.futures
-    if not _FULL_ORACLES:
-        pool = concurrent.futures.ThreadPoolExecutor(max_workers=len(FULL))
-        genomes = {}
-
-        def build(c):
-            key = c["genome"]
-            if key not in genomes:
-                genomes[key] = pool.submit(oracle.synth_genome, key, SEED_G)
-            g = genomes[key].result()
-            return g, oracle.ShardSet(c["k"], c["L"], genome=g, nreads=c["reads"], seed_r=SEED_R, threads=64)
-        for nm, c in FULL.items():
-            genomes.setdefault(c["genome"], pool.submit(oracle.synth_genome, c["genome"], SEED_G))
-        for nm, c in FULL.items():
-            _FULL_ORACLES[nm] = pool.submit(build, c)
-    return _FULL_ORACLES[name]
+    return oracle.ShardSet(k, L, genome=genome, nreads=R, seed_r=SEED_R, expect_keys=min(len(genome), R * (L - k + 1)), **model)
 
 
 def assert_digest_equal(t, ss, n):
@@ -120,9 +96,8 @@ def test_full_size_config(gpu, name):
     free, _total = torch.cuda.mem_get_info()
     if free < 250 * (1 << 30):
         pytest.skip("needs a whole MI355X (250 GiB of free HBM)")
-    if host_mem_gib() < 100:
-        pytest.fail("the full-size oracle tables need ~70 GiB of host memory")
-    fut = full_oracle_future(name)      # (starts every configuration's oracle on first use)
+    if host_mem_gib() < 40:
+        pytest.fail("the full-size oracle table needs ~20 GiB of host memory")
     g, r = synth(gpu, G, R, L)
     n_expect = R * (L - k + 1)
     t = KCT(k, capacity=G)
@@ -148,12 +123,8 @@ def test_full_size_config(gpu, name):
     sample = np.concatenate([rk, rk ^ np.uint64(0x5555555555555555)])
     sample_counts = np.array(t.get_hash_array(sample), dtype=np.uint64)
     # THE ORACLE'S TABLE OF THE WHOLE INPUT: digests equal, and every sampled key's count equal
-    genome, ss = fut.result()
-    assert np.array_equal(g.cpu().numpy(), genome), "host and device genomes differ"
-    for first in (0, R - 2000):   # ... and the host generator reproduces the device's reads at both ends of the stream
-        dev = r[first * (L + 1): (first + 2000) * (L + 1)].cpu().numpy().reshape(2000, L + 1)
-        assert np.array_equal(dev, oracle.synth_reads(genome, first, 2000, L, SEED_R)), "host and device generators differ"
-    del g, genome
+    ss = oracle_shardset(gpu, g, r, R, L, k)
+    del g
     assert_digest_equal(t, ss, n)
     assert sample_counts.tolist() == [ss.get_hash(int(h)) for h in sample.tolist()]
     if name == "C4-shard":  # 4.8x10^8 pairs: the whole dump, pair by pair
