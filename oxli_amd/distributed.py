@@ -239,12 +239,17 @@ class _Exchanger:
             return 1
 
 
-def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, mode="auto"):
+def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, mode="auto", max_windows=None):
     """Counts this rank's device-resident record stream by the EARLY route: K1 here, entries to their owner GPUs with three
     all-to-alls, K1b / K2 on the owners (``kct_consume_device_routed``).  Every rank must call it, with tables of one
     capacity.  ``mode``: "compact" (k <= 21) and "dedupe64" (k <= 32) count packed k-mers first and hash each distinct one
     when the table is read -- right for deep coverage, where an owner meets every k-mer many times; "hash" hashes every window
     (any k <= 64; low coverage); "auto" picks by k.  Returns (k-mers this rank counted as an owner, stats dict).
+
+    A pass keeps K1's regions, the send and receive buffers and K1b's regions in HBM at once (~4.4 entries of 4 or 8 bytes per
+    window start): a stream too long for that is cut into passes of ``max_windows`` window starts (default: what 60 % of the
+    free HBM of the tightest rank allows), each with its own exchange; consecutive passes overlap by k - 1 bytes, so no window
+    is lost or counted twice.
 
     Afterwards the ranks' tables are a disjoint partition of the key space (by k-mer slice for the dedupe-first modes, by
     hash slice -- the late route's owner rule -- for "hash"): ``global_scalar_sum`` of ``len`` / ``sum_counts`` gives the
@@ -257,24 +262,45 @@ def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, mo
         raise ValueError("the early route moves packed k-mers / hashes only: a store_kmers table would lose its hash -> k-mer map")
     if mode == "auto":
         mode = "compact" if table.ksize <= 21 else "dedupe64" if table.ksize <= 32 else "hash"
+    k = table.ksize
     dev = torch.device("cuda", torch.cuda.current_device())
     host = dist.get_backend(group) != "nccl"
-    # one capacity on every rank (the senders' bins follow the owners' table geometry)
-    cap = torch.tensor([table.capacity, -table.capacity], dtype=torch.int64, device="cpu" if host else dev)
-    dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
-    if int(cap[0]) != -int(cap[1]):
-        raise ValueError(f"the early route needs tables of one capacity on every rank (have {-int(cap[1])} .. {int(cap[0])} slots)")
-    ex = _Exchanger(group, dev)
-    n, stats = C.c_uint64(), (C.c_uint64 * 8)()
-    st = table._lib.kct_consume_device_routed(table._h, C.c_void_p(int(data_ptr)), int(nbytes), int(consumed_bytes), world, rank,
-                                              EARLY_MODES[mode], ex.alloc_ptr, ex.xchg_ptr, None, C.byref(n), stats)
+    cdev = "cpu" if host else dev
+    # one capacity on every rank (the senders' bins follow the owners' table geometry); the passes every rank will make
+    esz = 4 if mode == "compact" else 8
+    windows = max(int(nbytes) - k + 1, 0)
+    if max_windows is None:
+        free = torch.cuda.mem_get_info()[0]
+        max_windows = max(1 << 24, int(0.6 * free / (4.4 * esz)))
+    max_windows = max(1 << 16, int(max_windows) & ~0xFFFF)
+    mine = torch.tensor([table.capacity, -table.capacity, -(-windows // max_windows) if windows else 1], dtype=torch.int64, device=cdev)
+    dist.all_reduce(mine, op=dist.ReduceOp.MAX, group=group)
+    if int(mine[0]) != -int(mine[1]):
+        raise ValueError(f"the early route needs tables of one capacity on every rank (have {-int(mine[1])} .. {int(mine[0])} slots)")
+    passes = max(1, int(mine[2]))
+    step = ((-(-windows // passes)) + 0xFFFF) & ~0xFFFF if windows else 0   # window starts per pass, a multiple of 2^16 (16-byte aligned cuts)
+    keys = ("entries_sent", "entries_received", "entry_bytes", "overflow_sent", "overflow_received", "exchange_us", "blocks_abandoned", "skewed")
+    total_n, agg, bytes_sent, err, status = 0, dict.fromkeys(keys, 0), 0, None, 0
+    for p in range(passes):
+        off = min(p * step, int(nbytes))
+        length = min(int(nbytes) - off, step + k - 1) if p + 1 < passes else int(nbytes) - off
+        ex = _Exchanger(group, dev)
+        n, stats = C.c_uint64(), (C.c_uint64 * 8)()
+        st = table._lib.kct_consume_device_routed(table._h, C.c_void_p(int(data_ptr) + off), max(length, 0), int(consumed_bytes) if p == 0 else 0,
+                                                  world, rank, EARLY_MODES[mode], ex.alloc_ptr, ex.xchg_ptr, None, C.byref(n), stats)
+        total_n += n.value
+        for kk, v in zip(keys, stats):
+            agg[kk] = int(v) if kk in ("entry_bytes",) else agg[kk] + int(v)
+        bytes_sent += ex.bytes_sent
+        err = err or ex.error
+        status = status or st
+        del ex
     # a failure on ANY rank is every rank's failure (tables are then inconsistent across the job)
-    bad = torch.tensor([1 if st != 0 else 0], dtype=torch.int64, device="cpu" if host else dev)
+    bad = torch.tensor([1 if status != 0 else 0], dtype=torch.int64, device=cdev)
     dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
-    if ex.error is not None:
-        raise ex.error
-    table._check(st)
+    if err is not None:
+        raise err
+    table._check(status)
     if int(bad.item()):
         raise RuntimeError("the early route failed on another rank: clear the tables and use the late route (merge_across_ranks)")
-    keys = ("entries_sent", "entries_received", "entry_bytes", "overflow_sent", "overflow_received", "exchange_us", "blocks_abandoned", "skewed")
-    return n.value, dict(zip(keys, (int(v) for v in stats)), mode=mode, bytes_sent=ex.bytes_sent)
+    return total_n, dict(agg, mode=mode, bytes_sent=bytes_sent, passes=passes)

@@ -80,7 +80,9 @@ def early(mode, k, per_rank, G, L, rank, world, genome, reads, dev_reads):
 
     t = KmerCountTable(k, capacity=max(G // world, 400_000))
     half = (per_rank // 2) * (L + 1)
-    n1, s1 = consume_device_early(t, dev_reads.data_ptr(), half, (per_rank // 2) * L, mode=mode)
+    # (the first call is cut into passes of 2^22 window starts: several exchanges, windows across the cuts counted once)
+    n1, s1 = consume_device_early(t, dev_reads.data_ptr(), half, (per_rank // 2) * L, mode=mode, max_windows=1 << 22)
+    assert s1["passes"] == -(-(half - k + 1) // (1 << 22)) > 1, s1
     n2, s2 = consume_device_early(t, dev_reads.data_ptr() + half, dev_reads.numel() - half, (per_rank - per_rank // 2) * L, mode=mode)
     assert s1["mode"] == mode and s1["entry_bytes"] == (4 if mode == "compact" else 8) and not s1["skewed"]
     assert s1["entries_sent"] > 0 and s1["entries_received"] > 0
