@@ -84,7 +84,7 @@ MULTI = {
     "C4": (100_000_000, 150, 21, 500_000_000),
     "C5": (10_000_000, 10_000, 51, 3_100_000_000),
 }
-ALL_CONFIGS = ["cold_C2", "packed_C2", "e2e_C2", "per_record"] + list(BIG) + list(ERR) + list(MULTI)
+ALL_CONFIGS = ["cold_C2", "packed_C2", "e2e_C2", "per_record", "k51_deep"] + list(BIG) + list(ERR) + list(MULTI)
 
 
 def parse():
@@ -500,6 +500,39 @@ def main():
                                     "gate": {"n_and_sum_counts": bool(ok)}, **rep}
             assert ablate or ok
             del pc, pv
+        if "k51_deep" in want:
+            # k > 32 with deep coverage of a small genome (1 M x 150 bp, k=51, genome 2 Mbp; steady-state steps as the headline's): the
+            # 128-bit dedupe-first variant (chosen from the second step on) against hashing every window
+            Gk, kk = 2_000_000, 51
+            gk = torch.empty(Gk, dtype=torch.uint8, device="cuda")
+            rk = torch.empty(R * (L + 1), dtype=torch.uint8, device="cuda")
+            assert lib.kct_synth_genome_device(gk.data_ptr(), Gk, SEED_G, stream) == 0
+            assert lib.kct_synth_reads_device(rk.data_ptr(), gk.data_ptr(), Gk, 0, R, L, SEED_R, stream) == 0
+            torch.cuda.synchronize()
+            nk_step, res51 = R * (L - kk + 1), {}
+            for path in ("auto", "partitioned"):
+                t51 = KmerCountTable(kk, capacity=Gk)
+                t51.set_path(path)
+
+                def job51():
+                    n_ = 0
+                    for _s in range(args.steps):
+                        n_ += t51.consume_device(rk.data_ptr(), rk.numel(), R * L)
+                    return n_
+                timed_call(t51, job51, False)
+                runs = [timed_call(t51, job51, False) for _ in range(5)]
+                dt, n, prof = sorted(runs, key=lambda r_: r_[0])[len(runs) // 2]
+                res51[path] = (nk_step * args.steps / dt, dt, prof, (n, len(t51), t51.sum_counts) + t51.digest())
+                del t51
+            rep, _ = kernel_report(res51["auto"][2], nk_step * args.steps, L / (L - kk + 1) + 24.0, None)
+            ok = res51["auto"][3] == res51["partitioned"][3] and res51["auto"][3][0] == nk_step * args.steps
+            configs["k51_deep"] = {"kmers_per_s": res51["auto"][0], "seconds": res51["auto"][1], "steps": args.steps,
+                                   "partitioned_path_kmers_per_s": res51["partitioned"][0], "vs_partitioned": res51["auto"][0] / res51["partitioned"][0],
+                                   "path_chosen": "128-bit dedupe-first" if any("raw128" in kn for kn in res51["auto"][2]) else "hash every window",
+                                   "what": "1 M x 150 bp per step, k=51, genome 2 Mbp, steady state (event timing on)",
+                                   "gate": {"equals_partitioned_path": bool(ok)}, **rep}
+            assert ablate or ok
+            del gk, rk
         host = None
         if "e2e_C2" in want or "per_record" in want:
             host = reads0.cpu().numpy().reshape(R, L + 1)

@@ -276,8 +276,8 @@ KCT_API kct_status kct_sync(kct_table *t);
 
 /* Which device path bulk ingest uses: 0 = chosen per pass (default), 1 = direct path only (one
  * HBM atomic per k-mer), 2 = partitioned path whenever the table geometry allows (radix-partition
- * the hashes by 128-KiB table block, count each block in LDS), 3 = dedupe-first whenever k <= 32 and the
- * pass is large enough (count PACKED k-mers into a shadow table; their counts stay pending until something
+ * the hashes by 128-KiB table block, count each block in LDS), 3 = dedupe-first whenever k <= 64 and the
+ * pass is large enough (k <= 21: compact 32-bit entries, k <= 32: 64-bit, 33..64: 128-bit mix128 pairs; count PACKED k-mers into a shadow table; their counts stay pending until something
  * reads the table, when every k-mer with a pending count is hashed once and added -- every reading call
  * converts first, so no call can observe the difference).  Mode 0 picks dedupe-first when what the table
  * already holds says that a pass repeats few k-mers many times.  The tables' contents are identical; in

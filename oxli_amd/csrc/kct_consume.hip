@@ -77,6 +77,18 @@ template <>
 struct PartitionCompactByK<0> {
     static void run(int, hipStream_t, int, const unsigned char *, u64, u64, const kct::PartitionArgs &) {}
 };
+// the 128-bit dedupe-first variant (33 <= k <= 64): mix128 pairs, 16-byte entries
+template <int K>
+struct PartitionRaw128ByK {
+    static void run(int k, hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, u64 ntiles, const kct::PartitionArgs &a) {
+        if (k == K) hipLaunchKernelGGL((kct::partition_windows_kernel<2, K, 3>), dim3(grid), dim3(kct::kPartThreads), 0, s, stream, nbytes, k, ntiles, a);
+        else PartitionRaw128ByK<K - 1>::run(k, s, grid, stream, nbytes, ntiles, a);
+    }
+};
+template <>
+struct PartitionRaw128ByK<32> {
+    static void run(int, hipStream_t, int, const unsigned char *, u64, u64, const kct::PartitionArgs &) {}
+};
 template <>
 struct PartitionByK<0> {
     static void run(int k, hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, u64 ntiles, const kct::PartitionArgs &a) {
@@ -319,9 +331,12 @@ kct_status flush_compact(kct_table *t) {
 
 kct_status flush_shadow64(kct_table *t);
 
+kct_status flush_shadow128(kct_table *t);
+
 kct_status flush_shadow(kct_table *t) {
     KCT_TRY(flush_compact(t));
     KCT_TRY(flush_shadow64(t));
+    KCT_TRY(flush_shadow128(t));
     if (t->pending_pairs) {  // pairs that dedupe-first passes set aside while the table was lazily empty
         const u64 n = t->pending_pairs;
         t->pending_pairs = 0;
@@ -625,6 +640,137 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     o.new_keys = new_keys + new_in_table;
     o.blocked = blocked;
     return after_dedupe_pass(t, true, npos, o, probe);
+}
+
+
+// ---- 128-bit dedupe-first pass (33 <= k <= 64) ------------------------------------------------------------------------------------
+// K1 (MODE 3) partitions mix128 pairs of the packed k-mers by x into 1024 bins; aggregate_blocks128_kernel counts them into the
+// 128-bit shadow (1024 blocks x 4096 slots, one level whatever the table's size); what overflows a ring (or a shadow block) is
+// hashed and goes to the real table with the direct insert; reading the table converts the pending counts (shadow128_flush_kernel).
+kct_status flush_shadow128(kct_table *t) {
+    if (!t->s128_dirty) return KCT_OK;
+    t->s128_dirty = false;
+    t->s128_windows = 0;
+    KCT_TRY(materialize(t));
+    KCT_TRY(t->d_spill.reserve(std::max<u64>(t->s128_keys, 1) * 16));
+    KCT_TRY(zero_counters(t));
+    {
+        ProfScope ps(t, "shadow128_flush_kernel");
+        hipLaunchKernelGGL(kct::shadow128_flush_kernel, dim3(merge_grid(1024ULL << kct::kBlockBits128)), dim3(kct::kBlock), 0, t->stream, t->shadow128, 1024u,
+                           view(t, std::max<u64>(t->s128_keys, 1)), (int)t->k, t->d_counters);
+    }
+    HIP_TRY(hipGetLastError());
+    u64 c[4], spilled;
+    KCT_TRY(read_counters(t, c, &spilled));
+    t->n_keys += c[kct::CTR_NEWKEYS];
+    if (spilled) {
+        u64 ignored = 0;
+        KCT_TRY(t->d_aux2.reserve(spilled * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(replay_spill(t, spilled, &ignored));
+    }
+    return KCT_OK;
+}
+
+kct_status consume_raw128(kct_table *t, const unsigned char *d_stream, u64 chunk_bytes, u64 npos, u64 *n_out, bool *handled) {
+    *handled = false;
+    const int k = t->k, nwg = t->num_cus;
+    if (!t->shadow128) {
+        if (hipMalloc((void **)&t->shadow128, 1024 * kct::kBlockWords128 * 8) != hipSuccess) { (void)hipGetLastError(); t->dedupe128_off = true; return KCT_OK; }
+        t->s128_empty = true; t->s128_keys = 0;
+    }
+    // u32 counts with bit 31 taken: a pending count grows by at most the window starts consumed
+    if (t->s128_dirty && t->s128_windows + npos >= (1ULL << 31)) KCT_TRY(flush_shadow128(t));
+    const u64 P = 1024;
+    const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile, tiles_per_wg = (ntiles + nwg - 1) / nwg;
+    const unsigned int region_cap = (region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)P) + 3u) & ~3u;  // entries of 16 B: four per line
+    const unsigned int ovf_cap = overflow_capacity(tiles_per_wg * kct::kPartTile);
+    KCT_TRY(materialize(t));
+    KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * 16));
+    KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
+    KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 16 + (u64)nwg * 4));
+    KCT_TRY(t->d_spill.reserve((u64)nwg * ovf_cap * 16));
+    KCT_TRY(zero_counters(t));
+    du64 *d_overflow = t->d_counters + kNumCounters + 6;
+    unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + 2 * (u64)nwg * ovf_cap);
+    kct::PartitionArgs pa;
+    pa.mask = (P << kct::kBlockBits128) - 1; pa.block_bits = kct::kBlockBits128; pa.pbits = 10;
+    pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
+    pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
+    pa.ablate = t->ablate;
+    packed_args(t, d_stream, &pa);
+    {
+        ProfScope ps(t, "partition_windows_kernel<raw128>");
+        PartitionRaw128ByK<64>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
+    }
+    HIP_TRY(hipGetLastError());
+    kct::Aggregate128Args aa;
+    aa.words = t->shadow128; aa.scratch = (const ulonglong2 *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
+    aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
+    aa.fresh = t->s128_empty ? 1 : 0; aa.overflow = d_overflow; aa.nblocks = (unsigned int)P;
+    KCT_TRY(failed_blocks(t, P, &aa.failed));
+    aa.counters = t->d_counters;
+    {
+        ProfScope ps(t, "aggregate_blocks128_kernel");
+        hipLaunchKernelGGL(kct::aggregate_blocks128_kernel, dim3((unsigned)std::min<u64>(P, (u64)nwg)), dim3(kct::kPartThreads), 0, t->stream, aa);
+    }
+    HIP_TRY(hipGetLastError());
+    // K1's overflow entries: hashed, into the real table with the direct insert (same submission)
+    kct::TableView mv = view(t, (u64)nwg * ovf_cap);
+    mv.spill_n = t->d_counters + kNumCounters + 5;
+    {
+        ProfScope ps(t, "merge_entries128_kernel");
+        hipLaunchKernelGGL(kct::merge_entries128_kernel, dim3(256), dim3(kct::kBlock), 0, t->stream, (const ulonglong2 *)t->d_irr.p, (const unsigned int *)d_ovf_count,
+                           nwg, (u64)ovf_cap, 0ULL, 0ULL, (const unsigned int *)nullptr, 0ULL, (const du64 *)d_overflow, mv, t->d_counters, k);
+    }
+    HIP_TRY(hipGetLastError());
+    u64 c[4], unused;
+    KCT_TRY(read_counters(t, c, &unused));
+    if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // K1 gave up: every kernel after it exited early, nothing was touched
+    *handled = true;
+    const u64 counted = c[kct::CTR_COUNTED], new_keys = c[kct::CTR_NEW_BY_ZERO], spilled = t->h_counters[kNumCounters + 5];
+    const u64 nfailed = t->h_counters[kNumCounters + 7], blocked = t->h_counters[kNumCounters + 3];
+    t->s128_empty = false; t->s128_dirty = true;
+    t->s128_keys += new_keys; t->s128_windows += npos;
+    KCT_DBG(t, "128-bit dedupe pass: npos=%llu counted=%llu new keys=%llu (total %llu) abandoned=%llu blocks / %llu entries merged=%llu spilled=%llu\n",
+            (unsigned long long)npos, (unsigned long long)counted, (unsigned long long)new_keys, (unsigned long long)t->s128_keys, (unsigned long long)nfailed,
+            (unsigned long long)blocked, (unsigned long long)c[kct::CTR_TOTAL_ADDED], (unsigned long long)spilled);
+    *n_out += counted + c[kct::CTR_TOTAL_ADDED];
+    t->n_keys += c[kct::CTR_NEWKEYS];
+    u64 new_in_table = c[kct::CTR_NEWKEYS];
+    if (spilled) {
+        KCT_TRY(t->d_aux2.reserve(spilled * 16));
+        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, mv.spill, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
+        KCT_TRY(replay_spill(t, spilled, n_out));
+    }
+    if (nfailed) {  // shadow blocks that overflowed: their entries are hashed and counted into the real table
+        KCT_TRY(t->d_spill.reserve(std::max<u64>(blocked, 1) * 16));
+        HIP_TRY(hipMemsetAsync(t->d_counters, 0, (kNumCounters + 1) * sizeof(u64), t->stream));
+        const kct::TableView tv = view(t, std::max<u64>(blocked, 1));
+        {
+            ProfScope ps(t, "merge_entries128_kernel");
+            hipLaunchKernelGGL(kct::merge_entries128_kernel, dim3((unsigned)std::min<u64>(nfailed * nwg, 4096)), dim3(kct::kBlock), 0, t->stream, aa.scratch, aa.region_count,
+                               aa.nregions, 0ULL, aa.seg_stride, aa.block_stride, (const unsigned int *)t->d_failed.p, nfailed, (const du64 *)nullptr, tv, t->d_counters, k);
+        }
+        HIP_TRY(hipGetLastError());
+        u64 c3[4], sp3;
+        KCT_TRY(read_counters(t, c3, &sp3));
+        *n_out += c3[kct::CTR_TOTAL_ADDED];
+        t->n_keys += c3[kct::CTR_NEWKEYS];
+        new_in_table += c3[kct::CTR_NEWKEYS];
+        if (sp3) {
+            KCT_TRY(t->d_aux2.reserve(sp3 * 16));
+            HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, sp3 * 16, hipMemcpyDeviceToDevice, t->stream));
+            KCT_TRY(replay_spill(t, sp3, n_out));
+        }
+    }
+    // too few repeats, or the fixed-size shadow is filling up: convert and go back to hashing every window
+    if (t->force_path != 3 && ((new_keys + new_in_table) * 3 > npos || blocked * 50 > npos || t->s128_keys > kShadow128Keys)) {
+        KCT_TRY(flush_shadow128(t));
+        t->dedupe128_off = true;
+        t->dedupe_hint = false;
+    } else t->dedupe_hint = true;
+    return KCT_OK;
 }
 
 // One pass of the partitioned path over window starts [0, npos) of d_stream.  *handled = false
@@ -957,6 +1103,11 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
                 t->expect_new_keys = per_key < 6.0;  // fewer than six k-mers per distinct one: the first pass is mostly first sightings
                 continue;
             }
+        }
+        if (dedupe128_pays(t, npos)) {
+            bool handled = false;
+            KCT_TRY(consume_raw128(t, d_stream + done, chunk_bytes, npos, n_out, &handled));
+            if (handled) { done += npos; t->windows_since_read += npos; continue; }
         }
         if (compact_pays(t, npos)) {
             bool handled = false;

@@ -114,7 +114,7 @@ kct_status use_consume(kct_table *t) {
 
 kct_status use(kct_table *t) {
     KCT_TRY(use_consume(t));
-    if (t->shadow_dirty || t->s32_dirty || t->pending_pairs) {   // reads must observe every earlier consume()
+    if (t->shadow_dirty || t->s32_dirty || t->s128_dirty || t->pending_pairs) {   // reads must observe every earlier consume()
         KCT_DBG(t, "use(): converting pending counts (%llu / %llu shadow keys)\n", (unsigned long long)t->shadow_keys, (unsigned long long)t->s32_keys);
         KCT_TRY(flush_shadow(t));
         KCT_DBG(t, "use(): converted\n");
@@ -419,6 +419,8 @@ void kct_destroy(kct_table *t) {
     if (t->shadow32) (void)hipFree(t->shadow32);
     if (t->probe_shadow) (void)hipFree(t->probe_shadow);
     if (t->probe_shadow32) (void)hipFree(t->probe_shadow32);
+    if (t->shadow128) (void)hipFree(t->shadow128);
+    t->d_unpack.release();
     for (auto &b : t->h_file) b.release();
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
@@ -431,6 +433,7 @@ kct_status kct_clear(kct_table *t) {
     t->lazy_empty = true;  // the memset is issued by materialize() only if something needs it
     t->shadow_empty = true; t->shadow_dirty = false; t->shadow_keys = 0; t->dedupe_off = false;  // pending counts are forgotten too
     t->s32_empty = true; t->s32_dirty = false; t->s32_keys = 0; t->s32_windows = 0; t->compact_off = false;
+    t->s128_empty = true; t->s128_dirty = false; t->s128_keys = 0; t->s128_windows = 0; t->dedupe128_off = false;
     t->n_keys = 0; t->consumed = 0; t->zero_present = false; t->zero_count = 0;
     t->expect_new_keys = false;
     if (t->pending_pairs) { t->pending_pairs = 0; HIP_TRY(hipMemsetAsync(t->d_counters + kNumCounters + 8, 0, 8, t->stream)); }
@@ -771,6 +774,8 @@ kct_status kct_release_scratch(kct_table *t) {
     if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; t->s32_empty = true; t->s32_keys = 0; t->s32_windows = 0; }
     if (t->probe_shadow) { (void)hipFree(t->probe_shadow); t->probe_shadow = nullptr; }
     if (t->probe_shadow32) { (void)hipFree(t->probe_shadow32); t->probe_shadow32 = nullptr; }
+    if (t->shadow128) { (void)hipFree(t->shadow128); t->shadow128 = nullptr; t->s128_empty = true; t->s128_keys = 0; t->s128_windows = 0; }
+    t->d_unpack.release();
     t->h_stage.release(); t->h_pending.release();
     for (auto &b : t->h_file) b.release();
     return KCT_OK;
@@ -791,10 +796,11 @@ kct_status kct_set_deferred(kct_table *t, int on) {
 kct_status kct_set_path(kct_table *t, int mode) {
     KCT_TRY(use(t));
     if (mode < 0 || mode > 3) { set_err("mode must be 0, 1, 2 or 3"); return KCT_ERR_ARG; }
-    if (mode == 3 && t->k > 32) { set_err("the dedupe-first path needs k <= 32"); return KCT_ERR_ARG; }
+    if (mode == 3 && t->k > 64) { set_err("the dedupe-first paths need k <= 64"); return KCT_ERR_ARG; }
     t->force_path = mode;
     t->dedupe_off = false;
     t->compact_off = false;
+    t->dedupe128_off = false;
     t->dedupe_hint = false;  // what earlier passes taught this table about its input is forgotten too
     return KCT_OK;
 }

@@ -197,6 +197,11 @@ struct kct_table {
     unsigned int s32_bin0 = 0, s32_nbins = 1024;
     bool s32_empty = true, s32_dirty = false, compact_off = false;
     u64 s32_keys = 0, s32_windows = 0;  // keys it holds; window starts counted into it since its last flush (u32 counts!)
+    // 128-bit variant (33 <= k <= 64): 1024 blocks x 4096 slots of {x, y, u32 count} (80 MiB), keyed by mix128 pairs; whatever the
+    // table's size (its conversion inserts with atomics) -- for inputs of up to ~2.5 M distinct k-mers
+    du64 *shadow128 = nullptr;
+    bool s128_empty = true, s128_dirty = false, dedupe128_off = false;
+    u64 s128_keys = 0, s128_windows = 0;
     // the dedupe probe's own small shadows (kept between calls, swapped in for the probe pass only)
     du64 *probe_shadow = nullptr;
     unsigned int *probe_shadow32 = nullptr;

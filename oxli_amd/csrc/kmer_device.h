@@ -238,6 +238,18 @@ __device__ __host__ __forceinline__ u64 unmix64(u64 x) {
     return x;
 }
 
+// Two words (33 <= k <= 64: the packed k-mer is w0 = high word, w1 = low word): two Feistel rounds with mix64 as the round function --
+// a bijection of 128 bits whatever mix64 is.  x (the word every partition / slot / bin decision looks at) depends non-linearly on
+// every input bit; y is the companion word that makes the pair identify the k-mer.
+__device__ __host__ __forceinline__ void mix128(u64 w0, u64 w1, u64 &x, u64 &y) {
+    y = w0 ^ mix64(w1 + 0x9e3779b97f4a7c15ULL);
+    x = w1 ^ mix64(y + 0x3c6ef372fe94f82aULL);
+}
+__device__ __host__ __forceinline__ void unmix128(u64 x, u64 y, u64 &w0, u64 &w1) {
+    w1 = x ^ mix64(y + 0x3c6ef372fe94f82aULL);
+    w0 = y ^ mix64(w1 + 0x9e3779b97f4a7c15ULL);
+}
+
 // The same on 42 bits (k <= 21: a packed k-mer is at most 42 bits): the compact dedupe-first path splits the result
 // into a 10-bit bin and a 32-bit entry.  A multiplication mod 2^42 by an odd constant and the xor-shift by 21 (its own
 // inverse on 42 bits) are bijections of [0, 2^42).

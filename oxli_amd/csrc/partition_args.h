@@ -118,6 +118,24 @@ struct AggregatePairsArgs {
     u64 *counters;       // CTR_TOTAL_ADDED (counts placed), CTR_NEWKEYS
 };
 
+// ---- 128-bit dedupe-first path (33 <= k <= 64): a shadow of 1024 blocks x 4096 slots keyed by mix128 pairs {x, y} ----------------
+constexpr int kBlockBits128 = 12;                   // 4096 slots: 32 KiB of x + 32 KiB of y + 16 KiB of counts = 80 KiB, one CU's LDS share
+constexpr u32 kSlots128 = 1u << kBlockBits128;
+constexpr u64 kBlockWords128 = (u64)kSlots128 * 2 + kSlots128 / 2;  // u64 words per block in HBM: x[S], y[S], count[S] (u32)
+constexpr u32 kClaimed128 = 0x80000000u;            // count word, bit 31: the slot's y has been written (its x was claimed by CAS)
+struct Aggregate128Args {
+    u64 *words;          // [1024 blocks][x[S] | y[S] | count[S] u32]
+    const ulonglong2 *scratch;  // region (seg, b) at scratch + seg * seg_stride + b * block_stride (entries)
+    u64 seg_stride, block_stride;
+    const u32 *region_count;    // [blocks][nregions]
+    int nregions;
+    int fresh;
+    const u64 *overflow; // K1's abandon flag
+    u32 nblocks;
+    FailedBlocks failed;
+    u64 *counters;       // CTR_COUNTED, CTR_NEW_BY_ZERO (new shadow keys)
+};
+
 struct PendingList {
     u64 *pairs = nullptr;  // 2 * cap words
     u64 cap = 0;

@@ -112,9 +112,11 @@ __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *f
 template <int KW, int KC, int MODE = 0>
 __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
                                                                          u64 ntiles, PartitionArgs a) {
-    using T = typename std::conditional<MODE == 2, u32, u64>::type;
+    // MODE 3 (33 <= k <= 64, dedupe-first): mix128 values of the two packed words as 16-byte {x, y} entries: bins and slots come from x.
+    using T = typename std::conditional<MODE == 2, u32, typename std::conditional<MODE == 3, ulonglong2, u64>::type>::type;
+    using PH = typename std::conditional<MODE == 3, u64, T>::type;  // the pending append's (first) word
     constexpr int kEntries = kRingEntries * 8 / sizeof(T);  // the ring is 128 KiB either way
-    constexpr int kFlushEvery = MODE == 2 ? 8 : 4;          // windows between flushes
+    constexpr int kFlushEvery = MODE == 2 ? 8 : MODE == 3 ? 2 : 4;  // windows between flushes: a quarter of the ring per interval
     __shared__ __attribute__((aligned(16))) T ring[kEntries];
     __shared__ u64 cur[1024];  // per bin: fill (low half) | flushed (high half)
     constexpr u32 kListCap = KW == 0 ? 1792 : 2048;  // the bytewise path's raw tile leaves a little less LDS
@@ -140,7 +142,11 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     const u32 D = (u32)(kEntries >> a.pbits), dmask = D - 1;
     const int dshift = __builtin_ctz((unsigned)kEntries) - a.pbits;  // log2 D
     static_assert(kRingEntries == 1 << 14, "dshift assumes a 16384-entry (u64) ring");
-    for (int i = threadIdx.x; i < kEntries; i += kPartThreads) ring[i] = 0;
+    {
+        T zero;
+        memset(&zero, 0, sizeof zero);
+        for (int i = threadIdx.x; i < kEntries; i += kPartThreads) ring[i] = zero;
+    }
     for (int i = threadIdx.x; i < 1024; i += kPartThreads) cur[i] = 0;
     if (threadIdx.x == 0) { ovf_n = 0; fcount = 0; }
     T *my_scratch = reinterpret_cast<T *>(a.scratch) + (u64)blockIdx.x * P * a.region_cap;  // region_cap counts entries
@@ -150,11 +156,13 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     // region: an LDS cursor and a plain 8-byte store, no global atomic, no cross-lane traffic.
     // The host folds those regions in afterwards with the direct atomic kernel, which combines
     // equal neighbours -- so the hot loop needs no duplicate detection at all.
-    u64 *my_ovf = a.ovf + (u64)blockIdx.x * a.ovf_cap;
-    auto overflow_hash = [&](u64 h) {
+    u64 *my_ovf = a.ovf + (u64)blockIdx.x * a.ovf_cap * (MODE == 3 ? 2 : 1);  // (MODE 3: two words per overflow entry)
+    auto overflow_hash = [&](u64 h, u64 y = 0) {
         const u32 i = atomicAdd(&ovf_n, 1u);
-        if (i < a.ovf_cap) my_ovf[i] = h;
-        else *a.overflow = 1ULL;
+        if (i < a.ovf_cap) {
+            if constexpr (MODE == 3) { my_ovf[2 * i] = h; my_ovf[2 * i + 1] = y; }
+            else my_ovf[i] = h;
+        } else *a.overflow = 1ULL;
     };
     auto flush_lines = [&](bool drain) {
         return ring_flush<kListCap, T>(ring, cur, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_hash);
@@ -220,17 +228,22 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         // block's flush mark is read as soon as its hash exists, but the returned position is only
         // consumed -- and the hash written into the ring -- after window j+1 has been hashed, so the
         // LDS round trip hides under ~130 VALU instructions instead of stalling the wave.
-        T pend_h = 0;
+        PH pend_h = 0;
+        u64 pend_y = 0, aux_y = 0;  // (MODE 3: the companion word of the pending append / of the window just mixed)
         u32 pend_b = 0, pend_pos = 0, pend_mark = 0;
         auto commit = [&]() {
             if (pend_h) {
-                if (pend_pos - pend_mark < D) ring[(pend_b << dshift) + (pend_pos & dmask)] = pend_h;  // slot's previous tenant is flushed
+                if (pend_pos - pend_mark < D) {  // slot's previous tenant is flushed
+                    if constexpr (MODE == 3) ring[(pend_b << dshift) + (pend_pos & dmask)] = make_ulonglong2(pend_h, pend_y);
+                    else ring[(pend_b << dshift) + (pend_pos & dmask)] = pend_h;
+                } else if constexpr (MODE == 3) overflow_hash(pend_h, pend_y);
                 else overflow_hash(MODE == 2 ? (((u64)pend_b << 32) | pend_h | (1ULL << 63)) : (u64)pend_h);  // ring full: position stays a 0 hole
                 pend_h = 0;
             }
         };
         auto sink = [&](int j, bool good, u64 h) {
             commit();  // the previous window's append
+            if (MODE == 3 && good && h == 0 && !(a.ablate & 1)) overflow_hash(0ULL, aux_y);  // (x = 0, the ring's hole marker: one value in 2^64)
             if (good && h != 0 && !(a.ablate & 1)) {
                 if (MODE == 2 && (u32)h == 0) overflow_hash(h);  // (one value in 2^32: its low half is the hole marker)
                 else {
@@ -241,7 +254,8 @@ if constexpr (MODE == 2) pend_b = (u32)(h >> 32) & 1023u;
                     const u64 cw = atomicAdd(&cur[pend_b], 1ULL);
                     pend_pos = (u32)cw;
                     pend_mark = (u32)(cw >> 32);
-                    pend_h = (T)h;
+                    pend_h = (PH)h;
+                    if constexpr (MODE == 3) pend_y = aux_y;
                 }
             }
             if ((j & (kFlushEvery - 1)) == kFlushEvery - 1 && !(a.ablate & 2)) {  // every fourth (eighth) step: move every full line out
@@ -250,7 +264,7 @@ if constexpr (MODE == 2) pend_b = (u32)(h >> 32) & 1023u;
             }
         };
         if constexpr (KW == 0) walk_windows<0, 0, kPartWPT>(lds, k, sink);
-        else walk_windows_encoded<KW, KC, true, MODE>(tcodes, tvalid, k, sink, ascii4, pm1, pm2);
+        else walk_windows_encoded<KW, KC, true, MODE>(tcodes, tvalid, k, sink, ascii4, pm1, pm2, &aux_y);
         commit();
     }
     while (flush_lines(true)) {}  // drain: partial lines go out zero-padded; repeat while the list was too short
@@ -1094,6 +1108,255 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_pairs_kernel(Aggregate
         if (sum_tot) atomicAdd(shard + CTR_TOTAL_ADDED, sum_tot);
         if (sum_new) atomicAdd(shard + CTR_NEWKEYS, sum_new);
         if (sum_nz) atomicAdd(shard + CTR_NEW_BY_ZERO, sum_nz);
+    }
+}
+
+
+// =================================================================================================
+// 128-bit dedupe-first path (33 <= k <= 64).  The packed k-mer is two words; K1 (MODE 3) partitions 16-byte {x, y} = mix128 entries
+// by x into 1024 bins; this is K2 for them: one workgroup per shadow block of 4096 slots (x, y, u32 count in LDS), general insert
+// only.  Claim protocol for a two-word key: CAS on the slot's x word; the winner then writes y and sets bit 31 of the count word;
+// whoever finds its own x in a slot waits for that bit before comparing y.  The loops are wave-uniform, so within a wave every
+// claim of a step has been completed (program order) before any lane of that wave waits; across waves the wait is a plain spin.
+// =================================================================================================
+constexpr int kWaveQueue128 = 96;  // deferred entries per wave (16 B each: 24 KiB for the sixteen waves)
+__global__ __launch_bounds__(kPartThreads) void aggregate_blocks128_kernel(Aggregate128Args a) {
+    __shared__ __attribute__((aligned(16))) u64 kx[kSlots128], ky[kSlots128];
+    __shared__ __attribute__((aligned(16))) u32 cn[kSlots128];
+    __shared__ __attribute__((aligned(16))) unsigned char tags[kSlots128];  // one fingerprint byte per slot (0 = not (yet) claimed)
+    __shared__ __attribute__((aligned(16))) ulonglong2 wq[(kPartThreads / 64) * kWaveQueue128];
+    __shared__ u64 s_counted, s_new;
+    __shared__ u32 s_failed;
+    if (*a.overflow) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kWaves = kPartThreads / 64, kInFlight = 6;
+    constexpr u32 kSlab = 64 * kInFlight;
+    auto tag_of = [](u64 x) -> u32 { const u32 tg = (u32)(x >> 32) & 0xFFu; return tg ? tg : 1u; };
+    u64 sum_counted = 0, sum_new = 0;
+    for (u32 b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+        u64 *gb = a.words + (u64)b * kBlockWords128;
+        if (threadIdx.x == 0) { s_counted = 0; s_new = 0; s_failed = 0; }
+        uint4 *x4 = reinterpret_cast<uint4 *>(kx), *y4 = reinterpret_cast<uint4 *>(ky), *c4 = reinterpret_cast<uint4 *>(cn);
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(gb);
+        for (u32 i = threadIdx.x; i < kSlots128 / 2; i += kPartThreads) {
+            x4[i] = a.fresh ? make_uint4(0, 0, 0, 0) : g4[i];
+            y4[i] = a.fresh ? make_uint4(0, 0, 0, 0) : g4[kSlots128 / 2 + i];
+        }
+        for (u32 i = threadIdx.x; i < kSlots128 / 4; i += kPartThreads) c4[i] = a.fresh ? make_uint4(0, 0, 0, 0) : g4[kSlots128 + i];
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < kSlots128 / 4; i += kPartThreads) {  // four slots per thread: their tags as one 4-byte word
+            u32 w = 0;
+            if (!a.fresh) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const u64 xx = kx[4 * i + q]; w |= (xx ? tag_of(xx) : 0u) << (8 * q); }
+            }
+            reinterpret_cast<u32 *>(tags)[i] = w;
+        }
+        __syncthreads();
+        u32 counted = 0, newkeys = 0;
+        // General insert (wave-uniform loops; `active` lanes carry an entry).  A group is four slots.
+        auto insert = [&](const ulonglong2 e, bool active) {
+            const u64 x = e.x, y = e.y;
+            bool pending = active && x != 0;  // (x = 0: hole / padding)
+            u32 g = (u32)x & (kSlots128 - 1) & ~3u;
+            for (u32 round = 0; round < kSlots128 / 4; ++round) {
+                if (!__any(pending)) break;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bool mine = false;
+                    u64 cur = 0;
+                    if (pending) {
+                        cur = kx[g + i];
+                        if (cur == 0) {
+                            cur = atomicCAS(&kx[g + i], 0ULL, x);
+                            if (cur == 0) {
+                                ky[g + i] = y;
+                                __threadfence_block();
+                                atomicOr(&cn[g + i], kClaimed128);
+                                tags[g + i] = (unsigned char)tag_of(x);  // (last: a tag in place means the slot is complete)
+                                mine = true; cur = x; ++newkeys;
+                            }
+                        }
+                    }
+                    if (pending && cur == x) {
+                        if (!mine) while (!(atomicOr(&cn[g + i], 0u) & kClaimed128)) {}
+                        if (ky[g + i] == y) { atomicAdd(&cn[g + i], 1u); pending = false; ++counted; }
+                    }
+                }
+                g = (g + 4) & (kSlots128 - 1);
+            }
+            if (pending) s_failed = 1u;  // block full: the whole block is abandoned (FailedBlocks)
+        };
+        ulonglong2 *myq = wq + wave * kWaveQueue128;
+        u32 qn = 0;  // wave-uniform
+        auto drain = [&](u32 keep_below) {
+            while (qn > keep_below) {
+                const u32 take = qn < 64 ? qn : 64;
+                qn -= take;
+                const bool act = (u32)lane < take;
+                insert(act ? myq[qn + lane] : make_ulonglong2(0, 0), act);
+            }
+        };
+        // Fast path: a repeat sighting of a key that sits in its home group -- four tag bytes (one 4-byte read), a SWAR byte match,
+        // the two key words to confirm, one ds_add.  Everything else is parked in the wave's queue for the general insert.
+        auto fast = [&](const ulonglong2 e) {
+            bool miss = e.x != 0;
+            if (e.x != 0) {
+                const u32 g = (u32)e.x & (kSlots128 - 1) & ~3u;
+                const u32 t4 = *reinterpret_cast<const u32 *>(tags + g);
+                const u32 xo = t4 ^ (tag_of(e.x) * 0x01010101u);
+                const u32 z = (xo - 0x01010101u) & ~xo & 0x80808080u;  // lowest set bit marks the first equal byte
+                if (z) {
+                    const u32 idx = (u32)__builtin_ctz(z) >> 3;
+                    if (kx[g + idx] == e.x && ky[g + idx] == e.y) { atomicAdd(&cn[g + idx], 1u); ++counted; miss = false; }
+                }
+            }
+            const u64 m = __ballot(miss);
+            if (m) {
+                const u32 pos = qn + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                if (miss) myq[pos] = e;
+                qn += (u32)__popcll(m);
+                if (qn > kWaveQueue128 - 64) drain(31);
+            }
+        };
+        // one level: nregions short regions per block, one wave each; all of a lane's loads of a slab are issued before the first insert
+        const u32 *my_counts = a.region_count + (u64)b * a.nregions;
+        for (int seg = wave; seg < a.nregions; seg += kWaves) {
+            const u32 cnt = my_counts[seg];
+            const ulonglong2 *region = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride;
+            for (u32 s0 = 0; s0 < cnt; s0 += kSlab) {
+                ulonglong2 v[kInFlight];
+#pragma unroll
+                for (int j = 0; j < kInFlight; ++j) { const u32 i = s0 + lane + 64 * j; v[j] = i < cnt ? region[i] : make_ulonglong2(0, 0); }
+#pragma unroll
+                for (int j = 0; j < kInFlight; ++j) fast(v[j]);
+            }
+        }
+        drain(0);
+        const u64 wc = wave_sum((u64)counted), wn = wave_sum((u64)newkeys);
+        if (lane == 0) { atomicAdd(&s_counted, wc); atomicAdd(&s_new, wn); }
+        __syncthreads();
+        if (s_failed) {
+            if (a.fresh) for (u32 i = threadIdx.x; i < kBlockWords128 / 2; i += kPartThreads) reinterpret_cast<uint4 *>(gb)[i] = make_uint4(0, 0, 0, 0);
+            if (threadIdx.x == 0) {
+                u64 entries = 0;
+                for (int r = 0; r < a.nregions; ++r) entries += my_counts[r];
+                a.failed.list[atomicAdd(a.failed.n, 1ULL)] = b;
+                atomicAdd(a.failed.entries, entries);
+            }
+        } else {
+            uint4 *o4 = reinterpret_cast<uint4 *>(gb);
+            for (u32 i = threadIdx.x; i < kSlots128 / 2; i += kPartThreads) { o4[i] = x4[i]; o4[kSlots128 / 2 + i] = y4[i]; }
+            for (u32 i = threadIdx.x; i < kSlots128 / 4; i += kPartThreads) o4[kSlots128 + i] = c4[i];
+            if (threadIdx.x == 0) { sum_counted += s_counted; sum_new += s_new; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        u64 *shard = a.counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (sum_counted) atomicAdd(shard + CTR_COUNTED, sum_counted);
+        if (sum_new) atomicAdd(shard + CTR_NEW_BY_ZERO, sum_new);
+    }
+}
+
+// mix128 pair of a packed canonical k-mer -> its MurmurHash3 value (33 <= k <= 64)
+__device__ __forceinline__ u64 hash_of_mixed128(u64 x, u64 y, int k, const u32 *lut) {
+    Packed<2> p;
+    unmix128(x, y, p.w[0], p.w[1]);
+    left_align(p, k);
+    return hash_packed<2, true>(p, k, lut);
+}
+
+// the 128-bit shadow's pending counts -> the real table: every slot with a count is turned back into its k-mer, hashed once and
+// added with the direct insert; the count returns to zero (bit 31 stays), the key stays.  At most 2.7 M k-mers: ~0.1 ns each.
+__global__ __launch_bounds__(kBlock) void shadow128_flush_kernel(u64 *__restrict__ shadow, u32 nblocks, TableView main, int k, u64 *counters) {
+    __shared__ u32 ascii4[256];
+    __shared__ u64 s_tot, s_new;
+    fill_ascii4_lut(ascii4, threadIdx.x, kBlock);
+    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; }
+    __syncthreads();
+    u64 tot = 0, nk = 0;
+    const u64 slots = (u64)nblocks << kBlockBits128;
+    for (u64 s = (u64)blockIdx.x * kBlock + threadIdx.x; s < slots; s += (u64)gridDim.x * kBlock) {
+        u64 *blk = shadow + (s >> kBlockBits128) * kBlockWords128;
+        const u32 i = (u32)s & (kSlots128 - 1);
+        u32 *cp = reinterpret_cast<u32 *>(blk + 2 * kSlots128) + i;
+        const u32 c = *cp & ~kClaimed128;
+        if (c == 0) continue;
+        *cp = kClaimed128;
+        const u64 h = hash_of_mixed128(blk[i], blk[kSlots128 + i], k, ascii4);
+        if (h == 0) continue;  // lib.rs:589: hash 0 is skipped
+        const AddResult r = table_add<false>(main, h, (u64)c);
+        if (!r.spilled) { tot += c; nk += r.claimed; }
+    }
+    tot = wave_sum(tot); nk = wave_sum(nk);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
+    }
+}
+
+// {x, y} entries that did not reach the 128-bit shadow -> the real table with the direct insert: K1's overflow regions
+// (failed_list == nullptr: nregions regions of up to region_cap entries, counts[r] each) or the scratch regions of the shadow
+// blocks K2 abandoned (failed_list: for each listed block its nregions regions at scratch + seg * seg_stride + b * block_stride).
+// Equal neighbours are folded per wave first.  Every entry below its region's count is live (x may be 0 in an overflow region).
+__global__ __launch_bounds__(kBlock) void merge_entries128_kernel(const ulonglong2 *__restrict__ scratch, const u32 *__restrict__ counts, int nregions,
+                                                                  u64 region_cap, u64 seg_stride, u64 block_stride, const u32 *failed_list, u64 nfailed,
+                                                                  const u64 *abort, TableView table, u64 *counters, int k) {
+    __shared__ u64 s_tot, s_new;
+    __shared__ u32 ascii4[256];
+    if (abort && *abort) return;
+    fill_ascii4_lut(ascii4, threadIdx.x, kBlock);
+    if (threadIdx.x == 0) { s_tot = 0; s_new = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64 tot = 0, nk = 0;
+    const u64 nwork = failed_list ? nfailed * (u64)nregions : (u64)nregions;
+    for (u64 w = blockIdx.x; w < nwork; w += gridDim.x) {
+        const ulonglong2 *src;
+        u32 cnt;
+        bool skip_holes;
+        if (failed_list) {
+            const u32 b = failed_list[w / nregions];
+            const u64 seg = w % nregions;
+            cnt = counts[(u64)b * nregions + seg];
+            src = scratch + seg * seg_stride + (u64)b * block_stride;
+            skip_holes = true;   // ring regions: x = 0 is a hole
+        } else { cnt = counts[w]; src = scratch + w * region_cap; skip_holes = false; }
+        for (u32 base = 64u * wave; base < cnt; base += kBlock) {
+            const u32 i = base + lane;
+            ulonglong2 e = make_ulonglong2(0, 0);
+            bool pending = i < cnt;
+            if (pending) e = src[i];
+            if (skip_holes && e.x == 0) pending = false;
+            bool is_leader = false;
+            u64 c = 0, act;
+            while ((act = __ballot(pending)) != 0) {
+                const int leader = __ffsll((long long)act) - 1;
+                const u64 xl = read_lane64(e.x, leader), yl = read_lane64(e.y, leader);
+                const u64 same = __ballot(pending && e.x == xl && e.y == yl);
+                if (lane == leader) { is_leader = true; c = (u64)__popcll(same); }
+                if ((same >> lane) & 1ULL) pending = false;
+            }
+            if (is_leader) {
+                const u64 hh = hash_of_mixed128(e.x, e.y, k, ascii4);
+                if (hh != 0) {
+                    const AddResult res = table_add<false>(table, hh, c);
+                    if (!res.spilled) { tot += c; nk += res.claimed; }
+                }
+            }
+        }
+    }
+    tot = wave_sum(tot); nk = wave_sum(nk);
+    if (lane == 0) { atomicAdd(&s_tot, tot); atomicAdd(&s_new, nk); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 *shard = counters + (blockIdx.x % kCounterShards) * kCounterStride;
+        if (s_tot) atomicAdd(shard + CTR_TOTAL_ADDED, s_tot);
+        if (s_new) atomicAdd(shard + CTR_NEWKEYS, s_new);
     }
 }
 

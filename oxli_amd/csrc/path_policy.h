@@ -143,6 +143,23 @@ bool compact_pays(const T *t, pu64 npos) {
     return known <= (pu64)((double)(1ULL << (kCompactBlockBits + kPolicyBlockBitsMax)) * 0.6);
 }
 
+// The 128-bit variant (33 <= k <= 64): a fixed shadow of 1024 x 4096 slots holds ~2.5 M k-mers at most, and its conversion inserts
+// with atomics (~0.1 ns per pending k-mer): for deep coverage of SMALL genomes only -- 32 windows per known k-mer between reads.
+// Its 16-byte entries flush K1's ring every second window and double K2's stream, so it only beats hashing every window where the
+// hash is long: measured at C2 size on a 2 Mbp genome (tools/k51_probe.py) k = 33: 7.9 against 8.6x10^10 k-mers/s hashing, k = 51:
+// 7.6 against 6.6, k = 64: 7.3 against 5.5 -- chosen by itself from k = 40 on, forced (set_path 3) at any k in 33..64.
+constexpr pu64 kShadow128Keys = (pu64)(0.6 * 1024 * 4096);
+constexpr int kDedupe128MinK = 40;
+template <class T>
+bool dedupe128_pays(const T *t, pu64 npos) {
+    if (t->k <= 32 || t->k > 64 || t->dedupe128_off || npos < (1ULL << 22)) return false;
+    if (t->force_path == 3) return true;
+    if (t->force_path != 0 || t->k < kDedupe128MinK) return false;
+    const pu64 known = std::max<pu64>(t->n_keys, t->s128_keys);
+    if (known == 0) return t->dedupe_hint;
+    return known <= kShadow128Keys && known * 32 <= t->windows_since_read + std::max<pu64>(npos, t->call_windows_left);
+}
+
 // A large call into a table that knows nothing about its input (no keys, no hint from earlier passes): is this deep
 // coverage of few k-mers (dedupe-first pays) or mostly distinct ones?  The first 2^22 window starts go through the
 // dedupe-first kernels as a PROBE -- unless no shadow this call could pay for exists anyway.
@@ -177,9 +194,10 @@ bool probe_verdict(const T *t, double per_key, pu64 call_windows) {
 
 // The path of a pass of npos window starts, in the order consume_stream tries them (a path that abandons a pass hands it to
 // the next): 3 = compact dedupe-first, 2 = 64-bit dedupe-first, 1 = partitioned (hash every window), 0 = direct atomic kernel.
-enum PassPath { PASS_DIRECT = 0, PASS_PARTITIONED = 1, PASS_DEDUPE64 = 2, PASS_COMPACT = 3 };
+enum PassPath { PASS_DIRECT = 0, PASS_PARTITIONED = 1, PASS_DEDUPE64 = 2, PASS_COMPACT = 3, PASS_DEDUPE128 = 4 };
 template <class T>
 PassPath choose_path(const T *t, pu64 npos) {
+    if (dedupe128_pays(t, npos)) return PASS_DEDUPE128;
     if (compact_pays(t, npos)) return PASS_COMPACT;
     if (dedupe_pays(t, npos)) return PASS_DEDUPE64;
     if (partition_geometry_ok(t) && t->force_path != 1 && (t->force_path == 2 || partition_pays(t, npos))) return PASS_PARTITIONED;

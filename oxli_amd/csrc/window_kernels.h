@@ -84,9 +84,10 @@ __device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, in
 // RAW = 1 (k <= 32 only): the sink receives mix64(packed canonical k-mer + 1) instead of the MurmurHash3 value --
 // the dedupe-first path counts k-mers first and hashes each distinct one once (partition_kernels.h).
 // RAW = 2 (k <= 21): mix42(packed canonical k-mer), a 42-bit value, with bit 63 set.
+// RAW = 3 (33 <= k <= 64): mix128 of the two packed words: the sink receives x, the companion word y is left in *aux.
 template <int KW, int KC, bool LUT = false, int RAW = 0, class Sink>
 __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const unsigned short *valid, int k_rt, Sink &&sink,
-                                                     const u32 *lut = nullptr, const u64 *mul1 = nullptr, const u64 *mul2 = nullptr) {
+                                                     const u32 *lut = nullptr, const u64 *mul1 = nullptr, const u64 *mul2 = nullptr, u64 *aux = nullptr) {
     constexpr int WPT = 16, NW = 2 * KW + 1;  // code words covering bases 0 .. 15 + k
     const int k = KC > 0 ? KC : k_rt;
     u32 w[NW];
@@ -143,7 +144,7 @@ __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const uns
     }
     // fully unrolled where the window's work is long (hashing: K1 -2 %) or the loop's own branches weigh (compact: -3 %; the
     // every-eighth-window flush test becomes static); the 64-bit raw mode is 2 % faster unrolled by four
-    constexpr int kUnroll = RAW == 1 ? 4 : WPT;
+    constexpr int kUnroll = (RAW == 1 || RAW == 3) ? 4 : WPT;
 #pragma unroll kUnroll
     for (int j = 0; j < WPT; ++j) {
         const bool good = run >= k;
@@ -156,6 +157,9 @@ __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const uns
             } else if constexpr (RAW == 2) {
                 static_assert(KW == 1 && (KC == 0 || KC <= 21), "the compact dedupe-first path needs 2k <= 42 bits");
                 h = mix42(c.w[0]) | (1ULL << 63);  // bit 63: "not the zero hash" for the sink's h != 0 test; the sink drops it
+            } else if constexpr (RAW == 3) {
+                static_assert(KW == 2, "two packed words per k-mer");
+                mix128(c.w[0], c.w[1], h, *aux);
             } else {
                 left_align(c, k);
                 h = hash_packed<KW, LUT>(c, k, lut, mul1, mul2);

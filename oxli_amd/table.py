@@ -595,7 +595,7 @@ class KmerCountTable:
 
     def set_path(self, mode):
         """0 = choose per pass, 1 = direct atomic path only, 2 = partitioned path whenever possible,
-        3 = dedupe-first path (k <= 32) whenever the pass is large enough."""
+        3 = dedupe-first path (k <= 64) whenever the pass is large enough."""
         self._check(self._lib.kct_set_path(self._h, {"auto": 0, "direct": 1, "partitioned": 2, "dedupe": 3}.get(mode, mode)))
 
     # ---- in-library kernel timing (bench.py) ----------------------------------------------------------

@@ -8,8 +8,8 @@ struct FakeTable {   // the members path_policy.h reads, with kct_table's names
     uint64_t cap = 1 << 16;
     int block_bits = 13;
     int force_path = 0;
-    bool dedupe_off = false, compact_off = false, dedupe_hint = false, auto_sized = false, shadow_dirty = false, s32_dirty = false;
-    uint64_t n_keys = 0, shadow_keys = 0, s32_keys = 0, windows_since_read = 0, call_windows_left = 0;
+    bool dedupe_off = false, compact_off = false, dedupe_hint = false, auto_sized = false, shadow_dirty = false, s32_dirty = false, dedupe128_off = false;
+    uint64_t n_keys = 0, shadow_keys = 0, s32_keys = 0, s128_keys = 0, windows_since_read = 0, call_windows_left = 0;
     FakeTune tune;
 };
 

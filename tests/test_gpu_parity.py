@@ -478,9 +478,10 @@ def test_partitioned_path_every_k_up_to_64(KCT):
         assert_same_table(dev, ref)
 
 
-@pytest.mark.parametrize("k", [1, 5, 16, 21, 31, 32])
+@pytest.mark.parametrize("k", [1, 5, 16, 21, 31, 32, 33, 41, 51, 64])
 def test_dedupe_first_path_matches_oracle(KCT, k):
-    """Dedupe-first path (k <= 32): packed k-mers are counted in LDS scratch blocks, each distinct one is hashed once.
+    """Dedupe-first paths (compact k <= 21, 64-bit k <= 32, 128-bit 33 <= k <= 64): packed k-mers are counted in LDS shadow blocks, each
+    distinct one is hashed once.
     Deep coverage of a small genome (its home ground), bad bytes, lower case, homopolymers, short records."""
     rng = random.Random(7000 + k)
     genome = rand_dna(rng, 40000)
@@ -502,7 +503,7 @@ def test_dedupe_first_path_matches_oracle(KCT, k):
     dev.set_path("dedupe")
     dev.profile(True)
     assert dev.consume_batch(recs) == n_ref
-    want = "aggregate_blocks32_kernel" if k <= 21 else "aggregate_blocks_kernel<shadow>"   # compact variant for 2k <= 42 bits
+    want = "aggregate_blocks32_kernel" if k <= 21 else "aggregate_blocks_kernel<shadow>" if k <= 32 else "aggregate_blocks128_kernel"
     assert want in dev.profile_read()                                     # really that path
     assert_same_table(dev, ref)
     # a second pass into the live table (every key exists already), through the automatic choice this time
@@ -512,7 +513,8 @@ def test_dedupe_first_path_matches_oracle(KCT, k):
     assert auto.consume_batch(recs) == n_ref
     # few keys, many k-mers: dedupe-first was chosen -- the 64-bit variant at every k here: 4.8x10^6 windows do not pay for the compact
     # variant's fixed 64 MiB shadow (0.15 windows per shadow byte, path_policy.h), but do for the table-sized 8 MiB one
-    assert "aggregate_blocks_kernel<shadow>" in auto.profile_read()
+    # (33 <= k < 40: the 128-bit variant is slower than hashing every window and is not chosen by itself)
+    assert ("aggregate_blocks_kernel<shadow>" if k <= 32 else "aggregate_blocks128_kernel" if k >= 40 else "aggregate_blocks_kernel") in auto.profile_read()
     for r in recs:
         ref.consume(r)
     assert_same_table(auto, ref)

@@ -204,6 +204,37 @@ def test_C2_with_sequencing_errors_equals_the_oracle_table(gpu, model):
         assert_digest_equal(t, ss, n)
 
 
+@pytest.mark.parametrize("k", [33, 51, 64])
+def test_128_bit_dedupe_first_at_C2_size_equals_the_oracle_table(gpu, k):
+    """33 <= k <= 64, deep coverage of a 2 Mbp genome (1 M x 150 bp): K1 partitions mix128 pairs of the two packed words (16-byte
+    entries), aggregate_blocks128_kernel counts them into the 1024 x 4096-slot shadow (two-word keys claimed by CAS + flag),
+    the conversion hashes each distinct k-mer once.  Forced and automatic (second pass), against the oracle's table pair by pair."""
+    torch, KCT, _ = gpu
+    G, R, L = 2_000_000, 1_000_000, 150
+    g, r = synth(gpu, G, R, L, seed_g=7, seed_r=8)
+    genome = g.cpu().numpy()
+    ss = oracle.ShardSet(k, L, genome=genome, nreads=R, seed_r=8, expect_keys=G)
+    d = ss.digest()
+    assert d["n"] == R * (L - k + 1)
+    t = KCT(k, capacity=G)
+    t.set_path("dedupe")
+    t.profile(True)
+    n = t.consume_device(r.data_ptr(), r.numel(), R * L)
+    prof = t.profile_read()
+    assert "aggregate_blocks128_kernel" in prof and "partition_windows_kernel<raw128>" in prof and "partition_windows_kernel" not in prof, prof
+    dk, dc = t.dump_arrays(1)
+    assert "shadow128_flush_kernel" in t.profile_read()
+    assert dk.size == d["len"] and ss.mismatches(dk, dc) == 0
+    assert_digest_equal(t, ss, n)
+    a = KCT(k, capacity=G)                     # automatic: the first pass hashes every window, the second knows 2 M k-mers at 50 windows each
+    assert a.consume_device(r.data_ptr(), r.numel(), R * L) == n
+    a.profile(True)
+    assert a.consume_device(r.data_ptr(), r.numel(), R * L) == n
+    assert ("aggregate_blocks128_kernel" in a.profile_read()) == (k >= 40), a.profile_read()   # (slower than hashing below k = 40: not chosen)
+    ak, ac = a.dump_arrays(1)
+    assert np.array_equal(ak, dk) and np.array_equal(ac, 2 * dc)
+
+
 def _oracle_table(reads, L, k):
     threads = max(1, min(16, len(os.sched_getaffinity(0))))
     tab, kmers, _ = oracle.baseline_consume(reads, L, k, threads, native=False)

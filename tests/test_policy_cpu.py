@@ -53,7 +53,13 @@ def test_headline_shapes(pol):
     assert pol.policy_probe_wanted(C.byref(cold), C2_WINDOWS) == 1       # ... and a call of 1.5x10^8 windows is probed first
     assert choose(table(dedupe_hint=1), C2_WINDOWS) == COMPACT           # the steady state: cleared table, hint kept
     assert choose(table(k=31, dedupe_hint=1), C2_WINDOWS) == DEDUPE64
-    assert choose(table(k=51, dedupe_hint=1), C2_WINDOWS) == PARTITIONED  # k > 32: no dedupe-first path
+    assert choose(table(k=51), C2_WINDOWS) == PARTITIONED                 # k > 32, nothing known: hash every window
+    assert choose(table(k=51, dedupe_hint=1), C2_WINDOWS) == 4            # ... the 128-bit dedupe-first variant once a pass of it paid off
+    assert choose(table(k=51, n_keys=2_000_000), C2_WINDOWS) == 4         # 75 windows per known k-mer ahead, and they fit its fixed shadow
+    assert choose(table(k=51, n_keys=5_000_000), C2_WINDOWS) == PARTITIONED   # more k-mers than 1024 x 4096 slots take
+    assert choose(table(k=51, n_keys=2_000_000), 40_000_000) == PARTITIONED   # 20 per known k-mer: not worth a conversion by atomics
+    assert choose(table(k=65, dedupe_hint=1), C2_WINDOWS) == PARTITIONED
+    assert choose(table(k=39, n_keys=2_000_000), C2_WINDOWS) == PARTITIONED and choose(table(k=40, n_keys=2_000_000), C2_WINDOWS) == 4   # pays from k = 40
     assert choose(table(n_keys=5_000_000), C2_WINDOWS) == COMPACT        # 30 windows per known k-mer ahead
     assert choose(table(n_keys=5_000_000), 40_000_000) == PARTITIONED    # 8 per known k-mer: not worth a conversion
     assert choose(table(n_keys=5_000_000, windows_since_read=10 ** 9), 40_000_000) == COMPACT   # ... unless reads are rare
@@ -62,7 +68,8 @@ def test_headline_shapes(pol):
     assert choose(table(), 500_000) == DIRECT and choose(table(cap=1 << 16), C2_WINDOWS) == DIRECT   # small pass / tiny table
     for force, want in ((1, DIRECT), (2, PARTITIONED), (3, COMPACT)):
         assert choose(table(force_path=force), C2_WINDOWS) == want
-    assert choose(table(force_path=3, k=31), C2_WINDOWS) == DEDUPE64 and choose(table(force_path=3, k=41), C2_WINDOWS) == PARTITIONED
+    assert choose(table(force_path=3, k=31), C2_WINDOWS) == DEDUPE64 and choose(table(force_path=3, k=41), C2_WINDOWS) == 4
+    assert choose(table(force_path=3, k=90), C2_WINDOWS) == PARTITIONED
 
 
 def test_a_shadow_must_be_paid_for(pol):

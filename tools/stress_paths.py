@@ -49,8 +49,6 @@ for it in range(iters):
     for path in ("partitioned", "dedupe", "auto", "direct", "packed", "routed"):
         if path == "direct" and N * L > (100_000_000 if big else 30_000_000):
             continue
-        if path == "dedupe" and k > 32:
-            continue
         if path == "routed" and G < 50_000:   # a handful of k-mers at 10^7 windows: the early route refuses such skew (its rings
             continue                          # cannot fall back to the direct kernel); the late route is the tool for it
         cap = int(rng.choice([0, G, 4 * G])) or 0
