@@ -22,7 +22,16 @@ constexpr u64 kSeed = 42;  // lib.rs:75, 582
 constexpr u64 kC1 = 0x87c37b91114253d5ULL;
 constexpr u64 kC2 = 0x4cf5ad432745937fULL;
 
-__device__ __forceinline__ u64 rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+// rotl of a 64-bit value as two v_alignbit_b32 (r is a compile-time constant at every call site: MurmurHash3's 27, 31, 33); the
+// compiler's own expansion is two 64-bit shifts and two ors (K1 hashing -3.4 %)
+__device__ __forceinline__ u64 rotl64(u64 x, int r) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    u32 nlo, nhi;
+    if (r < 32) { nhi = __builtin_amdgcn_alignbit(hi, lo, 32 - r); nlo = __builtin_amdgcn_alignbit(lo, hi, 32 - r); }
+    else if (r == 32) { nhi = lo; nlo = hi; }
+    else { nhi = __builtin_amdgcn_alignbit(lo, hi, 64 - r); nlo = __builtin_amdgcn_alignbit(hi, lo, 64 - r); }
+    return ((u64)nhi << 32) | nlo;
+}
 
 __device__ __forceinline__ u64 fmix64(u64 k) {
     k ^= k >> 33;
@@ -53,6 +62,11 @@ struct Murmur {
     __device__ __forceinline__ void tail(u64 k1, u64 k2, int rem) {
         if (rem > 8) { k2 *= kC2; k2 = rotl64(k2, 33); k2 *= kC1; h2 ^= k2; }
         k1 *= kC1; k1 = rotl64(k1, 31); k1 *= kC2; h1 ^= k1;
+    }
+    // the tail with k1 * c1 (and, for rem > 8, k2 * c2) already formed (pre-multiplied tables)
+    __device__ __forceinline__ void tail_premul(u64 k1c1, u64 k2c2, int rem) {
+        if (rem > 8) { k2c2 = rotl64(k2c2, 33); k2c2 *= kC1; h2 ^= k2c2; }
+        k1c1 = rotl64(k1c1, 31); k1c1 *= kC2; h1 ^= k1c1;
     }
     __device__ __forceinline__ u64 finish(u64 len) {
         h1 ^= len; h2 ^= len;
@@ -188,6 +202,22 @@ __device__ __forceinline__ void fill_premul_luts(u64 *mul1, u64 *mul2, int tid, 
         mul2[b] = (u64)v * kC2;
     }
 }
+// The TAIL's first multiply the same way (compile-time k only).  Of the tail's rem = k mod 16 bytes, one 4-byte piece is cut short:
+// m = ((rem - 1) & 3) + 1 of its bytes count (the rest are zero bytes, not 'A').  tmul[b] = (ascii4(b) masked to m bytes) * c, with
+// c = c1 if that piece belongs to k1 (rem <= 8), c2 if to k2.  m == 4 needs no table (the piece is whole: mul1 / mul2 serve).
+__device__ __forceinline__ constexpr int tail_piece_bytes(int k) { return (((k & 15) - 1) & 3) + 1; }
+__device__ __forceinline__ constexpr bool tail_needs_lut(int k) { return (k & 15) != 0 && tail_piece_bytes(k) != 4; }
+__device__ __forceinline__ void fill_tail_lut(u64 *tmul, int tid, int nthreads, int k) {
+    const int m = tail_piece_bytes(k);
+    const u64 c = (k & 15) > 8 ? kC2 : kC1;
+    const u32 mask = m >= 4 ? 0xFFFFFFFFu : (1u << (8 * m)) - 1u;
+    for (int b = tid; b < 256; b += nthreads) {
+        u32 v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v |= ((0x54474341u >> (8 * ((b >> (6 - 2 * j)) & 3))) & 0xFFu) << (8 * j);  // "ACGT"[code]
+        tmul[b] = (u64)(v & mask) * c;
+    }
+}
 __device__ __forceinline__ u64 premul_word(const u64 *mul, u32 b_lo, u32 b_hi) {  // (ascii4(b_lo) | ascii4(b_hi) << 32) * c
     const u64 lo = mul[b_lo];
     const u32 hi = reinterpret_cast<const u32 *>(mul)[2 * b_hi];  // low half of the second product
@@ -196,17 +226,32 @@ __device__ __forceinline__ u64 premul_word(const u64 *mul, u32 b_lo, u32 b_hi) {
 
 // MurmurHash3_x64_128(seed 42).h1 of the ASCII text of a left-aligned packed k-mer.
 // One 32-bit chunk of the packed form = 16 bases = exactly one 16-byte murmur block.
-template <int KW, bool LUT = false>
-__device__ __forceinline__ u64 hash_packed(const Packed<KW> &a, int k, const u32 *lut = nullptr, const u64 *mul1 = nullptr, const u64 *mul2 = nullptr) {
+// PRE (compile time, so that no dead path stays in the kernel): bit 0 = whole blocks through the pre-multiplied tables mul1 / mul2,
+// bit 1 = the tail too (tmul where the tail's last piece is cut short).
+template <int KW, bool LUT = false, int PRE = 0>
+__device__ __forceinline__ u64 hash_packed(const Packed<KW> &a, int k, const u32 *lut = nullptr, const u64 *mul1 = nullptr, const u64 *mul2 = nullptr,
+                                           const u64 *tmul = nullptr) {
     Murmur m;
     const int nblocks = k >> 4, rem = k & 15;
 #pragma unroll
     for (int b = 0; b < 2 * KW; ++b) {
         if (b * 16 < k) {
             u32 chunk = (b & 1) ? (u32)a.w[b >> 1] : (u32)(a.w[b >> 1] >> 32);
-            if constexpr (LUT) {
-                if (mul1 && b < nblocks) {  // a whole block: both words through the pre-multiplied tables
+            if constexpr (LUT && (PRE & 1) != 0) {
+                if (b < nblocks) {  // a whole block: both words through the pre-multiplied tables
                     m.block_premul(premul_word(mul1, chunk >> 24, (chunk >> 16) & 0xFFu), premul_word(mul2, (chunk >> 8) & 0xFFu, chunk & 0xFFu));
+                    continue;
+                }
+                if ((PRE & 2) != 0 && b == nblocks && rem != 0) {  // the tail's first multiplies likewise (k at compile time)
+                    const u32 B0 = chunk >> 24, B1 = (chunk >> 16) & 0xFFu, B2 = (chunk >> 8) & 0xFFu, B3 = chunk & 0xFFu;
+                    const int mp = tail_piece_bytes(k);
+                    u64 k1c1, k2c2 = 0;
+                    if (rem >= 8) k1c1 = premul_word(mul1, B0, B1);
+                    else if (rem > 4) k1c1 = mul1[B0] + ((u64)(u32)(mp == 4 ? mul1[B1] : tmul[B1]) << 32);
+                    else k1c1 = mp == 4 ? mul1[B0] : tmul[B0];
+                    if (rem > 12) k2c2 = mul2[B2] + ((u64)(u32)(mp == 4 ? mul2[B3] : tmul[B3]) << 32);
+                    else if (rem > 8) k2c2 = mp == 4 ? mul2[B2] : tmul[B2];
+                    m.tail_premul(k1c1, k2c2, rem);
                     continue;
                 }
             }

@@ -137,6 +137,12 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     __shared__ u64 mul1[kPremul ? 256 : 1], mul2[kPremul ? 256 : 1];
     if constexpr (kPremul) fill_premul_luts(mul1, mul2, threadIdx.x, kPartThreads);
     const u64 *pm1 = kPremul ? mul1 : nullptr, *pm2 = kPremul ? mul2 : nullptr;
+    // ... and the tail's first multiply, where k is known at compile time and the tail's last piece is cut short (kmer_device.h): K1 -3 %
+    constexpr bool kTailLut = kPremul && KC > 0 && tail_needs_lut(KC);
+    constexpr int kPre = (kPremul ? 1 : 0) | ((kPremul && KC > 0 && (KC & 15) != 0) ? 2 : 0);  // (a whole last piece needs no table of its own)
+    __shared__ u64 tmul[kTailLut ? 256 : 1];
+    if constexpr (kTailLut) fill_tail_lut(tmul, threadIdx.x, kPartThreads, KC);
+    const u64 *ptm = kTailLut ? tmul : nullptr;
     const int P = 1 << a.pbits;
     const u32 lmask = a.world ? (1u << a.pl_bits) - 1u : (u32)(P - 1);  // bits of the (local) super-bin inside a bin number
     const u32 D = (u32)(kEntries >> a.pbits), dmask = D - 1;
@@ -264,7 +270,7 @@ if constexpr (MODE == 2) pend_b = (u32)(h >> 32) & 1023u;
             }
         };
         if constexpr (KW == 0) walk_windows<0, 0, kPartWPT>(lds, k, sink);
-        else walk_windows_encoded<KW, KC, true, MODE>(tcodes, tvalid, k, sink, ascii4, pm1, pm2, &aux_y);
+        else walk_windows_encoded<KW, KC, true, MODE, kPre>(tcodes, tvalid, k, sink, ascii4, pm1, pm2, &aux_y, ptm);
         commit();
     }
     while (flush_lines(true)) {}  // drain: partial lines go out zero-padded; repeat while the list was too short

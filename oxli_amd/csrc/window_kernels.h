@@ -85,9 +85,10 @@ __device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, in
 // the dedupe-first path counts k-mers first and hashes each distinct one once (partition_kernels.h).
 // RAW = 2 (k <= 21): mix42(packed canonical k-mer), a 42-bit value, with bit 63 set.
 // RAW = 3 (33 <= k <= 64): mix128 of the two packed words: the sink receives x, the companion word y is left in *aux.
-template <int KW, int KC, bool LUT = false, int RAW = 0, class Sink>
+template <int KW, int KC, bool LUT = false, int RAW = 0, int PRE = 0, class Sink>
 __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const unsigned short *valid, int k_rt, Sink &&sink,
-                                                     const u32 *lut = nullptr, const u64 *mul1 = nullptr, const u64 *mul2 = nullptr, u64 *aux = nullptr) {
+                                                     const u32 *lut = nullptr, const u64 *mul1 = nullptr, const u64 *mul2 = nullptr, u64 *aux = nullptr,
+                                                     const u64 *tmul = nullptr) {
     constexpr int WPT = 16, NW = 2 * KW + 1;  // code words covering bases 0 .. 15 + k
     const int k = KC > 0 ? KC : k_rt;
     u32 w[NW];
@@ -162,7 +163,7 @@ __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const uns
                 mix128(c.w[0], c.w[1], h, *aux);
             } else {
                 left_align(c, k);
-                h = hash_packed<KW, LUT>(c, k, lut, mul1, mul2);
+                h = hash_packed<KW, LUT, PRE>(c, k, lut, mul1, mul2, tmul);
             }
         }
         sink(j, good, h);
