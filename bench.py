@@ -116,7 +116,7 @@ def source_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "oxli_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith(".h") and name != "kct_internal.h":
+        if name.endswith(".h") and name not in ("kct_internal.h", "path_policy.h"):  # (host-only headers do not change what was measured)
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]

@@ -147,9 +147,10 @@ bool compact_pays(const T *t, pu64 npos) {
 // with atomics (~0.1 ns per pending k-mer): for deep coverage of SMALL genomes only -- 32 windows per known k-mer between reads.
 // Its 16-byte entries flush K1's ring every second window and double K2's stream, so it only beats hashing every window where the
 // hash is long: measured at C2 size on a 2 Mbp genome (tools/k51_probe.py) k = 33: 7.9 against 8.6x10^10 k-mers/s hashing, k = 51:
-// 7.6 against 6.6, k = 64: 7.3 against 5.5 -- chosen by itself from k = 40 on, forced (set_path 3) at any k in 33..64.
+// 7.6 against 6.6, k = 64: 7.3 against 5.5; the hashing K1 has since become 8 % faster (rotl / tail tables: 7.2 at k = 51) -- chosen by
+// itself from k = 48 on, forced (set_path 3) at any k in 33..64.
 constexpr pu64 kShadow128Keys = (pu64)(0.6 * 1024 * 4096);
-constexpr int kDedupe128MinK = 40;
+constexpr int kDedupe128MinK = 48;
 template <class T>
 bool dedupe128_pays(const T *t, pu64 npos) {
     if (t->k <= 32 || t->k > 64 || t->dedupe128_off || npos < (1ULL << 22)) return false;

@@ -230,7 +230,7 @@ def test_128_bit_dedupe_first_at_C2_size_equals_the_oracle_table(gpu, k):
     assert a.consume_device(r.data_ptr(), r.numel(), R * L) == n
     a.profile(True)
     assert a.consume_device(r.data_ptr(), r.numel(), R * L) == n
-    assert ("aggregate_blocks128_kernel" in a.profile_read()) == (k >= 40), a.profile_read()   # (slower than hashing below k = 40: not chosen)
+    assert ("aggregate_blocks128_kernel" in a.profile_read()) == (k >= 48), a.profile_read()   # (slower than hashing below k = 48: not chosen)
     ak, ac = a.dump_arrays(1)
     assert np.array_equal(ak, dk) and np.array_equal(ac, 2 * dc)
 

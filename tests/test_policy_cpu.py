@@ -59,7 +59,7 @@ def test_headline_shapes(pol):
     assert choose(table(k=51, n_keys=5_000_000), C2_WINDOWS) == PARTITIONED   # more k-mers than 1024 x 4096 slots take
     assert choose(table(k=51, n_keys=2_000_000), 40_000_000) == PARTITIONED   # 20 per known k-mer: not worth a conversion by atomics
     assert choose(table(k=65, dedupe_hint=1), C2_WINDOWS) == PARTITIONED
-    assert choose(table(k=39, n_keys=2_000_000), C2_WINDOWS) == PARTITIONED and choose(table(k=40, n_keys=2_000_000), C2_WINDOWS) == 4   # pays from k = 40
+    assert choose(table(k=47, n_keys=2_000_000), C2_WINDOWS) == PARTITIONED and choose(table(k=48, n_keys=2_000_000), C2_WINDOWS) == 4   # pays from k = 48
     assert choose(table(n_keys=5_000_000), C2_WINDOWS) == COMPACT        # 30 windows per known k-mer ahead
     assert choose(table(n_keys=5_000_000), 40_000_000) == PARTITIONED    # 8 per known k-mer: not worth a conversion
     assert choose(table(n_keys=5_000_000, windows_since_read=10 ** 9), 40_000_000) == COMPACT   # ... unless reads are rare
