@@ -739,7 +739,7 @@ def main():
             for route, mode in routes.items():
                 # late: a rank's private table meets k-mers from all over the genome; early: an owner holds 1 / world of the key space
                 distinct_rank = min(Gb, per * (Lb - kb + 1)) if route == "late" else distinct_global // world + (1 << 16)
-                t = KmerCountTable(kb, capacity=max(distinct_rank, 400_000))
+                t = KmerCountTable(kb, capacity=max(distinct_rank, 400_000), device=local)
                 stats = {}
 
                 def job():
