@@ -1,9 +1,9 @@
-// kct_consume.hip -- bulk ingest behind the C ABI: the launch policy of the direct and the partitioned
-// (one- and two-level) counting paths, staging of host input, and the entry points that hash windows.
+// kct_consume.hip -- the counting passes over a device-resident record stream: the direct and the partitioned (one- and two-level)
+// paths, the dedupe-first variants and their conversions, and the launchers of their kernels (which only this file instantiates).
+// Which path counts a pass: path_policy.h.  Host staging, deferred mode and the C-ABI entry points: kct_entry.hip.
 #include "kct_internal.h"
 
 #include <type_traits>
-#include <emmintrin.h>
 #include "partition_kernels.h"
 #include "path_policy.h"
 
@@ -26,13 +26,6 @@ template <int KW, int KC>
 struct CountLauncher {
     static void run(hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, int k, kct::TableView tv, du64 *ctr) {
         hipLaunchKernelGGL((kct::count_windows_kernel<KW, KC>), dim3(grid), dim3(kct::kBlock), 0, s, stream, nbytes, k, tv, ctr);
-    }
-};
-
-template <int KW, int KC>
-struct HashLauncher {
-    static void run(hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, int k, u64 nwin, du64 *out, du64 *fb) {
-        hipLaunchKernelGGL((kct::hash_windows_kernel<KW, KC>), dim3(grid), dim3(kct::kBlock), 0, s, stream, nbytes, k, nwin, out, fb);
     }
 };
 
@@ -1130,10 +1123,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         const unsigned char *chunk = d_stream + done;
         if (t->packed_codes) {  // the direct kernel reads bytes: the chunk's ASCII image
             const u64 g0 = done >> 4, ng = (chunk_bytes + 15) >> 4;
-            KCT_TRY(t->d_unpack.reserve(ng * 16 + 16));
-            ProfScope ps(t, "unpack_stream_kernel");
-            hipLaunchKernelGGL(kct::unpack_stream_kernel, dim3((unsigned)std::min<u64>((ng + kct::kBlock - 1) / kct::kBlock, 1u << 16)), dim3(kct::kBlock), 0, t->stream,
-                               t->packed_codes + g0, t->packed_valid + g0, ng, (unsigned char *)t->d_unpack.p);
+            KCT_TRY(unpack_stream(t, t->packed_codes + g0, t->packed_valid + g0, ng));
             chunk = (const unsigned char *)t->d_unpack.p;
         }
         const int grid = (int)((npos + kct::kTile - 1) / kct::kTile);
@@ -1169,10 +1159,7 @@ kct_status consume_stream_packed(kct_table *t, const unsigned int *d_codes, cons
     if (nbases < t->k) return KCT_OK;
     const u64 ng = (nbases + 15) >> 4;
     if (t->k > 64) {  // bytewise kernels only
-        KCT_TRY(t->d_unpack.reserve(ng * 16 + 16));
-        hipLaunchKernelGGL(kct::unpack_stream_kernel, dim3((unsigned)std::min<u64>((ng + kct::kBlock - 1) / kct::kBlock, 1u << 16)), dim3(kct::kBlock), 0, t->stream,
-                           d_codes, d_valid, ng, (unsigned char *)t->d_unpack.p);
-        HIP_TRY(hipGetLastError());
+        KCT_TRY(unpack_stream(t, d_codes, d_valid, ng));
         return consume_stream(t, (const unsigned char *)t->d_unpack.p, nbases, n_out);
     }
     t->packed_codes = d_codes; t->packed_valid = d_valid;
@@ -1182,466 +1169,4 @@ kct_status consume_stream_packed(kct_table *t, const unsigned int *d_codes, cons
     return st;
 }
 
-
-// ---- host packer: ASCII -> 2-bit codes + validity bits (the host twin of kmer_device.h encode16) -----------------------
-#include <tmmintrin.h>
-static inline void encode16_scalar(const unsigned char *p, unsigned int *codes, unsigned short *valid) {
-    unsigned int c = 0, v = 0;
-    for (int i = 0; i < 16; ++i) {
-        const unsigned b = p[i] | 0x20u;
-        const bool ok = b == 'a' || b == 'c' || b == 'g' || b == 't';
-        unsigned int x = (p[i] >> 1) & 3u;
-        x ^= x >> 1;  // A0 C1 G2 T3
-        c = (c << 2) | (ok ? x : 0u);
-        v = (v << 1) | (ok ? 1u : 0u);
-    }
-    *codes = c; *valid = (unsigned short)v;
-}
-__attribute__((target("ssse3"))) static inline void encode16_ssse3(const unsigned char *p, unsigned int *codes, unsigned short *valid) {
-    const __m128i v = _mm_loadu_si128((const __m128i *)p), up = _mm_or_si128(v, _mm_set1_epi8(0x20));
-    const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(up, _mm_set1_epi8('a')), _mm_cmpeq_epi8(up, _mm_set1_epi8('c'))),
-                                    _mm_or_si128(_mm_cmpeq_epi8(up, _mm_set1_epi8('g')), _mm_cmpeq_epi8(up, _mm_set1_epi8('t'))));
-    __m128i x = _mm_and_si128(_mm_srli_epi16(v, 1), _mm_set1_epi8(3));
-    x = _mm_xor_si128(x, _mm_and_si128(_mm_srli_epi16(x, 1), _mm_set1_epi8(1)));
-    x = _mm_and_si128(x, ok);
-    const __m128i p2 = _mm_maddubs_epi16(x, _mm_set1_epi16(0x0104));      // base 2i * 4 + base 2i+1
-    const __m128i p4 = _mm_madd_epi16(p2, _mm_set1_epi32(0x00010010));    // pair 2j * 16 + pair 2j+1: four bases per 32-bit lane
-    const __m128i sh = _mm_shuffle_epi8(p4, _mm_set_epi8(-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12));
-    *codes = (unsigned int)_mm_cvtsi128_si32(sh);                         // bases 0-3 in the top byte
-    *valid = (unsigned short)(__builtin_bitreverse16((unsigned short)_mm_movemask_epi8(ok)));
-}
-static void encode_groups(const unsigned char *p, size_t ngroups, unsigned int *codes, unsigned short *valid) {
-    static const bool ssse3 = __builtin_cpu_supports("ssse3");
-    if (ssse3) for (size_t g = 0; g < ngroups; ++g) encode16_ssse3(p + 16 * g, codes + g, valid + g);
-    else for (size_t g = 0; g < ngroups; ++g) encode16_scalar(p + 16 * g, codes + g, valid + g);
-}
-
-// host bytes -> pinned staging -> device stream buffer (padded with '\n' to a multiple of 16)
-kct_status upload_stream(kct_table *t, size_t nbytes) {
-    const size_t padded = (nbytes + 15) & ~(size_t)15;
-    KCT_TRY(t->d_stream.reserve(padded + 16));
-    HIP_TRY(hipMemcpyAsync(t->d_stream.p, t->h_stage.p, padded, hipMemcpyHostToDevice, t->stream));
-    return KCT_OK;
-}
-
-kct_status stage_single(kct_table *t, const char *seq, size_t len) {
-    const size_t padded = (len + 15) & ~(size_t)15;
-    KCT_TRY(t->h_stage.reserve(padded + 16));
-    memcpy(t->h_stage.p, seq, len);
-    memset((char *)t->h_stage.p + len, '\n', padded + 16 - len);
-    return upload_stream(t, len);
-}
-
-// ---- deferred mode -------------------------------------------------------------------------------------------
-constexpr size_t kPendingBytes = (size_t)64 << 20;
-
-// Valid k-windows of one record: the host-side twin of the device's window rule (all k bytes in ACGTacgt).
-// Used only for the number deferred consume() returns; the counting itself happens on the device at flush.
-u64 host_valid_windows(const unsigned char *s, size_t len, size_t k) {
-    // sixteen bytes at a time (SSE2, the x86-64 baseline): (c | 0x20) is one of a, c, g, t exactly for the eight valid bytes
-    const __m128i lower = _mm_set1_epi8(0x20), ca = _mm_set1_epi8('a'), cc = _mm_set1_epi8('c'), cg = _mm_set1_epi8('g'), ct = _mm_set1_epi8('t');
-    u64 n = 0;
-    size_t run = 0, i = 0;  // run: valid bytes ending at the current position
-    for (; i + 16 <= len; i += 16) {
-        const __m128i v = _mm_or_si128(_mm_loadu_si128((const __m128i *)(s + i)), lower);
-        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, ca), _mm_cmpeq_epi8(v, cc)), _mm_or_si128(_mm_cmpeq_epi8(v, cg), _mm_cmpeq_epi8(v, ct)));
-        const unsigned m = (unsigned)_mm_movemask_epi8(ok);
-        if (m == 0xFFFFu) {  // windows END at each of the 16 positions whose run has reached k
-            run += 16;
-            if (run >= k) n += std::min<size_t>(16, run - k + 1);
-        } else {
-            for (int j = 0; j < 16; ++j) {
-                run = (m >> j) & 1u ? run + 1 : 0;
-                n += run >= k;
-            }
-        }
-    }
-    for (; i < len; ++i) {
-        const unsigned char c = s[i] | 0x20;
-        run = (c == 'a' || c == 'c' || c == 'g' || c == 't') ? run + 1 : 0;
-        n += run >= k;
-    }
-    return n;
-}
-
-kct_status flush_pending(kct_table *t) {
-    const size_t used = t->pending_used;
-    if (!used) return KCT_OK;
-    const u64 records = t->pending_records;
-    t->pending_used = 0;  // consume_stream -> ... -> use() must not re-enter
-    t->pending_records = 0;
-    const size_t padded = (used + 15) & ~(size_t)15;
-    memset((char *)t->h_pending.p + used, '\n', padded + 16 - used);
-    // Nothing has been counted yet if the upload cannot be made: the records stay buffered and the call can be retried
-    // (after kct_release_scratch, say).  Once the device pass has started, a failure leaves the table short of counts that
-    // earlier consume() calls have already reported: it is poisoned, and every later call fails until kct_clear.
-    kct_status st = t->d_stream.reserve(padded + 16);
-    if (st == KCT_OK && hipMemcpyAsync(t->d_stream.p, t->h_pending.p, padded + 16, hipMemcpyHostToDevice, t->stream) != hipSuccess) {
-        set_err("hipMemcpyAsync of the buffered records failed");
-        st = KCT_ERR_HIP;
-    }
-    if (st != KCT_OK) { t->pending_used = used; t->pending_records = records; return st; }
-    u64 n = 0;
-    st = consume_stream(t, (const unsigned char *)t->d_stream.p, used, &n);
-    if (st != KCT_OK) t->poisoned = true;
-    return st;
-}
-
-// hashes of all windows of the staged stream [0, nbytes) into d_aux; returns first bad window index
-kct_status hash_stream(kct_table *t, u64 nbytes, u64 nwin, u64 *first_bad) {
-    KCT_TRY(t->d_aux.reserve(nwin * 8));
-    du64 *d_fb = t->d_counters + kNumCounters + 1;  // scratch word 1
-    HIP_TRY(hipMemsetAsync(d_fb, 0xFF, 8, t->stream));
-    const int grid = (int)((nwin + kct::kTile - 1) / kct::kTile);
-    {
-        ProfScope ps(t, "hash_windows_kernel");
-        dispatch_k<HashLauncher>((int)t->k, t->stream, grid, (const unsigned char *)t->d_stream.p, nbytes, (int)t->k, nwin,
-                                 (du64 *)t->d_aux.p, d_fb);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(t->h_counters, d_fb, 8, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(hipStreamSynchronize(t->stream));
-    *first_bad = t->h_counters[0] == ~0ULL ? nwin : t->h_counters[0];
-    return KCT_OK;
-}
-
 }  // namespace kcth
-
-using namespace kcth;
-
-extern "C" {
-
-kct_status kct_hash_windows(kct_table *t, const char *seq, size_t len, uint64_t *hashes_out, size_t cap, uint64_t *n_windows,
-                            uint64_t *first_bad) {
-    KCT_TRY(use_consume(t));
-    if ((!seq && len) || !n_windows || !first_bad) { set_err("null argument"); return KCT_ERR_ARG; }
-    const u64 nwin = len >= t->k ? len - t->k + 1 : 0;
-    *n_windows = nwin;
-    *first_bad = nwin;
-    if (nwin == 0) return KCT_OK;
-    KCT_TRY(stage_single(t, seq, len));
-    KCT_TRY(hash_stream(t, len, nwin, first_bad));
-    const size_t ncopy = std::min<size_t>(cap, nwin);
-    if (ncopy && hashes_out) HIP_TRY(hipMemcpy(hashes_out, t->d_aux.p, ncopy * 8, hipMemcpyDeviceToHost));
-    return KCT_OK;
-}
-
-kct_status kct_hash_kmer(kct_table *t, const char *kmer, size_t len, uint64_t *hash_out) {
-    KCT_TRY(use_consume(t));
-    if (!kmer || !hash_out) { set_err("null argument"); return KCT_ERR_ARG; }
-    if ((uint8_t)len != t->k) { set_err("wrong ksize"); return KCT_ERR_WRONG_KSIZE; }  // lib.rs:66 `len as u8`
-    u64 nwin, fb, h = 0;
-    KCT_TRY(kct_hash_windows(t, kmer, t->k, &h, 1, &nwin, &fb));  // first window only (lib.rs:78 `.next()`)
-    if (fb == 0) { set_err("invalid DNA character in k-mer"); return KCT_ERR_INVALID_DNA; }
-    *hash_out = h;
-    return KCT_OK;
-}
-
-kct_status kct_count(kct_table *t, const char *kmer, size_t len, uint64_t *count_out) {
-    KCT_TRY(use(t));
-    if ((uint8_t)len != t->k) { set_err("kmer size does not match count table ksize"); return KCT_ERR_WRONG_KSIZE; }
-    u64 h;
-    KCT_TRY(kct_hash_kmer(t, kmer, len, &h));
-    u64 c = 0;
-    KCT_TRY(point_add(t, h, &c));
-    t->consumed += len;  // lib.rs:153
-    if (count_out) *count_out = c;
-    return KCT_OK;
-}
-
-kct_status kct_get(kct_table *t, const char *kmer, size_t len, uint64_t *count_out) {
-    KCT_TRY(use(t));
-    if ((uint8_t)len != t->k) { set_err("kmer size does not match count table ksize"); return KCT_ERR_WRONG_KSIZE; }
-    u64 h;
-    KCT_TRY(kct_hash_kmer(t, kmer, len, &h));
-    return kct_get_hash(t, h, count_out);
-}
-
-int kct_consume_will_defer(const kct_table *t, size_t len, int skip_bad) {
-    return t && !t->poisoned && t->deferred && skip_bad && len + 64 < kPendingBytes / 2 && (len < t->k || t->pending_used + len + 1 + 64 <= t->h_pending.cap) ? 1 : 0;
-}
-
-kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out) {
-    if (t && t->deferred && skip_bad && len + 64 < kPendingBytes / 2) {
-        // deferred mode: buffer the record, answer from the host-side validity scan, count later
-        if ((!seq && len) || !n_out) { set_err("null argument"); return KCT_ERR_ARG; }
-        *n_out = 0;
-        if (len >= t->k) {
-            if (t->pending_used + len + 1 + 64 > t->h_pending.cap) {  // (the common call touches no HIP API at all)
-                KCT_TRY(use_device(t));
-                // the pinned buffer grows geometrically from 1 MiB to its full 64 MiB: a table that sees a few records pins little
-                if (t->pending_used + len + 1 > kPendingBytes) KCT_TRY(flush_pending(t));
-                size_t want = std::max<size_t>(t->h_pending.cap, (size_t)1 << 20);
-                while (want < kPendingBytes + 64 && t->pending_used + len + 1 + 64 > want) want *= 2;
-                KCT_TRY(t->h_pending.reserve_keep(std::min(want, kPendingBytes + 64), t->pending_used));
-            }
-            char *dst = (char *)t->h_pending.p + t->pending_used;
-            memcpy(dst, seq, len);
-            dst[len] = '\n';
-            t->pending_used += len + 1;
-            t->pending_records += 1;
-            *n_out = host_valid_windows((const unsigned char *)seq, len, t->k);
-        }
-        t->consumed += len;
-        return KCT_OK;
-    }
-    KCT_TRY(use_consume(t));
-    if ((!seq && len) || !n_out) { set_err("null argument"); return KCT_ERR_ARG; }
-    *n_out = 0;
-    const u64 k = t->k;
-    if (len < k) { t->consumed += len; return KCT_OK; }  // zero windows (lib.rs: max_index = 0), consumed still grows
-    KCT_TRY(stage_single(t, seq, len));
-    u64 use_bytes = len;
-    bool bad = false;
-    if (!skip_bad) {
-        const u64 nwin = len - k + 1;
-        u64 fb;
-        KCT_TRY(hash_stream(t, len, nwin, &fb));  // validity of every window, on the device
-        if (fb < nwin) { bad = true; use_bytes = fb + k - 1; }  // windows 0..fb-1 end before byte fb+k-1
-    }
-    KCT_TRY(consume_stream(t, (const unsigned char *)t->d_stream.p, use_bytes, n_out));
-    if (bad) { set_err("bad k-mer encountered at position %llu", (unsigned long long)*n_out); return KCT_ERR_BAD_KMER; }
-    t->consumed += len;
-    return KCT_OK;
-}
-
-kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *offsets, size_t nrec, int skip_bad,
-                             uint64_t *n_total, uint64_t *bad_record, uint64_t *bad_position) {
-    KCT_TRY(use_consume(t));
-    if (!n_total || (nrec && !offsets)) { set_err("null argument"); return KCT_ERR_ARG; }
-    if (nrec && !bytes && offsets[nrec] != offsets[0]) { set_err("null argument"); return KCT_ERR_ARG; }  // all-empty records need no bytes
-    *n_total = 0;
-    if (bad_record) *bad_record = nrec;
-    if (bad_position) *bad_position = 0;
-    if (nrec == 0) return KCT_OK;
-    const u64 total = offsets[nrec] - offsets[0];
-    const u64 stream_len = total + nrec;  // one '\n' after every record
-    const size_t padded = (stream_len + 15) & ~(size_t)15;
-    const size_t off_bytes = skip_bad ? 0 : (nrec + 1) * 8;
-    KCT_DBG(t, "batch: %zu records, %llu bytes\n", nrec, (unsigned long long)stream_len);
-    KCT_TRY(t->h_stage.reserve(padded + 16 + off_bytes));
-    char *dst = (char *)t->h_stage.p;
-    u64 *rec_off = (u64 *)(dst + padded + 16);  // 16-aligned since padded is
-    // Pack the records into the record stream: record r lands at (offsets[r] - offsets[0]) + r, one
-    // separator behind it.  Positions are known up front, so large batches are packed by several threads.
-    for (size_t r = 0; r < nrec; ++r)
-        if (offsets[r + 1] < offsets[r]) { set_err("offsets must be non-decreasing"); return KCT_ERR_ARG; }
-    const u64 base0 = offsets[0];
-    auto pack_range = [&](size_t r0, size_t r1) {
-        for (size_t r = r0; r < r1; ++r) {
-            const u64 n = offsets[r + 1] - offsets[r], w = (offsets[r] - base0) + r;
-            if (!skip_bad) rec_off[r] = w;
-            memcpy(dst + w, bytes + offsets[r], n);
-            dst[w + n] = '\n';
-        }
-    };
-    KCT_TRY(t->d_stream.reserve(padded + 16));
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t max_threads = (size_t)t->tune.pack_threads;
-    const size_t nthreads = stream_len >= (8u << 20) ? std::min<size_t>({max_threads, hw ? hw : 1, nrec}) : 1;
-    if (skip_bad && t->packed_upload && t->k <= 64 && nthreads > 1) {
-        // PACKED upload: every part of the batch starts on a 16-base boundary of the stream (extra separator bytes in front of
-        // it -- any number of invalid bases may sit between two records), so the packers can encode their parts independently:
-        // each streams its records (+ one separator each) through a small buffer and writes one code word + one validity word
-        // per 16 bases -- 0.375 B per base cross the PCIe link instead of 1.
-        const size_t nslices = std::min<size_t>(nrec, std::max<size_t>(4, std::min<size_t>(16, stream_len >> 22)));
-        const size_t parts = std::min<size_t>(nthreads, std::max<size_t>(1, nrec / nslices));
-        const size_t nitems = nslices * parts;
-        std::vector<size_t> cut(nitems + 1);
-        for (size_t i = 0; i <= nitems; ++i) {
-            const u64 lo = base0 + total * i / nitems;
-            cut[i] = i == nitems ? nrec : (size_t)(std::lower_bound(offsets, offsets + nrec, lo) - offsets);
-        }
-        cut[0] = 0;
-        std::vector<u64> pos(nitems + 1);
-        pos[0] = 0;
-        for (size_t i = 0; i < nitems; ++i) pos[i + 1] = (pos[i] + (offsets[cut[i + 1]] - offsets[cut[i]]) + (cut[i + 1] - cut[i]) + 15) & ~(u64)15;
-        const u64 nbases = pos[nitems], ng = nbases >> 4;
-        const u64 valid_off = (ng * 4 + 255) & ~(u64)255;
-        KCT_TRY(t->h_stage.reserve(valid_off + ng * 2 + 64));
-        KCT_TRY(t->d_stream.reserve(valid_off + ng * 2 + 64));
-        unsigned int *h_codes = (unsigned int *)t->h_stage.p;
-        unsigned short *h_valid = (unsigned short *)((char *)t->h_stage.p + valid_off);
-        std::vector<std::atomic<int>> packed(nslices);
-        for (auto &r : packed) r.store(0, std::memory_order_relaxed);
-        std::atomic<size_t> next_item{0};
-        WorkerPool &pool = WorkerPool::instance();
-        pool.start(nthreads, [&](size_t) {
-            constexpr size_t kBuf = 4096;
-            unsigned char buf[kBuf + 16];
-            for (;;) {
-                const size_t it = next_item.fetch_add(1, std::memory_order_relaxed);
-                if (it >= nitems) break;
-                size_t g = pos[it] >> 4, fill = 0;
-                auto drain = [&](bool all) {  // encode the buffer's whole groups (all: pad the rest with separators first)
-                    if (all) while (fill & 15) buf[fill++] = '\n';
-                    const size_t n = fill >> 4;
-                    encode_groups(buf, n, h_codes + g, h_valid + g);
-                    g += n;
-                    const size_t rest = fill - 16 * n;
-                    if (rest) memmove(buf, buf + 16 * n, rest);
-                    fill = rest;
-                };
-                for (size_t r = cut[it]; r < cut[it + 1]; ++r) {
-                    const unsigned char *src = (const unsigned char *)bytes + offsets[r];
-                    size_t n = (size_t)(offsets[r + 1] - offsets[r]);
-                    while (n) {
-                        const size_t take = std::min(n, kBuf - fill);
-                        memcpy(buf + fill, src, take);
-                        fill += take; src += take; n -= take;
-                        if (fill == kBuf) drain(false);
-                    }
-                    buf[fill++] = '\n';
-                    if (fill == kBuf) drain(false);
-                }
-                drain(true);
-                for (; g < (pos[it + 1] >> 4); ++g) { h_codes[g] = 0; h_valid[g] = 0; }  // (never: a part's groups are exactly its bytes, padded)
-                packed[it / parts].fetch_add(1, std::memory_order_release);
-            }
-        });
-        hipError_t copy_err = hipSuccess;
-        char *d_base = (char *)t->d_stream.p;
-        for (size_t sl = 0; sl < nslices; ++sl) {
-            while (packed[sl].load(std::memory_order_acquire) < (int)parts) std::this_thread::yield();
-            const u64 g0 = pos[sl * parts] >> 4, g1 = pos[(sl + 1) * parts] >> 4;
-            if (g1 > g0 && copy_err == hipSuccess) copy_err = hipMemcpyAsync(d_base + g0 * 4, h_codes + g0, (g1 - g0) * 4, hipMemcpyHostToDevice, t->stream);
-            if (g1 > g0 && copy_err == hipSuccess) copy_err = hipMemcpyAsync(d_base + valid_off + g0 * 2, h_valid + g0, (g1 - g0) * 2, hipMemcpyHostToDevice, t->stream);
-        }
-        pool.wait();
-        HIP_TRY(copy_err);
-        KCT_DBG(t, "batch: packed upload of %llu bases enqueued\n", (unsigned long long)nbases);
-        KCT_TRY(consume_stream_packed(t, (const unsigned int *)d_base, (const unsigned short *)(d_base + valid_off), nbases, n_total));
-        t->consumed += total;
-        return KCT_OK;
-    }
-    if (nthreads <= 1) {
-        pack_range(0, nrec);
-        if (!skip_bad) rec_off[nrec] = stream_len;
-        memset(dst + stream_len, '\n', padded + 16 - stream_len);
-        HIP_TRY(hipMemcpyAsync(t->d_stream.p, dst, padded, hipMemcpyHostToDevice, t->stream));
-    } else {
-        // The stream is cut into slices (by bytes: records may be ragged) and every slice into parts; the packers take the
-        // parts in order, so ALL of them work on the slice that is uploaded next, and this thread starts a slice's H2D copy
-        // as soon as its last part is packed: the copy runs under the packing of the slices behind it and only one slice's
-        // copy is left when the packing ends.  (Slices of ~10 MB: every copy costs ~15 us on top of its transfer.)
-        const size_t nslices = std::min<size_t>(nrec, std::max<size_t>(4, std::min<size_t>(16, stream_len >> 22)));
-        const size_t parts = std::min<size_t>(nthreads, std::max<size_t>(1, nrec / nslices));
-        const size_t nitems = nslices * parts;
-        std::vector<size_t> cut(nitems + 1);
-        for (size_t i = 0; i <= nitems; ++i) {
-            const u64 lo = base0 + total * i / nitems;
-            cut[i] = i == nitems ? nrec : (size_t)(std::lower_bound(offsets, offsets + nrec, lo) - offsets);
-        }
-        cut[0] = 0;
-        std::vector<std::atomic<int>> packed(nslices);
-        for (auto &r : packed) r.store(0, std::memory_order_relaxed);
-        std::atomic<size_t> next_item{0};
-        WorkerPool &pool = WorkerPool::instance();  // (threads that outlive the call: starting them cost more than the packing)
-        pool.start(nthreads, [&](size_t) {
-            for (;;) {
-                const size_t it = next_item.fetch_add(1, std::memory_order_relaxed);
-                if (it >= nitems) break;
-                if (cut[it + 1] > cut[it]) pack_range(cut[it], cut[it + 1]);
-                packed[it / parts].fetch_add(1, std::memory_order_release);
-            }
-        });
-        hipError_t copy_err = hipSuccess;
-        for (size_t sl = 0; sl < nslices; ++sl) {
-            while (packed[sl].load(std::memory_order_acquire) < (int)parts) std::this_thread::yield();
-            const size_t r0 = cut[sl * parts], r1 = cut[(sl + 1) * parts];
-            const u64 b0 = r0 < nrec ? (offsets[r0] - base0) + r0 : stream_len;
-            u64 b1 = r1 < nrec ? (offsets[r1] - base0) + r1 : stream_len;
-            if (sl + 1 == nslices) {  // the tail slice carries the padding
-                if (!skip_bad) rec_off[nrec] = stream_len;
-                memset(dst + stream_len, '\n', padded + 16 - stream_len);
-                b1 = padded;
-            }
-            if (b1 > b0 && copy_err == hipSuccess)
-                copy_err = hipMemcpyAsync((char *)t->d_stream.p + b0, dst + b0, b1 - b0, hipMemcpyHostToDevice, t->stream);
-        }
-        KCT_DBG(t, "batch: last slice enqueued\n");
-        pool.wait();
-        HIP_TRY(copy_err);
-        if (t->debug) { HIP_TRY(hipStreamSynchronize(t->stream)); KCT_DBG(t, "batch: upload done\n"); }
-    }
-
-    if (!skip_bad) {
-        KCT_TRY(t->d_aux.reserve(off_bytes));
-        HIP_TRY(hipMemcpyAsync(t->d_aux.p, rec_off, off_bytes, hipMemcpyHostToDevice, t->stream));
-        du64 *d_q = t->d_counters + kNumCounters + 1;
-        HIP_TRY(hipMemsetAsync(d_q, 0xFF, 8, t->stream));
-        const u64 nthreads = (stream_len + 15) / 16;
-        {
-            ProfScope ps(t, "first_bad_byte_kernel");
-            hipLaunchKernelGGL(kct::first_bad_byte_kernel, dim3((unsigned)((nthreads + kct::kBlock - 1) / kct::kBlock)), dim3(kct::kBlock), 0,
-                               t->stream, (const unsigned char *)t->d_stream.p, stream_len, (int)t->k, (const du64 *)t->d_aux.p, (u64)nrec, d_q);
-        }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(t->h_counters, d_q, 8, hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        const u64 q = t->h_counters[0];
-        if (q != ~0ULL) {
-            // Record r holds q.  The per-record loop the reference runs would count records
-            // [0, r) whole, then the windows of r before its first bad one, then raise.
-            const size_t r = (size_t)(std::upper_bound(rec_off, rec_off + nrec + 1, q) - rec_off) - 1;
-            const u64 in_rec = q - rec_off[r];
-            const u64 fbw = in_rec + 1 >= t->k ? in_rec + 1 - t->k : 0;  // index of r's first bad window
-            u64 n_before = 0, n_prefix = 0;
-            KCT_TRY(consume_stream(t, (const unsigned char *)t->d_stream.p, rec_off[r], &n_before));
-            const u64 prefix = fbw + t->k - 1;  // bytes of r that its windows 0..fbw-1 cover
-            if (fbw > 0) {
-                // a 16-byte aligned copy of the prefix, in a buffer nothing inside consume_stream touches (its passes
-                // reallocate / overwrite d_aux2 and d_spill when they replay spills)
-                KCT_TRY(t->d_prefix.reserve(((prefix + 15) & ~(u64)15) + 16));
-                HIP_TRY(hipMemcpyAsync(t->d_prefix.p, (const char *)t->d_stream.p + rec_off[r], prefix, hipMemcpyDeviceToDevice, t->stream));
-                KCT_TRY(consume_stream(t, (const unsigned char *)t->d_prefix.p, prefix, &n_prefix));
-            }
-            t->consumed += offsets[r] - offsets[0];  // r raised before lib.rs:604
-            *n_total = n_before + n_prefix;
-            if (bad_record) *bad_record = r;
-            if (bad_position) *bad_position = n_prefix;
-            set_err("bad k-mer encountered at position %llu (record %llu)", (unsigned long long)n_prefix, (unsigned long long)r);
-            return KCT_ERR_BAD_KMER;
-        }
-    }
-    KCT_TRY(consume_stream(t, (const unsigned char *)t->d_stream.p, stream_len, n_total));
-    KCT_DBG(t, "batch: counted\n");
-    t->consumed += total;
-    return KCT_OK;
-}
-
-kct_status kct_consume_device_packed(kct_table *t, const void *d_codes, const void *d_valid, size_t nbases, uint64_t consumed_bytes, uint64_t *n_total) {
-    KCT_TRY(use_consume(t));
-    if (!n_total || ((!d_codes || !d_valid) && nbases)) { set_err("null argument"); return KCT_ERR_ARG; }
-    if (((uintptr_t)d_codes & 3) != 0 || ((uintptr_t)d_valid & 1) != 0) { set_err("d_codes / d_valid must be 4- / 2-byte aligned"); return KCT_ERR_ARG; }
-    KCT_TRY(consume_stream_packed(t, (const unsigned int *)d_codes, (const unsigned short *)d_valid, nbases, n_total));
-    t->consumed += consumed_bytes;
-    return KCT_OK;
-}
-
-kct_status kct_pack_stream_device(const void *d_stream, size_t nbytes, void *d_codes, void *d_valid, void *stream) {
-    const u64 ng = ((u64)nbytes + 15) >> 4;
-    if (!ng) return KCT_OK;
-    if (!d_stream || !d_codes || !d_valid || ((uintptr_t)d_stream & 15)) { set_err("null or misaligned argument"); return KCT_ERR_ARG; }
-    hipLaunchKernelGGL(kct::pack_stream_kernel, dim3((unsigned)std::min<u64>((ng + kct::kBlock - 1) / kct::kBlock, 1u << 16)), dim3(kct::kBlock), 0, (hipStream_t)stream,
-                       (const unsigned char *)d_stream, (u64)nbytes, (unsigned int *)d_codes, (unsigned short *)d_valid, ng);
-    HIP_TRY(hipGetLastError());
-    return KCT_OK;
-}
-
-kct_status kct_set_packed_upload(kct_table *t, int on) {
-    if (!t) { set_err("null table handle"); return KCT_ERR_ARG; }
-    t->packed_upload = on != 0;
-    return KCT_OK;
-}
-
-kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes, uint64_t *n_total) {
-    KCT_TRY(use_consume(t));
-    if (!n_total || (!d_stream && nbytes)) { set_err("null argument"); return KCT_ERR_ARG; }
-    if (((uintptr_t)d_stream & 15) != 0) { set_err("d_stream must be 16-byte aligned"); return KCT_ERR_ARG; }
-    KCT_TRY(consume_stream(t, (const unsigned char *)d_stream, nbytes, n_total));
-    t->consumed += consumed_bytes;
-    return KCT_OK;
-}
-
-}  // extern "C"

@@ -288,6 +288,7 @@ kct_status point_add(kct_table *t, u64 h, u64 *count_out);
 // kct_consume.hip
 kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 *n_out);
 kct_status consume_stream_packed(kct_table *t, const unsigned int *d_codes, const unsigned short *d_valid, u64 nbases, u64 *n_out);
+kct_status unpack_stream(kct_table *t, const unsigned int *d_codes, const unsigned short *d_valid, u64 ng);  // kct_entry.hip
 // ... its kernels' launchers and sizing rules, for kct_route.hip (which does not instantiate the kernels itself)
 void launch_partition(kct_table *t, int mode /* 0 hashes, 1 mix64 values, 2 compact */, const unsigned char *d_stream, u64 chunk_bytes, u64 ntiles,
                       const kct::PartitionArgs &pa);
