@@ -195,25 +195,55 @@ KCT_API kct_status kct_consume_device_packed(kct_table *t, const void *d_codes, 
 KCT_API kct_status kct_pack_stream_device(const void *d_stream, size_t nbytes, void *d_codes, void *d_valid, void *stream);
 KCT_API kct_status kct_set_packed_upload(kct_table *t, int on);
 
-/* ---- multi-GPU "early" route: entries travel to the GPU that owns their slice of the key space -----------
- * One call = one pass: K1 over THIS rank's records with its bins grouped by owner, three all-to-alls through the caller's
- * callbacks (region sizes, entries of 4 or 8 bytes, the few entries that overflowed K1's LDS ring), then K1b / K2 on the
- * entries this rank OWNS (oxli_amd/csrc/kct_route.hip).  Every rank of the job must make the same calls with the same world,
- * mode and table capacity.  mode: 0 = MurmurHash3 values (any k <= 64) counted into the table; 1 = mix64 values of packed
- * k-mers (k <= 32) and 2 = compact 32-bit entries (k <= 21) counted into the shadow tables (dedupe-first: converted when the
- * table is read).  The ranks' tables end up a disjoint partition of the key space: add() semantics (lib.rs:778-837) hold for
- * their union.  *n_owned = k-mers counted by this rank as an owner (summed over ranks: the job's n); stats8 (optional):
- * entries sent to / received from other ranks, bytes per entry, overflow entries sent / received, microseconds in the
- * exchange callbacks, K2 blocks abandoned, 1 if this rank's input was too skewed (its share then was NOT counted: error).
- *   alloc(user, bytes)    -> a device buffer the exchange can send from (valid until the routed call returns)
- *   exchange(user, d_send, send_elems[world], elem_bytes, &d_recv, recv_elems[world]) -> 0 on success: an all-to-all with
- *                            uneven splits; d_send came from alloc; rank r's part is send_elems[r] elements, parts in rank
- *                            order; *d_recv (valid until the routed call returns) holds the parts received, in rank order.
- * world == 1 with null callbacks is a loop-back (tests).  A future Rust caller implements the callbacks with ncclSend/ncclRecv. */
-typedef void *(*kct_alloc_fn)(void *user, uint64_t bytes);
-typedef int (*kct_exchange_fn)(void *user, const void *d_send, const uint64_t *send_elems, uint32_t elem_bytes, void **d_recv, uint64_t *recv_elems);
+/* ---- multi-GPU "early" route: every k-mer is counted by the GPU that owns it; SUPER-K-MERS cross the wire ---------
+ * Independent records (README.md:96-98) and per-key sums (add(), lib.rs:778-837) let the key space be partitioned: owner(k-mer) =
+ * hash(minimiser) * world >> 16, the minimiser being the smallest (in a scrambled order) canonical 8-mer inside the k-mer -- the same
+ * for a k-mer and its reverse complement, and mostly the same for consecutive windows of a read.  Each rank cuts ITS records into
+ * maximal runs of good windows with one owner and sends every run as 2-bit bases plus one start bit per window (~1 byte per window at
+ * k = 21, ~0.45 at k = 51); every owner counts what it receives with the table's ordinary bulk path.  The ranks' tables end up a
+ * disjoint partition of the key space: len / sum_counts of the global table are sums over ranks.  k <= 64.
+ *
+ * The library runs the whole call -- passes, pipelining (pass p + 1 is cut while pass p is on the wire, and is on the wire while pass
+ * p is counted), error agreement -- and asks the caller only for the collective, through kct_exchange_ops (every rank of the job makes
+ * the same call with the same world; all callbacks return 0 on success):
+ *   alloc(user, bytes)          a device buffer the collective can send from / receive into; release(user, p) gives it back (may be NULL)
+ *   exchange_sizes(user, send, nvals, recv)
+ *                               blocking all-to-all in HOST memory: send[r * nvals ..] goes to rank r, recv[r * nvals ..] came from
+ *                               rank r (nvals uint64 each)
+ *   start(user, d_send, send_off, send_bytes, d_recv, recv_off, recv_bytes)
+ *                               begins an all-to-all of byte ranges: rank r is sent d_send[send_off[r] .. + send_bytes[r]) and what
+ *                               rank r sends lands at d_recv[recv_off[r] .. + recv_bytes[r]) (the sizes were agreed by
+ *                               exchange_sizes; the send buffer is complete when start is called); may return at once
+ *   wait(user)                  returns when the exchange started last has delivered every byte of d_recv
+ * At most one exchange is in flight.  csrc/kct_rccl.cpp is an implementation over RCCL (ncclSend / ncclRecv on its own stream),
+ * oxli_amd/distributed.py one over torch.distributed.  world == 1 with ops == NULL is a loop-back.
+ *   max_windows   window starts per pass (0 = what HBM allows, at least four passes for a long stream)
+ *   *n_owned      k-mers this rank counted as an owner (summed over ranks: the job's n)
+ *   stats16       optional: windows sent to / received from other ranks, bytes sent / received, runs cut, passes, microseconds in
+ *                 the split / blocked in the exchange / in the owner's counting, region retries, window starts of this rank
+ * A failure on any rank (a full HBM, a failed collective) ends the call on EVERY rank with an error: the tables then hold a partial
+ * count and must be cleared. */
+typedef struct kct_exchange_ops {
+    void *user;
+    void *(*alloc)(void *user, uint64_t bytes);
+    void (*release)(void *user, void *p);
+    int (*exchange_sizes)(void *user, const uint64_t *send, uint32_t nvals, uint64_t *recv);
+    int (*start)(void *user, const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv, const uint64_t *recv_off,
+                 const uint64_t *recv_bytes);
+    int (*wait)(void *user);
+} kct_exchange_ops;
 KCT_API kct_status kct_consume_device_routed(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes, uint32_t world, uint32_t rank,
-                                             int mode, kct_alloc_fn alloc, kct_exchange_fn exchange, void *user, uint64_t *n_owned, uint64_t *stats8);
+                                             const kct_exchange_ops *ops, uint64_t max_windows, uint64_t *n_owned, uint64_t *stats16);
+
+/* The sender half alone (tests, tools, a caller with its own transport): this rank's records cut into super-k-mers for `world` owners.
+ * *d_parts (device memory owned by the table, valid until its next bulk call) holds owner o's part at part_off[o] .. + part_bytes[o]:
+ * the 16-byte base units (64 bases: 2 bits each, first base in the most significant bits of the first 32-bit word) of its
+ * kct_superkmer_streams(t) streams, then their start units (128 windows: bit w % 64 of 64-bit word w / 64 = window w begins a run);
+ * dir[o * streams + s] = windows | base units << 32 of stream s.  A run of n windows is n + k - 1 bases; windows are numbered in the
+ * order their runs lie in the stream. */
+KCT_API kct_status kct_superkmer_split_device(kct_table *t, const void *d_stream, size_t nbytes, uint32_t world, const void **d_parts,
+                                              uint64_t *part_off, uint64_t *part_bytes, uint64_t *dir);
+KCT_API uint32_t kct_superkmer_streams(const kct_table *t);
 
 /* An order-free digest of the table's contents, computed by one scan on the device: sum and xor over all keys of
  * hash * count, and the sum of count^2 (all wrapping u64).  Not in the reference; it lets a table of 10^8 .. 10^9 keys be

@@ -46,7 +46,9 @@ SIGNATURES = {
     "kct_consume_device_packed": (ci, [vp, vp, vp, sz, u64, u64p]),
     "kct_pack_stream_device": (ci, [vp, sz, vp, vp, vp]),
     "kct_set_packed_upload": (ci, [vp, ci]),
-    "kct_consume_device_routed": (ci, [vp, vp, sz, u64, C.c_uint32, C.c_uint32, ci, vp, vp, vp, u64p, u64p]),
+    "kct_consume_device_routed": (ci, [vp, vp, sz, u64, C.c_uint32, C.c_uint32, vp, u64, u64p, u64p]),
+    "kct_superkmer_split_device": (ci, [vp, vp, sz, C.c_uint32, C.POINTER(vp), u64p, u64p, u64p]),
+    "kct_superkmer_streams": (C.c_uint32, [vp]),
     "kct_consume_file": (ci, [vp, cp, ci, u64p, u64p, u64p]),
     "kct_len": (ci, [vp, u64p]),
     "kct_sum_counts": (ci, [vp, u64p]),
@@ -85,6 +87,18 @@ SIGNATURES = {
     "kct_synth_reads_device": (ci, [vp, vp, u64, u64, u64, C.c_uint32, u64, vp]),
     "kct_synth_reads_device_ex": (ci, [vp, vp, u64, u64, u64, C.c_uint32, u64, C.c_uint32, C.c_uint32, u64, u64, vp]),
 }
+
+
+
+class ExchangeOps(C.Structure):
+    """``kct_exchange_ops`` of include/kct.h: the collective the early multi-GPU route asks its caller for."""
+    ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)
+    RELEASE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+    SIZES = C.CFUNCTYPE(C.c_int, C.c_void_p, u64p, C.c_uint32, u64p)
+    START = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, C.c_void_p, u64p, u64p)
+    WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    _fields_ = [("user", C.c_void_p), ("alloc", ALLOC), ("release", RELEASE), ("exchange_sizes", SIZES), ("start", START), ("wait", WAIT)]
+
 
 _lib = None
 

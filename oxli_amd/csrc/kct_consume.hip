@@ -91,6 +91,7 @@ struct PartitionByK<0> {
 
 void launch_partition(kct_table *t, int mode, const unsigned char *d_stream, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa) {
     const int k = t->k, nwg = t->num_cus;
+    if (pa.runs.groups) { launch_partition_runs(t, mode, chunk_bytes, ntiles, pa); return; }  // received super-k-mers (kct_runs.hip)
     ProfScope ps(t, mode == 2 ? "partition_windows_kernel<compact>" : mode == 1 ? "partition_windows_kernel<raw>" : "partition_windows_kernel");
     if (mode == 2) PartitionCompactByK<21>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
     else if (mode == 1) PartitionRawByK<32>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
@@ -124,8 +125,14 @@ void launch_merge_overflow(kct_table *t, int mode, const du64 *regions, const un
 }
 
 
-// packed input: the K1 launch reads groups instead of bytes (PartitionArgs::pcodes)
+// packed input: the K1 launch reads groups instead of bytes (PartitionArgs::pcodes); super-k-mer input: it walks windows
+// (PartitionArgs::runs; d_stream then counts windows from runs_base, 64 per group)
 static void packed_args(const kct_table *t, const unsigned char *d_stream, kct::PartitionArgs *pa) {
+    if (t->runs_in.groups) {
+        pa->runs = t->runs_in;
+        pa->runs.groups += (u64)(d_stream - t->runs_base) >> 6;
+        return;
+    }
     if (!t->packed_codes) return;
     const u64 g0 = (u64)(d_stream - t->packed_base) >> 4;
     pa->pcodes = t->packed_codes + g0;
@@ -514,10 +521,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
     pa.ablate = t->ablate;
     packed_args(t, d_stream, &pa);
-    {
-        ProfScope ps(t, "partition_windows_kernel<compact>");
-        PartitionCompactByK<21>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
-    }
+    launch_partition(t, 2, d_stream, chunk_bytes, ntiles, pa);
     HIP_TRY(hipGetLastError());
     kct::Aggregate32Args aa;
     aa.words = t->shadow32; aa.block_bits = kct::kBlockBitsMax; aa.sbits = sbits;
@@ -836,11 +840,7 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
         pa.ovf = (du64 *)t->d_irr.p + c * nwg * ovf_cap; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count + c * nwg; pa.overflow = d_overflow;
         pa.ablate = t->ablate;  // measurement only; wrong counts when set
         packed_args(t, d_stream + off, &pa);
-        {
-            ProfScope ps(t, raw ? "partition_windows_kernel<raw>" : "partition_windows_kernel");
-            if (raw) PartitionRawByK<32>::run(k, t->stream, nwg, d_stream + off, bytes_c, ntiles_c, pa);
-            else PartitionByK<64>::run(k, t->stream, nwg, d_stream + off, bytes_c, ntiles_c, pa);
-        }
+        launch_partition(t, raw ? 1 : 0, d_stream + off, bytes_c, ntiles_c, pa);
         HIP_TRY(hipGetLastError());
         if (!two_level) break;
         kct::RepartitionArgs ra;
@@ -1097,7 +1097,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
                 continue;
             }
         }
-        if (dedupe128_pays(t, npos)) {
+        if (!t->runs_in.groups && dedupe128_pays(t, npos)) {
             bool handled = false;
             KCT_TRY(consume_raw128(t, d_stream + done, chunk_bytes, npos, n_out, &handled));
             if (handled) { done += npos; t->windows_since_read += npos; continue; }
@@ -1116,6 +1116,27 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
             bool handled = false;
             KCT_TRY(consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, false, false, nullptr, sub_chunks));
             if (handled) { done += npos; t->windows_since_read += npos; continue; }
+        }
+        if (t->runs_in.groups) {  // super-k-mer windows on the direct path (small passes): an ASCII image, k bytes + a separator per window
+            const u64 piece = std::min<u64>(npos, 1ULL << 22), g0 = (u64)(d_stream + done - t->runs_base) >> 6;
+            kct::RunsInput in = t->runs_in;
+            in.groups += g0;
+            const u64 ng = (piece + 63) >> 6, img = ng * 64 * (u64)(k + 1);
+            KCT_TRY(t->d_unpack.reserve(img + 16));
+            launch_expand_runs(t, in, ng, (unsigned char *)t->d_unpack.p);
+            HIP_TRY(hipGetLastError());
+            const kct::RunsInput keep = t->runs_in;
+            const unsigned char *keep_base = t->runs_base;
+            t->runs_in = kct::RunsInput(); t->runs_base = nullptr;
+            const u64 left = t->call_windows_left, since = t->windows_since_read;
+            u64 n_piece = 0;
+            const kct_status st = consume_stream(t, (const unsigned char *)t->d_unpack.p, img, &n_piece);   // (the image is the table's own buffer: d_unpack is not used below)
+            t->runs_in = keep; t->runs_base = keep_base;
+            t->call_windows_left = left; t->windows_since_read = since + piece;
+            KCT_TRY(st);
+            *n_out += n_piece;
+            done += piece;
+            continue;
         }
         KCT_TRY(materialize(t));
         KCT_TRY(t->d_spill.reserve(npos * 16));
@@ -1150,6 +1171,19 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
     KCT_DBG(t, "consume_stream: done\n");
     if (t->auto_sized && t->cap == cap_at_entry && nbytes >= (1u << 20)) t->auto_sized = false;  // the table has found its size
     return KCT_OK;
+}
+
+// Counts received SUPER-K-MERS (partition_args.h RunsInput; the early route's owner side): 64 * ngroups virtual windows, whatever path
+// the table's policy picks -- K1's RUNS instantiations walk the windows directly, the direct path gets an ASCII image.
+kct_status consume_stream_runs(kct_table *t, const kct::RunsInput &in, u64 ngroups, u64 *n_out) {
+    *n_out = 0;
+    if (!ngroups) return KCT_OK;
+    if (t->k > 64) { set_err("super-k-mer input needs k <= 64"); return KCT_ERR_ARG; }
+    t->runs_in = in;
+    t->runs_base = (const unsigned char *)(uintptr_t)0x200000000000ULL;  // an origin for window offsets; never dereferenced
+    const kct_status st = consume_stream(t, t->runs_base, ngroups * 64 + t->k - 1, n_out);
+    t->runs_in = kct::RunsInput(); t->runs_base = nullptr;
+    return st;
 }
 
 // Counts a PACKED record stream (window_kernels.h pack_stream_kernel's format): the partition kernels read the groups directly;

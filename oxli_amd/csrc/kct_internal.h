@@ -174,6 +174,10 @@ struct kct_table {
     const unsigned int *packed_codes = nullptr;
     const unsigned short *packed_valid = nullptr;
     const unsigned char *packed_base = nullptr;
+    // super-k-mer input (the early route's owner side, kct_route.hip): set while received runs are being counted; `d_stream` pointers
+    // are then WINDOW offsets from runs_base (never dereferenced) and runs_in.groups describes window 0's group
+    kct::RunsInput runs_in;
+    const unsigned char *runs_base = nullptr;
     bool packed_upload = true;  // kct_consume_batch packs large skip-bad batches on the host and uploads 0.375 B per base
     bool auto_sized = true; // no capacity hint / reserve yet: bulk ingest ramps its launch size up with the table
     kcth::Tuning tune;      // measurement switches, fixed at create time
@@ -221,7 +225,9 @@ struct kct_table {
     du64 *d_counters = nullptr;  // kNumCounters tallies + 8 scratch words (device)
     u64 *h_counters = nullptr;   // pinned mirror
     kcth::DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort, d_scratch2, d_regions2, d_irr2, d_pairs_ovf,
-        d_unpack,  // the ASCII image of a packed chunk, for the kernels that read bytes
+        d_unpack,  // the ASCII image of a packed chunk (or of a chunk of super-k-mer windows), for the kernels that read bytes
+        d_sk_bases, d_sk_starts, d_sk_meta, d_sk_lists, d_sk_dir, d_sk_send, d_sk_recv,  // early route: (workgroup, owner) regions, counts,
+                                                                                 // gather lists, run directory, loop-back slabs
         d_failed,  // K2: the numbers of the blocks it abandoned (partition_kernels.h FailedBlocks)
         d_prefix;  // error mode: the offending record's valid prefix (its own buffer: consume_stream reuses d_aux2 / d_spill)
     kcth::PinnedBuf h_stage;
@@ -289,6 +295,13 @@ kct_status point_add(kct_table *t, u64 h, u64 *count_out);
 kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 *n_out);
 kct_status consume_stream_packed(kct_table *t, const unsigned int *d_codes, const unsigned short *d_valid, u64 nbases, u64 *n_out);
 kct_status unpack_stream(kct_table *t, const unsigned int *d_codes, const unsigned short *d_valid, u64 ng);  // kct_entry.hip
+kct_status consume_stream_runs(kct_table *t, const kct::RunsInput &in, u64 ngroups, u64 *n_out);  // received super-k-mers (kct_route.hip)
+// kct_runs.hip: K1's super-k-mer instantiations and the early route's own kernels
+void launch_partition_runs(kct_table *t, int mode, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa);
+void launch_split(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 ntiles, const kct::SplitArgs &sa);
+void launch_gather_units(kct_table *t, const void *src, const du64 *src_off, const du64 *dst_off, const unsigned int *n, unsigned int count, void *dst);
+void launch_run_directory(kct_table *t, const kct::RunStream *streams, unsigned int nstreams, const du64 *starts, kct::RunGroup *groups);
+void launch_expand_runs(kct_table *t, const kct::RunsInput &in, u64 ngroups, unsigned char *out);
 // ... its kernels' launchers and sizing rules, for kct_route.hip (which does not instantiate the kernels itself)
 void launch_partition(kct_table *t, int mode /* 0 hashes, 1 mix64 values, 2 compact */, const unsigned char *d_stream, u64 chunk_bytes, u64 ntiles,
                       const kct::PartitionArgs &pa);

@@ -1,378 +1,344 @@
-// kct_route.hip -- the multi-GPU "early" route: entries go to the GPU that OWNS their slice of the key space
-// while they are being counted, so that every owner sees its k-mers at the input's FULL coverage.
+// kct_route.hip -- the multi-GPU "early" route: every k-mer is counted by the GPU that OWNS it, at the input's full
+// coverage, and what crosses xGMI is SUPER-K-MERS -- about one byte per window at k = 21, half a byte at k = 51 -- not one entry per
+// window.
 //
-//   every rank      K1 (partition_windows_kernel) over its own records, bins grouped by owner GPU:
-//                     compact entries (k <= 21): the bin is the top 10 bits of the 42-bit mix42 value; owner r holds the bins
-//                                                [ceil(1024 r / world), ceil(1024 (r + 1) / world))
-//                     64-bit entries (MurmurHash3 or mix64 values): bin = owner * 2^pl_bits + local super-bin,
-//                                                owner = floor(hi32(value) * world / 2^32)  (the late route's owner rule)
-//                   pack the regions of every owner's bins into one send buffer (pack_regions_kernel)
-//   exchange        three all-to-alls through the caller's callback (RCCL over xGMI in oxli_amd/distributed.py): the per-region
-//                   entry counts, the entries (4 or 8 bytes each), and the few entries that overflowed K1's LDS ring
-//   every owner     K1b (repartition_kernel, reading the received regions through an offset table) spreads each of its
-//                   super-bins over that super-bin's blocks; K2 counts them in LDS -- into the compact / 64-bit shadow table
-//                   (dedupe-first modes) or the real table (hashing mode); overflow entries take the direct insert.
+//   every rank      split_superkmers_kernel over its own records: owner(k-mer) = hash(minimiser) * world >> 16, maximal runs of good
+//                   windows with one owner as 2-bit bases + one start bit per window (superkmer_kernels.h); gather_units_kernel makes one
+//                   contiguous part per owner
+//   exchange        through the caller's kct_exchange_ops (RCCL over xGMI: csrc/kct_rccl.cpp; torch.distributed: oxli_amd/distributed.py):
+//                   a small host-side all-to-all of sizes (the per-stream directory rides along, and every rank's status: a failure
+//                   anywhere ends the call on EVERY rank before the next payload moves), then ONE all-to-all of the parts
+//   every owner     run_directory_kernel (one RunGroup per 64 windows), then the table's ORDINARY bulk path over the received windows
+//                   (consume_stream_runs: K1's RUNS instantiations read the runs; compact / 64-bit dedupe-first or hashing, one or two
+//                   levels, growth, probe -- whatever path_policy.h picks for a table of the owner's size: nothing about it is shared
+//                   between ranks, so no geometry has to agree)
 //
-// Reference semantics: independent records (README.md:96-98), per-key sums (add(), lib.rs:778-837).  The ranks' tables end up a
-// DISJOINT partition of the key space (by k-mer slice in the dedupe-first modes, by hash slice in hashing mode), so len /
-// sum_counts of the global table are sums over ranks, exactly as after the late route (merge_across_ranks).
+// The call is cut into passes and pipelined: while pass p's parts are on the wire the GPU splits pass p + 1, and while the owner side of
+// pass p runs, pass p + 1's parts are on the wire.
+//
+// Reference semantics: independent records (README.md:96-98), per-key sums (add(), lib.rs:778-837).  The ranks' tables end up a DISJOINT
+// partition of the key space (by minimiser), so len / sum_counts of the global table are sums over ranks, exactly as after the late
+// route (merge_across_ranks).
 #include "kct_internal.h"
 #include "path_policy.h"
 
 #include <numeric>
 
-namespace kct {
-
-// region rho = bin * nwg + wg of K1's output ([wg][P bins][region_cap]) -> dst + off[rho]; cnt[rho] entries (whole 64-byte lines)
-template <class T>
-__global__ __launch_bounds__(kBlock) void pack_regions_kernel(const T *__restrict__ scratch, u32 region_cap, const u32 *__restrict__ cnt,
-                                                              const u64 *__restrict__ off, u32 nregions, u32 nwg, u32 P, T *__restrict__ dst) {
-    constexpr u32 kVec = 16 / sizeof(T);
-    for (u32 rho = blockIdx.x; rho < nregions; rho += gridDim.x) {
-        const u32 bin = rho / nwg, wg = rho - bin * nwg, n = cnt[rho];
-        const uint4 *src = reinterpret_cast<const uint4 *>(scratch + ((u64)wg * P + bin) * region_cap);
-        uint4 *out = reinterpret_cast<uint4 *>(dst + off[rho]);
-        for (u32 i = threadIdx.x; i < n / kVec; i += kBlock) out[i] = src[i];
-    }
-}
-
-// owner of a 64-bit value as K1's overflow regions carry them
-template <int MODE>
-__device__ __forceinline__ u32 owner_of_value(u64 v, u32 world) {
-    if constexpr (MODE == 2) return (((u32)(v >> 32) & 1023u) * world) >> 10;  // compact: bit 63 | bin << 32 | entry
-    else return __umulhi((u32)(v >> 32), world);
-}
-
-// K1's overflow regions ([nwg][ovf_cap] values, counts[wg]) bucketed by owner: count pass (dst == nullptr), then scatter pass
-// (cursor[r] preset to owner r's start)
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void bucket_overflow_kernel(const u64 *__restrict__ regions, const u32 *__restrict__ counts, u32 nwg, u32 ovf_cap,
-                                                                 u32 world, u64 *cursor, u64 *dst) {
-    for (u32 wg = blockIdx.x; wg < nwg; wg += gridDim.x) {
-        const u32 n = counts[wg];
-        const u64 *src = regions + (u64)wg * ovf_cap;
-        for (u32 i = threadIdx.x; i < n; i += kBlock) {
-            const u64 v = src[i];
-            if (v == 0) continue;
-            const u64 pos = atomicAdd(&cursor[owner_of_value<MODE>(v, world)], 1ULL);
-            if (dst) dst[pos] = v;
-        }
-    }
-}
-
-}  // namespace kct
-
 namespace kcth {
 
 namespace {
 
-int ceil_log2(u64 v) { int b = 0; while ((1ULL << b) < v) ++b; return b; }
+// expected bases per window: a run of n windows is n + k - 1 bases, and a minimiser over W = k - m + 1 m-mers changes every (W + 1) / 2
+// windows on random sequence
+double bases_per_window(int k) {
+    const int m = std::min(k, 8), w = k - m + 1;
+    return 1.0 + 2.0 * (double)(k - 1) / (double)(w + 1);
+}
 
-struct Exchange {
+struct Slab {  // a send or receive buffer of the exchange (the caller's allocator, or the table's own for the loop-back)
+    void *p = nullptr;
+    u64 cap = 0;
+};
+
+struct Route {
     kct_table *t;
     unsigned world, rank;
-    kct_alloc_fn alloc;
-    kct_exchange_fn xfn;
-    void *user;
-    std::vector<void *> own;  // loopback (world == 1, no callbacks): buffers of this call
-    ~Exchange() { for (void *p : own) (void)hipFree(p); }
-    kct_status get(u64 bytes, void **p) {
-        bytes = std::max<u64>(bytes, 256);
-        if (alloc) {
-            *p = alloc(user, bytes);
-            if (!*p) { set_err("the exchange's allocator returned no buffer of %llu bytes", (unsigned long long)bytes); return KCT_ERR_NOMEM; }
+    const kct_exchange_ops *ops;
+    int nwg;
+    double wait_ms = 0;
+
+    kct_status slab(Slab &s, DevBuf &own, u64 bytes) {
+        bytes = std::max<u64>(bytes, 256) + 64;   // (K1 reads up to two words past a window's last base)
+        if (bytes <= s.cap) return KCT_OK;
+        if (!ops) {
+            KCT_TRY(own.reserve(bytes + bytes / 8));
+            s.p = own.p; s.cap = own.cap;
             return KCT_OK;
         }
-        HIP_TRY(hipMalloc(p, bytes));
-        own.push_back(*p);
+        HIP_TRY(hipStreamSynchronize(t->stream));   // (whatever still reads the old buffer)
+        if (s.p && ops->release) ops->release(ops->user, s.p);
+        s.p = ops->alloc(ops->user, bytes + bytes / 8);
+        s.cap = s.p ? bytes + bytes / 8 : 0;
+        if (!s.p) { set_err("the exchange's allocator returned no buffer of %llu bytes", (unsigned long long)(bytes + bytes / 8)); return KCT_ERR_NOMEM; }
         return KCT_OK;
     }
-    // all-to-all of send_elems[r] elements for rank r (contiguous, in rank order); waits for the table's stream first
-    kct_status run(const void *d_send, const std::vector<u64> &send_elems, unsigned elem_bytes, void **d_recv, std::vector<u64> &recv_elems) {
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        recv_elems.assign(world, 0);
-        if (!xfn) {  // loopback: one rank
-            *d_recv = const_cast<void *>(d_send);
-            recv_elems[0] = send_elems[0];
-            return KCT_OK;
-        }
-        *d_recv = nullptr;
-        const int rc = xfn(user, d_send, send_elems.data(), elem_bytes, d_recv, recv_elems.data());
-        if (rc != 0 || (!*d_recv && std::accumulate(recv_elems.begin(), recv_elems.end(), (u64)0) != 0)) {
-            set_err("the exchange callback failed (%d)", rc);
-            return KCT_ERR_ARG;
-        }
+    // all-to-all of nvals u64 per peer, host memory; slot 0 of every message is the sender's status
+    kct_status sizes(std::vector<u64> &send, unsigned nvals, std::vector<u64> &recv) {
+        recv.assign((size_t)world * nvals, 0);
+        if (!ops) { recv = send; return KCT_OK; }
+        const double t0 = now_ms();
+        const int rc = ops->exchange_sizes(ops->user, send.data(), nvals, recv.data());
+        wait_ms += now_ms() - t0;
+        if (rc != 0) { set_err("the exchange's size all-to-all failed (%d)", rc); return KCT_ERR_HIP; }
+        return KCT_OK;
+    }
+    // every rank learns whether ANY rank has failed; `mine` is passed through for the rank that did
+    kct_status agree(kct_status mine) {
+        if (!ops) return mine;
+        std::vector<u64> s(world, (u64)mine), r;
+        const kct_status st = sizes(s, 1, r);
+        if (st != KCT_OK) return mine != KCT_OK ? mine : st;
+        if (mine != KCT_OK) return mine;
+        for (unsigned p = 0; p < world; ++p)
+            if (r[p] != 0) { set_err("the early route failed on rank %u (status %llu): this rank's table is short of what that rank was to send", p, (unsigned long long)r[p]); return KCT_ERR_HIP; }
         return KCT_OK;
     }
 };
 
+struct PassOut {  // what the split of one pass left for the exchange
+    std::vector<u64> part_off, part_bytes;   // per owner, in the send slab
+    std::vector<u64> dir;                    // [owner][stream]: windows | base units << 32
+    u64 windows_out = 0, runs = 0, bytes = 0;
+    int retries = 0;
+};
+
+// this rank's records [d_stream, d_stream + nbytes) -> one part per owner in `send`
+kct_status split_pass(Route &r, const unsigned char *d_stream, u64 nbytes, Slab &send, DevBuf &own_send, PassOut &out) {
+    kct_table *t = r.t;
+    const int k = t->k, nwg = r.nwg;
+    const unsigned world = r.world;
+    const u64 nstreams = (u64)nwg * world;
+    out.part_off.assign(world, 0); out.part_bytes.assign(world, 0); out.dir.assign(nstreams, 0);
+    out.windows_out = out.runs = out.bytes = 0;
+    const u64 npos = nbytes >= (u64)k ? nbytes - k + 1 : 0;
+    if (!npos) return KCT_OK;
+    const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile, tiles_per_wg = (ntiles + nwg - 1) / nwg;
+    const double per_stream = (double)(tiles_per_wg * kct::kPartTile) / world;
+    u64 cap_units = (u64)(per_stream * bases_per_window(k) * 1.3 / 64.0) + 16, cap_sunits = (u64)(per_stream * 1.3 / 128.0) + 16;
+    std::vector<unsigned int> meta(4 * nstreams);
+    for (;;) {
+        KCT_TRY(t->d_sk_bases.reserve(nstreams * cap_units * 16));
+        KCT_TRY(t->d_sk_starts.reserve(nstreams * cap_sunits * 16));
+        KCT_TRY(t->d_sk_meta.reserve(4 * nstreams * 4 + 64));
+        du64 *d_overflow = (du64 *)((char *)t->d_sk_meta.p + 4 * nstreams * 4);
+        HIP_TRY(hipMemsetAsync(d_overflow, 0, 8, t->stream));
+        kct::SplitArgs sa;
+        sa.world = world;
+        sa.bases_out = (uint4 *)t->d_sk_bases.p; sa.cap_units = (unsigned int)cap_units;
+        sa.starts_out = (uint4 *)t->d_sk_starts.p; sa.cap_sunits = (unsigned int)cap_sunits;
+        unsigned int *m = (unsigned int *)t->d_sk_meta.p;
+        sa.nwin = m; sa.nunits = m + nstreams; sa.nsunits = m + 2 * nstreams; sa.nruns = m + 3 * nstreams;
+        sa.overflow = d_overflow;
+        sa.pcodes = nullptr; sa.pvalid = nullptr;
+        launch_split(t, d_stream, std::min<u64>(nbytes, npos + k - 1), ntiles, sa);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(meta.data(), t->d_sk_meta.p, 4 * nstreams * 4, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->h_counters, d_overflow, 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (t->h_counters[0] == 0) break;
+        // a region was too small (input far from random: many short runs, or one owner takes most): the counts say what is needed
+        u64 need_u = 0, need_s = 0;
+        for (u64 i = 0; i < nstreams; ++i) { need_u = std::max<u64>(need_u, meta[nstreams + i]); need_s = std::max<u64>(need_s, meta[2 * nstreams + i]); }
+        if (++out.retries > 3 || need_u >= (1ULL << 31) || need_s >= (1ULL << 31)) { set_err("the super-k-mer regions overflowed %d times", out.retries); return KCT_ERR_NOMEM; }
+        cap_units = std::max(cap_units, need_u + need_u / 16 + 16);
+        cap_sunits = std::max(cap_sunits, need_s + need_s / 16 + 16);
+        KCT_DBG(t, "split: regions too small, again with %llu / %llu units per stream\n", (unsigned long long)cap_units, (unsigned long long)cap_sunits);
+    }
+    // ---- one part per owner: [base units of its nwg streams][start units of its nwg streams] -------------------------------------------
+    const unsigned int *nwin = meta.data(), *nun = meta.data() + nstreams, *nsu = meta.data() + 2 * nstreams, *nrun = meta.data() + 3 * nstreams;
+    std::vector<u64> src_off(2 * nstreams), dst_off(2 * nstreams);
+    std::vector<unsigned int> cnt(2 * nstreams);
+    u64 total_units = 0;
+    for (unsigned o = 0; o < world; ++o) {
+        out.part_off[o] = total_units * 16;
+        for (int half = 0; half < 2; ++half)
+            for (int w = 0; w < nwg; ++w) {
+                const u64 i = (u64)w * world + o, j = (u64)half * nstreams + (u64)o * nwg + w;
+                src_off[j] = i * (half ? cap_sunits : cap_units);
+                dst_off[j] = total_units;
+                cnt[j] = half ? nsu[i] : nun[i];
+                total_units += cnt[j];
+                if (!half) { out.dir[(u64)o * nwg + w] = (u64)nwin[i] | ((u64)nun[i] << 32); out.windows_out += nwin[i]; out.runs += nrun[i]; }
+            }
+        out.part_bytes[o] = total_units * 16 - out.part_off[o];
+    }
+    out.bytes = total_units * 16;
+    KCT_TRY(r.slab(send, own_send, out.bytes));
+    const u64 list_bytes = 2 * nstreams * (8 + 8 + 4);
+    KCT_TRY(t->d_sk_lists.reserve(list_bytes));
+    du64 *d_src = (du64 *)t->d_sk_lists.p, *d_dst = d_src + 2 * nstreams;
+    unsigned int *d_cnt = (unsigned int *)(d_dst + 2 * nstreams);
+    HIP_TRY(hipMemcpyAsync(d_src, src_off.data(), 2 * nstreams * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(d_dst, dst_off.data(), 2 * nstreams * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(d_cnt, cnt.data(), 2 * nstreams * 4, hipMemcpyHostToDevice, t->stream));
+    launch_gather_units(t, t->d_sk_bases.p, d_src, d_dst, d_cnt, (unsigned)nstreams, send.p);
+    launch_gather_units(t, t->d_sk_starts.p, d_src + nstreams, d_dst + nstreams, d_cnt + nstreams, (unsigned)nstreams, send.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));   // (the host vectors above; and the exchange may read the slab from another stream)
+    return KCT_OK;
+}
+
+// the parts received from every peer (recv_off / recv_bytes, directories dir[peer][stream]) -> counted into this rank's table
+kct_status owner_pass(Route &r, const void *d_recv, const std::vector<u64> &recv_off, const std::vector<u64> &recv_bytes, const std::vector<u64> &dir, u64 *n_out, u64 *windows_in) {
+    kct_table *t = r.t;
+    const int nwg = r.nwg;
+    const unsigned world = r.world;
+    *n_out = 0; *windows_in = 0;
+    std::vector<kct::RunStream> streams;
+    streams.reserve((size_t)world * nwg);
+    u64 ngroups = 0;
+    for (unsigned p = 0; p < world; ++p) {
+        u64 units = 0, sunits = 0;
+        for (int w = 0; w < nwg; ++w) { const u64 d = dir[(u64)p * nwg + w]; units += d >> 32; sunits += ((d & 0xFFFFFFFFULL) + 127) / 128; }
+        if ((units + sunits) * 16 != recv_bytes[p]) { set_err("rank %u announced %llu bytes of super-k-mers and its directory adds up to %llu", p, (unsigned long long)recv_bytes[p], (unsigned long long)((units + sunits) * 16)); return KCT_ERR_ARG; }
+        u64 boff = recv_off[p], soff = recv_off[p] + units * 16;
+        for (int w = 0; w < nwg; ++w) {
+            const u64 d = dir[(u64)p * nwg + w], nwin = d & 0xFFFFFFFFULL;
+            if (nwin) {
+                if ((soff >> 3) >= (1ULL << 32)) { set_err("a pass of the early route may receive at most 32 GiB"); return KCT_ERR_ARG; }
+                kct::RunStream s;
+                s.bit0 = boff * 8; s.word0 = (unsigned int)(soff >> 3); s.nwin = (unsigned int)nwin; s.group0 = ngroups;
+                streams.push_back(s);
+                ngroups += (nwin + 63) >> 6;
+                *windows_in += nwin;
+            }
+            boff += (d >> 32) * 16; soff += ((nwin + 127) / 128) * 16;
+        }
+    }
+    if (!ngroups) return KCT_OK;
+    KCT_TRY(t->d_sk_dir.reserve(streams.size() * sizeof(kct::RunStream) + ngroups * sizeof(kct::RunGroup) + 64));
+    kct::RunGroup *d_groups = (kct::RunGroup *)t->d_sk_dir.p;
+    kct::RunStream *d_streams = (kct::RunStream *)(d_groups + ngroups);
+    HIP_TRY(hipMemcpyAsync(d_streams, streams.data(), streams.size() * sizeof(kct::RunStream), hipMemcpyHostToDevice, t->stream));
+    launch_run_directory(t, d_streams, (unsigned)streams.size(), (const du64 *)d_recv, d_groups);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));   // (`streams` is host memory)
+    kct::RunsInput in;
+    in.bases = (const unsigned int *)d_recv; in.starts = (const du64 *)d_recv; in.groups = d_groups;
+    return consume_stream_runs(t, in, ngroups, n_out);
+}
+
 }  // namespace
 
-kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbytes, unsigned world, unsigned rank, int mode, kct_alloc_fn alloc,
-                          kct_exchange_fn xfn, void *user, u64 *n_out, u64 stats[8]) {
+kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbytes, unsigned world, unsigned rank, const kct_exchange_ops *ops, u64 max_windows,
+                          u64 *n_out, u64 stats[16]) {
     *n_out = 0;
-    const int k = t->k, nwg = t->num_cus;
-    if (world < 1 || world > 64 || rank >= world || mode < 0 || mode > 2 || (world > 1 && (!xfn || !alloc))) { set_err("bad world / rank / mode / callbacks"); return KCT_ERR_ARG; }
-    if ((mode == 2 && k > 21) || (mode == 1 && k > 32) || k > 64 || k < 1) { set_err("mode %d does not take k = %d", mode, k); return KCT_ERR_ARG; }
-    if (t->block_bits != kct::kBlockBitsMax) { set_err("the early route needs a table of at least 2^19 slots"); return KCT_ERR_ARG; }
-    const int bbits = log2_u64(t->cap >> t->block_bits);
-    // ---- who owns which of K1's bins; the owner-side fan-out (sub_bits) ------------------------------------------------------
-    std::vector<unsigned> lo(world + 1);
-    int sub_bits, pl_bits = 0;
-    if (mode == 2) {
-        for (unsigned r = 0; r <= world; ++r) lo[r] = (r * 1024u + world - 1) / world;
-        const unsigned nb = lo[rank + 1] - lo[rank];
-        sub_bits = std::max(6, ceil_log2(((1ULL << bbits) + nb - 1) / nb));  // shadow slots ~ table slots, >= 64 blocks per super-bin
-        if (sub_bits > 10) { set_err("table too large for the early route at this world size"); return KCT_ERR_ARG; }
-    } else {
-        int pl_max = 0;
-        while ((2u << pl_max) * world <= 1024u) ++pl_max;
-        pl_bits = std::min(pl_max, bbits - 6);
-        if (pl_bits < 0) { set_err("the early route needs a table of at least 2^19 slots"); return KCT_ERR_ARG; }
-        sub_bits = bbits - pl_bits;
-        if (sub_bits > 10) { set_err("table too large for the early route at this world size"); return KCT_ERR_ARG; }
-        for (unsigned r = 0; r <= world; ++r) lo[r] = r << pl_bits;
+    const int k = t->k;
+    if (world < 1 || world > kct::kSkMaxWorld || rank >= world) { set_err("bad world / rank"); return KCT_ERR_ARG; }
+    if (world > 1 && (!ops || !ops->alloc || !ops->exchange_sizes || !ops->start || !ops->wait)) { set_err("more than one rank needs the exchange callbacks"); return KCT_ERR_ARG; }
+    if (world == 1) ops = nullptr;
+    if (k > 64) { set_err("the early route takes k <= 64"); return KCT_ERR_ARG; }
+    Route r{t, world, rank, ops, t->num_cus};
+    // ---- passes: as many as the tightest rank needs (HBM: regions, two send and two receive slabs, the owner's scratch), at least
+    // four for a long stream so that the wire hides behind the kernels
+    const u64 windows = nbytes >= (u64)k ? nbytes - k + 1 : 0;
+    if (!max_windows) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const double held = (double)(t->d_scratch.cap + t->d_scratch2.cap + t->d_sk_bases.cap + t->d_sk_starts.cap);
+        const double per_window = 6.0 * bases_per_window(k) / 4.0 + 24.0;
+        max_windows = (u64)std::max(1.0 * (1 << 24), 0.6 * ((double)free_b + held) / per_window);
+        if (windows >= (1ULL << 28)) max_windows = std::min<u64>(max_windows, std::max<u64>(1ULL << 26, windows / 4));
     }
-    const unsigned nb_me = lo[rank + 1] - lo[rank], bins_used = lo[world];
-    const unsigned esz = mode == 2 ? 4 : 8;
-    // K1's ring is split over 2^pbits bins: as few as hold the bins in use, so that a bin is as deep as it can be
-    const int pbits = mode == 2 ? 10 : std::max(1, ceil_log2(bins_used));
-    const u64 P = 1ULL << pbits;
-    Exchange ex{t, world, rank, alloc, xfn, user, {}};
-    // the shadow the entries will be counted into (dedupe-first modes) -- first of all: making it may convert what an older
-    // shadow holds, which uses the scratch buffers below
-    if (mode == 2) {
-        bool ok = true;
-        KCT_TRY(ensure_shadow32(t, 10 + sub_bits, &ok, nb_me, lo[rank]));
-        if (!ok) { set_err("no room for the compact shadow table"); return KCT_ERR_NOMEM; }
-        if (t->s32_dirty && t->s32_windows >= (1ULL << 38)) KCT_TRY(flush_shadow(t));  // (u32 counts: see aggregate_blocks32_kernel; a pass brings < 2^38)
-    } else if (mode == 1) {
-        bool ok = true;
-        KCT_TRY(ensure_shadow(t, t->cap, &ok));
-        if (!ok) { set_err("no room for the shadow table"); return KCT_ERR_NOMEM; }
-    }
-
-    // ---- K1 over this rank's records --------------------------------------------------------------------------------------
-    const u64 npos = nbytes >= (u64)k ? nbytes - k + 1 : 0;
-    const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
-    const u64 tiles_per_wg = (ntiles + nwg - 1) / nwg;
-    unsigned int region_cap = region_capacity((double)(tiles_per_wg * kct::kPartTile) / (double)bins_used);
-    region_cap = (region_cap + 15u) & ~15u;
-    // (an abandoned pass cannot fall back to the direct kernel here: room for EVERY entry of a workgroup, up to the 2^20 the ring's
-    // position arithmetic allows -- only a workgroup with more than a million overflowing entries makes the call fail)
-    const unsigned int ovf_cap = (unsigned int)std::min<u64>(1ULL << 20, std::max<u64>(4096, tiles_per_wg * kct::kPartTile));
-    KCT_TRY(t->d_scratch.reserve((u64)nwg * P * region_cap * esz));
-    KCT_TRY(t->d_regions.reserve((u64)nwg * P * 4));
-    KCT_TRY(t->d_irr.reserve((u64)nwg * ovf_cap * 8 + (u64)nwg * 4));
-    KCT_TRY(zero_counters(t));
-    du64 *d_overflow = t->d_counters + kNumCounters + 6;
-    unsigned int *d_ovf_count = (unsigned int *)((du64 *)t->d_irr.p + (u64)nwg * ovf_cap);
-    kct::PartitionArgs pa;
-    pa.mask = t->cap - 1; pa.block_bits = kct::kBlockBitsMax + sub_bits; pa.pbits = pbits;
-    pa.scratch = (du64 *)t->d_scratch.p; pa.region_cap = region_cap; pa.region_count = (unsigned int *)t->d_regions.p;
-    pa.ovf = (du64 *)t->d_irr.p; pa.ovf_cap = ovf_cap; pa.ovf_count = d_ovf_count; pa.overflow = d_overflow;
-    pa.ablate = 0;
-    if (mode != 2) { pa.world = world; pa.pl_bits = pl_bits; }
-    launch_partition(t, mode, d_stream, std::min<u64>(nbytes, npos + k - 1), ntiles, pa);
-    HIP_TRY(hipGetLastError());
-    // the region sizes, the overflow sizes and the abandon flag
-    const u64 nreg = (u64)bins_used * nwg;
-    std::vector<unsigned int> h_cnt(nreg), h_ovf(nwg);
-    HIP_TRY(hipMemcpyAsync(h_cnt.data(), t->d_regions.p, nreg * 4, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(hipMemcpyAsync(h_ovf.data(), d_ovf_count, (u64)nwg * 4, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(hipMemcpyAsync(t->h_counters, d_overflow, 8, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(hipStreamSynchronize(t->stream));
-    const bool abandoned = t->h_counters[0] != 0;  // an overflow region overflowed (hopelessly skewed input): this rank sends nothing
-    if (abandoned) { std::fill(h_cnt.begin(), h_cnt.end(), 0u); std::fill(h_ovf.begin(), h_ovf.end(), 0u); HIP_TRY(hipMemsetAsync(t->d_regions.p, 0, nreg * 4, t->stream)); }
-
-    // ---- pack: every owner's regions, contiguous, in (bin, workgroup) order -------------------------------------------------
-    std::vector<u64> h_off(nreg + 1);
-    h_off[0] = 0;
-    for (u64 i = 0; i < nreg; ++i) h_off[i + 1] = h_off[i] + h_cnt[i];
-    const u64 total_send = h_off[nreg];
-    std::vector<u64> send_cnt(world), send_ent(world), recv_cnt, recv_ent, recv_ovf;
-    for (unsigned r = 0; r < world; ++r) {
-        send_cnt[r] = (u64)(lo[r + 1] - lo[r]) * nwg;
-        send_ent[r] = h_off[(u64)lo[r + 1] * nwg] - h_off[(u64)lo[r] * nwg];
-    }
-    void *d_send_cnt = nullptr, *d_send = nullptr;
-    KCT_TRY(ex.get(nreg * 4, &d_send_cnt));
-    KCT_TRY(ex.get(total_send * esz, &d_send));
-    HIP_TRY(hipMemcpyAsync(d_send_cnt, t->d_regions.p, nreg * 4, hipMemcpyDeviceToDevice, t->stream));
-    KCT_TRY(t->d_aux.reserve((nreg + 1) * 8));
-    HIP_TRY(hipMemcpyAsync(t->d_aux.p, h_off.data(), (nreg + 1) * 8, hipMemcpyHostToDevice, t->stream));
-    if (total_send) {
-        ProfScope ps(t, "pack_regions_kernel");
-        const unsigned grid = (unsigned)std::min<u64>(nreg, 1u << 16);
-        if (mode == 2) hipLaunchKernelGGL(kct::pack_regions_kernel<unsigned int>, dim3(grid), dim3(kct::kBlock), 0, t->stream, (const unsigned int *)t->d_scratch.p,
-                                          region_cap, (const unsigned int *)t->d_regions.p, (const du64 *)t->d_aux.p, (unsigned)nreg, (unsigned)nwg, (unsigned)P, (unsigned int *)d_send);
-        else hipLaunchKernelGGL(kct::pack_regions_kernel<du64>, dim3(grid), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_scratch.p, region_cap,
-                                (const unsigned int *)t->d_regions.p, (const du64 *)t->d_aux.p, (unsigned)nreg, (unsigned)nwg, (unsigned)P, (du64 *)d_send);
-        HIP_TRY(hipGetLastError());
-    }
-    // ---- K1's overflow entries, bucketed by owner ----------------------------------------------------------------------------
-    u64 ovf_total = 0;
-    for (unsigned v : h_ovf) ovf_total += v;
-    std::vector<u64> send_ovf(world, 0);
-    void *d_send_ovf = nullptr;
-    KCT_TRY(ex.get(ovf_total * 8, &d_send_ovf));
-    KCT_TRY(t->d_aux2.reserve((u64)world * 8 + 64));
-    du64 *d_cursor = (du64 *)t->d_aux2.p;  // one cursor per owner
-    if (ovf_total) {
-        HIP_TRY(hipMemsetAsync(d_cursor, 0, (u64)world * 8, t->stream));
-        auto bucket = [&](du64 *dst) {
-            const unsigned grid = (unsigned)std::min<int>(nwg, 1024);
-            if (mode == 2) hipLaunchKernelGGL(kct::bucket_overflow_kernel<2>, dim3(grid), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p, (const unsigned int *)d_ovf_count, (unsigned)nwg, ovf_cap, world, d_cursor, dst);
-            else hipLaunchKernelGGL(kct::bucket_overflow_kernel<0>, dim3(grid), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr.p, (const unsigned int *)d_ovf_count, (unsigned)nwg, ovf_cap, world, d_cursor, dst);
-        };
-        bucket(nullptr);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(send_ovf.data(), d_cursor, (u64)world * 8, hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        std::vector<u64> start(world, 0);
-        for (unsigned r = 1; r < world; ++r) start[r] = start[r - 1] + send_ovf[r - 1];
-        HIP_TRY(hipMemcpyAsync(d_cursor, start.data(), (u64)world * 8, hipMemcpyHostToDevice, t->stream));
-        bucket((du64 *)d_send_ovf);
-        HIP_TRY(hipGetLastError());
-    }
-    // ---- the three all-to-alls --------------------------------------------------------------------------------------------------
-    void *d_recv_cnt = nullptr, *d_recv = nullptr, *d_recv_ovf = nullptr;
-    const double t0 = now_ms();
-    KCT_TRY(ex.run(d_send_cnt, send_cnt, 4, &d_recv_cnt, recv_cnt));
-    KCT_TRY(ex.run(d_send, send_ent, esz, &d_recv, recv_ent));
-    KCT_TRY(ex.run(d_send_ovf, send_ovf, 8, &d_recv_ovf, recv_ovf));
-    const double exchange_ms = now_ms() - t0;
-    for (unsigned p = 0; p < world; ++p)
-        if (recv_cnt[p] != (u64)nb_me * nwg) { set_err("rank %u sent %llu region counts, expected %llu: the ranks' tables differ in geometry", p, (unsigned long long)recv_cnt[p], (unsigned long long)nb_me * nwg); return KCT_ERR_ARG; }
-    // ---- owner side: the received regions as K1b's input ([super-bin][segment = (peer, workgroup)]) ---------------------------
-    const u64 nseg = (u64)world * nwg, nidx = (u64)nb_me * nseg;
-    std::vector<unsigned int> h_rc(nidx), h_c2(nidx);
-    std::vector<u64> h_o2(nidx);
-    HIP_TRY(hipMemcpy(h_rc.data(), d_recv_cnt, nidx * 4, hipMemcpyDeviceToHost));
-    u64 total_recv = 0;
-    for (unsigned p = 0; p < world; ++p) {
-        u64 run = 0;
-        for (unsigned s = 0; s < nb_me; ++s)
-            for (int w = 0; w < nwg; ++w) {
-                const unsigned int c = h_rc[((u64)p * nb_me + s) * nwg + w];
-                const u64 i = (u64)s * nseg + (u64)p * nwg + w;
-                h_c2[i] = c; h_o2[i] = total_recv + run;
-                run += c;
-            }
-        if (run != recv_ent[p]) { set_err("rank %u announced %llu entries and sent %llu", p, (unsigned long long)run, (unsigned long long)recv_ent[p]); return KCT_ERR_ARG; }
-        total_recv += run;
-    }
-    u64 recv_ovf_total = 0;
-    for (u64 v : recv_ovf) recv_ovf_total += v;
-    KCT_TRY(t->d_regions.reserve(std::max<u64>((u64)nwg * P * 4, nidx * 4)));
-    KCT_TRY(t->d_aux.reserve(nidx * 8 + 64));
-    HIP_TRY(hipMemcpyAsync(t->d_regions.p, h_c2.data(), nidx * 4, hipMemcpyHostToDevice, t->stream));
-    HIP_TRY(hipMemcpyAsync(t->d_aux.p, h_o2.data(), nidx * 8, hipMemcpyHostToDevice, t->stream));
-    du64 *d_ovf_total = (du64 *)((char *)t->d_aux.p + nidx * 8);
-    HIP_TRY(hipMemcpyAsync(d_ovf_total, &recv_ovf_total, 8, hipMemcpyHostToDevice, t->stream));
-
-    // ---- K1b: every super-bin of mine over its 2^sub_bits blocks ---------------------------------------------------------------
-    // (a writer's sixteen waves take one input segment each: more than nseg / 16 writers would find nothing to read)
-    const u64 B = (u64)nb_me << sub_bits, W = std::max<u64>(1, std::min<u64>((u64)nwg / nb_me, nseg / 16));
-    unsigned int out_cap = region_capacity((double)total_recv / (double)B / (double)W);
-    out_cap = (out_cap + 63u) & ~63u;
-    // K1b's overflow regions: room for EVERY entry of the busiest workgroup (an abandoned pass cannot fall back to the direct kernel
-    // here), up to the 2^20 the ring's position arithmetic allows.  Workgroup (s, w) reads segments 16 w + wave, + 16 W, ...
-    u64 busiest = 0;
-    for (unsigned sb = 0; sb < nb_me; ++sb)
-        for (u64 w = 0; w < W; ++w) {
-            u64 sum = 0;
-            for (u64 seg0 = w * 16; seg0 < nseg; seg0 += W * 16)
-                for (u64 seg = seg0; seg < std::min<u64>(seg0 + 16, nseg); ++seg) sum += h_c2[(u64)sb * nseg + seg];
-            busiest = std::max(busiest, sum);
+    max_windows = std::max<u64>(1 << 16, max_windows & ~0xFFFFULL);
+    std::vector<u64> sz(world * 2), rz;
+    for (unsigned p = 0; p < world; ++p) { sz[2 * p] = 0; sz[2 * p + 1] = windows ? (windows + max_windows - 1) / max_windows : 1; }
+    KCT_TRY(r.sizes(sz, 2, rz));
+    u64 passes = 1;
+    for (unsigned p = 0; p < world; ++p) passes = std::max(passes, rz[2 * p + 1]);
+    if (passes > (1u << 20)) { set_err("a rank asked for %llu passes", (unsigned long long)passes); return KCT_ERR_ARG; }
+    const u64 step = windows ? (((windows + passes - 1) / passes) + 0xFFFF) & ~0xFFFFULL : 0;  // window starts per pass (16-byte aligned cuts)
+    auto pass_range = [&](u64 p, u64 *off, u64 *len) {
+        *off = std::min(p * step, nbytes);
+        *len = p + 1 < passes ? std::min(nbytes - *off, step + k - 1) : nbytes - *off;
+        if (*off >= nbytes || *len < (u64)k) *len = 0;
+    };
+    Slab send[2], recv[2];
+    PassOut po[2];
+    const unsigned nvals = 2 + (unsigned)r.nwg;
+    std::vector<u64> msg((size_t)world * nvals), got[2];
+    std::vector<u64> recv_off[2], recv_bytes[2], dirs[2];
+    for (int b = 0; b < 2; ++b) { po[b].part_off.assign(world, 0); po[b].part_bytes.assign(world, 0); po[b].dir.assign((size_t)r.nwg * world, 0); }
+    u64 st_windows_out = 0, st_windows_in = 0, st_bytes_out = 0, st_bytes_in = 0, st_runs = 0, st_retries = 0;
+    double split_ms = 0, owner_ms = 0;
+    kct_status status = KCT_OK;
+    // cut(p): this rank's records of pass p -> one part per owner in send[p & 1].  A local failure is kept in `status`: the rank then
+    // stays in step with its peers (every collective below is still made) and announces the failure in its next size message.
+    auto cut = [&](u64 p) {
+        const int b = (int)(p & 1);
+        u64 off, len;
+        pass_range(p, &off, &len);
+        const double t0 = now_ms();
+        if (status == KCT_OK) status = split_pass(r, d_stream + off, len, send[b], b ? t->d_sk_recv : t->d_sk_send, po[b]);
+        split_ms += now_ms() - t0;
+        if (status != KCT_OK) { po[b].part_off.assign(world, 0); po[b].part_bytes.assign(world, 0); po[b].dir.assign((size_t)r.nwg * world, 0); }
+    };
+    // post(p): sizes and directories of pass p to every peer (with this rank's status), room for what will arrive, then the payload
+    // starts.  Returns non-OK on EVERY rank alike (the job is over), OK with the transfer under way otherwise.
+    auto post = [&](u64 p) -> kct_status {
+        const int b = (int)(p & 1);
+        for (unsigned q = 0; q < world; ++q) {
+            msg[(size_t)q * nvals] = (u64)status;
+            msg[(size_t)q * nvals + 1] = po[b].part_bytes[q];
+            for (int w = 0; w < r.nwg; ++w) msg[(size_t)q * nvals + 2 + w] = po[b].dir[(size_t)q * r.nwg + w];
         }
-    const unsigned int ovf2_cap = (unsigned int)std::min<u64>(1ULL << 20, std::max<u64>(4096, busiest));
-    KCT_TRY(t->d_scratch2.reserve(B * W * out_cap * esz));
-    KCT_TRY(t->d_regions2.reserve(B * W * 4));
-    KCT_TRY(t->d_irr2.reserve((u64)nb_me * W * ovf2_cap * 8 + (u64)nb_me * W * 4));
-    unsigned int *d_ovf2_count = (unsigned int *)((du64 *)t->d_irr2.p + (u64)nb_me * W * ovf2_cap);
-    kct::RepartitionArgs ra;
-    ra.mask = (mode == 2 ? compact_slots(t) : t->cap) - 1; ra.block_bits = kct::kBlockBitsMax; ra.sub_bits = sub_bits;
-    ra.in = d_recv; ra.in_cap = 0; ra.in_count = (const unsigned int *)t->d_regions.p; ra.in_off = (const du64 *)t->d_aux.p;
-    ra.nseg = (int)nseg; ra.nbins = (int)nb_me; ra.writers = (int)W;
-    ra.out = t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
-    ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow; ra.ovf_n = nullptr;
-    ra.bin0 = lo[rank];
-    ra.min_lines = repartition_min_lines(t, mode == 2 ? kct::kRingEntries * 2 : kct::kRingEntries, sub_bits, (int)esz);
-    HIP_TRY(hipMemsetAsync(d_overflow, 0, 8, t->stream));  // (K1's flag has been read; K1b raises it again if ITS overflow regions overflow)
-    launch_repartition(t, mode, (unsigned)(nb_me * W), ra, false);
-    HIP_TRY(hipGetLastError());
-
-    // ---- K2: one workgroup per block, counts in LDS ------------------------------------------------------------------------------
-    kct::FailedBlocks fb;
-    KCT_TRY(failed_blocks(t, B, &fb));
-    const void *k2_scratch = t->d_scratch2.p;
-    const unsigned int *k2_counts = (const unsigned int *)t->d_regions2.p;
-    if (mode == 2) {
-        kct::Aggregate32Args aa;
-        aa.words = t->shadow32; aa.block_bits = kct::kBlockBitsMax; aa.sbits = 10 + sub_bits;
-        aa.scratch = (const unsigned int *)k2_scratch; aa.seg_stride = out_cap; aa.block_stride = W * out_cap;
-        aa.region_count = k2_counts; aa.nregions = (int)W;
-        aa.fresh = t->s32_empty ? 1 : 0; aa.overflow = d_overflow; aa.ablate = 0; aa.failed = fb; aa.counters = t->d_counters; aa.nblocks = (unsigned int)B;
-        launch_aggregate32(t, (unsigned)std::min<u64>(B, 2 * (u64)nwg), aa);
-    } else {
-        kct::AggregateArgs aa;
-        aa.words = mode == 1 ? t->shadow : t->slots; aa.block_bits = kct::kBlockBitsMax; aa.pbits = bbits;
-        aa.scratch = (const du64 *)k2_scratch; aa.seg_stride = out_cap; aa.block_stride = W * out_cap;
-        aa.region_count = k2_counts; aa.nregions = (int)W;
-        aa.fresh = (mode == 1 ? t->shadow_empty : t->lazy_empty) ? 1 : 0; aa.overflow = d_overflow; aa.ablate = 0; aa.nblocks = (unsigned int)B;
-        aa.failed = fb; aa.counters = t->d_counters;
-        launch_aggregate64(t, (unsigned)std::min<u64>(B, (u64)nwg), aa, mode == 1);
+        kct_status st = r.sizes(msg, nvals, got[b]);
+        recv_off[b].assign(world, 0); recv_bytes[b].assign(world, 0); dirs[b].assign((size_t)world * r.nwg, 0);
+        u64 total = 0;
+        if (st == KCT_OK)
+            for (unsigned q = 0; q < world; ++q) {
+                if (got[b][(size_t)q * nvals] != 0 && status == KCT_OK && st == KCT_OK) {
+                    set_err("the early route failed on rank %u (status %llu) before pass %llu was exchanged", q, (unsigned long long)got[b][(size_t)q * nvals], (unsigned long long)p);
+                    st = KCT_ERR_HIP;
+                }
+                recv_off[b][q] = total; recv_bytes[b][q] = got[b][(size_t)q * nvals + 1];
+                total += recv_bytes[b][q];
+                for (int w = 0; w < r.nwg; ++w) dirs[b][(size_t)q * r.nwg + w] = got[b][(size_t)q * nvals + 2 + w];
+            }
+        if (status != KCT_OK) st = status;
+        if (st == KCT_OK && ops) st = r.slab(recv[b], t->d_sk_recv, total);
+        st = r.agree(st);   // (a rank without room for what it is to receive must not leave its peers inside the collective)
+        if (st != KCT_OK) return st;
+        if (!ops) { recv[b] = send[b]; return KCT_OK; }   // loop-back: one rank
+        if (ops->start(ops->user, send[b].p, po[b].part_off.data(), po[b].part_bytes.data(), recv[b].p, recv_off[b].data(), recv_bytes[b].data()) != 0) {
+            set_err("the exchange failed to start");   // (every rank's collective fails with it)
+            return KCT_ERR_HIP;
+        }
+        return KCT_OK;
+    };
+    cut(0);
+    kct_status job = post(0);   // the JOB's state: changes on every rank in the same collective
+    for (u64 p = 0; p < passes && job == KCT_OK; ++p) {
+        const int b = (int)(p & 1);
+        // pass p + 1 is cut while pass p is on the wire, and goes on the wire before pass p is counted: transfers run beside kernels
+        if (p + 1 < passes) cut(p + 1);
+        if (ops) {
+            const double t0 = now_ms();
+            if (ops->wait(ops->user) != 0 && status == KCT_OK) { set_err("the exchange failed"); status = KCT_ERR_HIP; }
+            r.wait_ms += now_ms() - t0;
+        }
+        for (unsigned q = 0; q < world; ++q) {   // what crossed to / from OTHER ranks
+            if (q == rank) continue;
+            st_bytes_out += po[b].part_bytes[q]; st_bytes_in += recv_bytes[b][q];
+            for (int w = 0; w < r.nwg; ++w) { st_windows_out += po[b].dir[(size_t)q * r.nwg + w] & 0xFFFFFFFFULL; st_windows_in += dirs[b][(size_t)q * r.nwg + w] & 0xFFFFFFFFULL; }
+        }
+        st_runs += po[b].runs; st_retries += po[b].retries;
+        if (p + 1 < passes) job = post(p + 1);
+        if (job == KCT_OK && status == KCT_OK) {
+            const double t0 = now_ms();
+            u64 n = 0, win = 0;
+            status = owner_pass(r, recv[b].p, recv_off[b], recv_bytes[b], dirs[b], &n, &win);
+            owner_ms += now_ms() - t0;
+            *n_out += n;
+        }
     }
-    HIP_TRY(hipGetLastError());
-    u64 c[4], unused;
-    KCT_TRY(read_counters(t, c, &unused));
-    if (t->h_counters[kNumCounters + 6] != 0) { set_err("the received entries are too skewed for the early route (K1b's overflow regions overflowed)"); return KCT_ERR_ARG; }
-    const u64 nfailed = t->h_counters[kNumCounters + 7], failed_entries = t->h_counters[kNumCounters + 3];
-    const u64 counted = c[kct::CTR_COUNTED], new_in_k2 = mode == 2 ? c[kct::CTR_NEW_BY_ZERO] : c[kct::CTR_NEWKEYS];
-    if (mode == 0) { t->lazy_empty = false; t->n_keys += new_in_k2; }
-    else if (mode == 1) { t->shadow_empty = false; t->shadow_dirty = true; t->shadow_keys += new_in_k2; }
-    else { t->s32_empty = false; t->s32_dirty = true; t->s32_keys += new_in_k2; t->s32_windows += total_recv; }
-
-    // ---- what did not pass a ring: K1b's overflow regions and the overflow entries received -> the real table, direct insert ------
-    u64 ovf2_total = 0;
-    KCT_TRY(overflow_total(t, d_ovf2_count, (size_t)(nb_me * W), nullptr, 0, &ovf2_total));
-    KCT_TRY(materialize(t));
-    const u64 spill_cap = std::max<u64>(ovf2_total + recv_ovf_total, 1);
-    KCT_TRY(t->d_spill.reserve(spill_cap * 16));
-    HIP_TRY(hipMemsetAsync(t->d_counters, 0, (kNumCounters + 1) * sizeof(u64), t->stream));  // tallies and the spill cursor
-    kct::TableView mv = view(t, spill_cap);
-    launch_merge_overflow(t, mode, (const du64 *)t->d_irr2.p, d_ovf2_count, (int)(nb_me * W), ovf2_cap, nullptr, mv, nullptr);
-    if (recv_ovf_total) launch_merge_overflow(t, mode, (const du64 *)d_recv_ovf, nullptr, (int)((recv_ovf_total + 65535) / 65536), 65536u, nullptr, mv, d_ovf_total);
-    HIP_TRY(hipGetLastError());
-    u64 c2[4], spilled;
-    KCT_TRY(read_counters(t, c2, &spilled));
-    *n_out += counted + c2[kct::CTR_TOTAL_ADDED];
-    t->n_keys += c2[kct::CTR_NEWKEYS];
-    if (spilled) {
-        KCT_TRY(t->d_aux2.reserve(spilled * 16));
-        HIP_TRY(hipMemcpyAsync(t->d_aux2.p, t->d_spill.p, spilled * 16, hipMemcpyDeviceToDevice, t->stream));
-        KCT_TRY(replay_spill(t, spilled, n_out));
-    }
-    if (nfailed) {  // blocks K2 had to abandon: their entries are (hashed and) counted into the real table
-        u64 tl[4] = {0, 0, 0, 0};
-        KCT_TRY(recount_failed(t, mode, k2_scratch, out_cap, W * out_cap, k2_counts, (int)W, nfailed, failed_entries, 10 + sub_bits, tl));
-        *n_out += tl[kct::CTR_TOTAL_ADDED];
-    }
-    if (mode == 1 && t->shadow && (double)t->shadow_keys > kMaxLoad * (double)t->shadow_cap) { KCT_TRY(flush_shadow(t)); KCT_TRY(grow_to(t, t->cap * 2)); }
-    if (mode == 2 && (double)t->s32_keys > 0.8 * (double)compact_slots(t)) KCT_TRY(flush_shadow(t));
-    t->windows_since_read += total_recv;
-    HIP_TRY(hipStreamSynchronize(t->stream));  // (the exchange buffers may be released when this call returns)
+    if (status == KCT_OK) status = job;
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    if (world > 1) status = r.agree(status);   // (the last owner pass may have failed somewhere)
+    if (ops && ops->release)
+        for (int b = 0; b < 2; ++b) {
+            if (send[b].p) ops->release(ops->user, send[b].p);
+            if (recv[b].p) ops->release(ops->user, recv[b].p);
+        }
     if (stats) {
-        stats[0] = total_send - send_ent[rank]; stats[1] = total_recv - recv_ent[rank];  // entries that crossed to / from OTHER ranks
-        stats[2] = esz; stats[3] = ovf_total; stats[4] = recv_ovf_total; stats[5] = (u64)(exchange_ms * 1000.0); stats[6] = nfailed; stats[7] = abandoned ? 1 : 0;
+        stats[0] = st_windows_out; stats[1] = st_windows_in; stats[2] = st_bytes_out; stats[3] = st_bytes_in; stats[4] = st_runs; stats[5] = passes;
+        stats[6] = (u64)(split_ms * 1000.0); stats[7] = (u64)(r.wait_ms * 1000.0); stats[8] = (u64)(owner_ms * 1000.0); stats[9] = st_retries;
+        stats[10] = windows; stats[11] = 0; stats[12] = 0; stats[13] = 0; stats[14] = 0; stats[15] = 0;
     }
-    KCT_DBG(t, "routed pass (mode %d, rank %u of %u): npos=%llu sent=%llu recv=%llu entries of %u B, overflow sent=%llu recv=%llu, counted=%llu merged=%llu new=%llu abandoned blocks=%llu exchange=%.3f ms\n",
-            mode, rank, world, (unsigned long long)npos, (unsigned long long)total_send, (unsigned long long)total_recv, esz, (unsigned long long)ovf_total,
-            (unsigned long long)recv_ovf_total, (unsigned long long)counted, (unsigned long long)c2[kct::CTR_TOTAL_ADDED], (unsigned long long)new_in_k2,
-            (unsigned long long)nfailed, exchange_ms);
-    if (abandoned) { set_err("this rank's input is too skewed for the early route (its share was NOT counted)"); return KCT_ERR_ARG; }
-    return KCT_OK;
+    KCT_DBG(t, "routed call (rank %u of %u): %llu window starts in %llu passes; %llu runs; sent %llu B / %llu windows, received %llu B / %llu windows; split %.3f ms, waiting %.3f ms, owner %.3f ms\n",
+            rank, world, (unsigned long long)windows, (unsigned long long)passes, (unsigned long long)st_runs, (unsigned long long)st_bytes_out, (unsigned long long)st_windows_out,
+            (unsigned long long)st_bytes_in, (unsigned long long)st_windows_in, split_ms, r.wait_ms, owner_ms);
+    return status;
 }
 
 }  // namespace kcth
@@ -380,13 +346,34 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
 using namespace kcth;
 
 extern "C" kct_status kct_consume_device_routed(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes, uint32_t world, uint32_t rank,
-                                                int mode, kct_alloc_fn alloc, kct_exchange_fn exchange, void *user, uint64_t *n_owned, uint64_t *stats8) {
+                                                const kct_exchange_ops *ops, uint64_t max_windows, uint64_t *n_owned, uint64_t *stats16) {
     KCT_TRY(use_consume(t));
     if (!n_owned || (!d_stream && nbytes)) { set_err("null argument"); return KCT_ERR_ARG; }
     if (((uintptr_t)d_stream & 15) != 0) { set_err("d_stream must be 16-byte aligned"); return KCT_ERR_ARG; }
     u64 n = 0;
-    const kct_status st = consume_routed(t, (const unsigned char *)d_stream, nbytes, world, rank, mode, alloc, exchange, user, &n, stats8);
+    const kct_status st = consume_routed(t, (const unsigned char *)d_stream, nbytes, world, rank, ops, max_windows, &n, stats16);
     *n_owned = n;
     if (st == KCT_OK) t->consumed += consumed_bytes;
     return st;
 }
+
+// The sender half alone (tests, tools): this rank's records cut into super-k-mers for `world` owners.  *d_parts (owned by the table, valid
+// until its next bulk call) holds owner o's part at part_off[o] .. + part_bytes[o]: the base units of its streams, then their start
+// units; dir[o * streams + s] = windows | base units << 32 of stream s (streams = kct_superkmer_streams(t)).
+extern "C" kct_status kct_superkmer_split_device(kct_table *t, const void *d_stream, size_t nbytes, uint32_t world, const void **d_parts, uint64_t *part_off,
+                                                 uint64_t *part_bytes, uint64_t *dir) {
+    KCT_TRY(use_consume(t));
+    if (!d_parts || !part_off || !part_bytes || !dir || (!d_stream && nbytes)) { set_err("null argument"); return KCT_ERR_ARG; }
+    if (world < 1 || world > kct::kSkMaxWorld || t->k > 64) { set_err("bad world, or k > 64"); return KCT_ERR_ARG; }
+    if (((uintptr_t)d_stream & 15) != 0) { set_err("d_stream must be 16-byte aligned"); return KCT_ERR_ARG; }
+    Route r{t, world, 0, nullptr, t->num_cus};
+    Slab send;
+    PassOut po;
+    KCT_TRY(split_pass(r, (const unsigned char *)d_stream, nbytes, send, t->d_sk_send, po));
+    *d_parts = send.p;
+    for (unsigned o = 0; o < world; ++o) { part_off[o] = po.part_off[o]; part_bytes[o] = po.part_bytes[o]; }
+    for (size_t i = 0; i < po.dir.size(); ++i) dir[i] = po.dir[i];
+    return KCT_OK;
+}
+
+extern "C" uint32_t kct_superkmer_streams(const kct_table *t) { return t ? (uint32_t)t->num_cus : 0; }

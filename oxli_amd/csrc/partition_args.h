@@ -6,6 +6,47 @@
 
 namespace kct {
 
+// A stream of super-k-mers: bases[] holds runs back to back, 16 bases per word, first base in bits 31:30 (as PartitionArgs::pcodes);
+// a run of n windows is n + k - 1 bases.  Windows are numbered in the order their runs lie in bases[]; bit (w & 63) of starts[w >> 6]
+// says that window w is the first of its run.  Several such streams (one per sending workgroup and peer) are made ONE virtual
+// window space of 64-window groups by a directory: group g's windows are lanes 0 .. nvalid-1, lane l's k-mer begins at bit
+//     bit_base + 2 * (l + (k - 1) * popcount(starts[start_word] & ((2 << l) - 1)))      of bases[]
+// (bit_base already accounts for the runs in front of the group; bit 0 = the most significant bit of bases[0]).
+struct RunGroup {
+    u64 bit_base;
+    u32 start_word;      // index into starts[]
+    u32 nvalid;          // windows in this group (64 except for a stream's last group; 0 = padding)
+};
+struct RunsInput {
+    const u32 *bases = nullptr;
+    const u64 *starts = nullptr;
+    const RunGroup *groups = nullptr;   // the groups of THIS launch (null = not a runs launch)
+};
+
+// ---- the early route's sender (superkmer_kernels.h) ----
+constexpr u32 kSkMaxWorld = 64;   // owners a split can address (one byte per window in LDS, per-owner LDS staging)
+struct SplitArgs {
+    u32 world;
+    uint4 *bases_out;      // [nwg][world][cap_units] 16-byte units of 64 bases
+    uint4 *starts_out;     // [nwg][world][cap_sunits] 16-byte units of 128 start bits
+    u32 cap_units, cap_sunits;
+    u32 *nwin;             // [nwg][world] windows written
+    u32 *nunits;           // [nwg][world] base units the stream needs (more than cap_units: *overflow is set, nothing beyond the region was written)
+    u32 *nsunits;          // [nwg][world] start units likewise
+    u32 *nruns;            // [nwg][world] runs (statistics)
+    u64 *overflow;
+    const u32 *pcodes; const unsigned short *pvalid;  // packed input (PartitionArgs::pcodes) instead of ASCII
+};
+
+// One received stream: its bases begin at bit bit0 of bases[], its start bits at starts[word0], it holds nwin windows, and its groups
+// are group0 .. group0 + ceil(nwin / 64) - 1 of the owner's virtual window space.
+struct RunStream {
+    u64 bit0;
+    u64 group0;
+    u32 word0;
+    u32 nwin;
+};
+
 struct PartitionArgs {
     u64 mask;            // table capacity - 1
     int block_bits;      // log2(slots per block)
@@ -18,15 +59,15 @@ struct PartitionArgs {
     u32 *ovf_count;      // [nwg]
     u64 *overflow;       // set to 1 if an overflow region itself overflowed: the pass is abandoned
     int ablate;          // measurement only: bit 0 = skip the ring append, bit 1 = skip the flush phases
-    // owner-first binning (the multi-GPU "early" route, kct_route.hip; u64 entries only -- compact entries' bins are the value's
-    // top 10 bits either way): bin = owner * 2^pl_bits + local super-bin, owner = floor(hi32(value) * world / 2^32)
-    u32 world = 0;       // 0 = off
-    int pl_bits = 0;
     // PACKED input ("packed base arrays", BASELINE north star): the record stream as 2-bit codes + validity bits, sixteen bases
     // per group -- codes[g] (first base in bits 31:30) and valid[g] (first base in bit 15), exactly what encode16 makes of the
     // ASCII stream.  When pcodes is set, `stream` is ignored and group g of this launch is pcodes[g] / pvalid[g].  (k <= 64.)
     const u32 *pcodes = nullptr;
     const unsigned short *pvalid = nullptr;
+    // SUPER-K-MER input (the multi-GPU early route's wire format, superkmer_kernels.h): runs of consecutive good windows as
+    // 2-bit bases with no separators, one start bit per window.  K1's RUNS instantiations walk the WINDOWS (64 per group), not
+    // byte positions: `stream` / `nbytes` then only say how many (nbytes - k + 1 = 64 * groups of this launch).
+    RunsInput runs;
 };
 
 struct RepartitionArgs {

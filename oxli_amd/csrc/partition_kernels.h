@@ -5,6 +5,7 @@
 
 #include "window_kernels.h"
 #include "partition_args.h"
+#include "k1_kernel.h"
 
 namespace kct {
 
@@ -30,257 +31,6 @@ namespace kct {
 // overflow region that merge_overflow_kernel folds in afterwards with the direct atomic insert,
 // so results are identical.
 // =================================================================================================
-
-// ---- LDS write-combining ring shared by both partition levels ------------------------------------------
-// Bin b owns ring[b*D .. b*D+D).  Its cursor word cur[b] holds `fill` (positions handed out) in the low half and
-// `flushed` (positions that have left the ring) in the high half, so ONE 64-bit LDS add returns both.  An append takes
-// position pos = fill++ and lands in slot pos % D unless the slot's previous tenant (position pos - D) has not left
-// yet, i.e. pos - flushed >= D;
-// such an append goes to the caller's overflow region and its position stays a HOLE in the sequence.
-// Position p of bin b is stored at offset p of the bin's output region (zeros = padding / holes).
-// ring_flush moves 64-byte lines (8 positions) out:
-//   step 1  each bin's thread lists its ready lines.  Lines at or beyond flushed + D were never in the
-//           ring (all holes): they are listed as ZERO lines, because their slots alias the lines in front;
-//   step 2  groups of four adjacent lanes move one listed line, 16 bytes each: one whole-line store per
-//           group, and only as many wave instructions as there are lines.
-// Returns (workgroup-uniformly) whether the list was too short for everything that was ready.
-// T = u64 (hashes / mix64 values, 8 per line) or u32 (the compact dedupe-first path: the bin number is the value's
-// upper half, 16 per line); a value handed to overflow_hash is always the full 64-bit one.
-// ovf_hi (u32 rings only): the upper half of a value handed to overflow_hash -- 0 = derive it from the bin (K1: the bin
-// IS the value's top 10 bits), otherwise a fixed word (K1b: the super-bin, the sub-bin bits are inside the entry).
-template <u32 LISTCAP, class T, class Overflow>
-__device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *fcount, int P, u32 D,
-                                           T *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash, u64 bin_stride = 0, u64 ovf_hi = 0,
-                                           u32 min_lines = 1) {
-    // min_lines: a bin's lines leave the ring only that many at a time (adjacent lane groups then store adjacent lines:
-    // 128- or 256-byte writes instead of lone 64-byte ones); the drain takes whatever is left.
-    constexpr u32 CH = 64 / sizeof(T);  // positions per 64-byte line
-    const u32 dmask = D - 1;
-    if (bin_stride == 0) bin_stride = out_cap;  // distance between the regions of consecutive bins
-    const int dshift = __builtin_ctz(D);  // D is a power of two: shifts instead of quarter-rate multiplies
-    __syncthreads();  // appends of this interval are in the ring; *fcount == 0
-    for (int b = threadIdx.x; b < P; b += kPartThreads) {
-        const u64 cw = cur[b];
-        const u32 f0 = (u32)(cw >> 32), top = (u32)cw;
-        u32 f = f0;
-        while (drain ? (int)(top - f) > 0 : top - f >= CH * min_lines) {
-            const u32 want = drain ? 1u : min_lines;
-            const u32 slot = atomicAdd(fcount, want);
-            const u32 fit = slot >= LISTCAP ? 0u : (LISTCAP - slot < want ? LISTCAP - slot : want);  // every slot below LISTCAP gets written
-            for (u32 l = 0; l < fit; ++l, f += CH) flist[slot + l] = (u32)b | (f << 10) | (f - f0 >= D ? 0x80000000u : 0u);
-            if (fit < want) break;  // list full: the remaining lines wait for the next call
-        }
-        if (f != f0) atomicAdd(&cur[b], (u64)(f - f0) << 32);  // (appenders bump the low half concurrently)
-    }
-    __syncthreads();
-    const u32 listed = *fcount, nlist = listed < LISTCAP ? listed : LISTCAP;
-    for (u32 item = threadIdx.x; item < 4 * nlist; item += kPartThreads) {
-        const u32 e = flist[item >> 2], q = item & 3u, b = e & 1023u, f = (e >> 10) & 0x1FFFFFu;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (!(e >> 31)) {
-            uint4 *src = reinterpret_cast<uint4 *>(&ring[(b << dshift) + (f & dmask)]) + q;
-            v = *src;
-            *src = make_uint4(0, 0, 0, 0);
-        }
-        if (f + CH <= out_cap) {
-            reinterpret_cast<uint4 *>(out_base + (u64)b * bin_stride + f)[q] = v;
-        } else if constexpr (sizeof(T) == 8) {  // region full (badly skewed input): hand the entries to the overflow region
-            const u64 e0 = ((u64)v.y << 32) | v.x, e1 = ((u64)v.w << 32) | v.z;
-            if (e0) overflow_hash(e0);
-            if (e1) overflow_hash(e1);
-        } else if constexpr (sizeof(T) == 16) {  // {hash, count} pairs
-            const u64 h = ((u64)v.y << 32) | v.x, c = ((u64)v.w << 32) | v.z;
-            if (h) overflow_hash(h, c);
-        } else {
-            const u64 hi = ovf_hi ? ovf_hi : (((u64)b << 32) | (1ULL << 63));  // compact values travel with bit 63 set (0 stays "nothing")
-            if (v.x) overflow_hash(hi | v.x);
-            if (v.y) overflow_hash(hi | v.y);
-            if (v.z) overflow_hash(hi | v.z);
-            if (v.w) overflow_hash(hi | v.w);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) *fcount = 0;
-    return listed > LISTCAP;
-}
-
-
-// MODE 0: MurmurHash3 values (u64 entries).  MODE 1 (dedupe-first, k <= 32): mix64(packed k-mer + 1) values (u64).
-// MODE 2 (compact dedupe-first, k <= 21): mix42(packed k-mer) values, of which the bin is the top 10 bits and the ring /
-// the scratch regions carry only the low 32 (u32 entries: half the partition traffic, a ring twice as deep, so a flush
-// every eight windows instead of four); a value whose low half is 0 -- the hole marker -- takes the overflow route.
-template <int KW, int KC, int MODE = 0>
-__global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
-                                                                         u64 ntiles, PartitionArgs a) {
-    // MODE 3 (33 <= k <= 64, dedupe-first): mix128 values of the two packed words as 16-byte {x, y} entries: bins and slots come from x.
-    using T = typename std::conditional<MODE == 2, u32, typename std::conditional<MODE == 3, ulonglong2, u64>::type>::type;
-    using PH = typename std::conditional<MODE == 3, u64, T>::type;  // the pending append's (first) word
-    constexpr int kEntries = kRingEntries * 8 / sizeof(T);  // the ring is 128 KiB either way
-    constexpr int kFlushEvery = MODE == 2 ? 8 : MODE == 3 ? 2 : 4;  // windows between flushes: a quarter of the ring per interval
-    __shared__ __attribute__((aligned(16))) T ring[kEntries];
-    __shared__ u64 cur[1024];  // per bin: fill (low half) | flushed (high half)
-    constexpr u32 kListCap = KW == 0 ? 1792 : 2048;  // the bytewise path's raw tile leaves a little less LDS
-    __shared__ u32 flist[kListCap];  // lines ready to leave the ring: block | position << 10 | hole << 31
-    __shared__ u32 fcount;
-    __shared__ u32 ovf_n;
-    // the staged tile: raw bytes for the bytewise path (k > 64), pre-encoded 2-bit words otherwise
-    constexpr int kTileBytes = KW == 0 ? kPartTile + kHaloMax + 16 : 16;
-    constexpr int kTileWords = KW == 0 ? 4 : kPartThreads + 16;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kTileBytes];
-    __shared__ u32 tcodes[kTileWords];
-    __shared__ unsigned short tvalid[kTileWords];
-    __shared__ u32 ascii4[(KW == 0 || MODE != 0) ? 1 : 256];  // four packed bases -> four ASCII bytes (only the hashing mode needs it)
-    if constexpr (KW != 0 && MODE == 0) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
-    // MurmurHash3's first multiply of every whole 16-base block comes out of pre-multiplied tables (kmer_device.h):
-    // K1 -1 % at k = 21, -2 % at k = 31, -4 % at k = 51
-    constexpr bool kPremul = KW != 0 && MODE == 0 && (KC == 0 || KC >= 16);
-    __shared__ u64 mul1[kPremul ? 256 : 1], mul2[kPremul ? 256 : 1];
-    if constexpr (kPremul) fill_premul_luts(mul1, mul2, threadIdx.x, kPartThreads);
-    const u64 *pm1 = kPremul ? mul1 : nullptr, *pm2 = kPremul ? mul2 : nullptr;
-    // ... and the tail's first multiply, where k is known at compile time and the tail's last piece is cut short (kmer_device.h): K1 -3 %
-    constexpr bool kTailLut = kPremul && KC > 0 && tail_needs_lut(KC);
-    constexpr int kPre = (kPremul ? 1 : 0) | ((kPremul && KC > 0 && (KC & 15) != 0) ? 2 : 0);  // (a whole last piece needs no table of its own)
-    __shared__ u64 tmul[kTailLut ? 256 : 1];
-    if constexpr (kTailLut) fill_tail_lut(tmul, threadIdx.x, kPartThreads, KC);
-    const u64 *ptm = kTailLut ? tmul : nullptr;
-    const int P = 1 << a.pbits;
-    const u32 lmask = a.world ? (1u << a.pl_bits) - 1u : (u32)(P - 1);  // bits of the (local) super-bin inside a bin number
-    const u32 D = (u32)(kEntries >> a.pbits), dmask = D - 1;
-    const int dshift = __builtin_ctz((unsigned)kEntries) - a.pbits;  // log2 D
-    static_assert(kRingEntries == 1 << 14, "dshift assumes a 16384-entry (u64) ring");
-    {
-        T zero;
-        memset(&zero, 0, sizeof zero);
-        for (int i = threadIdx.x; i < kEntries; i += kPartThreads) ring[i] = zero;
-    }
-    for (int i = threadIdx.x; i < 1024; i += kPartThreads) cur[i] = 0;
-    if (threadIdx.x == 0) { ovf_n = 0; fcount = 0; }
-    T *my_scratch = reinterpret_cast<T *>(a.scratch) + (u64)blockIdx.x * P * a.region_cap;  // region_cap counts entries
-
-    // A hash whose ring slot is still occupied (many lanes hitting one block in the same few steps:
-    // homopolymers, tandem repeats) or whose region is full goes to this workgroup's overflow
-    // region: an LDS cursor and a plain 8-byte store, no global atomic, no cross-lane traffic.
-    // The host folds those regions in afterwards with the direct atomic kernel, which combines
-    // equal neighbours -- so the hot loop needs no duplicate detection at all.
-    u64 *my_ovf = a.ovf + (u64)blockIdx.x * a.ovf_cap * (MODE == 3 ? 2 : 1);  // (MODE 3: two words per overflow entry)
-    auto overflow_hash = [&](u64 h, u64 y = 0) {
-        const u32 i = atomicAdd(&ovf_n, 1u);
-        if (i < a.ovf_cap) {
-            if constexpr (MODE == 3) { my_ovf[2 * i] = h; my_ovf[2 * i + 1] = y; }
-            else my_ovf[i] = h;
-        } else *a.overflow = 1ULL;
-    };
-    auto flush_lines = [&](bool drain) {
-        return ring_flush<kListCap, T>(ring, cur, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_hash);
-    };
-
-    // A tile is kPartTile + k - 1 <= 1024 + 16 sixteen-byte chunks: one per thread plus a halo that
-    // the first 16 threads carry.  The NEXT tile's chunks are loaded into registers before the
-    // current tile is hashed, so the HBM latency hides under ~100 us of hashing.
-    auto load_chunk = [&](u64 tile_base, int c) -> uint4 {
-        const u64 off = tile_base + 16ULL * (u64)c;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (off + 16 <= nbytes) v = *reinterpret_cast<const uint4 *>(stream + off);
-        else if (off < nbytes) {
-            unsigned char tmp[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) tmp[i] = (off + i < nbytes) ? stream[off + i] : (unsigned char)0;
-            v = *reinterpret_cast<uint4 *>(tmp);
-        }
-        return v;
-    };
-    // packed input: a group's code word and validity bits travel in .x / .y of the same prefetch registers
-    const bool packed = KW != 0 && a.pcodes != nullptr;  // (workgroup-uniform)
-    auto load_group = [&](u64 tile_base, int c) -> uint4 {
-        const u64 g = (tile_base >> 4) + (u64)c, off = g << 4;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (off < nbytes) {
-            v.x = a.pcodes[g];
-            u32 vb = a.pvalid[g];
-            if (off + 16 > nbytes) vb &= ~((1u << (16 - (u32)(nbytes - off))) - 1u);  // bases at or beyond nbytes do not exist
-            v.y = vb;
-        }
-        return v;
-    };
-    auto load_any = [&](u64 tile_base, int c) -> uint4 { return packed ? load_group(tile_base, c) : load_chunk(tile_base, c); };
-    uint4 pre_main = make_uint4(0, 0, 0, 0), pre_halo = make_uint4(0, 0, 0, 0);
-    if (blockIdx.x < ntiles) {
-        pre_main = load_any((u64)blockIdx.x * kPartTile, threadIdx.x);
-        if (threadIdx.x < 16) pre_halo = load_any((u64)blockIdx.x * kPartTile, kPartThreads + threadIdx.x);
-    }
-    for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        __syncthreads();  // the previous tile's readers are done with `lds`; ring/fill init is visible
-        if constexpr (KW == 0) {
-            reinterpret_cast<uint4 *>(lds)[threadIdx.x] = pre_main;
-            if (threadIdx.x < 16) reinterpret_cast<uint4 *>(lds)[kPartThreads + threadIdx.x] = pre_halo;
-        } else {
-            u32 c, v;
-            if (packed) { c = pre_main.x; v = pre_main.y; }
-            else encode16(pre_main, c, v);
-            tcodes[threadIdx.x] = c; tvalid[threadIdx.x] = (unsigned short)v;
-            if (threadIdx.x < 16) {
-                if (packed) { c = pre_halo.x; v = pre_halo.y; }
-                else encode16(pre_halo, c, v);
-                tcodes[kPartThreads + threadIdx.x] = c; tvalid[kPartThreads + threadIdx.x] = (unsigned short)v;
-            }
-        }
-        __syncthreads();
-        const u64 next = tile + gridDim.x;
-        if (next < ntiles) {
-            pre_main = load_any(next * kPartTile, threadIdx.x);
-            if (threadIdx.x < 16) pre_halo = load_any(next * kPartTile, kPartThreads + threadIdx.x);
-        }
-        // The append is software-pipelined: window j's ring cursor is bumped (ds_add_rtn_u32) and the
-        // block's flush mark is read as soon as its hash exists, but the returned position is only
-        // consumed -- and the hash written into the ring -- after window j+1 has been hashed, so the
-        // LDS round trip hides under ~130 VALU instructions instead of stalling the wave.
-        PH pend_h = 0;
-        u64 pend_y = 0, aux_y = 0;  // (MODE 3: the companion word of the pending append / of the window just mixed)
-        u32 pend_b = 0, pend_pos = 0, pend_mark = 0;
-        auto commit = [&]() {
-            if (pend_h) {
-                if (pend_pos - pend_mark < D) {  // slot's previous tenant is flushed
-                    if constexpr (MODE == 3) ring[(pend_b << dshift) + (pend_pos & dmask)] = make_ulonglong2(pend_h, pend_y);
-                    else ring[(pend_b << dshift) + (pend_pos & dmask)] = pend_h;
-                } else if constexpr (MODE == 3) overflow_hash(pend_h, pend_y);
-                else overflow_hash(MODE == 2 ? (((u64)pend_b << 32) | pend_h | (1ULL << 63)) : (u64)pend_h);  // ring full: position stays a 0 hole
-                pend_h = 0;
-            }
-        };
-        auto sink = [&](int j, bool good, u64 h) {
-            commit();  // the previous window's append
-            if (MODE == 3 && good && h == 0 && !(a.ablate & 1)) overflow_hash(0ULL, aux_y);  // (x = 0, the ring's hole marker: one value in 2^64)
-            if (good && h != 0 && !(a.ablate & 1)) {
-                if (MODE == 2 && (u32)h == 0) overflow_hash(h);  // (one value in 2^32: its low half is the hole marker)
-                else {
-                    // bin = the pbits hash bits above the block (or super-bin) offset; the top bits in compact mode
-if constexpr (MODE == 2) pend_b = (u32)(h >> 32) & 1023u;
-                    else  // (branch-free: with world = 0 the owner term vanishes and lmask = P - 1; measured faster than a uniform branch)
-                        pend_b = (__umulhi((u32)(h >> 32), a.world) << a.pl_bits) | ((u32)(h >> a.block_bits) & lmask);
-                    const u64 cw = atomicAdd(&cur[pend_b], 1ULL);
-                    pend_pos = (u32)cw;
-                    pend_mark = (u32)(cw >> 32);
-                    pend_h = (PH)h;
-                    if constexpr (MODE == 3) pend_y = aux_y;
-                }
-            }
-            if ((j & (kFlushEvery - 1)) == kFlushEvery - 1 && !(a.ablate & 2)) {  // every fourth (eighth) step: move every full line out
-                commit();
-                flush_lines(false);
-            }
-        };
-        if constexpr (KW == 0) walk_windows<0, 0, kPartWPT>(lds, k, sink);
-        else walk_windows_encoded<KW, KC, true, MODE, kPre>(tcodes, tvalid, k, sink, ascii4, pm1, pm2, &aux_y, ptm);
-        commit();
-    }
-    while (flush_lines(true)) {}  // drain: partial lines go out zero-padded; repeat while the list was too short
-    for (int b = threadIdx.x; b < P; b += kPartThreads) {
-        const u32 f = (u32)(cur[b] >> 32);
-        a.region_count[(u64)b * gridDim.x + blockIdx.x] = f < a.region_cap ? f : a.region_cap;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) a.ovf_count[blockIdx.x] = ovf_n < a.ovf_cap ? ovf_n : a.ovf_cap;
-}
 
 // ---- second partition level (tables with more than 1024 blocks) ---------------------------------------
 // K1 can only fan out to 1024 bins (the LDS ring).  For larger tables its bins are SUPER-BINS of

@@ -1,0 +1,435 @@
+// superkmer_kernels.h -- the multi-GPU early route's SENDER side: cut a record stream into super-k-mers grouped by owner GPU.
+//
+// Why: every window's k-mer must reach the GPU that owns it (add() semantics, lib.rs:778-837: per-key sums, so the key space is
+// partitioned).  Sending one 4- or 8-byte entry per window makes the job xGMI-bound.  Consecutive windows of a read
+// overlap in k - 1 bases, so the route sends BASES instead: the owner of a k-mer is a function of its MINIMISER -- the smallest (in a
+// scrambled order) canonical m-mer inside it, m = 8 -- which consecutive windows mostly share; a maximal run of windows with one owner
+// travels as n + k - 1 bases at 2 bits each plus one start bit per window: ~1 byte per window at k = 21 instead of 4, ~0.45 at k = 51
+// instead of 8.  The minimiser is taken over canonical m-mers, so a k-mer and its reverse complement (the same key, lib.rs:576-584 via
+// sourmash's canonical min) have the same owner whatever strand a read shows.
+//
+//   split_superkmers_kernel<K>   persistent, one 1024-thread workgroup per CU, tiles of 16,384 window starts (as K1):
+//        encode the tile (2-bit codes + validity), scramble every canonical m-mer into LDS, sliding minimum over the k - m + 1 m-mers of
+//        every window (packed 16-bit minima, log steps), owner = hash(minimiser) * world >> 16, runs = maximal stretches of good
+//        windows with one owner; every run gets its place in its owner's LDS staging by ONE ds_add_rtn_u64 (windows | bases << 32) and
+//        is copied there with a few ds_or_b32; whole 16-byte units leave for this workgroup's private region of the owner (no global
+//        atomics), the partial unit stays in LDS for the next tile.
+//   gather_units_kernel          packs the (workgroup, owner) regions into one contiguous slab per owner (the send buffer)
+//   run_directory_kernel         OWNER side: one RunGroup per 64 windows of every received stream (partition_args.h), so that K1's RUNS
+//                                instantiations find any window's bases with one popcount
+//   expand_runs_kernel           OWNER side fallback: windows -> an ASCII record stream (k bytes + '\n' each) for the kernels that read
+//                                bytes (the direct path on small passes)
+#pragma once
+#include "partition_args.h"
+
+namespace kct {
+
+constexpr int kSkM = 8;                       // minimiser length; a packed m-mer is 2m = 16 bits
+constexpr int kSkStageWords = 12 * 1024;      // LDS staging of outgoing bases, all owners together: 48 KiB = 196,608 bases
+constexpr u32 kSkMaxRun = 1024;               // windows: a longer run is cut (bounds the copy one thread makes)
+constexpr u32 kSkUnitBases = 64, kSkUnitWindows = 128;  // a 16-byte unit of bases / of start bits
+
+// a bijection of [0, 2^16): the order in which m-mers are compared (so that poly-A is not everybody's minimiser)
+__device__ __host__ __forceinline__ u32 sk_scramble(u32 x) {
+    x = (x * 0x9E3Bu) & 0xFFFFu; x ^= x >> 7;
+    x = (x * 0x6A75u) & 0xFFFFu; x ^= x >> 9;
+    return x;
+}
+// minima crowd near 0: spread them over the owners with one more odd multiply
+__device__ __host__ __forceinline__ u32 sk_owner(u32 minimiser, u32 world) { return (((minimiser * 0x9E37u) & 0xFFFFu) * world) >> 16; }
+
+__device__ __forceinline__ u32 sk_pkmin(u32 a, u32 b) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 r = __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b));
+    return __builtin_bit_cast(u32, r);
+}
+
+// A[] holds NV = 16 + W - 1 values as 16-bit pairs (value 2j in the low half of A[j]); afterwards the low/high halves of A[0..7] are
+// min(v[i .. i + W - 1]) for i = 0..15.  Doubling steps on packed pairs: shifting by an odd number of values costs one v_alignbit.
+template <int W, int NP>
+__device__ __forceinline__ void sk_sliding_min(u32 (&A)[NP]) {
+    int s = 1;
+    if constexpr (W >= 2) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) A[j] = sk_pkmin(A[j], __builtin_amdgcn_alignbit(j + 1 < NP ? A[j + 1] : 0xFFFFFFFFu, A[j], 16));
+        s = 2;
+    }
+#pragma unroll
+    for (int lvl = 0; lvl < 5; ++lvl) {
+        if (2 * s <= W) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) if (j + s / 2 < NP) A[j] = sk_pkmin(A[j], A[j + s / 2]);
+            s *= 2;
+        }
+    }
+    const int d = W - s;  // min over W = min(min over s at i, min over s at i + d)
+    if (d > 0) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            if (d % 2 == 0) { if (j + d / 2 < NP) A[j] = sk_pkmin(A[j], A[j + d / 2]); }
+            else if (j + (d + 1) / 2 < NP) A[j] = sk_pkmin(A[j], __builtin_amdgcn_alignbit(A[j + (d + 1) / 2], A[j + (d - 1) / 2], 16));
+        }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const unsigned char *__restrict__ stream, u64 nbytes, u64 ntiles, SplitArgs a) {
+    constexpr int M = K < kSkM ? K : kSkM, W = K - M + 1;
+    constexpr u32 MM = (1u << (2 * M)) - 1u;
+    constexpr int NV = 16 + W - 1, NP = (NV + 1) / 2;
+    constexpr int HT = (W - 1 + 15) / 16;                       // threads that also scramble the halo's m-mers
+    constexpr int kMmWords = kPartTile / 2 + 8 * HT + 8;
+    __shared__ u32 tc[1 + kPartThreads + 16 + 2];               // tile codes behind one zero word (a copy may look 32 bits to the left)
+    __shared__ unsigned short tv[kPartThreads + 16];
+    __shared__ __attribute__((aligned(16))) u32 mm[kMmWords];   // scrambled canonical m-mers, 16 bits each
+    __shared__ __attribute__((aligned(16))) unsigned char own[kPartTile + 16];
+    __shared__ unsigned short emask[kPartThreads + 1];
+    __shared__ __attribute__((aligned(16))) u32 sb[kSkStageWords];      // outgoing bases, [world][capBw]
+    __shared__ __attribute__((aligned(16))) u32 ss[kSkStageWords / 2];  // outgoing start bits, [world][capBw / 2]
+    __shared__ u64 cur[kSkMaxWorld];       // per owner: windows (low half) | bases (high half) staged, carry included
+    __shared__ u64 cnt[kSkMaxWorld];       // the same, counted ahead of the copy
+    __shared__ u32 filledB[kSkMaxWorld], filledS[kSkMaxWorld], runs_n[kSkMaxWorld];
+    __shared__ u32 s_fits;
+    const u32 world = a.world, t = threadIdx.x;
+    const u32 capBw = (u32)(kSkStageWords / world) & ~3u;      // staging words per owner (whole 16-byte units)
+    const u32 capB = capBw * 16u;                              // ... in bases, and as many window bits
+    // a sub-tile of g windows always fits: at most g / 2 runs of one owner (+ the few that kSkMaxRun cuts), K bases each, behind a
+    // carry of < 64 bases.  gsafe = the largest power of two g with (g / 2) K + 16 K + 64 <= capB (16 holds for every world <= 64)
+    u32 gsafe = 16;
+    while (gsafe < (u32)kPartTile && (u64)gsafe * K + 16 * K + 64 <= capB) gsafe <<= 1;
+    for (u32 i = t; i < (u32)kSkStageWords; i += kPartThreads) sb[i] = 0;
+    for (u32 i = t; i < (u32)kSkStageWords / 2; i += kPartThreads) ss[i] = 0;
+    if (t < kSkMaxWorld) { cur[t] = 0; cnt[t] = 0; filledB[t] = 0; filledS[t] = 0; runs_n[t] = 0; }
+    if (t == 0) { tc[0] = 0; emask[kPartThreads] = 0xFFFF; }
+    uint4 *my_bases = a.bases_out + (u64)blockIdx.x * world * a.cap_units;
+    uint4 *my_starts = a.starts_out + (u64)blockIdx.x * world * a.cap_sunits;
+
+    auto load_chunk = [&](u64 tile_base, int c) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (a.pcodes) {
+            const u64 g = (tile_base >> 4) + (u64)c, off = g << 4;
+            if (off < nbytes) {
+                v.x = a.pcodes[g];
+                u32 vb = a.pvalid[g];
+                if (off + 16 > nbytes) vb &= ~((1u << (16 - (u32)(nbytes - off))) - 1u);
+                v.y = vb;
+            }
+            return v;
+        }
+        const u64 off = tile_base + 16ULL * (u64)c;
+        if (off + 16 <= nbytes) v = *reinterpret_cast<const uint4 *>(stream + off);
+        else if (off < nbytes) {
+            unsigned char tmp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tmp[i] = (off + i < nbytes) ? stream[off + i] : (unsigned char)0;
+            v = *reinterpret_cast<uint4 *>(tmp);
+        }
+        return v;
+    };
+    uint4 pre_main = make_uint4(0, 0, 0, 0), pre_halo = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x < ntiles) {
+        pre_main = load_chunk((u64)blockIdx.x * kPartTile, t);
+        if (t < 16) pre_halo = load_chunk((u64)blockIdx.x * kPartTile, kPartThreads + t);
+    }
+    __syncthreads();
+    for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- the tile as 2-bit codes + validity bits -------------------------------------------------------------------------------
+        {
+            u32 c, v;
+            if (a.pcodes) { c = pre_main.x; v = pre_main.y; } else encode16(pre_main, c, v);
+            tc[1 + t] = c; tv[t] = (unsigned short)v;
+            if (t < 16) {
+                if (a.pcodes) { c = pre_halo.x; v = pre_halo.y; } else encode16(pre_halo, c, v);
+                tc[1 + kPartThreads + t] = c; tv[kPartThreads + t] = (unsigned short)v;
+            }
+            if (t == 0) { tc[1 + kPartThreads + 16] = 0; tc[1 + kPartThreads + 17] = 0; }
+        }
+        __syncthreads();
+        {
+            const u64 next = tile + gridDim.x;
+            if (next < ntiles) {
+                pre_main = load_chunk(next * kPartTile, t);
+                if (t < 16) pre_halo = load_chunk(next * kPartTile, kPartThreads + t);
+            }
+        }
+        // ---- every m-mer of the tile, canonical and scrambled ----------------------------------------------------------------------
+        auto scramble16 = [&](u32 c0, u32 c1, u32 *out8) {  // the m-mers starting at the 16 bases of c0 (c1 = the following 16 bases)
+            const u64 win = ((u64)c0 << 32) | c1;
+            u32 fw = (u32)(win >> (64 - 2 * M)) & MM;
+            u32 r = __builtin_bitreverse32(fw) >> (32 - 2 * M);
+            u32 rc = (((r >> 1) & 0x5555u) | ((r & 0x5555u) << 1)) ^ MM;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j) {
+                    fw = (u32)(win >> (64 - 2 * M - 2 * j)) & MM;
+                    rc = (rc >> 2) | ((3u - (fw & 3u)) << (2 * M - 2));
+                }
+                const u32 v = sk_scramble(fw < rc ? fw : rc);
+                if (j & 1) out8[j >> 1] |= v << 16; else out8[j >> 1] = v;
+            }
+        };
+        {
+            u32 o8[8];
+            scramble16(tc[1 + t], tc[2 + t], o8);
+            reinterpret_cast<uint4 *>(mm)[2 * t] = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+            reinterpret_cast<uint4 *>(mm)[2 * t + 1] = make_uint4(o8[4], o8[5], o8[6], o8[7]);
+            if ((int)t < HT) {  // the halo: m-mers that start beyond the tile's last window start
+                scramble16(tc[1 + kPartThreads + t], tc[2 + kPartThreads + t], o8);
+                reinterpret_cast<uint4 *>(mm)[2 * (kPartThreads + t)] = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+                reinterpret_cast<uint4 *>(mm)[2 * (kPartThreads + t) + 1] = make_uint4(o8[4], o8[5], o8[6], o8[7]);
+            }
+        }
+        __syncthreads();
+        // ---- minimiser and owner of each of this thread's 16 windows; 0xFF = not a good window -------------------------------------
+        u32 ow[4];  // sixteen owner bytes
+        {
+            u32 A[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) A[j] = mm[8 * t + j];
+            sk_sliding_min<W, NP>(A);
+            // validity as in walk_windows_encoded: run = valid bases in a row ending at the window's last base
+            constexpr int NWV = (15 + K + 15) / 16;
+            u64 vbits = 0; u32 vtail = 0;
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) {
+                const u64 v = tv[t + i];
+                if (i < 4) vbits |= v << (48 - 16 * i); else vtail = (u32)v;
+            }
+            int run;
+            {
+                u64 inv_hi = ~vbits;
+                if (K < 64) inv_hi &= ~0ULL << (64 - K);
+                run = inv_hi ? (int)__builtin_ctzll(inv_hi) - (64 - K) : K;
+            }
+            u32 vs;
+            {
+                const u64 v_lo = K < 64 ? (vbits << K) : 0ULL;
+                const u64 v_hi = K < 64 ? ((u64)vtail << 48) >> (64 - K) : (u64)vtail << 48;
+                vs = (u32)((v_lo | v_hi) >> 32);
+            }
+            ow[0] = ow[1] = ow[2] = ow[3] = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const u32 mn = (A[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                const u32 o = run >= K ? sk_owner(mn, world) : 0xFFu;
+                ow[j >> 2] |= o << (8 * (j & 3));
+                const bool ok = (int)vs < 0;
+                vs <<= 1;
+                run = ok ? run + 1 : 0;
+            }
+            reinterpret_cast<uint4 *>(own)[t] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+        __syncthreads();
+        // ---- runs: maximal stretches of good windows with one owner, cut every `cut` windows ----------------------------------------
+        const u32 prev_o = t ? own[16 * t - 1] : 0xFFu, next_o = t + 1 < kPartThreads ? own[16 * t + 16] : 0xFFu;
+        u32 smask = 0;
+        auto build_masks = [&](u32 cut) {
+            u32 em = 0;
+            smask = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const u32 o = (ow[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                const u32 op = j ? (ow[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 0xFFu : prev_o;
+                const u32 on = j < 15 ? (ow[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu : next_o;
+                const u32 p = 16 * t + j;
+                if (o != 0xFFu && (o != op || (p & (cut - 1)) == 0)) smask |= 1u << j;
+                if (o != 0xFFu && (o != on || ((p + 1) & (cut - 1)) == 0)) em |= 1u << j;
+            }
+            emask[t] = (unsigned short)em;
+        };
+        // visit(j, n, owner) for every run that starts at this thread's window j, first <= 16 t + j < last
+        auto for_runs = [&](u32 first, u32 last, auto &&visit) {
+            if (16 * t + 16 <= first || 16 * t >= last) return;
+            u32 sm = smask;
+            const u32 mye = emask[t];
+            while (sm) {
+                const u32 j = (u32)__builtin_ctz(sm);
+                sm &= sm - 1;
+                u32 n;
+                const u32 e = mye >> j;
+                if (e) n = (u32)__builtin_ctz(e) + 1;
+                else {
+                    n = 16 - j;
+                    u32 tt = t + 1;
+                    for (;;) {
+                        const u32 e2 = emask[tt];   // (emask[1024] = all ones: the tile's end)
+                        if (e2) { n += (u32)__builtin_ctz(e2) + 1; break; }
+                        n += 16; ++tt;
+                    }
+                }
+                visit(j, n, (ow[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+            }
+        };
+        build_masks(kSkMaxRun);
+        if (t < world) cnt[t] = cur[t];
+        if (t == 0) s_fits = 1;
+        __syncthreads();
+        for_runs(0, kPartTile, [&](u32, u32 n, u32 o) { atomicAdd(&cnt[o], (u64)n | ((u64)(n + K - 1) << 32)); });
+        __syncthreads();
+        if (t < world && (u32)(cnt[t] >> 32) > capB) s_fits = 0;   // (windows <= bases, and the start bits have as much room)
+        __syncthreads();
+        const bool fits = s_fits != 0;
+        const u32 sub = fits ? (u32)kPartTile : gsafe;
+        if (!fits) {  // (rare: far more runs than random sequence gives) -- the tile goes out in pieces that cannot overflow the staging
+            __syncthreads();
+            build_masks(sub < kSkMaxRun ? sub : kSkMaxRun);
+            __syncthreads();
+        }
+        for (u32 first = 0; first < (u32)kPartTile; first += sub) {
+            for_runs(first, first + sub, [&](u32 j, u32 n, u32 o) {
+                const u32 L = n + K - 1;
+                const u64 cw = atomicAdd(&cur[o], (u64)n | ((u64)L << 32));
+                const u32 wpos = (u32)cw, bpos = (u32)(cw >> 32);
+                atomicAdd(&runs_n[o], 1u);
+                atomicOr(&ss[o * (capBw / 2) + (wpos >> 5)], 1u << (wpos & 31u));
+                // L bases from tile bit 2 (16 t + j) to staging bit 2 bpos (both MSB-first), one destination word at a time
+                u32 *dst = sb + o * capBw;
+                const u32 dbit = 2 * bpos, sbit = 32 + 2 * (16 * t + j), nbits = 2 * L;
+                const u32 dw1 = (dbit + nbits - 1) >> 5;
+                for (u32 dw = dbit >> 5; dw <= dw1; ++dw) {
+                    const int rel = (int)(dw << 5) - (int)dbit;          // this word's first bit, counted from the run's first bit
+                    const u32 sp = (u32)((int)sbit + rel);               // >= 1: tc[0] is a zero word
+                    const u32 wi = sp >> 5, sh = sp & 31u;
+                    u32 val = (u32)(((((u64)tc[wi] << 32) | tc[wi + 1]) << sh) >> 32);
+                    if (rel < 0) val &= 0xFFFFFFFFu >> (u32)(-rel);
+                    const int past = rel + 32 - (int)nbits;
+                    if (past > 0) val &= 0xFFFFFFFFu << (u32)past;
+                    atomicOr(&dst[dw], val);
+                }
+            });
+            __syncthreads();
+            // ---- whole 16-byte units leave for this workgroup's regions; the partial ones stay for the next tile ----------------------
+            for (u32 o = 0; o < world; ++o) {
+                const u64 cw = cur[o];
+                const u32 ub = (u32)(cw >> 32) / kSkUnitBases, us = (u32)cw / kSkUnitWindows;
+                const u32 fb = filledB[o], fs = filledS[o];
+                for (u32 u = t; u < ub + us; u += kPartThreads) {
+                    if (u < ub) {
+                        uint4 *src = reinterpret_cast<uint4 *>(sb + o * capBw) + u;
+                        const uint4 v = *src;
+                        *src = make_uint4(0, 0, 0, 0);
+                        if (fb + u < a.cap_units) my_bases[(u64)o * a.cap_units + fb + u] = v;
+                    } else {
+                        const u32 w = u - ub;
+                        uint4 *src = reinterpret_cast<uint4 *>(ss + o * (capBw / 2)) + w;
+                        const uint4 v = *src;
+                        *src = make_uint4(0, 0, 0, 0);
+                        if (fs + w < a.cap_sunits) my_starts[(u64)o * a.cap_sunits + fs + w] = v;
+                    }
+                }
+            }
+            __syncthreads();
+            if (t < world) {
+                const u64 cw = cur[t];
+                const u32 tb = (u32)(cw >> 32), tw = (u32)cw, ub = tb / kSkUnitBases, us = tw / kSkUnitWindows;
+                if (ub) {
+                    uint4 *base = reinterpret_cast<uint4 *>(sb + t * capBw);
+                    const uint4 v = base[ub];
+                    base[ub] = make_uint4(0, 0, 0, 0);
+                    base[0] = v;
+                }
+                if (us) {
+                    uint4 *base = reinterpret_cast<uint4 *>(ss + t * (capBw / 2));
+                    const uint4 v = base[us];
+                    base[us] = make_uint4(0, 0, 0, 0);
+                    base[0] = v;
+                }
+                filledB[t] += ub; filledS[t] += us;
+                cur[t] = (u64)(tw % kSkUnitWindows) | ((u64)(tb % kSkUnitBases) << 32);
+            }
+            __syncthreads();
+        }
+    }
+    // ---- the partial units, zero-padded; what every stream holds -----------------------------------------------------------------------
+    if (t < world) {
+        const u64 cw = cur[t];
+        const u32 rb = (u32)(cw >> 32), rw = (u32)cw;
+        u32 fb = filledB[t], fs = filledS[t];
+        const u32 nwin = fs * kSkUnitWindows + rw;
+        if (rb) {
+            if (fb < a.cap_units) my_bases[(u64)t * a.cap_units + fb] = *reinterpret_cast<uint4 *>(sb + t * capBw);
+            ++fb;
+        }
+        if (rw) {
+            if (fs < a.cap_sunits) my_starts[(u64)t * a.cap_sunits + fs] = *reinterpret_cast<uint4 *>(ss + t * (capBw / 2));
+            ++fs;
+        }
+        const u64 idx = (u64)blockIdx.x * world + t;
+        a.nwin[idx] = nwin; a.nunits[idx] = fb; a.nsunits[idx] = fs; a.nruns[idx] = runs_n[t];
+        if (fb > a.cap_units || fs > a.cap_sunits) *a.overflow = 1ULL;
+    }
+}
+
+// n[i] 16-byte units from src + src_off[i] to dst + dst_off[i] (offsets in units): region packing / slab assembly
+__global__ __launch_bounds__(kBlock) void gather_units_kernel(const uint4 *__restrict__ src, const u64 *__restrict__ src_off, const u64 *__restrict__ dst_off,
+                                                              const u32 *__restrict__ n, u32 count, uint4 *__restrict__ dst) {
+    for (u32 i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint4 *s = src + src_off[i];
+        uint4 *d = dst + dst_off[i];
+        const u32 m = n[i];
+        for (u32 u = threadIdx.x; u < m; u += kBlock) d[u] = s[u];
+    }
+}
+
+// One 256-thread workgroup per stream (strided): running popcount of the start bits -> one RunGroup per 64 windows.
+__global__ __launch_bounds__(kBlock) void run_directory_kernel(const RunStream *__restrict__ streams, u32 nstreams, const u64 *__restrict__ starts, int k,
+                                                               RunGroup *__restrict__ groups) {
+    __shared__ u32 wsum[kBlock / 64];
+    __shared__ u64 carry;
+    for (u32 s = blockIdx.x; s < nstreams; s += gridDim.x) {
+        const RunStream st = streams[s];
+        const u32 ng = (st.nwin + 63) >> 6;
+        if (threadIdx.x == 0) carry = 0;
+        __syncthreads();
+        for (u32 g0 = 0; g0 < ng; g0 += kBlock) {
+            const u32 g = g0 + threadIdx.x;
+            const u32 pc = g < ng ? (u32)__popcll(starts[st.word0 + g]) : 0u;
+            // exclusive prefix inside the workgroup: wave scan, then the waves' totals
+            u32 incl = pc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 v = __shfl_up(incl, off);
+                if ((int)(threadIdx.x & 63) >= off) incl += v;
+            }
+            if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            u32 before = 0;
+            for (u32 w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
+            const u64 runs_before = carry + before + incl - pc;   // run starts in front of this group
+            if (g < ng) {
+                RunGroup rg;
+                rg.bit_base = st.bit0 + 2ULL * (64ULL * g + (u64)(k - 1) * (runs_before - 1ULL));  // (wraps for runs_before = 0: the group's first window is a start)
+                rg.start_word = st.word0 + g;
+                const u32 left = st.nwin - 64u * g;
+                rg.nvalid = left < 64u ? left : 64u;
+                groups[st.group0 + g] = rg;
+            }
+            __syncthreads();
+            if (threadIdx.x == kBlock - 1) carry += before + incl;
+            __syncthreads();
+        }
+    }
+}
+
+// Windows [64 * group0, 64 * (group0 + ngroups)) as an ASCII record stream: window v = k bytes + '\n' at out + (v - 64 * group0) * (k + 1)
+// (an absent window: k + 1 separators).  For the kernels that read bytes.
+__global__ __launch_bounds__(kBlock) void expand_runs_kernel(RunsInput in, u64 ngroups, int k, unsigned char *__restrict__ out) {
+    const u32 lane = threadIdx.x & 63u;
+    for (u64 g = (u64)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); g < ngroups; g += (u64)gridDim.x * (kBlock / 64)) {
+        const RunGroup d = in.groups[g];
+        unsigned char *o = out + (g * 64 + lane) * (u64)(k + 1);
+        if (lane < d.nvalid) {
+            const u64 below = in.starts[d.start_word] & ((2ULL << lane) - 1ULL);
+            const u64 bit = d.bit_base + 2ULL * ((u64)lane + (u64)(k - 1) * (u64)__popcll(below));
+            for (int i = 0; i < k; ++i) {
+                const u64 b = bit + 2ULL * i;
+                o[i] = (unsigned char)((0x54474341u >> (8 * ((in.bases[b >> 5] >> (30 - (b & 31))) & 3u))) & 0xFFu);
+            }
+            o[k] = '\n';
+        } else {
+            for (int i = 0; i <= k; ++i) o[i] = '\n';
+        }
+    }
+}
+
+}  // namespace kct

@@ -13,6 +13,7 @@
 // 350 kbp record is simply many tiles.
 #pragma once
 #include "device_common.h"
+#include "partition_args.h"
 
 namespace kct {
 
@@ -177,6 +178,83 @@ __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const uns
             push_rc(rc, 3u - code, k);
             run = ok ? run + 1 : 0;
         }
+    }
+}
+
+// Same contract for a SUPER-K-MER launch (partition_args.h RunsInput; the multi-GPU early route's wire format): the thread's WPT
+// windows are window (threadIdx.x & 63) of groups group0 + wave, + 16, + 32, ... -- a wave takes one 64-window group per step.  Every
+// window is assembled from its run's packed bases (no rolling: there is no "previous window" to roll from at a run start, and
+// assembling costs what rolling does); the lanes of a wave read overlapping words, which the L1 serves.  The NEXT step's words are
+// requested before the current window is hashed.
+template <int KW, int KC, bool LUT = false, int RAW = 0, int PRE = 0, class Sink>
+__device__ __forceinline__ void walk_windows_runs(const RunsInput &in, u64 group0, u64 ngroups, int k_rt, Sink &&sink, const u32 *lut = nullptr,
+                                                  const u64 *mul1 = nullptr, const u64 *mul2 = nullptr, u64 *aux = nullptr, const u64 *tmul = nullptr) {
+    constexpr int WPT = 16, NX = 2 * KW + 1;  // words that hold 2k bits at any 2-bit offset
+    const int k = KC > 0 ? KC : k_rt;
+    const u32 lane = threadIdx.x & 63u;
+    constexpr u64 kStep = kPartThreads / 64;
+    struct Fetch { u32 x[NX]; u32 sh; bool good; };
+    auto fetch = [&](u64 g) -> Fetch {
+        Fetch f;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) f.x[i] = 0;
+        f.sh = 0; f.good = false;
+        if (g < ngroups) {
+            const RunGroup d = in.groups[g];
+            if (lane < d.nvalid) {
+                const u64 below = in.starts[d.start_word] & ((2ULL << lane) - 1ULL);  // run starts at or before this window
+                const u64 bit = d.bit_base + 2ULL * ((u64)lane + (u64)(k - 1) * (u64)__popcll(below));
+                const u32 *p = in.bases + (bit >> 5);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) f.x[i] = p[i];
+                f.sh = (u32)bit & 31u; f.good = true;
+            }
+        }
+        return f;
+    };
+    u64 g = group0 + (threadIdx.x >> 6);
+    Fetch cur = fetch(g);
+#pragma unroll 4
+    for (int j = 0; j < WPT; ++j) {
+        g += kStep;
+        Fetch nxt = cur;
+        if (j + 1 < WPT) nxt = fetch(g);
+        u64 h = 0;
+        if (cur.good) {
+            // the 2k bits from bit cur.sh of x[], left-aligned: base 0 in bits 63:62 of top.w[0]
+            u32 t32[2 * KW];
+#pragma unroll
+            for (int i = 0; i < 2 * KW; ++i) t32[i] = (u32)(((((u64)cur.x[i] << 32) | cur.x[i + 1]) << cur.sh) >> 32);
+            Packed<KW> top, fw, rc;
+#pragma unroll
+            for (int i = 0; i < KW; ++i) top.w[i] = ((u64)t32[2 * i] << 32) | t32[2 * i + 1];
+            {   // forward strand: shift right so that base k-1 sits in the low 2 bits
+                const int s = 64 * KW - 2 * k, ws = s >> 6, bs = s & 63;
+#pragma unroll
+                for (int i = 0; i < KW; ++i) {
+                    u64 lo = 0, hi = 0;
+#pragma unroll
+                    for (int jj = 0; jj < KW; ++jj) {
+                        if (jj == i - ws) lo = top.w[jj];
+                        if (jj == i - ws - 1) hi = top.w[jj];
+                    }
+                    fw.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KW; ++i) rc.w[i] = ~reverse_pairs64(top.w[KW - 1 - i]);  // (whatever follows base k-1 in `top` lands above bit 2k)
+            mask_k(rc, k);
+            Packed<KW> c = less_eq(fw, rc) ? fw : rc;
+            if constexpr (RAW == 1) h = mix64(c.w[0] + 1ULL);
+            else if constexpr (RAW == 2) h = mix42(c.w[0]) | (1ULL << 63);
+            else if constexpr (RAW == 3) mix128(c.w[0], c.w[1], h, *aux);
+            else {
+                left_align(c, k);
+                h = hash_packed<KW, LUT, PRE>(c, k, lut, mul1, mul2, tmul);
+            }
+        }
+        sink(j, cur.good, h);
+        cur = nxt;
     }
 }
 

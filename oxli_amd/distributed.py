@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["owner_of", "partition_by_owner", "exchange_route", "exchange_pairs", "merge_across_ranks", "global_scalar_sum",
-           "consume_device_early", "EARLY_MODES"]
+           "consume_device_early", "ROUTE_STATS"]
 
 
 def owner_of(hashes_i64: torch.Tensor, world: int) -> torch.Tensor:
@@ -177,130 +177,125 @@ def merge_across_ranks(table, group=None):
     return recv.shape[0]
 
 
-# ---- the EARLY route: entries travel to their owner while they are counted (csrc/kct_route.hip) -----------------------------
-EARLY_MODES = {"hash": 0, "dedupe64": 1, "compact": 2}
+# ---- the EARLY route: super-k-mers travel to the GPU that owns them (csrc/kct_route.hip) ------------------------------------------
+ROUTE_STATS = ("windows_sent", "windows_received", "bytes_sent", "bytes_received", "runs", "passes", "split_us", "exchange_wait_us",
+               "owner_us", "region_retries", "window_starts")
 
 
 class _Exchanger:
-    """The two callbacks ``kct_consume_device_routed`` needs, over ``torch.distributed``: device buffers come from torch
-    (so that the collective can take them as tensors), the all-to-all is ``all_to_all_single`` on bytes with uneven splits
-    (RCCL over xGMI with the nccl backend; staged through host memory when ranks share a GPU under gloo)."""
+    """``kct_exchange_ops`` over ``torch.distributed``: device buffers come from torch (so that the collective can take them as
+    tensors), the size exchange is an ``all_to_all_single`` of int64, the payload an ``all_to_all_single`` on bytes with uneven splits
+    (RCCL over xGMI with the nccl backend, asynchronous: the library cuts and counts other passes meanwhile; staged through host
+    memory, synchronously, when ranks share a GPU under gloo).  The library packs every peer's part back to back in rank order, which
+    is the layout ``all_to_all_single`` wants."""
 
     def __init__(self, group, dev):
         import ctypes as C
+
+        from ._lib import ExchangeOps
         self.group, self.dev = group, dev
         self.world = dist.get_world_size(group)
         self.host = dist.get_backend(group) != "nccl"
-        self.keep = {}      # device address -> tensor (send buffers handed to the library)
-        self.recv = []      # received buffers, alive until the routed call returns
+        self.keep = {}       # device address -> tensor
+        self.work = None
+        self.pending = None  # (received host tensor, destination) of a host-staged exchange
         self.error = None
-        self.bytes_sent = 0
-        self._alloc = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)(self.alloc)
-        self._xchg = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p),
-                                 C.POINTER(C.c_uint64))(self.exchange)
-        self.alloc_ptr = C.cast(self._alloc, C.c_void_p)
-        self.xchg_ptr = C.cast(self._xchg, C.c_void_p)
+        self._cb = (ExchangeOps.ALLOC(self.alloc), ExchangeOps.RELEASE(self.release), ExchangeOps.SIZES(self.sizes), ExchangeOps.START(self.start),
+                    ExchangeOps.WAIT(self.wait))
+        self.ops = ExchangeOps(None, *self._cb)
+        self.ptr = C.cast(C.pointer(self.ops), C.c_void_p)
+
+    def _guard(self, fn, fail):
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001 -- reported through the library's status; raised by consume_device_early
+            self.error = self.error or e
+            return fail
 
     def alloc(self, _user, nbytes):
-        try:
+        def go():
             t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
             self.keep[t.data_ptr()] = t
             return t.data_ptr()
-        except Exception as e:  # noqa: BLE001 -- reported through the library's status
-            self.error = e
-            return None
+        return self._guard(go, None)
 
-    def exchange(self, _user, d_send, send_elems, elem_bytes, d_recv, recv_elems):
-        try:
-            world, eb = self.world, int(elem_bytes)
-            send = [int(send_elems[i]) for i in range(world)]
-            buf = self.keep[int(d_send)][: sum(send) * eb]
-            meta = torch.tensor(send, dtype=torch.int64, device="cpu" if self.host else self.dev)
-            got = torch.empty_like(meta)
-            dist.all_to_all_single(got, meta, group=self.group)
-            recv = [int(v) for v in got.cpu().tolist()]
-            src = buf.cpu() if self.host else buf
-            out = torch.empty(sum(recv) * eb, dtype=torch.uint8, device=src.device)
-            dist.all_to_all_single(out, src, output_split_sizes=[r * eb for r in recv], input_split_sizes=[s_ * eb for s_ in send],
-                                   group=self.group)
-            if self.host:
-                out = out.to(self.dev)
-            torch.cuda.synchronize()
-            if out.numel() == 0:
-                out = torch.empty(256, dtype=torch.uint8, device=self.dev)
-            self.recv.append(out)
-            self.bytes_sent += (sum(send) - send[dist.get_rank(self.group)]) * eb
-            d_recv[0] = out.data_ptr()
-            for i in range(world):
-                recv_elems[i] = recv[i]
+    def release(self, _user, p):
+        self.keep.pop(int(p or 0), None)
+
+    def sizes(self, _user, send, nvals, recv):
+        def go():
+            n = self.world * int(nvals)
+            src = torch.from_numpy(_as_i64([int(send[i]) for i in range(n)]))   # (uint64 values travel as int64 bit patterns)
+            if not self.host:
+                src = src.to(self.dev)
+            out = torch.empty_like(src)
+            dist.all_to_all_single(out, src, group=self.group)
+            vals = out.cpu().numpy().view("uint64")
+            for i in range(n):
+                recv[i] = int(vals[i])
             return 0
-        except Exception as e:  # noqa: BLE001
-            self.error = e
-            return 1
+        return self._guard(go, 1)
+
+    def _view(self, base, nbytes):
+        for addr, t in self.keep.items():
+            if addr <= base and base + nbytes <= addr + t.numel():
+                return t[base - addr: base - addr + nbytes]
+        raise KeyError("the exchange was handed a buffer that did not come from its allocator")
+
+    def start(self, _user, d_send, send_off, send_bytes, d_recv, recv_off, recv_bytes):
+        def go():
+            w = self.world
+            sb, rb = [int(send_bytes[i]) for i in range(w)], [int(recv_bytes[i]) for i in range(w)]
+            assert all(int(send_off[i]) == sum(sb[:i]) for i in range(w)) and all(int(recv_off[i]) == sum(rb[:i]) for i in range(w))
+            src = self._view(int(d_send or 0), sum(sb)) if sum(sb) else torch.empty(0, dtype=torch.uint8, device=self.dev)
+            dst = self._view(int(d_recv or 0), sum(rb)) if sum(rb) else torch.empty(0, dtype=torch.uint8, device=self.dev)
+            if self.host:
+                got = torch.empty(sum(rb), dtype=torch.uint8)
+                dist.all_to_all_single(got, src.cpu(), output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+                dst.copy_(got)
+                torch.cuda.synchronize()
+            else:
+                self.work = dist.all_to_all_single(dst, src, output_split_sizes=rb, input_split_sizes=sb, group=self.group, async_op=True)
+            return 0
+        return self._guard(go, 1)
+
+    def wait(self, _user):
+        def go():
+            if self.work is not None:
+                self.work.wait()
+                self.work = None
+                torch.cuda.current_stream().synchronize()   # (the library counts on a stream of its own)
+            return 0
+        return self._guard(go, 1)
 
 
-def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, mode="auto", max_windows=None):
-    """Counts this rank's device-resident record stream by the EARLY route: K1 here, entries to their owner GPUs with three
-    all-to-alls, K1b / K2 on the owners (``kct_consume_device_routed``).  Every rank must call it, with tables of one
-    capacity.  ``mode``: "compact" (k <= 21) and "dedupe64" (k <= 32) count packed k-mers first and hash each distinct one
-    when the table is read -- right for deep coverage, where an owner meets every k-mer many times; "hash" hashes every window
-    (any k <= 64; low coverage); "auto" picks by k.  Returns (k-mers this rank counted as an owner, stats dict).
+def _as_i64(values):
+    import numpy as np
+    return np.array(values, dtype=np.uint64).view(np.int64)
 
-    A pass keeps K1's regions, the send and receive buffers and K1b's regions in HBM at once (~4.4 entries of 4 or 8 bytes per
-    window start): a stream too long for that is cut into passes of ``max_windows`` window starts (default: what 60 % of the
-    free HBM of the tightest rank allows), each with its own exchange; consecutive passes overlap by k - 1 bytes, so no window
-    is lost or counted twice.
 
-    Afterwards the ranks' tables are a disjoint partition of the key space (by k-mer slice for the dedupe-first modes, by
-    hash slice -- the late route's owner rule -- for "hash"): ``global_scalar_sum`` of ``len`` / ``sum_counts`` gives the
-    global table's, and no ``merge_across_ranks`` is needed."""
+def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, max_windows=0):
+    """Counts this rank's device-resident record stream by the EARLY route (``kct_consume_device_routed``): every k-mer is counted by
+    the rank that owns it -- owner = hash(minimiser) -- and what travels is super-k-mers: runs of consecutive windows with one owner as
+    2-bit bases + a start bit per window.  Every rank must call it.  The owner side is the table's ordinary bulk path (``set_path``
+    applies); tables need not agree on anything.  ``max_windows``: window starts per pass (0 = chosen by the library from free HBM;
+    passes are pipelined: one is on the wire while the previous one is counted).  Returns (k-mers this rank counted as an owner,
+    stats dict).
+
+    Afterwards the ranks' tables are a disjoint partition of the key space: ``global_scalar_sum`` of ``len`` / ``sum_counts`` gives the
+    global table's, and no ``merge_across_ranks`` is needed.  A failure on any rank raises on every rank."""
     import ctypes as C
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if getattr(table, "store_kmers", False):
-        raise ValueError("the early route moves packed k-mers / hashes only: a store_kmers table would lose its hash -> k-mer map")
-    if mode == "auto":
-        mode = "compact" if table.ksize <= 21 else "dedupe64" if table.ksize <= 32 else "hash"
-    k = table.ksize
+        raise ValueError("the early route moves packed bases only: a store_kmers table would lose its hash -> k-mer map")
     dev = torch.device("cuda", torch.cuda.current_device())
-    host = dist.get_backend(group) != "nccl"
-    cdev = "cpu" if host else dev
-    # one capacity on every rank (the senders' bins follow the owners' table geometry); the passes every rank will make
-    esz = 4 if mode == "compact" else 8
-    windows = max(int(nbytes) - k + 1, 0)
-    if max_windows is None:
-        free = torch.cuda.mem_get_info()[0]
-        max_windows = max(1 << 24, int(0.6 * free / (4.4 * esz)))
-    max_windows = max(1 << 16, int(max_windows) & ~0xFFFF)
-    mine = torch.tensor([table.capacity, -table.capacity, -(-windows // max_windows) if windows else 1], dtype=torch.int64, device=cdev)
-    dist.all_reduce(mine, op=dist.ReduceOp.MAX, group=group)
-    if int(mine[0]) != -int(mine[1]):
-        raise ValueError(f"the early route needs tables of one capacity on every rank (have {-int(mine[1])} .. {int(mine[0])} slots)")
-    passes = max(1, int(mine[2]))
-    step = ((-(-windows // passes)) + 0xFFFF) & ~0xFFFF if windows else 0   # window starts per pass, a multiple of 2^16 (16-byte aligned cuts)
-    keys = ("entries_sent", "entries_received", "entry_bytes", "overflow_sent", "overflow_received", "exchange_us", "blocks_abandoned", "skewed")
-    total_n, agg, bytes_sent, err, status = 0, dict.fromkeys(keys, 0), 0, None, 0
-    for p in range(passes):
-        off = min(p * step, int(nbytes))
-        length = min(int(nbytes) - off, step + k - 1) if p + 1 < passes else int(nbytes) - off
-        ex = _Exchanger(group, dev)
-        n, stats = C.c_uint64(), (C.c_uint64 * 8)()
-        st = table._lib.kct_consume_device_routed(table._h, C.c_void_p(int(data_ptr) + off), max(length, 0), int(consumed_bytes) if p == 0 else 0,
-                                                  world, rank, EARLY_MODES[mode], ex.alloc_ptr, ex.xchg_ptr, None, C.byref(n), stats)
-        total_n += n.value
-        for kk, v in zip(keys, stats):
-            agg[kk] = int(v) if kk in ("entry_bytes",) else agg[kk] + int(v)
-        bytes_sent += ex.bytes_sent
-        err = err or ex.error
-        status = status or st
-        del ex
-    # a failure on ANY rank is every rank's failure (tables are then inconsistent across the job)
-    bad = torch.tensor([1 if status != 0 else 0], dtype=torch.int64, device=cdev)
-    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
-    if err is not None:
-        raise err
-    table._check(status)
-    if int(bad.item()):
-        raise RuntimeError("the early route failed on another rank: clear the tables and use the late route (merge_across_ranks)")
-    return total_n, dict(agg, mode=mode, bytes_sent=bytes_sent, passes=passes)
+    ex = _Exchanger(group, dev) if world > 1 else None
+    n, stats = C.c_uint64(), (C.c_uint64 * 16)()
+    st = table._lib.kct_consume_device_routed(table._h, C.c_void_p(int(data_ptr)), int(nbytes), int(consumed_bytes), world, rank,
+                                              ex.ptr if ex else None, int(max_windows), C.byref(n), stats)
+    if ex is not None and ex.error is not None:
+        raise ex.error
+    table._check(st)
+    return n.value, dict(zip(ROUTE_STATS, (int(v) for v in stats)))

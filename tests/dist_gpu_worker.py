@@ -2,11 +2,11 @@
 own device table.  Every rank counts its shard of one read stream, merge_across_ranks() makes the tables the owner
 partitions of the global table, and rank 0 checks their union against the oracle's count of the whole stream.
 
-    python -m torch.distributed.run --nproc-per-node W tests/dist_gpu_worker.py <k> <reads per rank> <genome> [route]
+    python -m torch.distributed.run --nproc-per-node W tests/dist_gpu_worker.py <k> <reads per rank> <genome> [route] [read length]
 
-route: "late" (default: private tables, then merge_across_ranks) or "early:compact" / "early:dedupe64" / "early:hash"
-(consume_device_early: entries travel to their owners while they are counted; two passes, so that the second one meets live
-tables and shadows).
+route: "late" (default: private tables, then merge_across_ranks) or "early:auto" / "early:dedupe" / "early:partitioned"
+(consume_device_early: super-k-mers travel to the rank that owns them and are counted there by the named path of the table's policy;
+two calls, the first cut into several pipelined passes, so that later passes meet live tables and shadows).
 """
 import os
 import sys
@@ -22,13 +22,13 @@ sys.path.insert(0, ROOT)
 def main():
     k, per_rank, G = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     route = sys.argv[4] if len(sys.argv) > 4 else "late"
-    L = 150
+    L = int(sys.argv[5]) if len(sys.argv) > 5 else 150
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle
     from oxli_amd import KmerCountTable
-    from oxli_amd.distributed import consume_device_early, global_scalar_sum, merge_across_ranks, owner_of
+    from oxli_amd.distributed import global_scalar_sum, merge_across_ranks, owner_of
 
     genome = oracle.synth_genome(G, 42)
     reads = oracle.synth_reads(genome, rank * per_rank, per_rank, L, 1337)
@@ -72,26 +72,27 @@ def main():
     dist.destroy_process_group()
 
 
-def early(mode, k, per_rank, G, L, rank, world, genome, reads, dev_reads):
-    """Two early-route passes (the rank's reads in two halves) into owner-sized tables; union of the ranks' tables == oracle."""
+def early(path, k, per_rank, G, L, rank, world, genome, reads, dev_reads):
+    """Two early-route calls (the rank's reads in two halves) into owner-sized tables; union of the ranks' tables == oracle."""
     import oracle
     from oxli_amd import KmerCountTable
-    from oxli_amd.distributed import consume_device_early, global_scalar_sum, owner_of
+    from oxli_amd.distributed import consume_device_early, global_scalar_sum
 
     t = KmerCountTable(k, capacity=max(G // world, 400_000))
+    t.set_path(path)
     half = (per_rank // 2) * (L + 1)
-    # (the first call is cut into passes of 2^22 window starts: several exchanges, windows across the cuts counted once)
-    n1, s1 = consume_device_early(t, dev_reads.data_ptr(), half, (per_rank // 2) * L, mode=mode, max_windows=1 << 22)
+    # (the first call is cut into passes of 2^22 window starts: several exchanges in flight beside the counting, windows across the
+    # cuts -- inside a record for long reads -- counted once)
+    n1, s1 = consume_device_early(t, dev_reads.data_ptr(), half, (per_rank // 2) * L, max_windows=1 << 22)
     assert s1["passes"] == -(-(half - k + 1) // (1 << 22)) > 1, s1
-    n2, s2 = consume_device_early(t, dev_reads.data_ptr() + half, dev_reads.numel() - half, (per_rank - per_rank // 2) * L, mode=mode)
-    assert s1["mode"] == mode and s1["entry_bytes"] == (4 if mode == "compact" else 8) and not s1["skewed"]
-    assert s1["entries_sent"] > 0 and s1["entries_received"] > 0
+    n2, s2 = consume_device_early(t, dev_reads.data_ptr() + half, dev_reads.numel() - half, (per_rank - per_rank // 2) * L)
+    assert s1["windows_sent"] > 0 and s1["windows_received"] > 0 and s1["bytes_sent"] > 0
+    assert s1["bytes_sent"] < (0.75 if k < 30 else 0.5) * 4 * s1["windows_sent"], s1        # far fewer bytes than one 4-byte entry per window
     total_n = global_scalar_sum(n1 + n2, "cpu")
-    assert total_n == world * per_rank * (L - k + 1), total_n
-    keys, counts = t.dump_arrays(1)          # (reading the table converts what the dedupe-first modes left pending)
-    if mode == "hash":                       # hashing mode partitions by the late route's owner rule
-        assert np.all(owner_of(torch.from_numpy(keys.view(np.int64).copy()), world).numpy() == rank)
-    assert global_scalar_sum(t.sum_counts, "cpu") == world * per_rank * (L - k + 1)
+    expect = world * per_rank * (L - k + 1)
+    assert total_n == expect, (total_n, expect)
+    keys, counts = t.dump_arrays(1)          # (reading the table converts what the dedupe-first paths left pending)
+    assert global_scalar_sum(t.sum_counts, "cpu") == expect
     assert global_scalar_sum(t.consumed, "cpu") == world * per_rank * L
     parts = [None] * world
     dist.all_gather_object(parts, (keys, counts))
@@ -106,7 +107,8 @@ def early(mode, k, per_rank, G, L, rank, world, genome, reads, dev_reads):
         assert np.array_equal(gk[order], rk) and np.array_equal(gc[order], rc), "union of the owner tables differs from the oracle"
         sizes = [int(p[0].size) for p in parts]
         assert min(sizes) > 0.5 * rk.size / world, sizes     # every owner holds about its share
-        print(f"DIST_GPU_OK world={world} distinct={rk.size} route=early:{mode} sent={s1['entries_sent'] + s2['entries_sent']}")
+        sent = s1["bytes_sent"] + s2["bytes_sent"]
+        print(f"DIST_GPU_OK world={world} distinct={rk.size} route=early:{path} bytes_sent={sent} bytes_per_window={sent / max(1, s1['windows_sent'] + s2['windows_sent']):.3f}")
     dist.barrier()
     dist.destroy_process_group()
 

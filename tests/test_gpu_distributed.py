@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,k,per_rank,genome", [(2, 21, 40_000, 300_000), (4, 31, 20_000, 200_000), (3, 21, 400_000, 2_000_000)])
+@pytest.mark.parametrize("world,k,per_rank,genome", [(2, 21, 40_000, 300_000), (4, 31, 20_000, 200_000), (3, 21, 400_000, 2_000_000), (8, 21, 150_000, 2_000_000)])
 def test_ranks_sharing_one_gpu_merge_to_the_oracle_table(world, k, per_rank, genome):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
@@ -30,16 +30,20 @@ def test_ranks_sharing_one_gpu_merge_to_the_oracle_table(world, k, per_rank, gen
     assert f"DIST_GPU_OK world={world}" in out.stdout, out.stdout[-2000:]
 
 
-@pytest.mark.parametrize("world,k,per_rank,genome,mode", [(2, 21, 400_000, 2_000_000, "compact"), (3, 21, 300_000, 2_000_000, "compact"),
-                                                           (4, 31, 200_000, 2_000_000, "dedupe64"), (2, 51, 200_000, 2_000_000, "hash"),
-                                                           (3, 21, 300_000, 4_000_000, "hash"), (4, 21, 800_000, 6_000_000, "compact")])
-def test_ranks_sharing_one_gpu_early_route_equals_the_oracle_table(world, k, per_rank, genome, mode):
-    """The EARLY route (kct_consume_device_routed): K1 on every rank with owner-grouped bins, three all-to-alls
-    (gloo here, staged through the host), K1b / K2 on the owners -- C4-shaped input (150 bp reads, deep coverage), two passes
-    per rank.  The union of the owners' tables must be the oracle's table of the whole stream."""
+@pytest.mark.parametrize("world,k,per_rank,genome,path,L", [
+    (2, 21, 400_000, 2_000_000, "auto", 150), (3, 21, 300_000, 2_000_000, "dedupe", 150), (4, 31, 200_000, 2_000_000, "dedupe", 150),
+    (2, 51, 200_000, 2_000_000, "auto", 150), (3, 21, 300_000, 4_000_000, "partitioned", 150), (4, 21, 800_000, 6_000_000, "auto", 150),
+    # the target world: 8 ranks (7 peers each, owners of an eighth of the minimisers), C4-shaped
+    (8, 21, 300_000, 6_000_000, "auto", 150), (8, 31, 150_000, 3_000_000, "partitioned", 150),
+    # C5-shaped: 10 kbp reads at k = 51, passes of 2^22 window starts cut inside records
+    (8, 51, 2_400, 3_000_000, "auto", 10_000), (2, 51, 6_000, 2_000_000, "partitioned", 10_000)])
+def test_ranks_sharing_one_gpu_early_route_equals_the_oracle_table(world, k, per_rank, genome, path, L):
+    """The EARLY route (kct_consume_device_routed): every rank cuts its records into super-k-mers by owner, the parts
+    cross in pipelined all-to-alls (gloo here, staged through the host), every owner counts what it receives with the table's ordinary
+    bulk path.  The union of the owners' tables must be the oracle's table of the whole stream (add() semantics, lib.rs:778-837)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(k), str(per_rank), str(genome), f"early:{mode}"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(k), str(per_rank), str(genome), f"early:{path}", str(L)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-6000:]
-    assert f"DIST_GPU_OK world={world}" in out.stdout and f"route=early:{mode}" in out.stdout, out.stdout[-2000:]
+    assert f"DIST_GPU_OK world={world}" in out.stdout and f"route=early:{path}" in out.stdout, out.stdout[-2000:]
