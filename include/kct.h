@@ -216,7 +216,9 @@ KCT_API kct_status kct_set_packed_upload(kct_table *t, int on);
  *                               exchange_sizes; the send buffer is complete when start is called); may return at once
  *   wait(user)                  returns when the exchange started last has delivered every byte of d_recv
  * At most one exchange is in flight.  csrc/kct_rccl.cpp is an implementation over RCCL (ncclSend / ncclRecv on its own stream),
- * oxli_amd/distributed.py one over torch.distributed.  world == 1 with ops == NULL is a loop-back.
+ * oxli_amd/distributed.py one over torch.distributed.  world == 1 with ops == NULL is a loop-back; world > 1 with ops == NULL counts,
+ * of the records given, only the k-mers that `rank` owns and drops the rest -- for jobs in which every GPU reads ALL the input (no
+ * exchange at all: the union over the ranks is again the whole table), and what tools/route_profile.py times one owner's share with.
  *   max_windows   window starts per pass (0 = what HBM allows, at least four passes for a long stream)
  *   *n_owned      k-mers this rank counted as an owner (summed over ranks: the job's n)
  *   stats16       optional: windows sent to / received from other ranks, bytes sent / received, runs cut, passes, microseconds in

@@ -1034,13 +1034,14 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
     // dedupe-first path as a PROBE; the share of first sightings among them gives the number of distinct k-mers the
     // input draws from (as if uniformly -- position-sorted input shows its repeats even sooner), hence the windows per
     // distinct k-mer of the whole call.  Either way the probe's k-mers are counted; a wrong guess costs speed only.
-    const u64 call_windows = last_start + 1;
-    KCT_DBG(t, "consume_stream: %llu window starts, chunk limit %llu, table %llu slots\n", (unsigned long long)call_windows, (unsigned long long)chunk_limit,
-            (unsigned long long)t->cap);
+    const u64 here = last_start + 1;
+    const u64 call_windows = here + t->more_windows;  // (the early route feeds one job as several calls: the policy looks at the whole of it)
+    KCT_DBG(t, "consume_stream: %llu window starts (+ %llu announced), chunk limit %llu, table %llu slots\n", (unsigned long long)here,
+            (unsigned long long)t->more_windows, (unsigned long long)chunk_limit, (unsigned long long)t->cap);
     bool probe = probe_wanted(t, call_windows);
-    if (call_windows > chunk_limit) {  // passes of equal size
-        const u64 passes = (call_windows + chunk_limit - 1) / chunk_limit;
-        chunk_limit = std::min(chunk_limit, (((call_windows + passes - 1) / passes) + 0xFFFF) & ~(u64)0xFFFF);
+    if (here > chunk_limit) {  // passes of equal size
+        const u64 passes = (here + chunk_limit - 1) / chunk_limit;
+        chunk_limit = std::min(chunk_limit, (((here + passes - 1) / passes) + 0xFFFF) & ~(u64)0xFFFF);
     }
     while (done <= last_start) {
         KCT_TRY(maybe_grow(t));
@@ -1051,7 +1052,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
         const u64 ramp = t->auto_sized ? std::max<u64>(1ULL << 20, 4 * t->cap) : ~0ULL;
         const u64 npos = std::min<u64>({probe ? kProbeWindows : chunk_limit, ramp, last_start + 1 - done});
         const u64 chunk_bytes = std::min<u64>(nbytes - done, npos + k - 1);
-        t->call_windows_left = last_start + 1 - done;
+        t->call_windows_left = last_start + 1 - done + t->more_windows;
         if (probe) {
             probe = false;
             // A table of up to 1024 blocks has a small shadow anyway: the probe is an ordinary dedupe-first pass whose counts stay

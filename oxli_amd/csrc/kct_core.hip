@@ -421,6 +421,7 @@ void kct_destroy(kct_table *t) {
     if (t->probe_shadow32) (void)hipFree(t->probe_shadow32);
     if (t->shadow128) (void)hipFree(t->shadow128);
     t->d_unpack.release();
+    for (kcth::DevBuf *b : {&t->d_sk_bases, &t->d_sk_starts, &t->d_sk_meta, &t->d_sk_lists, &t->d_sk_dir, &t->d_sk_send, &t->d_sk_recv, &t->d_sk_inbox}) b->release();
     for (auto &b : t->h_file) b.release();
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
@@ -768,7 +769,8 @@ kct_status kct_release_scratch(kct_table *t) {
     KCT_TRY(use(t));  // nothing may be pending in a buffer that is about to go
     HIP_TRY(hipStreamSynchronize(t->stream));
     for (DevBuf *b : {&t->d_stream, &t->d_spill, &t->d_aux, &t->d_aux2, &t->d_scratch, &t->d_regions, &t->d_irr, &t->d_sort, &t->d_scratch2,
-                      &t->d_regions2, &t->d_irr2, &t->d_pairs_ovf, &t->d_prefix, &t->d_pending, &t->d_failed})
+                      &t->d_regions2, &t->d_irr2, &t->d_pairs_ovf, &t->d_prefix, &t->d_pending, &t->d_failed, &t->d_sk_bases, &t->d_sk_starts, &t->d_sk_meta,
+                      &t->d_sk_lists, &t->d_sk_dir, &t->d_sk_send, &t->d_sk_recv, &t->d_sk_inbox})
         b->release();
     if (t->shadow) { (void)hipFree(t->shadow); t->shadow = nullptr; t->shadow_cap = 0; t->shadow_empty = true; t->shadow_keys = 0; }
     if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; t->s32_empty = true; t->s32_keys = 0; t->s32_windows = 0; }

@@ -215,6 +215,7 @@ struct kct_table {
     u64 pending_pairs = 0;
     u64 windows_since_read = 0; // window starts consumed since anything last read the table (use()): how long the caller's runs are
     u64 call_windows_left = 0;  // window starts the running consume call still has to count (no read can come before them)
+    u64 more_windows = 0;       // ... and those of later passes of the same job, announced by the early route (kct_route.hip)
     bool expect_new_keys = false;  // the dedupe probe found (nearly) every k-mer new: K2's fast path claims slots itself (AggregateArgs::claim)
     bool dedupe_hint = false;   // the last dedupe-first pass paid off: a cleared table starts with that path again
     u64 n_keys = 0;        // distinct non-zero hashes in `slots`
@@ -226,7 +227,7 @@ struct kct_table {
     u64 *h_counters = nullptr;   // pinned mirror
     kcth::DevBuf d_stream, d_spill, d_aux, d_aux2, d_scratch, d_regions, d_irr, d_sort, d_scratch2, d_regions2, d_irr2, d_pairs_ovf,
         d_unpack,  // the ASCII image of a packed chunk (or of a chunk of super-k-mer windows), for the kernels that read bytes
-        d_sk_bases, d_sk_starts, d_sk_meta, d_sk_lists, d_sk_dir, d_sk_send, d_sk_recv,  // early route: (workgroup, owner) regions, counts,
+        d_sk_bases, d_sk_starts, d_sk_meta, d_sk_lists, d_sk_dir, d_sk_send, d_sk_recv, d_sk_inbox,  // early route: (workgroup, owner) regions, counts,
                                                                                  // gather lists, run directory, loop-back slabs
         d_failed,  // K2: the numbers of the blocks it abandoned (partition_kernels.h FailedBlocks)
         d_prefix;  // error mode: the offending record's valid prefix (its own buffer: consume_stream reuses d_aux2 / d_spill)

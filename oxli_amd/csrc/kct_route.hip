@@ -168,44 +168,61 @@ kct_status split_pass(Route &r, const unsigned char *d_stream, u64 nbytes, Slab 
     return KCT_OK;
 }
 
-// the parts received from every peer (recv_off / recv_bytes, directories dir[peer][stream]) -> counted into this rank's table
-kct_status owner_pass(Route &r, const void *d_recv, const std::vector<u64> &recv_off, const std::vector<u64> &recv_bytes, const std::vector<u64> &dir, u64 *n_out, u64 *windows_in) {
-    kct_table *t = r.t;
-    const int nwg = r.nwg;
-    const unsigned world = r.world;
-    *n_out = 0; *windows_in = 0;
+// What this rank has received and not yet counted: the passes' parts back to back in ONE buffer (about a byte per window, so a whole
+// call usually fits), counted together -- one pass of the table's bulk path over all of it instead of one per exchange: K2 and the
+// conversion visit every table block once per pass whatever the pass brings.
+struct Inbox {
+    Slab buf;
+    static constexpr u64 kFront = 64;   // (a stream never begins in the buffer's first 2 (k - 1) bits: partition_args.h RunGroup)
+    u64 used = kFront;                  // bytes of buf in use
     std::vector<kct::RunStream> streams;
-    streams.reserve((size_t)world * nwg);
-    u64 ngroups = 0;
-    for (unsigned p = 0; p < world; ++p) {
+    u64 groups = 0, windows = 0;
+};
+
+// the parts of one pass, received at buf + base (recv_off / recv_bytes per peer, directories dir[peer][stream]) -> the inbox's streams
+kct_status inbox_add(Route &r, Inbox &in, u64 base, const std::vector<u64> &recv_off, const std::vector<u64> &recv_bytes, const std::vector<u64> &dir) {
+    const int nwg = r.nwg;
+    for (unsigned p = 0; p < r.world; ++p) {
         u64 units = 0, sunits = 0;
         for (int w = 0; w < nwg; ++w) { const u64 d = dir[(u64)p * nwg + w]; units += d >> 32; sunits += ((d & 0xFFFFFFFFULL) + 127) / 128; }
         if ((units + sunits) * 16 != recv_bytes[p]) { set_err("rank %u announced %llu bytes of super-k-mers and its directory adds up to %llu", p, (unsigned long long)recv_bytes[p], (unsigned long long)((units + sunits) * 16)); return KCT_ERR_ARG; }
-        u64 boff = recv_off[p], soff = recv_off[p] + units * 16;
+        u64 boff = base + recv_off[p], soff = boff + units * 16;
         for (int w = 0; w < nwg; ++w) {
             const u64 d = dir[(u64)p * nwg + w], nwin = d & 0xFFFFFFFFULL;
             if (nwin) {
-                if ((soff >> 3) >= (1ULL << 32)) { set_err("a pass of the early route may receive at most 32 GiB"); return KCT_ERR_ARG; }
                 kct::RunStream s;
-                s.bit0 = boff * 8; s.word0 = (unsigned int)(soff >> 3); s.nwin = (unsigned int)nwin; s.group0 = ngroups;
-                streams.push_back(s);
-                ngroups += (nwin + 63) >> 6;
-                *windows_in += nwin;
+                s.bit0 = boff * 8; s.word0 = soff >> 3; s.nwin = (unsigned int)nwin; s.group0 = in.groups;
+                in.streams.push_back(s);
+                in.groups += (nwin + 63) >> 6;
+                in.windows += nwin;
             }
             boff += (d >> 32) * 16; soff += ((nwin + 127) / 128) * 16;
         }
     }
-    if (!ngroups) return KCT_OK;
-    KCT_TRY(t->d_sk_dir.reserve(streams.size() * sizeof(kct::RunStream) + ngroups * sizeof(kct::RunGroup) + 64));
-    kct::RunGroup *d_groups = (kct::RunGroup *)t->d_sk_dir.p;
-    kct::RunStream *d_streams = (kct::RunStream *)(d_groups + ngroups);
-    HIP_TRY(hipMemcpyAsync(d_streams, streams.data(), streams.size() * sizeof(kct::RunStream), hipMemcpyHostToDevice, t->stream));
-    launch_run_directory(t, d_streams, (unsigned)streams.size(), (const du64 *)d_recv, d_groups);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(t->stream));   // (`streams` is host memory)
-    kct::RunsInput in;
-    in.bases = (const unsigned int *)d_recv; in.starts = (const du64 *)d_recv; in.groups = d_groups;
-    return consume_stream_runs(t, in, ngroups, n_out);
+    return KCT_OK;
+}
+
+// everything in the inbox -> counted into this rank's table (`more` = windows later passes of the same call will still bring)
+kct_status inbox_count(Route &r, Inbox &in, u64 more, u64 *n_out) {
+    kct_table *t = r.t;
+    *n_out = 0;
+    kct_status st = KCT_OK;
+    if (in.groups) {
+        KCT_TRY(t->d_sk_dir.reserve(in.streams.size() * sizeof(kct::RunStream) + in.groups * sizeof(kct::RunGroup) + 64));
+        kct::RunGroup *d_groups = (kct::RunGroup *)t->d_sk_dir.p;
+        kct::RunStream *d_streams = (kct::RunStream *)(d_groups + in.groups);
+        HIP_TRY(hipMemcpyAsync(d_streams, in.streams.data(), in.streams.size() * sizeof(kct::RunStream), hipMemcpyHostToDevice, t->stream));
+        launch_run_directory(t, d_streams, (unsigned)in.streams.size(), (const du64 *)in.buf.p, d_groups);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(t->stream));   // (`streams` is host memory)
+        kct::RunsInput ri;
+        ri.bases = (const unsigned int *)in.buf.p; ri.groups = d_groups;
+        t->more_windows = more;
+        st = consume_stream_runs(t, ri, in.groups, n_out);
+        t->more_windows = 0;
+    }
+    in.streams.clear(); in.groups = in.windows = 0; in.used = Inbox::kFront;
+    return st;
 }
 
 }  // namespace
@@ -215,8 +232,9 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     *n_out = 0;
     const int k = t->k;
     if (world < 1 || world > kct::kSkMaxWorld || rank >= world) { set_err("bad world / rank"); return KCT_ERR_ARG; }
-    if (world > 1 && (!ops || !ops->alloc || !ops->exchange_sizes || !ops->start || !ops->wait)) { set_err("more than one rank needs the exchange callbacks"); return KCT_ERR_ARG; }
+    if (ops && (!ops->alloc || !ops->exchange_sizes || !ops->start || !ops->wait)) { set_err("kct_exchange_ops needs alloc, exchange_sizes, start and wait"); return KCT_ERR_ARG; }
     if (world == 1) ops = nullptr;
+    const bool solo = !ops && world > 1;   // no exchange: of this rank's OWN records, count the k-mers it owns (what its peers own is dropped)
     if (k > 64) { set_err("the early route takes k <= 64"); return KCT_ERR_ARG; }
     Route r{t, world, rank, ops, t->num_cus};
     // ---- passes: as many as the tightest rank needs (HBM: regions, two send and two receive slabs, the owner's scratch), at least
@@ -243,15 +261,31 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
         *len = p + 1 < passes ? std::min(nbytes - *off, step + k - 1) : nbytes - *off;
         if (*off >= nbytes || *len < (u64)k) *len = 0;
     };
-    Slab send[2], recv[2];
+    Slab send[2];
+    Inbox inbox;
     PassOut po[2];
     const unsigned nvals = 2 + (unsigned)r.nwg;
-    std::vector<u64> msg((size_t)world * nvals), got[2];
+    std::vector<u64> msg((size_t)world * nvals), got;
     std::vector<u64> recv_off[2], recv_bytes[2], dirs[2];
+    u64 recv_base[2] = {0, 0};
     for (int b = 0; b < 2; ++b) { po[b].part_off.assign(world, 0); po[b].part_bytes.assign(world, 0); po[b].dir.assign((size_t)r.nwg * world, 0); }
-    u64 st_windows_out = 0, st_windows_in = 0, st_bytes_out = 0, st_bytes_in = 0, st_runs = 0, st_retries = 0;
+    u64 st_windows_out = 0, st_windows_in = 0, st_bytes_out = 0, st_bytes_in = 0, st_runs = 0, st_retries = 0, st_counts = 0;
     double split_ms = 0, owner_ms = 0;
     kct_status status = KCT_OK;
+    // the inbox: room for the whole call where HBM allows (what arrives is about what leaves), at most 30 GiB (the directory's offsets)
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const u64 inbox_target = std::min<u64>({(u64)((double)windows * (bases_per_window(k) / 4.0 + 0.125) * (solo ? 1.5 / world : 1.25)) + (8ULL << 20),
+                                            (u64)(0.3 * (double)free_b), 30ULL << 30});
+    // count what the inbox holds (a local failure is kept in `status`, see cut)
+    auto count_inbox = [&](u64 more) {
+        const double t0 = now_ms();
+        u64 n = 0;
+        if (status == KCT_OK) { status = inbox_count(r, inbox, more, &n); ++st_counts; }
+        else { inbox.streams.clear(); inbox.groups = inbox.windows = 0; inbox.used = Inbox::kFront; }
+        owner_ms += now_ms() - t0;
+        *n_out += n;
+    };
     // cut(p): this rank's records of pass p -> one part per owner in send[p & 1].  A local failure is kept in `status`: the rank then
     // stays in step with its peers (every collective below is still made) and announces the failure in its next size message.
     auto cut = [&](u64 p) {
@@ -263,8 +297,9 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
         split_ms += now_ms() - t0;
         if (status != KCT_OK) { po[b].part_off.assign(world, 0); po[b].part_bytes.assign(world, 0); po[b].dir.assign((size_t)r.nwg * world, 0); }
     };
-    // post(p): sizes and directories of pass p to every peer (with this rank's status), room for what will arrive, then the payload
-    // starts.  Returns non-OK on EVERY rank alike (the job is over), OK with the transfer under way otherwise.
+    // post(p): sizes and directories of pass p to every peer (with this rank's status), room in the inbox for what will arrive -- what
+    // it holds is counted first if it has to be -- then the payload starts.  Returns non-OK on EVERY rank alike (the job is over), OK
+    // with the transfer under way otherwise.
     auto post = [&](u64 p) -> kct_status {
         const int b = (int)(p & 1);
         for (unsigned q = 0; q < world; ++q) {
@@ -272,25 +307,38 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
             msg[(size_t)q * nvals + 1] = po[b].part_bytes[q];
             for (int w = 0; w < r.nwg; ++w) msg[(size_t)q * nvals + 2 + w] = po[b].dir[(size_t)q * r.nwg + w];
         }
-        kct_status st = r.sizes(msg, nvals, got[b]);
+        kct_status st = r.sizes(msg, nvals, got);
         recv_off[b].assign(world, 0); recv_bytes[b].assign(world, 0); dirs[b].assign((size_t)world * r.nwg, 0);
         u64 total = 0;
         if (st == KCT_OK)
             for (unsigned q = 0; q < world; ++q) {
-                if (got[b][(size_t)q * nvals] != 0 && status == KCT_OK && st == KCT_OK) {
-                    set_err("the early route failed on rank %u (status %llu) before pass %llu was exchanged", q, (unsigned long long)got[b][(size_t)q * nvals], (unsigned long long)p);
+                if (solo && q != rank) continue;   // (no exchange: only what this rank cut for itself arrives)
+                if (got[(size_t)q * nvals] != 0 && status == KCT_OK && st == KCT_OK) {
+                    set_err("the early route failed on rank %u (status %llu) before pass %llu was exchanged", q, (unsigned long long)got[(size_t)q * nvals], (unsigned long long)p);
                     st = KCT_ERR_HIP;
                 }
-                recv_off[b][q] = total; recv_bytes[b][q] = got[b][(size_t)q * nvals + 1];
+                const unsigned from = solo ? rank : q;   // (the loop-back's "received" message is the one this rank wrote for that peer)
+                recv_off[b][q] = total; recv_bytes[b][q] = got[(size_t)from * nvals + 1];
                 total += recv_bytes[b][q];
-                for (int w = 0; w < r.nwg; ++w) dirs[b][(size_t)q * r.nwg + w] = got[b][(size_t)q * nvals + 2 + w];
+                for (int w = 0; w < r.nwg; ++w) dirs[b][(size_t)q * r.nwg + w] = got[(size_t)from * nvals + 2 + w];
             }
         if (status != KCT_OK) st = status;
-        if (st == KCT_OK && ops) st = r.slab(recv[b], t->d_sk_recv, total);
+        if (st == KCT_OK && inbox.used + total + 64 > inbox.buf.cap) {
+            if (inbox.groups) count_inbox((passes - p) * (inbox.windows / std::max<u64>(1, p)));   // (every earlier pass has been waited for)
+            if (status == KCT_OK && Inbox::kFront + total + 64 > inbox.buf.cap) status = r.slab(inbox.buf, t->d_sk_inbox, std::max(total, inbox_target) + Inbox::kFront);
+            st = status;
+        }
+        recv_base[b] = inbox.used;
         st = r.agree(st);   // (a rank without room for what it is to receive must not leave its peers inside the collective)
         if (st != KCT_OK) return st;
-        if (!ops) { recv[b] = send[b]; return KCT_OK; }   // loop-back: one rank
-        if (ops->start(ops->user, send[b].p, po[b].part_off.data(), po[b].part_bytes.data(), recv[b].p, recv_off[b].data(), recv_bytes[b].data()) != 0) {
+        inbox.used += total;
+        char *dst = (char *)inbox.buf.p + recv_base[b];
+        if (!ops) {   // loop-back: what this rank cut for itself is what it receives
+            for (unsigned q = 0; q < world; ++q)
+                if (recv_bytes[b][q]) HIP_TRY(hipMemcpyAsync(dst + recv_off[b][q], (const char *)send[b].p + po[b].part_off[solo ? rank : q], recv_bytes[b][q], hipMemcpyDeviceToDevice, t->stream));
+            return KCT_OK;
+        }
+        if (ops->start(ops->user, send[b].p, po[b].part_off.data(), po[b].part_bytes.data(), dst, recv_off[b].data(), recv_bytes[b].data()) != 0) {
             set_err("the exchange failed to start");   // (every rank's collective fails with it)
             return KCT_ERR_HIP;
         }
@@ -300,40 +348,35 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     kct_status job = post(0);   // the JOB's state: changes on every rank in the same collective
     for (u64 p = 0; p < passes && job == KCT_OK; ++p) {
         const int b = (int)(p & 1);
-        // pass p + 1 is cut while pass p is on the wire, and goes on the wire before pass p is counted: transfers run beside kernels
+        // pass p + 1 is cut while pass p is on the wire, and goes on the wire as soon as pass p has arrived
         if (p + 1 < passes) cut(p + 1);
         if (ops) {
             const double t0 = now_ms();
             if (ops->wait(ops->user) != 0 && status == KCT_OK) { set_err("the exchange failed"); status = KCT_ERR_HIP; }
             r.wait_ms += now_ms() - t0;
         }
+        if (status == KCT_OK) status = inbox_add(r, inbox, recv_base[b], recv_off[b], recv_bytes[b], dirs[b]);
         for (unsigned q = 0; q < world; ++q) {   // what crossed to / from OTHER ranks
             if (q == rank) continue;
-            st_bytes_out += po[b].part_bytes[q]; st_bytes_in += recv_bytes[b][q];
-            for (int w = 0; w < r.nwg; ++w) { st_windows_out += po[b].dir[(size_t)q * r.nwg + w] & 0xFFFFFFFFULL; st_windows_in += dirs[b][(size_t)q * r.nwg + w] & 0xFFFFFFFFULL; }
+            st_bytes_out += po[b].part_bytes[q]; st_bytes_in += solo ? 0 : recv_bytes[b][q];
+            for (int w = 0; w < r.nwg; ++w) { st_windows_out += po[b].dir[(size_t)q * r.nwg + w] & 0xFFFFFFFFULL; st_windows_in += solo ? 0 : dirs[b][(size_t)q * r.nwg + w] & 0xFFFFFFFFULL; }
         }
         st_runs += po[b].runs; st_retries += po[b].retries;
         if (p + 1 < passes) job = post(p + 1);
-        if (job == KCT_OK && status == KCT_OK) {
-            const double t0 = now_ms();
-            u64 n = 0, win = 0;
-            status = owner_pass(r, recv[b].p, recv_off[b], recv_bytes[b], dirs[b], &n, &win);
-            owner_ms += now_ms() - t0;
-            *n_out += n;
-        }
     }
+    if (job == KCT_OK) count_inbox(0);
     if (status == KCT_OK) status = job;
     HIP_TRY(hipStreamSynchronize(t->stream));
     if (world > 1) status = r.agree(status);   // (the last owner pass may have failed somewhere)
-    if (ops && ops->release)
-        for (int b = 0; b < 2; ++b) {
+    if (ops && ops->release) {
+        for (int b = 0; b < 2; ++b)
             if (send[b].p) ops->release(ops->user, send[b].p);
-            if (recv[b].p) ops->release(ops->user, recv[b].p);
-        }
+        if (inbox.buf.p) ops->release(ops->user, inbox.buf.p);
+    }
     if (stats) {
         stats[0] = st_windows_out; stats[1] = st_windows_in; stats[2] = st_bytes_out; stats[3] = st_bytes_in; stats[4] = st_runs; stats[5] = passes;
         stats[6] = (u64)(split_ms * 1000.0); stats[7] = (u64)(r.wait_ms * 1000.0); stats[8] = (u64)(owner_ms * 1000.0); stats[9] = st_retries;
-        stats[10] = windows; stats[11] = 0; stats[12] = 0; stats[13] = 0; stats[14] = 0; stats[15] = 0;
+        stats[10] = windows; stats[11] = st_counts; stats[12] = 0; stats[13] = 0; stats[14] = 0; stats[15] = 0;
     }
     KCT_DBG(t, "routed call (rank %u of %u): %llu window starts in %llu passes; %llu runs; sent %llu B / %llu windows, received %llu B / %llu windows; split %.3f ms, waiting %.3f ms, owner %.3f ms\n",
             rank, world, (unsigned long long)windows, (unsigned long long)passes, (unsigned long long)st_runs, (unsigned long long)st_bytes_out, (unsigned long long)st_windows_out,

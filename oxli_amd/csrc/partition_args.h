@@ -7,19 +7,20 @@
 namespace kct {
 
 // A stream of super-k-mers: bases[] holds runs back to back, 16 bases per word, first base in bits 31:30 (as PartitionArgs::pcodes);
-// a run of n windows is n + k - 1 bases.  Windows are numbered in the order their runs lie in bases[]; bit (w & 63) of starts[w >> 6]
-// says that window w is the first of its run.  Several such streams (one per sending workgroup and peer) are made ONE virtual
-// window space of 64-window groups by a directory: group g's windows are lanes 0 .. nvalid-1, lane l's k-mer begins at bit
-//     bit_base + 2 * (l + (k - 1) * popcount(starts[start_word] & ((2 << l) - 1)))      of bases[]
-// (bit_base already accounts for the runs in front of the group; bit 0 = the most significant bit of bases[0]).
+// a run of n windows is n + k - 1 bases.  Windows are numbered in the order their runs lie in bases[]; one start bit per window says
+// that it is the first of its run.  Several such streams (one per sending workgroup and peer) are made ONE virtual window space of
+// 64-window groups by a directory: group g's windows are lanes 0 .. nvalid-1, lane l's k-mer begins at bit
+//     base + 2 * (l + (k - 1) * popcount(starts & ((2 << l) - 1)))      of bases[]
+// (base accounts for the runs in front of the group and stands k - 1 bases further in front, so that the sum needs no "- 1": a stream
+// therefore never begins in the first 2 (k - 1) bits of bases[]; bit 0 = the most significant bit of bases[0]).  One 16-byte load
+// per group.
 struct RunGroup {
-    u64 bit_base;
-    u32 start_word;      // index into starts[]
-    u32 nvalid;          // windows in this group (64 except for a stream's last group; 0 = padding)
+    u64 base_nvalid;     // base (56 bits) | nvalid << 56: windows in this group (64 except for a stream's last group)
+    u64 starts;          // the group's start bits, lane l in bit l
 };
+constexpr u64 kRunBaseMask = (1ULL << 56) - 1ULL;
 struct RunsInput {
     const u32 *bases = nullptr;
-    const u64 *starts = nullptr;
     const RunGroup *groups = nullptr;   // the groups of THIS launch (null = not a runs launch)
 };
 
@@ -43,7 +44,7 @@ struct SplitArgs {
 struct RunStream {
     u64 bit0;
     u64 group0;
-    u32 word0;
+    u64 word0;
     u32 nwin;
 };
 

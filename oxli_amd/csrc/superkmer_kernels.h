@@ -383,7 +383,8 @@ __global__ __launch_bounds__(kBlock) void run_directory_kernel(const RunStream *
         __syncthreads();
         for (u32 g0 = 0; g0 < ng; g0 += kBlock) {
             const u32 g = g0 + threadIdx.x;
-            const u32 pc = g < ng ? (u32)__popcll(starts[st.word0 + g]) : 0u;
+            const u64 word = g < ng ? starts[st.word0 + g] : 0ULL;
+            const u32 pc = (u32)__popcll(word);
             // exclusive prefix inside the workgroup: wave scan, then the waves' totals
             u32 incl = pc;
 #pragma unroll
@@ -398,10 +399,9 @@ __global__ __launch_bounds__(kBlock) void run_directory_kernel(const RunStream *
             const u64 runs_before = carry + before + incl - pc;   // run starts in front of this group
             if (g < ng) {
                 RunGroup rg;
-                rg.bit_base = st.bit0 + 2ULL * (64ULL * g + (u64)(k - 1) * (runs_before - 1ULL));  // (wraps for runs_before = 0: the group's first window is a start)
-                rg.start_word = st.word0 + g;
                 const u32 left = st.nwin - 64u * g;
-                rg.nvalid = left < 64u ? left : 64u;
+                rg.base_nvalid = (st.bit0 + 2ULL * (64ULL * g + (u64)(k - 1) * runs_before) - 2ULL * (u64)(k - 1)) | ((u64)(left < 64u ? left : 64u) << 56);
+                rg.starts = word;
                 groups[st.group0 + g] = rg;
             }
             __syncthreads();
@@ -418,9 +418,9 @@ __global__ __launch_bounds__(kBlock) void expand_runs_kernel(RunsInput in, u64 n
     for (u64 g = (u64)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); g < ngroups; g += (u64)gridDim.x * (kBlock / 64)) {
         const RunGroup d = in.groups[g];
         unsigned char *o = out + (g * 64 + lane) * (u64)(k + 1);
-        if (lane < d.nvalid) {
-            const u64 below = in.starts[d.start_word] & ((2ULL << lane) - 1ULL);
-            const u64 bit = d.bit_base + 2ULL * ((u64)lane + (u64)(k - 1) * (u64)__popcll(below));
+        if (lane < (u32)(d.base_nvalid >> 56)) {
+            const u64 below = d.starts & ((2ULL << lane) - 1ULL);
+            const u64 bit = (d.base_nvalid & kRunBaseMask) + 2ULL * ((u64)lane + (u64)(k - 1) * (u64)__popcll(below));
             for (int i = 0; i < k; ++i) {
                 const u64 b = bit + 2ULL * i;
                 o[i] = (unsigned char)((0x54474341u >> (8 * ((in.bases[b >> 5] >> (30 - (b & 31))) & 3u))) & 0xFFu);

@@ -184,43 +184,59 @@ __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const uns
 // Same contract for a SUPER-K-MER launch (partition_args.h RunsInput; the multi-GPU early route's wire format): the thread's WPT
 // windows are window (threadIdx.x & 63) of groups group0 + wave, + 16, + 32, ... -- a wave takes one 64-window group per step.  Every
 // window is assembled from its run's packed bases (no rolling: there is no "previous window" to roll from at a run start, and
-// assembling costs what rolling does); the lanes of a wave read overlapping words, which the L1 serves.  The NEXT step's words are
-// requested before the current window is hashed.
+// assembling costs what rolling does); the lanes of a wave read overlapping words, which the L1 serves.  Two dependent loads stand
+// between a step and its k-mer (the group's descriptor -- wave-uniform -- then the bases), so the loop is software-pipelined: the
+// descriptor of step j + 3 and the bases of step j + 2 are requested before window j is hashed.
 template <int KW, int KC, bool LUT = false, int RAW = 0, int PRE = 0, class Sink>
 __device__ __forceinline__ void walk_windows_runs(const RunsInput &in, u64 group0, u64 ngroups, int k_rt, Sink &&sink, const u32 *lut = nullptr,
                                                   const u64 *mul1 = nullptr, const u64 *mul2 = nullptr, u64 *aux = nullptr, const u64 *tmul = nullptr) {
     constexpr int WPT = 16, NX = 2 * KW + 1;  // words that hold 2k bits at any 2-bit offset
     const int k = KC > 0 ? KC : k_rt;
     const u32 lane = threadIdx.x & 63u;
+    const u64 g0 = group0 + (u64)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: the descriptor loads can be scalar)
     constexpr u64 kStep = kPartThreads / 64;
     struct Fetch { u32 x[NX]; u32 sh; bool good; };
-    auto fetch = [&](u64 g) -> Fetch {
+    // (the directory is written by an earlier kernel and only read here: loads through the constant address space are scalar -- one
+    // s_load_dwordx4 per wave and step, the descriptor arithmetic on the scalar unit)
+    typedef const RunGroup __attribute__((address_space(4))) *ConstGroups;
+    const ConstGroups cgroups = (ConstGroups)(unsigned long long)in.groups;
+    auto describe = [&](int j) -> RunGroup {
+        RunGroup d;
+        d.base_nvalid = 0; d.starts = 0;
+        const u64 g = g0 + kStep * (u64)j;
+        if (g < ngroups) { d.base_nvalid = cgroups[g].base_nvalid; d.starts = cgroups[g].starts; }
+        return d;
+    };
+    // (no branches: a lane without a window -- the tail of a stream's last group, groups past the end -- reads the group's first word
+    // and its "k-mer" is dropped by the sink; nearly every lane has one)
+    auto fetch = [&](const RunGroup &d) -> Fetch {
         Fetch f;
+        f.good = lane < (u32)(d.base_nvalid >> 56);
+        // run starts at or before this window: the lanes below (v_mbcnt: two instructions) + its own bit
+        const u32 own = (u32)(d.starts >> lane) & 1u;
+        const u32 runs = __builtin_amdgcn_mbcnt_hi((u32)(d.starts >> 32), __builtin_amdgcn_mbcnt_lo((u32)d.starts, own));
+        // the group's base word is wave-uniform (scalar arithmetic); the lane's distance from it -- never negative, the base stands
+        // k - 1 bases in front of the group's first window's run (partition_args.h) -- fits 32 bits
+        const u64 base = d.base_nvalid & kRunBaseMask;
+        u32 rel = ((u32)base & 31u) + 2u * (lane + (u32)(k - 1) * runs);
+        rel = f.good ? rel : 0u;
+        const u32 *p = in.bases + (base >> 5) + (rel >> 5);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) f.x[i] = 0;
-        f.sh = 0; f.good = false;
-        if (g < ngroups) {
-            const RunGroup d = in.groups[g];
-            if (lane < d.nvalid) {
-                const u64 below = in.starts[d.start_word] & ((2ULL << lane) - 1ULL);  // run starts at or before this window
-                const u64 bit = d.bit_base + 2ULL * ((u64)lane + (u64)(k - 1) * (u64)__popcll(below));
-                const u32 *p = in.bases + (bit >> 5);
-#pragma unroll
-                for (int i = 0; i < NX; ++i) f.x[i] = p[i];
-                f.sh = (u32)bit & 31u; f.good = true;
-            }
-        }
+        for (int i = 0; i < NX; ++i) f.x[i] = p[i];
+        f.sh = rel & 31u;
         return f;
     };
-    u64 g = group0 + (threadIdx.x >> 6);
-    Fetch cur = fetch(g);
-#pragma unroll 4
+    RunGroup D[WPT + 3];
+    Fetch F[WPT + 2];
+    D[0] = describe(0); D[1] = describe(1); D[2] = describe(2);
+    F[0] = fetch(D[0]); F[1] = fetch(D[1]);
+#pragma unroll
     for (int j = 0; j < WPT; ++j) {
-        g += kStep;
-        Fetch nxt = cur;
-        if (j + 1 < WPT) nxt = fetch(g);
-        u64 h = 0;
-        if (cur.good) {
+        if (j + 3 < WPT) D[j + 3] = describe(j + 3);
+        if (j + 2 < WPT) F[j + 2] = fetch(D[j + 2]);
+        const Fetch &cur = F[j];
+        u64 h;
+        {
             // the 2k bits from bit cur.sh of x[], left-aligned: base 0 in bits 63:62 of top.w[0]
             u32 t32[2 * KW];
 #pragma unroll
@@ -254,7 +270,6 @@ __device__ __forceinline__ void walk_windows_runs(const RunsInput &in, u64 group
             }
         }
         sink(j, cur.good, h);
-        cur = nxt;
     }
 }
 

@@ -80,12 +80,13 @@ def early(path, k, per_rank, G, L, rank, world, genome, reads, dev_reads):
 
     t = KmerCountTable(k, capacity=max(G // world, 400_000))
     t.set_path(path)
-    half = (per_rank // 2) * (L + 1)
+    h = (per_rank // 2) & ~15                # (a multiple of 16 records: the second call's stream starts 16-byte aligned)
+    half = h * (L + 1)
     # (the first call is cut into passes of 2^22 window starts: several exchanges in flight beside the counting, windows across the
     # cuts -- inside a record for long reads -- counted once)
-    n1, s1 = consume_device_early(t, dev_reads.data_ptr(), half, (per_rank // 2) * L, max_windows=1 << 22)
+    n1, s1 = consume_device_early(t, dev_reads.data_ptr(), half, h * L, max_windows=1 << 22)
     assert s1["passes"] == -(-(half - k + 1) // (1 << 22)) > 1, s1
-    n2, s2 = consume_device_early(t, dev_reads.data_ptr() + half, dev_reads.numel() - half, (per_rank - per_rank // 2) * L)
+    n2, s2 = consume_device_early(t, dev_reads.data_ptr() + half, dev_reads.numel() - half, (per_rank - h) * L)
     assert s1["windows_sent"] > 0 and s1["windows_received"] > 0 and s1["bytes_sent"] > 0
     assert s1["bytes_sent"] < (0.75 if k < 30 else 0.5) * 4 * s1["windows_sent"], s1        # far fewer bytes than one 4-byte entry per window
     total_n = global_scalar_sum(n1 + n2, "cpu")

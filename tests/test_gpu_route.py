@@ -164,6 +164,32 @@ def test_loopback_route_with_skewed_input(gpu, k, path):
     assert t.consumed == ref.consumed
 
 
+@pytest.mark.parametrize("k,world", [(21, 3), (51, 8)])
+def test_owned_only_calls_partition_the_table(gpu, k, world):
+    """world > 1 without an exchange: each call counts, of ALL the records, only what its rank owns.  The ranks' tables are disjoint and
+    their union is the oracle's table."""
+    torch, KCT = gpu
+    G, R, L = 800_000, 100_000, 150
+    reads = oracle.synth_reads(oracle.synth_genome(G, 13), 0, R, L, 9)
+    tab, n_ref, _ = oracle.baseline_consume(reads, L, k, 8, native=False)
+    dev = torch.from_numpy(reads.reshape(-1)).cuda()
+    keys, counts, total = [], [], 0
+    for rank in range(world):
+        t = KCT(k, capacity=G // world + 100_000)
+        n, stats = C.c_uint64(), (C.c_uint64 * 16)()
+        t._check(t._lib.kct_consume_device_routed(t._h, C.c_void_p(dev.data_ptr()), dev.numel(), R * L, world, rank, None, 1 << 22, C.byref(n), stats))
+        total += n.value
+        a, b = t.dump_arrays(1)
+        keys.append(a); counts.append(b)
+        assert t.sum_counts == n.value and abs(n.value - n_ref / world) < 0.25 * n_ref / world
+    assert total == n_ref
+    gk, gc = np.concatenate(keys), np.concatenate(counts)
+    assert gk.size == np.unique(gk).size
+    order = np.argsort(gk, kind="stable")
+    rk, rc = tab.dump_arrays()
+    assert np.array_equal(gk[order], rk) and np.array_equal(gc[order], rc)
+
+
 def test_split_of_short_runs_overflowing_the_staging(gpu):
     """Windows that alternate between good and bad every few bases give far more runs per tile than random sequence: the split's LDS
     staging cannot take a whole tile (it goes out in pieces) and the regions sized for random input overflow (the split is redone with
@@ -197,7 +223,6 @@ def test_loopback_route_argument_checks(gpu):
     t = KCT(31, capacity=1_000_000)
     n, stats = C.c_uint64(), (C.c_uint64 * 16)()
     call = lambda world, rank: t._lib.kct_consume_device_routed(t._h, C.c_void_p(dev.data_ptr()), 1024, 0, world, rank, None, 0, C.byref(n), stats)  # noqa: E731
-    assert call(2, 0) != 0          # more than one rank needs callbacks
     assert call(1, 1) != 0 and call(0, 0) != 0 and call(65, 0) != 0
     big = KCT(71)                   # k > 64: not on this route
     assert big._lib.kct_consume_device_routed(big._h, C.c_void_p(dev.data_ptr()), 1024, 0, 1, 0, None, 0, C.byref(n), stats) != 0
