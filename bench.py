@@ -35,11 +35,16 @@ With N > 1 ranks (`python bench.py --gpus N` launches itself under torch.distrib
 same weak-scaled C2 job per rank + the late merge, and
   C4 / C5        BASELINE.json configs[3] / [4] as ONE strong-scaled job over the N ranks (100 M x 150 bp k=21 / 10 M x 10 kbp k=51,
                  reads split N ways), on both multi-GPU routes: "late" (private tables, then the owner all-to-all of
-                 {hash, count} pairs) and "early" (entries travel to their owner while they are counted); exchange and conversion
-                 inside the timed region; per rank: entries / pairs sent and received, exchange and merge ms; gated on n,
-                 sum_counts and on the routes agreeing on the global len and digests.  Ranks that SHARE a GPU (--backend gloo on a
-                 one-GPU box) run a reduced size and say so.  C5 runs only when named (--configs C4,C5): its late route needs a
-                 128 GiB private table per rank.
+                 {hash, count} pairs) and "early" (super-k-mers travel to the GPU that owns them -- about a byte per window -- and are
+                 counted there; passes pipelined); exchange and conversion inside the timed region; per rank: windows and bytes sent /
+                 received, ms in the split / blocked in the exchange / in the owner's counting; gated on n, sum_counts, on the routes
+                 agreeing on the global len and digests AND on the CPU oracle's digests of the job's union (tests/golden/
+                 config_digests.json at full size; computed on rank 0's host for the reduced sizes).  Ranks that SHARE a GPU
+                 (--backend gloo on a one-GPU box) run a reduced size and say so.  C5 runs only when named (--configs C4,C5): its late
+                 route needs a 128 GiB private table per rank.
+  north_star_streamed   the north-star run's 100 M reads fed the way a caller feeds them: 20 calls of 5 M reads and 100 calls of 1 M
+                 reads into ONE table that starts empty and hint-free (one conversion at the end); rate against the one-call run,
+                 the path every call took, gated on the oracle's digests.
 
 `roofline`: bound "hbm"; `achieved` = ALGORITHMIC bytes per step (k-mers x (L/(L-k+1) + 24) B) / the summed
 device time of every kernel of the step (HIP events on the table's stream, in an instrumented repetition of the job;
@@ -85,7 +90,7 @@ MULTI = {
     "C4": (100_000_000, 150, 21, 500_000_000),
     "C5": (10_000_000, 10_000, 51, 3_100_000_000),
 }
-ALL_CONFIGS = ["cold_C2", "packed_C2", "e2e_C2", "per_record", "k51_deep"] + list(BIG) + list(ERR) + list(MULTI)
+ALL_CONFIGS = ["cold_C2", "packed_C2", "e2e_C2", "per_record", "k51_deep"] + list(BIG) + ["north_star_streamed"] + list(ERR) + list(MULTI)
 
 
 def parse():
@@ -133,6 +138,25 @@ def pmc_summary():
         return {}
 
 
+def golden_digests():
+    """tests/golden/config_digests.json: the CPU oracle's digests of the full-size configurations (tests/golden/make_config_digests.py)."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "config_digests.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+DIGEST_FIELDS = ("len", "sum_counts", "min", "max", "sum_hc", "xor_hc", "sum_sq")
+
+
+def table_digest(t):
+    """The device table reduced the way the oracle's digests are (one scan each: kct_count_stats, kct_digest)."""
+    lo, hi, _sq = t._count_stats()
+    shc, xhc, ssq = t.digest()
+    return {"len": len(t), "sum_counts": t.sum_counts, "min": lo, "max": hi, "sum_hc": shc, "xor_hc": xhc, "sum_sq": ssq}
+
+
 def kernel_report(prof, kmers, b_alg, pmc_cfg):
     """Per-kernel ms, the algorithmic fraction over the summed kernel time and -- when PMC data of this build exists --
     measured HBM bytes, the measured fraction of peak and K1's VALU figures."""
@@ -173,7 +197,7 @@ def compact(res):
     if "roofline" in res:
         f = res["roofline"]
         out["roofline"] = {k: r(f.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "measured_frac", "frac_of_wall", "kernel",
-                                                     "kernel_ms_per_step", "alg_bytes_per_kmer", "pmc_source_sha")}
+                                                     "kernels_total_ms_per_step", "dominant_kernel_ms_per_step", "alg_bytes_per_kmer", "pmc_source_sha")}
         out["roofline"]["kernels_ms_per_step"] = f.get("kernels_ms_per_step")
         if f.get("valu"):
             out["roofline"]["valu"] = {"kernel": f["valu"]["kernel"], "insts_per_kmer": r(f["valu"]["valu_insts_per_window"], 1),
@@ -186,6 +210,13 @@ def compact(res):
                                "sample": f"first {b.get('sample_reads')} reads of the same stream, median of 3; best of key-space-sharded / read-sharded",
                                "value_1thread": r(b["value_1thread"], 0), "reads_sharded_tree_merge": b["reads_sharded_tree_merge"],
                                "keyspace_sharded": b["keyspace_sharded"], "host_cores": b["host_cores"]}
+    ns = res.get("configs", {}).get("north_star_k21", {})
+    if "kmers_per_s" in ns:   # the number the target sentence names (100 M x 150 bp, k=21, one GPU), at the top level
+        out["north_star"] = {"kmers_per_s": r(ns["kmers_per_s"], 0), "seconds": r(ns["seconds"], 5), "frac": r(ns.get("alg_frac")),
+                             "gate": "ok" if all(v for kk, v in ns.get("gate", {}).items() if kk != "sampled_keys") else "FAILED"}
+        st_ = res["configs"].get("north_star_streamed", {})
+        if "vs_one_call" in st_:
+            out["north_star"]["streamed_vs_one_call"] = r(st_["vs_one_call"], 3)
     if "configs" in res:
         out["configs"] = {}
         for name, c in res["configs"].items():
@@ -198,7 +229,10 @@ def compact(res):
             for k in ("alg_frac", "measured_frac", "hbm_bytes_per_kmer", "kmers_per_s_warm", "us_per_call", "us_per_call_loop_only", "vs_partitioned"):
                 if k in c:
                     e[k] = r(c[k], 0 if k == "kmers_per_s_warm" else 4)
-            for k in ("path_chosen", "world", "best_route", "note", "reads_total"):
+            if "feeds" in c:
+                e["vs_one_call"] = r(c["vs_one_call"], 3)
+                e["feeds"] = {kk: {"kmers_per_s": r(vv["kmers_per_s"], 0), "counting_launches": vv["counting_launches"]} for kk, vv in c["feeds"].items()}
+            for k in ("path_chosen", "world", "best_route", "note", "reads_total", "oracle_digests"):
                 if k in c:
                     e[k] = c[k]
             if "partitioned_path_kmers_per_s" in c:
@@ -310,6 +344,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ablate = bool(os.environ.get("KCT_ABLATE"))  # timing experiments that deliberately skip work: no result checks
     pmc = pmc_summary()
+    golden = golden_digests()
     med = statistics.median
     want = ALL_CONFIGS if args.configs == "all" else [] if args.configs == "none" else [c for c in args.configs.split(",") if c]
     if world > 1 and args.configs == "all":
@@ -425,7 +460,8 @@ def main():
                     "basis": "achieved = algorithmic bytes per step (25.15 B/k-mer x k-mers) / summed device time of every kernel of the step (HIP "
                              "events, instrumented repetition); traffic = PMC HBM bytes per step and measured_frac = traffic / kernel time / peak, "
                              "from profiles/pmc_r03.json when it matches this source tree (else null)",
-                    "alg_bytes_per_kmer": b_alg, "kmers_per_step": kmers_per_step, "kernel_ms_per_step": all_ms / args.steps,
+                    "alg_bytes_per_kmer": b_alg, "kmers_per_step": kmers_per_step, "kernels_total_ms_per_step": all_ms / args.steps,
+                    "dominant_kernel_ms_per_step": ms / args.steps,
                     "frac_of_wall": kmers_per_step * b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                     "dominant_kernel": {"name": dom, "avg_launch_ms": ms / launches if launches else None, "launches": launches},
                     "kernels_ms_per_step": {n_: round(v[1] / args.steps, 4) for n_, v in prof.items()},
@@ -616,12 +652,21 @@ def main():
                 hs = hs[hs != 0]
                 sample = np.concatenate([hs, hs ^ np.uint64(0x5555555555555555)])
                 got = np.array(t.get_hash_array(sample), dtype=np.uint64)
-                if checker:  # an oracle slice: every key of the slice is present with at least the slice's count
+                if checker:  # an oracle slice: the device's hash kernel finds exactly the slice's keys
                     ref = oracle.OracleTable(kb)
                     for i in range(ns):
                         ref.consume(sub[i, :Lb])
-                    rk, rc = ref.dump_arrays()
-                    gate["oracle_slice"] = bool(np.array_equal(rk, hs) and np.all(np.array(t.get_hash_array(rk), dtype=np.uint64) >= rc))
+                    rk, _rc = ref.dump_arrays()
+                    gate["oracle_slice_keys"] = bool(np.array_equal(rk, hs))
+                gd = golden.get(name)
+                if gd and (gd["reads"], gd["read_len"], gd["k"], gd["genome"]) == (Rb, Lb, kb, Gb):
+                    # THE ORACLE'S TABLE of the whole input (tests/golden/config_digests.json): len, sum_counts, min, max and the three
+                    # order-free digests EQUAL, n and consumed equal
+                    mine = table_digest(t)
+                    gate["equals_oracle_digests"] = bool(all(mine[f_] == gd[f_] for f_ in DIGEST_FIELDS) and n == gd["n"] and t.consumed == gd["consumed"])
+                else:
+                    gate["equals_oracle_digests"] = False
+                    entry["note"] = "no oracle digest of this size in tests/golden/config_digests.json"
                 t.release_scratch()
                 del t
                 torch.cuda.empty_cache()
@@ -641,6 +686,53 @@ def main():
             configs[name] = entry
             log(f"{name}: {entry['kmers_per_s']:.3g} k-mers/s, gate {'ok' if all(v for kk, v in gate.items() if kk != 'sampled_keys') else gate}")
             assert ablate or all(v for kk, v in gate.items() if kk != "sampled_keys"), (name, gate)
+            del r
+            torch.cuda.empty_cache()
+    # ------------------------------------------------------------------------------------------ the north-star run, fed in pieces
+    if rank == 0 and world == 1 and "north_star_streamed" in want:
+        Rb, Lb, kb, Gb = BIG["north_star_k21"]
+        free, _tot = torch.cuda.mem_get_info()
+        if free < 230 * (1 << 30):
+            configs["north_star_streamed"] = {"skipped": f"needs a whole MI355X: {free >> 30} GiB free"}
+        else:
+            g, r = synth(Gb, Rb, Lb)
+            del g
+            n_exp = Rb * (Lb - kb + 1)
+            gd = golden.get("north_star_k21", {})
+            entry = {"kmers": n_exp, "what": "the north-star run's 100 M reads as consecutive kct_consume_device calls into ONE table that starts empty and "
+                                             "hint-free; one conversion at the end (sync) inside the timed region; median of 3", "feeds": {}}
+            one_call = configs.get("north_star_k21", {}).get("kmers_per_s")
+            gate = {}
+            for calls in (1, 20, 100):
+                per = Rb // calls
+                nbytes = per * (Lb + 1)
+                assert per * calls == Rb and nbytes % 16 == 0
+                t = KmerCountTable(kb, capacity=Gb)
+
+                def feed():
+                    n_ = 0
+                    for i in range(calls):
+                        n_ += t.consume_device(r.data_ptr() + i * nbytes, nbytes, per * Lb)
+                    return n_
+                feed(); t.sync()                               # allocations
+                runs = [timed_call(t, feed, True, "auto") for _ in range(3)]
+                dt, n, prof = sorted(runs, key=lambda x: x[0])[1]
+                mine = table_digest(t)
+                ok = bool(gd) and all(mine[f_] == gd[f_] for f_ in DIGEST_FIELDS) and all(x[1] == n_exp for x in runs) and t.consumed == gd.get("consumed")
+                gate[f"{calls}_calls_equal_oracle_digests"] = bool(ok)
+                k1 = {kn: v[0] for kn, v in prof.items() if kn.startswith(("partition_windows_kernel", "count_windows_kernel"))}
+                entry["feeds"][str(calls)] = {"kmers_per_s": n_exp / dt, "seconds": dt, "seconds_min_max": [runs[0][0], runs[-1][0]] if False else [min(x[0] for x in runs), max(x[0] for x in runs)],
+                                              "counting_launches": k1, "kernel_ms_total": round(sum(v[1] for v in prof.values()), 3)}
+                t.release_scratch()
+                del t
+                torch.cuda.empty_cache()
+            base = entry["feeds"]["1"]["kmers_per_s"]
+            worst = min(entry["feeds"]["20"]["kmers_per_s"], entry["feeds"]["100"]["kmers_per_s"])
+            entry.update({"kmers_per_s": worst, "seconds": n_exp / worst, "vs_one_call": worst / base, "one_call_kmers_per_s": base,
+                          "one_call_kmers_per_s_in_north_star_k21": one_call, "gate": gate})
+            configs["north_star_streamed"] = entry
+            log(f"north_star_streamed: 1 call {base:.3g}, 20 calls {entry['feeds']['20']['kmers_per_s']:.3g}, 100 calls {entry['feeds']['100']['kmers_per_s']:.3g} k-mers/s, gate {gate}")
+            assert ablate or all(gate.values()), gate
             del r
             torch.cuda.empty_cache()
     # ------------------------------------------------------------------------------------------ inputs with sequencing errors
@@ -733,9 +825,7 @@ def main():
             torch.cuda.synchronize()
             del g
             distinct_global = min(Gb, n_exp_total)
-            # windows per distinct k-mer over the WHOLE job decide the early route's mode (an owner sees the full coverage)
-            deep = n_exp_total / distinct_global >= 16
-            routes = {"late": None, "early": ("compact" if kb <= 21 else "dedupe64" if kb <= 32 else "hash") if deep else "hash"}
+            routes = {"late": None, "early": "super-k-mers"}
             entry = {"world": world, "reads_total": per * world, "reads_per_rank": per, "read_len": Lb, "k": kb, "genome": Gb, "kmers": n_exp_total,
                      "scaling": "strong", "routes": {}}
             if note:
@@ -760,8 +850,9 @@ def main():
                         stats["pairs_received"] = merge_across_ranks(t)
                         stats["merge_ms"] = (time.perf_counter() - t_x) * 1e3
                     else:
-                        n, st_ = consume_device_early(t, r.data_ptr(), r.numel(), per * Lb, mode=mode)
+                        n, st_ = consume_device_early(t, r.data_ptr(), r.numel(), per * Lb)
                         stats.update(st_)
+                        stats["bytes_sent_per_window"] = st_["bytes_sent"] / max(1, st_["windows_sent"])
                     t.sync()        # the dedupe-first modes' conversion is part of the job
                     torch.cuda.synchronize()
                     dist.barrier()
@@ -780,7 +871,8 @@ def main():
                 gx = 0
                 for d in dg:
                     gx ^= d[3]
-                digests[route] = (glen, gsum, gshc, gx)
+                gsq = sum(d[4] for d in dg) & ((1 << 64) - 1)
+                digests[route] = (glen, gsum, gshc, gx, gsq)
                 entry["routes"][route] = {"kmers_per_s": n_exp_total / dt, "seconds": dt, "seconds_min_max": [runs[0][0], runs[-1][0]], "mode": mode,
                                           "n": n_all, "distinct_global": glen, "per_rank": per_rank_stats}
                 t.release_scratch()
@@ -788,6 +880,28 @@ def main():
                 torch.cuda.empty_cache()
             gate = {"n": all(v["n"] == n_exp_total for v in entry["routes"].values()), "sum_counts": all(d[1] == n_exp_total for d in digests.values()),
                     "routes_agree_on_len_and_digests": len(set(digests.values())) == 1}
+            # THE ORACLE'S TABLE of the job's union: the committed digests at full size (C4's union is the north-star run's input), else
+            # -- reduced sizes -- computed now on rank 0's host cores
+            gd = golden.get({"C4": "north_star_k21", "C5": "C5"}[name])
+            want_d = None
+            if gd and (gd["reads"], gd["read_len"], gd["k"], gd["genome"]) == (per * world, Lb, kb, Gb):
+                want_d = (gd["len"], gd["sum_counts"], gd["sum_hc"], gd["xor_hc"], gd["sum_sq"])
+                entry["oracle_digests"] = "tests/golden/config_digests.json"
+            elif n_exp_total <= 4_000_000_000 and not args.no_cpu_baseline:
+                if rank == 0:
+                    import oracle
+                    ss = oracle.ShardSet(kb, Lb, genome=oracle.synth_genome(Gb, SEED_G), nreads=per * world, seed_r=SEED_R, expect_keys=distinct_global)
+                    d_ = ss.digest()
+                    del ss
+                    want_d = (d_["len"], d_["sum_counts"], d_["sum_hc"], d_["xor_hc"], d_["sum_sq"])
+                box = [want_d]
+                dist.broadcast_object_list(box, src=0)
+                want_d = box[0]
+                entry["oracle_digests"] = "computed on rank 0's host (oracle.ShardSet)"
+            if want_d is not None:
+                gate["equals_oracle_digests"] = all(tuple(d) == tuple(want_d) for d in digests.values())
+            else:
+                entry["oracle_digests"] = None
             best = max(entry["routes"], key=lambda k_: entry["routes"][k_]["kmers_per_s"])
             entry.update({"kmers_per_s": entry["routes"][best]["kmers_per_s"], "seconds": entry["routes"][best]["seconds"], "best_route": best, "gate": gate})
             configs[name] = entry

@@ -12,7 +12,9 @@
  *   - Every function returns a kct_status; results come back through out-parameters.
  *     Nothing throws or aborts across the boundary.
  *   - A kct_table is NOT thread-safe: one caller at a time, like the reference's `&mut self`
- *     under the GIL (lib.rs:546).  All reads observe all earlier writes on the same handle.
+ *     under the GIL (lib.rs:546).  A second thread that enters while a call is running gets
+ *     KCT_ERR_BUSY (pyo3's "Already borrowed") -- it is never let in.  All reads observe all
+ *     earlier writes on the same handle.
  *   - Input buffers are borrowed for the duration of the call only.
  *   - There is no CPU fallback: without a usable gfx950 device every call that needs one
  *     fails with KCT_ERR_NO_DEVICE / KCT_ERR_HIP.
@@ -45,7 +47,8 @@ typedef enum kct_status {
     KCT_ERR_NOMEM = 5,          /* host or device allocation failed                                */
     KCT_ERR_HIP = 6,            /* a HIP runtime call failed; see kct_last_error()                 */
     KCT_ERR_ARG = 7,            /* null / misaligned / out-of-range argument                       */
-    KCT_ERR_NO_DEVICE = 8       /* no gfx950 device visible                                        */
+    KCT_ERR_NO_DEVICE = 8,      /* no gfx950 device visible                                        */
+    KCT_ERR_BUSY = 9            /* another thread is inside a call on this table (pyo3: "Already borrowed", lib.rs:546 &mut self) */
 } kct_status;
 
 /* Text of the most recent failure on this thread ("" if none). */
@@ -125,7 +128,12 @@ KCT_API kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint
 /* Same, for input already resident in HBM: `d_stream` is a 16-byte-aligned device pointer to
  * `nbytes` bytes in which records are separated by at least one non-ACGT byte (e.g. '\n');
  * skip_bad semantics.  `consumed` grows by `consumed_bytes` (the caller knows the record
- * lengths).  Runs on the table's stream and returns after it completes. */
+ * lengths).  Runs on the table's stream; the caller's buffer is free again when the call returns.
+ * A call that is SMALL for the table (fewer than 4 window starts per slot) is, in deferred mode (the default, kct_set_deferred),
+ * copied behind the earlier ones in HBM and counted with them -- when anything else touches the table, when 32 window starts per
+ * slot have gathered or the staging buffer (<= 32 GiB, a quarter of the free HBM) is full -- so that an input fed in pieces is
+ * counted in the passes, and on the path, of ONE large call; *n_total then comes from the copy kernel's own validity scan (the
+ * all-ACGT rule of lib.rs:586-600; it differs from the reference's n only if a window's true hash is 0, probability 2^-64). */
 KCT_API kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes,
                               uint64_t *n_total);
 
@@ -280,8 +288,8 @@ KCT_API kct_status kct_set_op(kct_table *a, kct_table *b, int op, uint64_t *hash
  * call needs the table (get, len, dump, add, ...), so every read still observes every earlier write.  *n_out
  * then comes from a host-side scan for valid windows (the same all-ACGT rule the device applies); it differs
  * from the reference's n only if a window's true hash is 0 (probability 2^-64 per window).  Hashing and
- * counting still happen on the device only.  Error mode (skip_bad == 0) is never deferred: it counts what is
- * buffered first, then runs synchronously.  A failure of the deferred pass itself (out of memory ...) is
+ * counting still happen on the device only.  The same switch governs the device-side twin (kct_consume_device above).  Error mode
+ * (skip_bad == 0) is never deferred: it counts what is buffered first, then runs synchronously.  A failure of the deferred pass itself (out of memory ...) is
  * reported by the call that triggers it. */
 KCT_API kct_status kct_set_deferred(kct_table *t, int on);
 

@@ -18,6 +18,7 @@ KCT_ERR_NOMEM = 5
 KCT_ERR_HIP = 6
 KCT_ERR_ARG = 7
 KCT_ERR_NO_DEVICE = 8
+KCT_ERR_BUSY = 9
 
 u8, u64, sz, vp, cp, ci = C.c_uint8, C.c_uint64, C.c_size_t, C.c_void_p, C.c_char_p, C.c_int
 u64p = C.POINTER(C.c_uint64)

@@ -69,6 +69,7 @@ kct_status retain(kct_table *t, u64 lo, u64 hi, bool has_drop, u64 drop, u64 *re
 extern "C" {
 
 kct_status kct_count_stats(kct_table *t, uint64_t *min_out, uint64_t *max_out, double *sum_squares_out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     u64 lo = ~0ULL, hi = 0;
     double sq = 0.0;
@@ -99,6 +100,7 @@ kct_status kct_count_stats(kct_table *t, uint64_t *min_out, uint64_t *max_out, d
 }
 
 kct_status kct_digest(kct_table *t, uint64_t *sum_hc_out, uint64_t *xor_hc_out, uint64_t *sum_sq_out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     u64 d[3] = {0, 0, 0};
     if (live_words(t)) {
@@ -121,6 +123,7 @@ kct_status kct_digest(kct_table *t, uint64_t *sum_hc_out, uint64_t *xor_hc_out, 
 }
 
 kct_status kct_histogram(kct_table *t, uint64_t *values_out, uint64_t *freq_out, size_t cap, uint64_t *n_out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     if (!n_out || (cap && (!values_out || !freq_out))) { set_err("null argument"); return KCT_ERR_ARG; }
     std::vector<u64> vals, freq;
@@ -174,11 +177,13 @@ kct_status kct_histogram(kct_table *t, uint64_t *values_out, uint64_t *freq_out,
 }
 
 kct_status kct_retain_counts(kct_table *t, uint64_t min_count, uint64_t max_count, uint64_t *removed_out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     return retain(t, min_count, max_count, false, 0, removed_out);
 }
 
 kct_status kct_remove_hash(kct_table *t, uint64_t hash, uint64_t *removed_out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     u64 gone = 0;
     if (hash == 0) {  // key 0 lives host-side
@@ -199,6 +204,8 @@ kct_status kct_remove_hash(kct_table *t, uint64_t hash, uint64_t *removed_out) {
 }
 
 kct_status kct_compare(kct_table *a, kct_table *b, uint64_t *common_out, uint64_t *dot_out) {
+    KCT_BORROW(a);
+    KCT_BORROW(b);
     KCT_TRY(use(b));
     KCT_TRY(use(a));
     KCT_TRY(same_device(a, b));
@@ -224,6 +231,8 @@ kct_status kct_compare(kct_table *a, kct_table *b, uint64_t *common_out, uint64_
 }
 
 kct_status kct_set_op(kct_table *a, kct_table *b, int op, uint64_t *hashes_out, size_t cap, uint64_t *n_out) {
+    KCT_BORROW(a);
+    KCT_BORROW(b);
     KCT_TRY(use(b));
     KCT_TRY(use(a));
     KCT_TRY(same_device(a, b));

@@ -109,6 +109,7 @@ kct_status use_device(kct_table *t) {
 kct_status use_consume(kct_table *t) {
     KCT_TRY(use_device(t));
     if (t->pending_used) KCT_TRY(flush_pending(t));  // (keeps the order of consumed records irrelevant, and `consumed` exact)
+    if (t->defer_used) KCT_TRY(flush_deferred_device(t));
     return KCT_OK;
 }
 
@@ -420,7 +421,7 @@ void kct_destroy(kct_table *t) {
     if (t->probe_shadow) (void)hipFree(t->probe_shadow);
     if (t->probe_shadow32) (void)hipFree(t->probe_shadow32);
     if (t->shadow128) (void)hipFree(t->shadow128);
-    t->d_unpack.release();
+    t->d_unpack.release(); t->d_defer.release();
     for (kcth::DevBuf *b : {&t->d_sk_bases, &t->d_sk_starts, &t->d_sk_meta, &t->d_sk_lists, &t->d_sk_dir, &t->d_sk_send, &t->d_sk_recv, &t->d_sk_inbox}) b->release();
     for (auto &b : t->h_file) b.release();
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
@@ -428,8 +429,10 @@ void kct_destroy(kct_table *t) {
 }
 
 kct_status kct_clear(kct_table *t) {
+    KCT_BORROW(t);
     KCT_TRY(use_device(t));
     t->pending_used = 0; t->pending_records = 0;  // buffered records are forgotten with everything else
+    t->defer_used = 0; t->defer_windows = 0;
     t->poisoned = false;
     t->lazy_empty = true;  // the memset is issued by materialize() only if something needs it
     t->shadow_empty = true; t->shadow_dirty = false; t->shadow_keys = 0; t->dedupe_off = false;  // pending counts are forgotten too
@@ -442,6 +445,7 @@ kct_status kct_clear(kct_table *t) {
 }
 
 kct_status kct_reserve(kct_table *t, uint64_t distinct) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     u64 want = next_pow2((u64)((double)distinct / kMaxLoad) + 1);
     t->auto_sized = false;
@@ -450,6 +454,7 @@ kct_status kct_reserve(kct_table *t, uint64_t distinct) {
 }
 
 kct_status kct_resize(kct_table *t, uint64_t distinct) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     u64 want = std::max(next_pow2((u64)((double)std::max<u64>(distinct, t->n_keys) / kMaxLoad) + 1), kMinSlots);
     t->auto_sized = false;
@@ -474,6 +479,7 @@ kct_status kct_resize(kct_table *t, uint64_t distinct) {
 }
 
 kct_status kct_count_hash(kct_table *t, uint64_t hash, uint64_t *count_out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     u64 c = 0;
     KCT_TRY(point_add(t, hash, &c));
@@ -482,6 +488,7 @@ kct_status kct_count_hash(kct_table *t, uint64_t hash, uint64_t *count_out) {
 }
 
 kct_status kct_get_hash_array(kct_table *t, const uint64_t *hashes, size_t n, uint64_t *counts_out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     if (n == 0) return KCT_OK;
     if (!hashes || !counts_out) { set_err("null argument"); return KCT_ERR_ARG; }
@@ -503,12 +510,14 @@ kct_status kct_get_hash_array(kct_table *t, const uint64_t *hashes, size_t n, ui
 }
 
 kct_status kct_get_hash(kct_table *t, uint64_t hash, uint64_t *count_out) {
+    KCT_BORROW(t);
     if (!count_out) { set_err("null argument"); return KCT_ERR_ARG; }
     if (hash == 0) { KCT_TRY(use(t)); *count_out = t->zero_present ? t->zero_count : 0; return KCT_OK; }  // host-side key
     return kct_get_hash_array(t, &hash, 1, count_out);
 }
 
 kct_status kct_set_hash(kct_table *t, uint64_t hash, uint64_t count) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     if (hash == 0) { t->zero_present = true; t->zero_count = count; return KCT_OK; }
     // make sure the key exists (adding 0 creates it without changing its count), then overwrite
@@ -528,12 +537,14 @@ kct_status kct_set_hash(kct_table *t, uint64_t hash, uint64_t count) {
 }
 
 kct_status kct_len(kct_table *t, uint64_t *out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     *out = t->n_keys + (t->zero_present ? 1 : 0);
     return KCT_OK;
 }
 
 kct_status kct_sum_counts(kct_table *t, uint64_t *out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     KCT_TRY(materialize(t));
     du64 *d_sum = t->d_counters + kNumCounters + 3;
@@ -549,12 +560,16 @@ kct_status kct_sum_counts(kct_table *t, uint64_t *out) {
     return KCT_OK;
 }
 
-kct_status kct_consumed(kct_table *t, uint64_t *out) { KCT_TRY(use_device(t)); *out = t->consumed; return KCT_OK; }
-kct_status kct_add_consumed(kct_table *t, uint64_t delta) { KCT_TRY(use_device(t)); t->consumed += delta; return KCT_OK; }
+kct_status kct_consumed(kct_table *t, uint64_t *out) {
+    KCT_BORROW(t); KCT_TRY(use_device(t)); *out = t->consumed; return KCT_OK; }
+kct_status kct_add_consumed(kct_table *t, uint64_t delta) {
+    KCT_BORROW(t); KCT_TRY(use_device(t)); t->consumed += delta; return KCT_OK; }
 uint8_t kct_ksize(const kct_table *t) { return t ? t->k : 0; }
-kct_status kct_capacity(kct_table *t, uint64_t *slots_out) { KCT_TRY(use(t)); *slots_out = t->cap; return KCT_OK; }
+kct_status kct_capacity(kct_table *t, uint64_t *slots_out) {
+    KCT_BORROW(t); KCT_TRY(use(t)); *slots_out = t->cap; return KCT_OK; }
 
 kct_status kct_export_device(kct_table *t, void *d_hashes, void *d_counts, size_t cap, uint64_t *n_out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     if (!n_out || (cap && (!d_hashes || !d_counts))) { set_err("null argument"); return KCT_ERR_ARG; }
     KCT_TRY(materialize(t));
@@ -573,6 +588,7 @@ kct_status kct_export_device(kct_table *t, void *d_hashes, void *d_counts, size_
 }
 
 kct_status kct_export_by_owner_device(kct_table *t, uint32_t nparts, void *d_pairs, size_t cap, uint64_t *part_counts, uint64_t *n_out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     if (!n_out || !part_counts || (cap && !d_pairs)) { set_err("null argument"); return KCT_ERR_ARG; }
     if (nparts == 0 || nparts > (uint32_t)kct::kMaxParts) { set_err("nparts must be 1..%d", kct::kMaxParts); return KCT_ERR_ARG; }
@@ -607,6 +623,7 @@ kct_status kct_export_by_owner_device(kct_table *t, uint32_t nparts, void *d_pai
 }
 
 kct_status kct_merge_pairs_device(kct_table *t, const void *d_pairs, size_t n, uint64_t *total_added, uint64_t *new_keys) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     u64 tl[4] = {0, 0, 0, 0};
     if (n) {
@@ -620,6 +637,7 @@ kct_status kct_merge_pairs_device(kct_table *t, const void *d_pairs, size_t n, u
 }
 
 kct_status kct_dump(kct_table *t, uint64_t *hashes_out, uint64_t *counts_out, size_t cap, int order, uint64_t *n_out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     if (!n_out) { set_err("null argument"); return KCT_ERR_ARG; }
     const u64 n_dev = t->n_keys;
@@ -676,6 +694,7 @@ kct_status kct_dump(kct_table *t, uint64_t *hashes_out, uint64_t *counts_out, si
 
 kct_status kct_merge_device(kct_table *t, const void *d_hashes, const void *d_counts, size_t n, uint64_t *total_added,
                             uint64_t *new_keys) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     u64 tl[4] = {0, 0, 0, 0};
     if (n) {
@@ -691,6 +710,7 @@ kct_status kct_merge_device(kct_table *t, const void *d_hashes, const void *d_co
 
 kct_status kct_merge_host(kct_table *t, const uint64_t *hashes, const uint64_t *counts, size_t n, uint64_t *total_added,
                           uint64_t *new_keys) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     if (total_added) *total_added = 0;
     if (new_keys) *new_keys = 0;
@@ -717,6 +737,8 @@ kct_status kct_merge_host(kct_table *t, const uint64_t *hashes, const uint64_t *
 }
 
 kct_status kct_add(kct_table *dst, kct_table *src, uint64_t *total_added, uint64_t *new_keys) {
+    KCT_BORROW(dst);
+    KCT_BORROW(src);
     if (!dst || !src) { set_err("null table handle"); return KCT_ERR_ARG; }
     if (dst->k != src->k) { set_err("KmerCountTables must have the same ksize"); return KCT_ERR_KSIZE_MISMATCH; }
     // snapshot src (lib.rs:791-795), then fold it into dst (lib.rs:798-806)
@@ -755,6 +777,7 @@ kct_status kct_add(kct_table *dst, kct_table *src, uint64_t *total_added, uint64
 }
 
 kct_status kct_set_stream(kct_table *t, void *hip_stream) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     HIP_TRY(hipStreamSynchronize(t->stream));
     prof_collect(t);
@@ -766,11 +789,12 @@ kct_status kct_set_stream(kct_table *t, void *hip_stream) {
 void *kct_get_stream(kct_table *t) { return t ? (void *)t->stream : nullptr; }
 
 kct_status kct_release_scratch(kct_table *t) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));  // nothing may be pending in a buffer that is about to go
     HIP_TRY(hipStreamSynchronize(t->stream));
     for (DevBuf *b : {&t->d_stream, &t->d_spill, &t->d_aux, &t->d_aux2, &t->d_scratch, &t->d_regions, &t->d_irr, &t->d_sort, &t->d_scratch2,
                       &t->d_regions2, &t->d_irr2, &t->d_pairs_ovf, &t->d_prefix, &t->d_pending, &t->d_failed, &t->d_sk_bases, &t->d_sk_starts, &t->d_sk_meta,
-                      &t->d_sk_lists, &t->d_sk_dir, &t->d_sk_send, &t->d_sk_recv, &t->d_sk_inbox})
+                      &t->d_sk_lists, &t->d_sk_dir, &t->d_sk_send, &t->d_sk_recv, &t->d_sk_inbox, &t->d_defer})
         b->release();
     if (t->shadow) { (void)hipFree(t->shadow); t->shadow = nullptr; t->shadow_cap = 0; t->shadow_empty = true; t->shadow_keys = 0; }
     if (t->shadow32) { (void)hipFree(t->shadow32); t->shadow32 = nullptr; t->s32_empty = true; t->s32_keys = 0; t->s32_windows = 0; }
@@ -784,18 +808,22 @@ kct_status kct_release_scratch(kct_table *t) {
 }
 
 kct_status kct_sync(kct_table *t) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));  // flushes what deferred mode has buffered
     HIP_TRY(hipStreamSynchronize(t->stream));
     return KCT_OK;
 }
 
 kct_status kct_set_deferred(kct_table *t, int on) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));  // flushes what is buffered
     t->deferred = on != 0;
+    t->defer_device = on != 0;
     return KCT_OK;
 }
 
 kct_status kct_set_path(kct_table *t, int mode) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     if (mode < 0 || mode > 3) { set_err("mode must be 0, 1, 2 or 3"); return KCT_ERR_ARG; }
     if (mode == 3 && t->k > 64) { set_err("the dedupe-first paths need k <= 64"); return KCT_ERR_ARG; }
@@ -807,9 +835,11 @@ kct_status kct_set_path(kct_table *t, int mode) {
     return KCT_OK;
 }
 
-kct_status kct_profile_enable(kct_table *t, int on) { KCT_TRY(use(t)); t->prof_on = on != 0; return KCT_OK; }
+kct_status kct_profile_enable(kct_table *t, int on) {
+    KCT_BORROW(t); KCT_TRY(use(t)); t->prof_on = on != 0; return KCT_OK; }
 
 kct_status kct_profile_reset(kct_table *t) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     prof_collect(t);
     t->prof.clear();
@@ -817,6 +847,7 @@ kct_status kct_profile_reset(kct_table *t) {
 }
 
 kct_status kct_profile_read(kct_table *t, int index, char *name_out, size_t name_cap, uint64_t *launches, double *total_ms) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     prof_collect(t);
     if (index < 0 || (size_t)index >= t->prof.size()) return KCT_ERR_ARG;

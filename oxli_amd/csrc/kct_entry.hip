@@ -139,6 +139,17 @@ kct_status flush_pending(kct_table *t) {
     return st;
 }
 
+// what kct_consume_device has staged (its calls' streams behind one another, each in records of its own) -> counted as one stream
+kct_status flush_deferred_device(kct_table *t) {
+    const size_t used = t->defer_used;
+    if (!used) return KCT_OK;
+    t->defer_used = 0; t->defer_windows = 0;   // consume_stream -> ... -> use() must not re-enter
+    u64 n = 0;
+    const kct_status st = consume_stream(t, (const unsigned char *)t->d_defer.p, used, &n);
+    if (st != KCT_OK) t->poisoned = true;   // (counts already reported to the caller are missing for good)
+    return st;
+}
+
 // hashes of all windows of the staged stream [0, nbytes) into d_aux; returns first bad window index
 kct_status hash_stream(kct_table *t, u64 nbytes, u64 nwin, u64 *first_bad) {
     KCT_TRY(t->d_aux.reserve(nwin * 8));
@@ -165,6 +176,7 @@ extern "C" {
 
 kct_status kct_hash_windows(kct_table *t, const char *seq, size_t len, uint64_t *hashes_out, size_t cap, uint64_t *n_windows,
                             uint64_t *first_bad) {
+    KCT_BORROW(t);
     KCT_TRY(use_consume(t));
     if ((!seq && len) || !n_windows || !first_bad) { set_err("null argument"); return KCT_ERR_ARG; }
     const u64 nwin = len >= t->k ? len - t->k + 1 : 0;
@@ -179,6 +191,7 @@ kct_status kct_hash_windows(kct_table *t, const char *seq, size_t len, uint64_t 
 }
 
 kct_status kct_hash_kmer(kct_table *t, const char *kmer, size_t len, uint64_t *hash_out) {
+    KCT_BORROW(t);
     KCT_TRY(use_consume(t));
     if (!kmer || !hash_out) { set_err("null argument"); return KCT_ERR_ARG; }
     if ((uint8_t)len != t->k) { set_err("wrong ksize"); return KCT_ERR_WRONG_KSIZE; }  // lib.rs:66 `len as u8`
@@ -190,6 +203,7 @@ kct_status kct_hash_kmer(kct_table *t, const char *kmer, size_t len, uint64_t *h
 }
 
 kct_status kct_count(kct_table *t, const char *kmer, size_t len, uint64_t *count_out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     if ((uint8_t)len != t->k) { set_err("kmer size does not match count table ksize"); return KCT_ERR_WRONG_KSIZE; }
     u64 h;
@@ -202,6 +216,7 @@ kct_status kct_count(kct_table *t, const char *kmer, size_t len, uint64_t *count
 }
 
 kct_status kct_get(kct_table *t, const char *kmer, size_t len, uint64_t *count_out) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     if ((uint8_t)len != t->k) { set_err("kmer size does not match count table ksize"); return KCT_ERR_WRONG_KSIZE; }
     u64 h;
@@ -214,7 +229,8 @@ int kct_consume_will_defer(const kct_table *t, size_t len, int skip_bad) {
 }
 
 kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out) {
-    if (t && t->deferred && skip_bad && len + 64 < kPendingBytes / 2) {
+    KCT_BORROW(t);
+    if (t && t->deferred && !t->poisoned && skip_bad && len + 64 < kPendingBytes / 2) {   // (a poisoned table: use_consume below reports it)
         // deferred mode: buffer the record, answer from the host-side validity scan, count later
         if ((!seq && len) || !n_out) { set_err("null argument"); return KCT_ERR_ARG; }
         *n_out = 0;
@@ -259,6 +275,7 @@ kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, 
 
 kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *offsets, size_t nrec, int skip_bad,
                              uint64_t *n_total, uint64_t *bad_record, uint64_t *bad_position) {
+    KCT_BORROW(t);
     KCT_TRY(use_consume(t));
     if (!n_total || (nrec && !offsets)) { set_err("null argument"); return KCT_ERR_ARG; }
     if (nrec && !bytes && offsets[nrec] != offsets[0]) { set_err("null argument"); return KCT_ERR_ARG; }  // all-empty records need no bytes
@@ -463,6 +480,7 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
 }
 
 kct_status kct_consume_device_packed(kct_table *t, const void *d_codes, const void *d_valid, size_t nbases, uint64_t consumed_bytes, uint64_t *n_total) {
+    KCT_BORROW(t);
     KCT_TRY(use_consume(t));
     if (!n_total || ((!d_codes || !d_valid) && nbases)) { set_err("null argument"); return KCT_ERR_ARG; }
     if (((uintptr_t)d_codes & 3) != 0 || ((uintptr_t)d_valid & 1) != 0) { set_err("d_codes / d_valid must be 4- / 2-byte aligned"); return KCT_ERR_ARG; }
@@ -482,15 +500,49 @@ kct_status kct_pack_stream_device(const void *d_stream, size_t nbytes, void *d_c
 }
 
 kct_status kct_set_packed_upload(kct_table *t, int on) {
+    KCT_BORROW(t);
     if (!t) { set_err("null table handle"); return KCT_ERR_ARG; }
     t->packed_upload = on != 0;
     return KCT_OK;
 }
 
 kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes, uint64_t *n_total) {
-    KCT_TRY(use_consume(t));
+    KCT_BORROW(t);
+    KCT_TRY(use_device(t));
+    if (t->pending_used) KCT_TRY(flush_pending(t));
     if (!n_total || (!d_stream && nbytes)) { set_err("null argument"); return KCT_ERR_ARG; }
     if (((uintptr_t)d_stream & 15) != 0) { set_err("d_stream must be 16-byte aligned"); return KCT_ERR_ARG; }
+    // A call that is small for the table is staged behind the earlier ones and counted with them (kct_internal.h defer_device): the
+    // table then sees ONE large pass -- its two-level paths, its dedupe probe -- where a caller feeds a large input in pieces.
+    const u64 npos = nbytes >= (u64)t->k ? (u64)nbytes - t->k + 1 : 0;
+    if (t->defer_device && t->k <= 255 && npos && npos < 4 * t->cap) {
+        const u64 padded = (((u64)nbytes + 15) & ~15ULL) + 16;   // (the stream, separators up to a 16-byte boundary, one unit of separators)
+        size_t free_b = 0, total_b = 0;
+        u64 limit = 32ULL << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) limit = std::min<u64>(limit, ((u64)free_b + t->d_defer.cap) / 4);
+        if (t->defer_used + padded > limit && t->defer_used) KCT_TRY(flush_deferred_device(t));
+        if (padded <= limit) {
+            KCT_TRY(t->d_defer.reserve_keep(t->defer_used + padded, t->defer_used, t->stream));
+            du64 *d_good = t->d_counters + kNumCounters + 2;   // scratch word 2
+            HIP_TRY(hipMemsetAsync(d_good, 0, 8, t->stream));
+            {
+                ProfScope ps(t, "stage_stream_kernel");
+                const u64 tiles = (padded + kct::kPartTile - 1) / kct::kPartTile;
+                hipLaunchKernelGGL(kct::stage_stream_kernel, dim3((unsigned)std::min<u64>(tiles, 4 * (u64)t->num_cus)), dim3(kct::kPartThreads), 0, t->stream,
+                                   (const unsigned char *)d_stream, (u64)nbytes, (int)t->k, (unsigned char *)t->d_defer.p + t->defer_used, padded, d_good);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(t->h_counters, d_good, 8, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));   // (the caller may reuse its buffer when this returns; n is wanted now)
+            *n_total = t->h_counters[0];
+            t->defer_used += padded;
+            t->defer_windows += npos;
+            t->consumed += consumed_bytes;
+            if (t->defer_windows >= 32 * t->cap) KCT_TRY(flush_deferred_device(t));
+            return KCT_OK;
+        }
+    }
+    if (t->defer_used) KCT_TRY(flush_deferred_device(t));
     KCT_TRY(consume_stream(t, (const unsigned char *)d_stream, nbytes, n_total));
     t->consumed += consumed_bytes;
     return KCT_OK;

@@ -221,6 +221,7 @@ struct Mapping {
 
 extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_bad, uint64_t *n_total, uint64_t *n_records,
                                        uint64_t *n_bases) {
+    KCT_BORROW(t);
     KCT_TRY(use_consume(t));
     if (!path || !n_total) { set_err("null argument"); return KCT_ERR_ARG; }
     if (!skip_bad) { set_err("kct_consume_file supports skip_bad_kmers=True only; use kct_consume_batch for error mode"); return KCT_ERR_ARG; }

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <pthread.h>
 #include <new>
 #include <string>
 #include <thread>
@@ -167,6 +168,20 @@ struct kct_table {
     kcth::PinnedBuf h_pending;
     size_t pending_used = 0;
     u64 pending_records = 0;
+    // ... and its device-side twin: kct_consume_device calls that are small for the table (fewer than 4 window starts per slot) are
+    // COPIED behind one another into d_defer (their good windows counted on the way, for the n the call returns) and counted together
+    // when anything else touches the table, when 32 window starts per slot have gathered, or when the buffer is full -- a caller that
+    // feeds a large input in pieces gets the passes (and the path choice) of one large call
+    bool defer_device = true;
+    kcth::DevBuf d_defer;
+    size_t defer_used = 0;
+    u64 defer_windows = 0;
+    // One caller at a time (the reference's `&mut self` under the GIL, lib.rs:546).  Call glue may release the GIL around a device
+    // pass (csrc/pyfast.c, ctypes, a pyo3 allow_threads), so a second thread CAN arrive: it is turned away (KCT_ERR_BUSY, pyo3's
+    // "Already borrowed") instead of racing the first one.  owner = the thread inside an entry point (0 = none); the same thread may
+    // nest (an entry point that calls another).
+    std::atomic<unsigned long long> owner{0};
+    int owner_depth = 0;
     bool poisoned = false;  // a device pass over buffered records failed half-way: counts already reported are missing for good,
                             // so every later call on this table fails too (kct_clear resets it)
     // packed input (2-bit codes + validity bits, 16 bases per group): set while a packed stream is being counted; the `d_stream`
@@ -242,6 +257,25 @@ struct kct_table {
 
 namespace kcth {
 
+struct Borrow {  // held by every C-ABI entry point for as long as it runs
+    kct_table *t;
+    bool ok = true;
+    explicit Borrow(kct_table *t_) : t(t_) {
+        if (!t) return;
+        const unsigned long long me = (unsigned long long)pthread_self() | 1ULL;
+        unsigned long long none = 0;
+        if (t->owner.load(std::memory_order_relaxed) == me) { ++t->owner_depth; return; }
+        if (t->owner.compare_exchange_strong(none, me, std::memory_order_acquire)) { t->owner_depth = 1; return; }
+        ok = false;
+        set_err("Already borrowed: another thread is inside a call on this table (a kct_table takes one caller at a time)");
+    }
+    ~Borrow() {
+        if (t && ok && --t->owner_depth == 0) t->owner.store(0, std::memory_order_release);
+    }
+    Borrow(const Borrow &) = delete;
+};
+#define KCT_BORROW(t) kcth::Borrow borrow_##t(t); if (!borrow_##t.ok) return KCT_ERR_BUSY
+
 struct ProfScope {
     kct_table *t;
     int idx = -1;
@@ -275,6 +309,7 @@ kct_status flush_shadow(kct_table *t);   // both shadows' pending counts and the
 void parallel_memcpy(void *dst, const void *src, size_t nbytes);  // several threads above 8 MiB
 kct_status use_device(kct_table *t);  // select the device only
 kct_status flush_pending(kct_table *t);
+kct_status flush_deferred_device(kct_table *t);  // kct_entry.hip: counts what kct_consume_device has staged
 kct::TableGeom geom(const kct_table *t);
 kct::TableView view(kct_table *t, u64 spill_cap);
 int log2_u64(u64 v);

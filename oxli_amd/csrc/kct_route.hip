@@ -233,7 +233,6 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     const int k = t->k;
     if (world < 1 || world > kct::kSkMaxWorld || rank >= world) { set_err("bad world / rank"); return KCT_ERR_ARG; }
     if (ops && (!ops->alloc || !ops->exchange_sizes || !ops->start || !ops->wait)) { set_err("kct_exchange_ops needs alloc, exchange_sizes, start and wait"); return KCT_ERR_ARG; }
-    if (world == 1) ops = nullptr;
     const bool solo = !ops && world > 1;   // no exchange: of this rank's OWN records, count the k-mers it owns (what its peers own is dropped)
     if (k > 64) { set_err("the early route takes k <= 64"); return KCT_ERR_ARG; }
     Route r{t, world, rank, ops, t->num_cus};
@@ -390,6 +389,7 @@ using namespace kcth;
 
 extern "C" kct_status kct_consume_device_routed(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes, uint32_t world, uint32_t rank,
                                                 const kct_exchange_ops *ops, uint64_t max_windows, uint64_t *n_owned, uint64_t *stats16) {
+    KCT_BORROW(t);
     KCT_TRY(use_consume(t));
     if (!n_owned || (!d_stream && nbytes)) { set_err("null argument"); return KCT_ERR_ARG; }
     if (((uintptr_t)d_stream & 15) != 0) { set_err("d_stream must be 16-byte aligned"); return KCT_ERR_ARG; }
@@ -405,6 +405,7 @@ extern "C" kct_status kct_consume_device_routed(kct_table *t, const void *d_stre
 // units; dir[o * streams + s] = windows | base units << 32 of stream s (streams = kct_superkmer_streams(t)).
 extern "C" kct_status kct_superkmer_split_device(kct_table *t, const void *d_stream, size_t nbytes, uint32_t world, const void **d_parts, uint64_t *part_off,
                                                  uint64_t *part_bytes, uint64_t *dir) {
+    KCT_BORROW(t);
     KCT_TRY(use_consume(t));
     if (!d_parts || !part_off || !part_bytes || !dir || (!d_stream && nbytes)) { set_err("null argument"); return KCT_ERR_ARG; }
     if (world < 1 || world > kct::kSkMaxWorld || t->k > 64) { set_err("bad world, or k > 64"); return KCT_ERR_ARG; }

@@ -102,6 +102,7 @@ extern "C" {
 const char *kct_load_rest_json(void) { return g_rest.c_str(); }
 
 kct_status kct_save(kct_table *t, const char *path, const char *tail_json) {
+    KCT_BORROW(t);
     KCT_TRY(use(t));
     if (!path || !tail_json) { set_err("null argument"); return KCT_ERR_ARG; }
     u64 n = 0;

@@ -49,8 +49,10 @@ static PyObject *fast_consume(PyObject *self, PyObject *const *args, Py_ssize_t 
     int st;
     /* A call that only appends to deferred mode's buffer (~60 ns) keeps the GIL: releasing and re-taking it would cost as much
      * again.  A call that will run a device pass -- the buffer is full, error mode, deferred mode off -- releases it, as ctypes
-     * does: other Python threads (a second feeder, torch.distributed's watchdog) must not stall behind the pass.  The str /
-     * bytes object stays alive through args[1]; its buffer is immutable. */
+     * does: other Python threads (torch.distributed's watchdog, a feeder of ANOTHER table) must not stall behind the pass.  A
+     * thread that calls into THIS table meanwhile is turned away by the library (KCT_ERR_BUSY -> RuntimeError("Already
+     * borrowed"), as pyo3 does for a `&mut self` method): a table takes one caller at a time.  The str / bytes object stays
+     * alive through args[1]; its buffer is immutable. */
     if (g_will_defer && g_will_defer((const void *)(uintptr_t)h, (size_t)len, skip)) st = g_consume((void *)(uintptr_t)h, p, (size_t)len, skip, &n);
     else {
         Py_BEGIN_ALLOW_THREADS

@@ -72,6 +72,25 @@ __device__ __forceinline__ void sk_sliding_min(u32 (&A)[NP]) {
     }
 }
 
+// 16-bit lanes of a 32-bit word (v_pk_* instructions)
+typedef unsigned short sk_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 sk_pk_scramble(u32 x) {  // sk_scramble on both halves
+    sk_us2 v = __builtin_bit_cast(sk_us2, x);
+    v *= (unsigned short)0x9E3Bu; v ^= v >> (unsigned short)7;
+    v *= (unsigned short)0x6A75u; v ^= v >> (unsigned short)9;
+    return __builtin_bit_cast(u32, v);
+}
+__device__ __forceinline__ u32 sk_pk_owner(u32 x, u32 world) {  // sk_owner on both halves (world <= 64: ten bits of the product suffice)
+    sk_us2 v = __builtin_bit_cast(sk_us2, x);
+    v *= (unsigned short)0x9E37u; v >>= (unsigned short)6;
+    v *= (unsigned short)world; v >>= (unsigned short)10;
+    return __builtin_bit_cast(u32, v);
+}
+// flags in bit 7 of the four bytes of f -> bits 0..3
+__device__ __forceinline__ u32 sk_gather4(u32 f) { return (((f >> 7) * 0x00204081u) >> 21) & 0xFu; }
+// 0x80 in every byte of d that is not zero
+__device__ __forceinline__ u32 sk_nonzero_bytes(u32 d) { return (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u; }
+
 template <int K>
 __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const unsigned char *__restrict__ stream, u64 nbytes, u64 ntiles, SplitArgs a) {
     constexpr int M = K < kSkM ? K : kSkM, W = K - M + 1;
@@ -87,22 +106,26 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
     __shared__ __attribute__((aligned(16))) u32 sb[kSkStageWords];      // outgoing bases, [world][capBw]
     __shared__ __attribute__((aligned(16))) u32 ss[kSkStageWords / 2];  // outgoing start bits, [world][capBw / 2]
     __shared__ u64 cur[kSkMaxWorld];       // per owner: windows (low half) | bases (high half) staged, carry included
-    __shared__ u64 cnt[kSkMaxWorld];       // the same, counted ahead of the copy
-    __shared__ u32 filledB[kSkMaxWorld], filledS[kSkMaxWorld], runs_n[kSkMaxWorld];
-    __shared__ u32 s_fits;
+    __shared__ u64 cur0[kSkMaxWorld];      // ... as it stood when the tile began (the carry alone)
+    __shared__ __attribute__((aligned(16))) uint4 carryB[kSkMaxWorld], carryS[kSkMaxWorld];  // the carried partial units, for a tile that has to be redone
+    __shared__ u32 filledB[kSkMaxWorld], filledS[kSkMaxWorld];
+    __shared__ u32 s_over, s_runs;
     const u32 world = a.world, t = threadIdx.x;
-    const u32 capBw = (u32)(kSkStageWords / world) & ~3u;      // staging words per owner (whole 16-byte units)
+    const u32 capBw = (u32)(kSkStageWords / world) & ~7u;      // staging words per owner (whole 16-byte units of bases AND of start bits)
     const u32 capB = capBw * 16u;                              // ... in bases, and as many window bits
+    const u32 capU = capBw / 4, capSU = capBw / 8;             // ... in units
+    const u32 invU = 0xFFFFFFFFu / capU + 1u, invSU = 0xFFFFFFFFu / capSU + 1u;   // unit index -> owner by a multiply (indices < 2^12)
     // a sub-tile of g windows always fits: at most g / 2 runs of one owner (+ the few that kSkMaxRun cuts), K bases each, behind a
     // carry of < 64 bases.  gsafe = the largest power of two g with (g / 2) K + 16 K + 64 <= capB (16 holds for every world <= 64)
     u32 gsafe = 16;
     while (gsafe < (u32)kPartTile && (u64)gsafe * K + 16 * K + 64 <= capB) gsafe <<= 1;
     for (u32 i = t; i < (u32)kSkStageWords; i += kPartThreads) sb[i] = 0;
     for (u32 i = t; i < (u32)kSkStageWords / 2; i += kPartThreads) ss[i] = 0;
-    if (t < kSkMaxWorld) { cur[t] = 0; cnt[t] = 0; filledB[t] = 0; filledS[t] = 0; runs_n[t] = 0; }
-    if (t == 0) { tc[0] = 0; emask[kPartThreads] = 0xFFFF; }
+    if (t < kSkMaxWorld) { cur[t] = 0; cur0[t] = 0; filledB[t] = 0; filledS[t] = 0; carryB[t] = make_uint4(0, 0, 0, 0); carryS[t] = make_uint4(0, 0, 0, 0); }
+    if (t == 0) { tc[0] = 0; emask[kPartThreads] = 0xFFFF; s_over = 0; s_runs = 0; }
     uint4 *my_bases = a.bases_out + (u64)blockIdx.x * world * a.cap_units;
     uint4 *my_starts = a.starts_out + (u64)blockIdx.x * world * a.cap_sunits;
+    u32 my_runs = 0;
 
     auto load_chunk = [&](u64 tile_base, int c) -> uint4 {
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -152,20 +175,41 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
                 if (t < 16) pre_halo = load_chunk(next * kPartTile, kPartThreads + t);
             }
         }
-        // ---- every m-mer of the tile, canonical and scrambled ----------------------------------------------------------------------
-        auto scramble16 = [&](u32 c0, u32 c1, u32 *out8) {  // the m-mers starting at the 16 bases of c0 (c1 = the following 16 bases)
-            const u64 win = ((u64)c0 << 32) | c1;
-            u32 fw = (u32)(win >> (64 - 2 * M)) & MM;
-            u32 r = __builtin_bitreverse32(fw) >> (32 - 2 * M);
-            u32 rc = (((r >> 1) & 0x5555u) | ((r & 0x5555u) << 1)) ^ MM;
+        // ---- every m-mer of the tile, canonical and scrambled: out8[i] = value 2 i | value 2 i + 1 << 16 -----------------------------
+        auto scramble16 = [&](u32 c0, u32 c1, u32 (&out8)[8]) {  // the m-mers starting at the 16 bases of c0 (c1 = the following 16 bases)
+            if constexpr (M == 8) {
+                // w_j = bases j .. j + 15: m-mer j in its high half, m-mer j + 8 in its low half -- one v_alignbit per PAIR of m-mers; the
+                // reverse complements likewise, out of the reverse complement R of all 32 bases: revcomp(w_j) = R >> 2 j, halves swapped
+                u64 y = __builtin_bitreverse64(((u64)c0 << 32) | c1);
+                y = ((y >> 1) & 0x5555555555555555ULL) | ((y & 0x5555555555555555ULL) << 1);
+                const u64 R = ~y;
+                const u32 Rhi = (u32)(R >> 32), Rlo = (u32)R;
+                u32 P[8];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (j) {
-                    fw = (u32)(win >> (64 - 2 * M - 2 * j)) & MM;
-                    rc = (rc >> 2) | ((3u - (fw & 3u)) << (2 * M - 2));
+                for (int j = 0; j < 8; ++j) {
+                    const u32 w = j ? __builtin_amdgcn_alignbit(c0, c1, 32 - 2 * j) : c0;
+                    const u32 r = j ? __builtin_amdgcn_alignbit(Rhi, Rlo, 2 * j) : Rlo;
+                    P[j] = sk_pk_scramble(sk_pkmin(w, __builtin_amdgcn_alignbit(r, r, 16)));   // high: value j, low: value j + 8
                 }
-                const u32 v = sk_scramble(fw < rc ? fw : rc);
-                if (j & 1) out8[j >> 1] |= v << 16; else out8[j >> 1] = v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    out8[i] = __builtin_amdgcn_perm(P[2 * i + 1], P[2 * i], 0x07060302u);       // value 2 i | value 2 i + 1 << 16
+                    out8[4 + i] = __builtin_amdgcn_perm(P[2 * i + 1], P[2 * i], 0x05040100u);   // value 8 + 2 i | value 9 + 2 i << 16
+                }
+            } else {
+                const u64 win = ((u64)c0 << 32) | c1;
+                u32 fw = (u32)(win >> (64 - 2 * M)) & MM;
+                u32 r = __builtin_bitreverse32(fw) >> (32 - 2 * M);
+                u32 rc = (((r >> 1) & 0x5555u) | ((r & 0x5555u) << 1)) ^ MM;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (j) {
+                        fw = (u32)(win >> (64 - 2 * M - 2 * j)) & MM;
+                        rc = (rc >> 2) | ((3u - (fw & 3u)) << (2 * M - 2));
+                    }
+                    const u32 v = sk_scramble(fw < rc ? fw : rc);
+                    if (j & 1) out8[j >> 1] |= v << 16; else out8[j >> 1] = v;
+                }
             }
         };
         {
@@ -180,61 +224,61 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
             }
         }
         __syncthreads();
-        // ---- minimiser and owner of each of this thread's 16 windows; 0xFF = not a good window -------------------------------------
-        u32 ow[4];  // sixteen owner bytes
+        // ---- minimiser and owner of each of this thread's 16 windows, one byte each; 0xFF = not a good window ----------------------------
+        u32 ow[4];
         {
             u32 A[NP];
 #pragma unroll
             for (int j = 0; j < NP; ++j) A[j] = mm[8 * t + j];
             sk_sliding_min<W, NP>(A);
-            // validity as in walk_windows_encoded: run = valid bases in a row ending at the window's last base
+            // good windows: K valid bases in a row -- an erosion of the validity bits (base b in bit 63 - b) by doubling shifts
             constexpr int NWV = (15 + K + 15) / 16;
-            u64 vbits = 0; u32 vtail = 0;
+            u32 good;  // window j in bit j
+            if constexpr (NWV <= 4) {
+                u64 e = 0;
 #pragma unroll
-            for (int i = 0; i < NWV; ++i) {
-                const u64 v = tv[t + i];
-                if (i < 4) vbits |= v << (48 - 16 * i); else vtail = (u32)v;
-            }
-            int run;
-            {
-                u64 inv_hi = ~vbits;
-                if (K < 64) inv_hi &= ~0ULL << (64 - K);
-                run = inv_hi ? (int)__builtin_ctzll(inv_hi) - (64 - K) : K;
-            }
-            u32 vs;
-            {
-                const u64 v_lo = K < 64 ? (vbits << K) : 0ULL;
-                const u64 v_hi = K < 64 ? ((u64)vtail << 48) >> (64 - K) : (u64)vtail << 48;
-                vs = (u32)((v_lo | v_hi) >> 32);
-            }
-            ow[0] = ow[1] = ow[2] = ow[3] = 0;
+                for (int i = 0; i < NWV; ++i) e |= (u64)tv[t + i] << (48 - 16 * i);
+                int sft = 1;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const u32 mn = (A[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                const u32 o = run >= K ? sk_owner(mn, world) : 0xFFu;
-                ow[j >> 2] |= o << (8 * (j & 3));
-                const bool ok = (int)vs < 0;
-                vs <<= 1;
-                run = ok ? run + 1 : 0;
+                for (int lvl = 0; lvl < 6; ++lvl) if (2 * sft <= K) { e &= e << sft; sft *= 2; }
+                if (K - sft > 0) e &= e << (K - sft);
+                good = __builtin_bitreverse32((u32)(e >> 32)) & 0xFFFFu;
+            } else {
+                unsigned __int128 e = 0;
+#pragma unroll
+                for (int i = 0; i < NWV; ++i) e |= (unsigned __int128)tv[t + i] << (112 - 16 * i);
+                int sft = 1;
+#pragma unroll
+                for (int lvl = 0; lvl < 6; ++lvl) if (2 * sft <= K) { e &= e << sft; sft *= 2; }
+                if (K - sft > 0) e &= e << (K - sft);
+                good = __builtin_bitreverse32((u32)(e >> 96)) & 0xFFFFu;
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const u32 o = __builtin_amdgcn_perm(sk_pk_owner(A[2 * w + 1], world), sk_pk_owner(A[2 * w], world), 0x06040200u);  // four owner bytes
+                const u32 ok = ((((good >> (4 * w)) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;                                    // 0xFF per good window
+                ow[w] = o | ~ok;
             }
             reinterpret_cast<uint4 *>(own)[t] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
         __syncthreads();
-        // ---- runs: maximal stretches of good windows with one owner, cut every `cut` windows ----------------------------------------
+        // ---- runs: maximal stretches of good windows with one owner, cut every `cut` windows (cut >= 16, a power of two) ---------------
         const u32 prev_o = t ? own[16 * t - 1] : 0xFFu, next_o = t + 1 < kPartThreads ? own[16 * t + 16] : 0xFFu;
         u32 smask = 0;
         auto build_masks = [&](u32 cut) {
             u32 em = 0;
             smask = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const u32 o = (ow[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                const u32 op = j ? (ow[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 0xFFu : prev_o;
-                const u32 on = j < 15 ? (ow[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu : next_o;
-                const u32 p = 16 * t + j;
-                if (o != 0xFFu && (o != op || (p & (cut - 1)) == 0)) smask |= 1u << j;
-                if (o != 0xFFu && (o != on || ((p + 1) & (cut - 1)) == 0)) em |= 1u << j;
+            for (int w = 0; w < 4; ++w) {
+                const u32 o = ow[w];
+                const u32 before = __builtin_amdgcn_alignbit(o, w ? ow[w - 1] : prev_o << 24, 24);   // every byte's left neighbour
+                const u32 after = __builtin_amdgcn_alignbit(w < 3 ? ow[w + 1] : next_o, o, 8);        // ... right neighbour
+                const u32 valid = ~o & 0x80808080u;                                                   // (owners are < 64; 0xFF = no window)
+                smask |= sk_gather4(sk_nonzero_bytes(o ^ before) & valid) << (4 * w);
+                em |= sk_gather4(sk_nonzero_bytes(o ^ after) & valid) << (4 * w);
             }
+            if (((16 * t) & (cut - 1)) == 0 && !(ow[0] & 0x80u)) smask |= 1u;
+            if (((16 * t + 16) & (cut - 1)) == 0 && !(ow[3] >> 31)) em |= 0x8000u;
             emask[t] = (unsigned short)em;
         };
         // visit(j, n, owner) for every run that starts at this thread's window j, first <= 16 t + j < last
@@ -260,87 +304,96 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
                 visit(j, n, (ow[j >> 2] >> (8 * (j & 3))) & 0xFFu);
             }
         };
-        build_masks(kSkMaxRun);
-        if (t < world) cnt[t] = cur[t];
-        if (t == 0) s_fits = 1;
-        __syncthreads();
-        for_runs(0, kPartTile, [&](u32, u32 n, u32 o) { atomicAdd(&cnt[o], (u64)n | ((u64)(n + K - 1) << 32)); });
-        __syncthreads();
-        if (t < world && (u32)(cnt[t] >> 32) > capB) s_fits = 0;   // (windows <= bases, and the start bits have as much room)
-        __syncthreads();
-        const bool fits = s_fits != 0;
-        const u32 sub = fits ? (u32)kPartTile : gsafe;
-        if (!fits) {  // (rare: far more runs than random sequence gives) -- the tile goes out in pieces that cannot overflow the staging
-            __syncthreads();
-            build_masks(sub < kSkMaxRun ? sub : kSkMaxRun);
-            __syncthreads();
-        }
-        for (u32 first = 0; first < (u32)kPartTile; first += sub) {
-            for_runs(first, first + sub, [&](u32 j, u32 n, u32 o) {
-                const u32 L = n + K - 1;
-                const u64 cw = atomicAdd(&cur[o], (u64)n | ((u64)L << 32));
-                const u32 wpos = (u32)cw, bpos = (u32)(cw >> 32);
-                atomicAdd(&runs_n[o], 1u);
-                atomicOr(&ss[o * (capBw / 2) + (wpos >> 5)], 1u << (wpos & 31u));
-                // L bases from tile bit 2 (16 t + j) to staging bit 2 bpos (both MSB-first), one destination word at a time
-                u32 *dst = sb + o * capBw;
-                const u32 dbit = 2 * bpos, sbit = 32 + 2 * (16 * t + j), nbits = 2 * L;
-                const u32 dw1 = (dbit + nbits - 1) >> 5;
-                for (u32 dw = dbit >> 5; dw <= dw1; ++dw) {
-                    const int rel = (int)(dw << 5) - (int)dbit;          // this word's first bit, counted from the run's first bit
-                    const u32 sp = (u32)((int)sbit + rel);               // >= 1: tc[0] is a zero word
-                    const u32 wi = sp >> 5, sh = sp & 31u;
-                    u32 val = (u32)(((((u64)tc[wi] << 32) | tc[wi + 1]) << sh) >> 32);
-                    if (rel < 0) val &= 0xFFFFFFFFu >> (u32)(-rel);
-                    const int past = rel + 32 - (int)nbits;
-                    if (past > 0) val &= 0xFFFFFFFFu << (u32)past;
-                    atomicOr(&dst[dw], val);
+        // a run takes its place in its owner's staging with ONE ds_add_rtn_u64 and is copied there; a run that would not fit raises s_over
+        auto emit = [&](u32 j, u32 n, u32 o) {
+            const u32 L = n + K - 1;
+            const u64 cw = atomicAdd(&cur[o], (u64)n | ((u64)L << 32));
+            const u32 wpos = (u32)cw, bpos = (u32)(cw >> 32);
+            if (bpos + L > capB) { s_over = 1u; return; }
+            atomicOr(&ss[o * (capBw / 2) + (wpos >> 5)], 1u << (wpos & 31u));
+            // L bases from tile bit 2 (16 t + j) to staging bit 2 bpos (both MSB-first), one destination word at a time
+            u32 *dst = sb + o * capBw;
+            const u32 dbit = 2 * bpos, sbit = 32 + 2 * (16 * t + j), nbits = 2 * L;
+            const u32 dw1 = (dbit + nbits - 1) >> 5;
+            for (u32 dw = dbit >> 5; dw <= dw1; ++dw) {
+                const int rel = (int)(dw << 5) - (int)dbit;          // this word's first bit, counted from the run's first bit
+                const u32 sp = (u32)((int)sbit + rel);               // >= 1: tc[0] is a zero word
+                const u32 wi = sp >> 5, sh = sp & 31u;
+                u32 val = (u32)(((((u64)tc[wi] << 32) | tc[wi + 1]) << sh) >> 32);
+                if (rel < 0) val &= 0xFFFFFFFFu >> (u32)(-rel);
+                const int past = rel + 32 - (int)nbits;
+                if (past > 0) val &= 0xFFFFFFFFu << (u32)past;
+                atomicOr(&dst[dw], val);
+            }
+        };
+        // whole 16-byte units leave for this workgroup's regions; the partial ones move to the front for the next tile
+        auto flush = [&]() {
+            for (u32 u = t; u < world * capU; u += kPartThreads) {
+                const u32 o = __umulhi(u, invU), ul = u - o * capU;
+                if (ul < (u32)(cur[o] >> 32) / kSkUnitBases) {
+                    uint4 *src = reinterpret_cast<uint4 *>(sb) + u;
+                    const uint4 v = *src;
+                    *src = make_uint4(0, 0, 0, 0);
+                    const u32 at = filledB[o] + ul;
+                    if (at < a.cap_units) my_bases[(u64)o * a.cap_units + at] = v;
                 }
-            });
-            __syncthreads();
-            // ---- whole 16-byte units leave for this workgroup's regions; the partial ones stay for the next tile ----------------------
-            for (u32 o = 0; o < world; ++o) {
-                const u64 cw = cur[o];
-                const u32 ub = (u32)(cw >> 32) / kSkUnitBases, us = (u32)cw / kSkUnitWindows;
-                const u32 fb = filledB[o], fs = filledS[o];
-                for (u32 u = t; u < ub + us; u += kPartThreads) {
-                    if (u < ub) {
-                        uint4 *src = reinterpret_cast<uint4 *>(sb + o * capBw) + u;
-                        const uint4 v = *src;
-                        *src = make_uint4(0, 0, 0, 0);
-                        if (fb + u < a.cap_units) my_bases[(u64)o * a.cap_units + fb + u] = v;
-                    } else {
-                        const u32 w = u - ub;
-                        uint4 *src = reinterpret_cast<uint4 *>(ss + o * (capBw / 2)) + w;
-                        const uint4 v = *src;
-                        *src = make_uint4(0, 0, 0, 0);
-                        if (fs + w < a.cap_sunits) my_starts[(u64)o * a.cap_sunits + fs + w] = v;
-                    }
+            }
+            for (u32 u = t; u < world * capSU; u += kPartThreads) {
+                const u32 o = __umulhi(u, invSU), ul = u - o * capSU;
+                if (ul < (u32)cur[o] / kSkUnitWindows) {
+                    uint4 *src = reinterpret_cast<uint4 *>(ss) + u;
+                    const uint4 v = *src;
+                    *src = make_uint4(0, 0, 0, 0);
+                    const u32 at = filledS[o] + ul;
+                    if (at < a.cap_sunits) my_starts[(u64)o * a.cap_sunits + at] = v;
                 }
             }
             __syncthreads();
             if (t < world) {
                 const u64 cw = cur[t];
                 const u32 tb = (u32)(cw >> 32), tw = (u32)cw, ub = tb / kSkUnitBases, us = tw / kSkUnitWindows;
-                if (ub) {
-                    uint4 *base = reinterpret_cast<uint4 *>(sb + t * capBw);
-                    const uint4 v = base[ub];
-                    base[ub] = make_uint4(0, 0, 0, 0);
-                    base[0] = v;
-                }
-                if (us) {
-                    uint4 *base = reinterpret_cast<uint4 *>(ss + t * (capBw / 2));
-                    const uint4 v = base[us];
-                    base[us] = make_uint4(0, 0, 0, 0);
-                    base[0] = v;
-                }
+                uint4 *bb = reinterpret_cast<uint4 *>(sb + t * capBw), *sbits = reinterpret_cast<uint4 *>(ss + t * (capBw / 2));
+                if (ub) { const uint4 v = bb[ub]; bb[ub] = make_uint4(0, 0, 0, 0); bb[0] = v; }
+                if (us) { const uint4 v = sbits[us]; sbits[us] = make_uint4(0, 0, 0, 0); sbits[0] = v; }
+                carryB[t] = bb[0]; carryS[t] = sbits[0];
                 filledB[t] += ub; filledS[t] += us;
-                cur[t] = (u64)(tw % kSkUnitWindows) | ((u64)(tb % kSkUnitBases) << 32);
+                cur[t] = cur0[t] = (u64)(tw % kSkUnitWindows) | ((u64)(tb % kSkUnitBases) << 32);
             }
             __syncthreads();
+        };
+        build_masks(kSkMaxRun);
+        __syncthreads();
+        my_runs += (u32)__builtin_popcount(smask);
+        for_runs(0, kPartTile, emit);
+        __syncthreads();
+        if (s_over == 0) flush();
+        else {
+            // (rare: far more runs than random sequence gives, or nearly all for one owner) -- the staging goes back to what the tile
+            // found, and the tile goes out in pieces that cannot overflow it
+            __syncthreads();
+            for (u32 i = t; i < (u32)kSkStageWords; i += kPartThreads) sb[i] = 0;
+            for (u32 i = t; i < (u32)kSkStageWords / 2; i += kPartThreads) ss[i] = 0;
+            if (t == 0) s_over = 0;
+            __syncthreads();
+            if (t < world) {
+                *reinterpret_cast<uint4 *>(sb + t * capBw) = carryB[t];
+                *reinterpret_cast<uint4 *>(ss + t * (capBw / 2)) = carryS[t];
+                cur[t] = cur0[t];
+            }
+            my_runs -= (u32)__builtin_popcount(smask);
+            build_masks(gsafe < kSkMaxRun ? gsafe : kSkMaxRun);
+            __syncthreads();
+            my_runs += (u32)__builtin_popcount(smask);
+            for (u32 first = 0; first < (u32)kPartTile; first += gsafe) {
+                for_runs(first, first + gsafe, emit);
+                __syncthreads();
+                flush();
+            }
         }
     }
     // ---- the partial units, zero-padded; what every stream holds -----------------------------------------------------------------------
+    atomicAdd(&s_runs, my_runs);
+    __syncthreads();
     if (t < world) {
         const u64 cw = cur[t];
         const u32 rb = (u32)(cw >> 32), rw = (u32)cw;
@@ -355,7 +408,7 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
             ++fs;
         }
         const u64 idx = (u64)blockIdx.x * world + t;
-        a.nwin[idx] = nwin; a.nunits[idx] = fb; a.nsunits[idx] = fs; a.nruns[idx] = runs_n[t];
+        a.nwin[idx] = nwin; a.nunits[idx] = fb; a.nsunits[idx] = fs; a.nruns[idx] = t == 0 ? s_runs : 0u;
         if (fb > a.cap_units || fs > a.cap_sunits) *a.overflow = 1ULL;
     }
 }

@@ -89,6 +89,8 @@ class KmerCountTable:
         msg = L.last_error()
         if st in (L.KCT_ERR_NOMEM,):
             raise MemoryError(msg)
+        if st == L.KCT_ERR_BUSY:
+            raise RuntimeError("Already borrowed")   # pyo3's message when a second thread enters a `&mut self` method (lib.rs:546)
         raise RuntimeError(f"libkct_hip error {st}: {msg}")
 
     # ---- hashing ----------------------------------------------------------------------------------

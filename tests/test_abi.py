@@ -49,6 +49,25 @@ def test_library_exports_nothing_else(lib):
     assert exported == _declared()   # built with -fvisibility=hidden: the C ABI is the only code the library exports
 
 
+def test_rccl_exchange_library_exports_its_header(lib, tmp_path):
+    """include/kct_rccl.h: kct_exchange_ops over RCCL, a library of its own (libkct_hip.so must not depend on RCCL)."""
+    import ctypes
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "kct_rccl.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(kct_rccl_[a-z_0-9]+)\s*\(", text))
+    assert {"kct_rccl_unique_id", "kct_rccl_create", "kct_rccl_ops", "kct_rccl_destroy"} <= declared
+    path = os.path.join(ROOT, "oxli_amd", "csrc", "libkct_rccl.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l} - {"_init", "_fini"}
+    assert exported == declared
+    handle = ctypes.CDLL(path)
+    assert all(hasattr(handle, n) for n in declared)
+    needed = subprocess.run(["readelf", "-d", lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()
+    src = tmp_path / "t.c"
+    src.write_text('#include "kct_rccl.h"\nint main(void){ kct_rccl *x = 0; (void)x; return KCT_RCCL_ID_BYTES == 128 ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")], check=True)
+
+
 def test_library_contains_gfx950_code_only(lib):
     data = open(lib.LIB_PATH, "rb").read()
     targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", data))

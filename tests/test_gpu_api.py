@@ -289,6 +289,33 @@ def test_c_program_through_the_abi(tmp_path):
     assert out[-1] == "error_mode status 3 position 1"      # KCT_ERR_BAD_KMER after one good 4-mer (ACGT | CGTN is bad)
 
 
+@pytest.mark.parametrize("k,R,L,G,passes", [(21, 200_000, 150, 2_000_000, 3), (51, 3_000, 10_000, 3_000_000, 4)])
+def test_c_program_routes_through_rccl_with_a_world_of_one(tmp_path, k, R, L, G, passes):
+    """tests/c_rccl_example.c: a plain-C process (no torch, no Python in it) drives kct_consume_device_routed with the RCCL
+    exchange of libkct_rccl.so -- communicator, size all-to-all, asynchronous ncclSend / ncclRecv payload, pipelined passes -- at
+    world = 1.  Its routed table, its directly counted table and the CPU oracle's must agree."""
+    import os
+    import subprocess
+
+    import oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_rccl_example"
+    libdir = os.path.join(root, "oxli_amd", "csrc")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+                    os.path.join(root, "tests", "c_rccl_example.c"), "-L", libdir, "-lkct_hip", "-lkct_rccl", "-L", "/opt/rocm/lib", "-lamdhip64",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    run = subprocess.run([str(exe), str(k), str(R), str(L), str(G), str(passes)], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    out = run.stdout.splitlines()
+    plain, routed, tail = out[0].split(), out[1].split(), out[2].split()
+    assert plain[0] == "plain" and routed[0] == "routed" and plain[1:] == routed[1:]
+    ss = oracle.ShardSet(k, L, genome=oracle.synth_genome(G, 42), nreads=R, seed_r=1337, threads=8)
+    d = ss.digest()
+    assert [int(v) for v in routed[2::2][:3]] == [d["n"], d["len"], d["sum_counts"]]
+    assert [int(v) for v in routed[8:11]] == [d["sum_hc"], d["xor_hc"], d["sum_sq"]]
+    assert int(tail[1]) == passes and int(tail[3]) > 0 and int(tail[7]) == 0
+
+
 # ---- analytics on the device (kct_analytics.hip) against plain dict arithmetic --------------------------
 def _random_table(KCT, rng, n, kspace, with_zero, k=21):
     t, d = KCT(k), {}

@@ -234,3 +234,45 @@ def test_batches_from_two_host_threads_share_the_packer_pool(KCT):
         dk, dc = t.dump_arrays(1)
         rk, rc = ref.dump_arrays()
         assert np.array_equal(dk, rk) and np.array_equal(dc, 3 * rc)
+
+
+def test_a_second_thread_is_turned_away_not_raced(KCT):
+    """One caller at a time (lib.rs:546: `&mut self` under the GIL; pyo3 raises "Already borrowed" for a second one).  ctypes and the
+    call glue release the GIL around device passes, so a second thread can arrive while a pass runs: it must get RuntimeError("Already
+    borrowed") -- and the table must come out exactly as the first thread's calls alone leave it."""
+    import threading
+
+    import torch
+    G, R, L, k = 2_000_000, 400_000, 150, 21
+    reads = oracle.synth_reads(oracle.synth_genome(G, 3), 0, R, L, 5)
+    dev = torch.from_numpy(reads.reshape(-1)).cuda()
+    t = KCT(k, capacity=G)
+    t.set_deferred(False)   # every consume_device call is a device pass of ~1 ms
+    stop, seen, errors = threading.Event(), [], []
+
+    def intruder():
+        while not stop.is_set():
+            try:
+                t.get_hash(12345)
+            except RuntimeError as e:   # noqa: PERF203
+                (seen if "Already borrowed" in str(e) else errors).append(str(e))
+    th = threading.Thread(target=intruder)
+    th.start()
+    total = 0
+    for _ in range(30):
+        while True:   # (whoever comes second is turned away: that can be this thread too)
+            try:
+                total += t.consume_device(dev.data_ptr(), dev.numel(), R * L)
+                break
+            except RuntimeError as e:
+                if "Already borrowed" not in str(e):
+                    raise
+    stop.set()
+    th.join()
+    assert not errors, errors[:3]
+    assert seen, "the second thread never met a running call (or was let in)"
+    assert total == 30 * R * (L - k + 1) and t.sum_counts == total
+    ref, _, _ = oracle.baseline_consume(reads, L, k, 8, native=False)
+    dk, dc = t.dump_arrays(1)
+    rk, rc = ref.dump_arrays()
+    assert np.array_equal(dk, rk) and np.array_equal(dc, 30 * rc)
