@@ -49,14 +49,13 @@ for it in range(iters):
     for path in ("partitioned", "dedupe", "auto", "direct", "packed", "routed"):
         if path == "direct" and N * L > (100_000_000 if big else 30_000_000):
             continue
-        if path == "routed" and G < 50_000:   # a handful of k-mers at 10^7 windows: the early route refuses such skew (its rings
-            continue                          # cannot fall back to the direct kernel); the late route is the tool for it
+        if path == "routed" and k > 64:       # the early route cuts super-k-mers for k <= 64
+            continue
         cap = int(rng.choice([0, G, 4 * G])) or 0
-        if path == "routed":   # the early route's loop-back (world = 1): needs a table of >= 2^19 slots
-            cap = max(cap, 400_000)
         t = KmerCountTable(k, capacity=cap)
-        t.set_path("auto" if path in ("packed", "routed") else path)
-        mode = int(rng.choice([0, 1, 2] if k <= 21 else [0, 1] if k <= 32 else [0]))
+        # the early route's loop-back (world = 1: split, run directory, K1 over runs): the owner side on a path of the table's policy
+        t.set_path("auto" if path == "packed" else str(rng.choice(["auto", "partitioned", "dedupe"])) if path == "routed" else path)
+        max_windows = int(rng.choice([0, 1 << 20, 1 << 22]))
         tot = 0
         for rep in range(2):
             for a, b in zip(cut[:-1], cut[1:]):
@@ -66,9 +65,9 @@ for it in range(iters):
                     g0 = a * (L + 1) // 16
                     tot += t.consume_device_packed(pc.data_ptr() + 4 * g0, pv.data_ptr() + 2 * g0, (b - a) * (L + 1), (b - a) * L)
                 elif path == "routed":
-                    n_, st_ = C.c_uint64(), (C.c_uint64 * 8)()
-                    t._check(lib.kct_consume_device_routed(t._h, C.c_void_p(r.data_ptr() + a * (L + 1)), (b - a) * (L + 1), (b - a) * L, 1, 0, mode,
-                                                           None, None, None, C.byref(n_), st_))
+                    n_, st_ = C.c_uint64(), (C.c_uint64 * 16)()
+                    t._check(lib.kct_consume_device_routed(t._h, C.c_void_p(r.data_ptr() + a * (L + 1)), (b - a) * (L + 1), (b - a) * L, 1, 0, None,
+                                                           max_windows, C.byref(n_), st_))
                     tot += n_.value
                 else:
                     tot += t.consume_device(r.data_ptr() + a * (L + 1), (b - a) * (L + 1), (b - a) * L)
