@@ -30,7 +30,9 @@ namespace kct {
 template <u32 LISTCAP, class T, class Overflow>
 __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *fcount, int P, u32 D,
                                            T *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash, u64 bin_stride = 0, u64 ovf_hi = 0,
-                                           u32 min_lines = 1) {
+                                           u32 min_lines = 1, u32 ovf_shift = 31) {
+    // ovf_shift (u32 rings, ovf_hi set): the bin's bits from ovf_shift up are added to the first-level bin in ovf_hi (K1b with grouped
+    // super-bins: the sub-bin's top bits are the first-level bin's low bits)
     // min_lines: a bin's lines leave the ring only that many at a time (adjacent lane groups then store adjacent lines:
     // 128- or 256-byte writes instead of lone 64-byte ones); the drain takes whatever is left.
     constexpr u32 CH = 64 / sizeof(T);  // positions per 64-byte line
@@ -71,7 +73,7 @@ __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *f
             const u64 h = ((u64)v.y << 32) | v.x, c = ((u64)v.w << 32) | v.z;
             if (h) overflow_hash(h, c);
         } else {
-            const u64 hi = ovf_hi ? ovf_hi : (((u64)b << 32) | (1ULL << 63));  // compact values travel with bit 63 set (0 stays "nothing")
+            const u64 hi = ovf_hi ? ovf_hi + ((u64)(b >> ovf_shift) << 32) : (((u64)b << 32) | (1ULL << 63));  // compact values travel with bit 63 set (0 stays "nothing")
             if (v.x) overflow_hash(hi | v.x);
             if (v.y) overflow_hash(hi | v.y);
             if (v.z) overflow_hash(hi | v.z);

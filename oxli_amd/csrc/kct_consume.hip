@@ -497,7 +497,10 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     if (t->s32_dirty && t->s32_windows + npos >= (1ULL << 39)) KCT_TRY(flush_compact(t));
     const int sbits = t->s32_sbits;
     const bool two_level = sbits > kCompactBlockBits;
-    const int pbits = kCompactBlockBits, sub_bits = sbits - pbits;  // K1's bins are always the value's top 10 bits
+    const int pbits = kCompactBlockBits;                             // K1's bins are always the value's top 10 bits
+    const int gbits = compact_group_bits(sbits), sub_bits = sbits - pbits + gbits;  // second level: 2^gbits bins per super-bin, 2^sub_bits blocks each
+    const u64 nsuper = (1ULL << pbits) >> gbits;
+    const u64 W2 = two_level_writers(nsuper, t->num_cus);           // workgroups per super-bin, so that the second level fills the chip
     const u64 P = 1ULL << pbits, B = 1ULL << sbits;
     const int nwg = t->num_cus;
     const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile;
@@ -528,29 +531,31 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     aa.scratch = (const unsigned int *)t->d_scratch.p; aa.seg_stride = P * region_cap; aa.block_stride = region_cap;
     aa.region_count = (const unsigned int *)t->d_regions.p; aa.nregions = nwg;
     unsigned int ovf2_cap = 0, *d_ovf2_count = nullptr;
+    u64 n2 = 0;
     if (two_level) {
         // second level: one workgroup per super-bin spreads its entries over the super-bin's 2^sub_bits shadow blocks
-        const unsigned int out_cap = (region_capacity((double)npos / (double)B) + 63u) & ~63u;  // 256-byte multiples
-        ovf2_cap = overflow_capacity(npos / P);
-        KCT_TRY(t->d_scratch2.reserve(B * out_cap * 4));
-        KCT_TRY(t->d_regions2.reserve(B * 4));
-        KCT_TRY(t->d_irr2.reserve(P * ovf2_cap * 8 + P * 4));
-        d_ovf2_count = (unsigned int *)((du64 *)t->d_irr2.p + P * ovf2_cap);
+        const unsigned int out_cap = (region_capacity((double)npos / (double)B / (double)W2) + 63u) & ~63u;  // 256-byte multiples
+        n2 = nsuper * W2;   // second-level workgroups
+        ovf2_cap = overflow_capacity(npos / n2);
+        KCT_TRY(t->d_scratch2.reserve(B * W2 * out_cap * 4));
+        KCT_TRY(t->d_regions2.reserve(B * W2 * 4));
+        KCT_TRY(t->d_irr2.reserve(n2 * ovf2_cap * 8 + n2 * 4));
+        d_ovf2_count = (unsigned int *)((du64 *)t->d_irr2.p + n2 * ovf2_cap);
         kct::RepartitionArgs ra;
-        ra.mask = compact_slots(t) - 1; ra.block_bits = kct::kBlockBitsMax; ra.sub_bits = sub_bits;
+        ra.mask = compact_slots(t) - 1; ra.block_bits = kct::kBlockBitsMax; ra.sub_bits = sub_bits; ra.gbits = gbits;
         ra.in = t->d_scratch.p; ra.in_cap = region_cap; ra.in_count = (const unsigned int *)t->d_regions.p;
-        ra.nseg = nwg; ra.nbins = (int)P; ra.writers = 1;
+        ra.nseg = nwg << gbits; ra.nbins = (int)P; ra.writers = (int)W2;
         ra.out = t->d_scratch2.p; ra.out_cap = out_cap; ra.out_count = (unsigned int *)t->d_regions2.p;
         ra.ovf = (du64 *)t->d_irr2.p; ra.ovf_cap = ovf2_cap; ra.ovf_count = d_ovf2_count; ra.overflow = d_overflow; ra.ovf_n = nullptr;
         ra.min_lines = repartition_min_lines(t, kct::kRingEntries * 2, sub_bits, 4);
         {
             ProfScope ps(t, "repartition_kernel<compact>");
             // (one flush per slab, as the 64-bit variant does, was measured: K1b -5 %, but more overflow entries: no gain overall)
-            hipLaunchKernelGGL((kct::repartition_kernel<unsigned int, false>), dim3((unsigned)P), dim3(kct::kPartThreads), 0, t->stream, ra);
+            hipLaunchKernelGGL((kct::repartition_kernel<unsigned int, false>), dim3((unsigned)n2), dim3(kct::kPartThreads), 0, t->stream, ra);
         }
         HIP_TRY(hipGetLastError());
-        aa.scratch = (const unsigned int *)t->d_scratch2.p; aa.seg_stride = out_cap; aa.block_stride = out_cap;
-        aa.region_count = (const unsigned int *)t->d_regions2.p; aa.nregions = 1;
+        aa.scratch = (const unsigned int *)t->d_scratch2.p; aa.seg_stride = out_cap; aa.block_stride = W2 * out_cap;
+        aa.region_count = (const unsigned int *)t->d_regions2.p; aa.nregions = (int)W2;
     }
     aa.fresh = t->s32_empty ? 1 : 0; aa.overflow = d_overflow; aa.ablate = t->ablate;
     KCT_TRY(failed_blocks(t, B, &aa.failed));
@@ -584,10 +589,10 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
     if (two_level) {
         KCT_TRY(read_counters(t, c, &unused));
         if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // K1 / K1b gave up: K2 exited early, nothing was touched
-        if (t->lazy_empty && t->h_counters[kNumCounters + 7] == 0) KCT_TRY(reserve_pending(t, d_ovf_count, nwg, d_ovf2_count, P, &pend));
+        if (t->lazy_empty && t->h_counters[kNumCounters + 7] == 0) KCT_TRY(reserve_pending(t, d_ovf_count, nwg, d_ovf2_count, n2, &pend));
         else {
             u64 total = 0;
-            KCT_TRY(overflow_total(t, d_ovf_count, nwg, d_ovf2_count, P, &total));
+            KCT_TRY(overflow_total(t, d_ovf_count, nwg, d_ovf2_count, n2, &total));
             KCT_TRY(materialize(t));
             KCT_TRY(t->d_spill.reserve(std::max<u64>(total, 1) * 16));
             mv = view(t, std::max<u64>(total, 1));
@@ -600,7 +605,7 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
                            (const unsigned int *)d_ovf_count, nwg, ovf_cap, (const du64 *)d_overflow, mv, t->d_counters, k, (const du64 *)nullptr, pend);
         if (two_level)
             hipLaunchKernelGGL(kct::merge_overflow_kernel<2>, dim3(256), dim3(kct::kBlock), 0, t->stream, (const du64 *)t->d_irr2.p,
-                               (const unsigned int *)d_ovf2_count, (int)P, ovf2_cap, (const du64 *)d_overflow, mv, t->d_counters, k, (const du64 *)nullptr, pend);
+                               (const unsigned int *)d_ovf2_count, (int)n2, ovf2_cap, (const du64 *)d_overflow, mv, t->d_counters, k, (const du64 *)nullptr, pend);
     }
     HIP_TRY(hipGetLastError());
     u64 c2[4];
@@ -1068,25 +1073,50 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
             if (swap32) { t->shadow32 = t->probe_shadow32; t->s32_sbits = kCompactBlockBits; t->s32_nbins = 1024; t->s32_bin0 = 0; t->s32_empty = true; }
             if (swap64) { t->shadow = t->probe_shadow; t->shadow_cap = t->shadow ? kProbeShadowSlots : 0; t->shadow_block_bits = kct::kBlockBitsMax; t->shadow_empty = true; }
             const u64 table_before = t->n_keys, n_before = *n_out;
-            DedupeOutcome seen;
+            DedupeOutcome seen, seen1;
             bool handled = false;
             kct_status st = KCT_OK;
-            if (use_compact) st = consume_compact(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true, dry_run ? &seen : nullptr);
-            if (st == KCT_OK && !handled && !t->dedupe_off && (!dry_run || swap64))
-                st = consume_partitioned(t, d_stream + done, chunk_bytes, npos, n_out, &handled, true, true, dry_run ? &seen : nullptr);
+            // a dry run is made in two halves: the first sightings at two depths tell k-mers that never repeat (sequencing errors) from
+            // deep coverage of few k-mers (path_policy.h per_distinct_two_depths)
+            const u64 h1 = dry_run && npos >= (1ULL << 18) ? (npos / 2) & ~(u64)0xFFFF : 0;
+            auto probe_piece = [&](u64 off, u64 n, DedupeOutcome *out) -> kct_status {
+                const u64 bytes = std::min<u64>(nbytes - done - off, n + k - 1);
+                handled = false;
+                kct_status s_ = KCT_OK;
+                if (use_compact) s_ = consume_compact(t, d_stream + done + off, bytes, n, n_out, &handled, true, dry_run ? out : nullptr);
+                if (s_ == KCT_OK && !handled && !t->dedupe_off && (!dry_run || swap64))
+                    s_ = consume_partitioned(t, d_stream + done + off, bytes, n, n_out, &handled, true, true, dry_run ? out : nullptr);
+                return s_;
+            };
+            if (h1) {
+                st = probe_piece(0, h1, &seen1);
+                if (st == KCT_OK && handled) {
+                    if (swap32) t->s32_empty = false;   // (the second half meets what the first one left in the probe's shadow)
+                    if (swap64) t->shadow_empty = false;
+                    st = probe_piece(h1, npos - h1, &seen);
+                    if (!handled) seen1 = DedupeOutcome();
+                }
+            } else st = probe_piece(0, npos, &seen);
             if (swap32) { t->probe_shadow32 = t->shadow32; t->shadow32 = big32; t->s32_sbits = big_sbits; t->s32_nbins = big_nbins; t->s32_bin0 = big_bin0; t->s32_empty = true; }
             if (swap64) { t->probe_shadow = t->shadow; t->shadow = big64; t->shadow_cap = big_cap; t->shadow_block_bits = big_bb; t->shadow_empty = true; }
             KCT_TRY(st);
             if (handled) {
                 u64 valid, fresh_keys;
-                if (dry_run) { valid = std::max<u64>(1, seen.counted + seen.blocked); fresh_keys = seen.new_keys + seen.blocked; }
+                if (dry_run) { valid = std::max<u64>(1, seen.counted + seen.blocked + seen1.counted + seen1.blocked); fresh_keys = seen.new_keys + seen.blocked + seen1.new_keys + seen1.blocked; }
                 else {
                     done += npos; t->windows_since_read += npos;
                     valid = std::max<u64>(1, *n_out - n_before);                                 // window starts that held a k-mer
                     fresh_keys = std::max(t->shadow_keys, t->s32_keys) + (t->n_keys - table_before);
                 }
                 const double x = draws_per_distinct((double)fresh_keys / (double)valid);         // the probe's k-mers per distinct k-mer
-                const double per_key = x * (double)call_windows / (double)npos;                  // ... the whole call's
+                double per_key = x * (double)call_windows / (double)npos;                        // ... the whole call's
+                // Two depths tell never-repeating k-mers from deep coverage -- where the sample is deep enough for its curve to bend
+                // (a fifth of the distinct k-mers seen; overlapping reads repeat k-mers in clusters, so a shallow sample's handful of
+                // repeats says nothing about curvature: the north-star run's probe sees 0.7 % of its k-mers)
+                if (h1 && seen1.counted + seen1.blocked && x >= 0.2) {
+                    const double v1 = (double)(seen1.counted + seen1.blocked), f1 = (double)(seen1.new_keys + seen1.blocked);
+                    per_key = per_distinct_two_depths(v1, f1, (double)valid, (double)fresh_keys, (double)valid * (double)call_windows / (double)npos);
+                }
                 const bool pays = probe_verdict(t, per_key, call_windows);
                 KCT_DBG(t, "dedupe probe%s: %llu k-mers, %llu first sightings -> ~%.3g k-mers per distinct k-mer over the call: %s\n", dry_run ? " (dry run)" : "",
                         (unsigned long long)valid, (unsigned long long)fresh_keys, per_key, pays ? "dedupe-first" : "hash every window");

@@ -90,7 +90,11 @@ struct RepartitionArgs {
     u32 min_lines;       // 64-byte lines of a bin that leave the ring together (1, 2 or 4; needs a ring depth of >= 4x that)
     const u64 *in_off = nullptr;  // optional [nbins][nseg]: region (seg, s) starts at in + in_off[s * nseg + seg] entries instead (packed
                                   // regions received from other GPUs, kct_route.hip)
-    u32 bin0 = 0;        // compact entries: the first-level bin of super-bin 0 (an owner GPU holds a RANGE of the 1024 bins)
+    u32 bin0 = 0;        // compact entries: the first-level bin of super-bin 0
+    // compact entries, shadows of fewer than 2^16 blocks: a super-bin is 2^gbits consecutive first-level bins (their regions: nseg =
+    // workgroups << gbits of them), so that a second-level workgroup still spreads over >= 64 blocks -- the bin's low gbits bits are
+    // the top bits of the sub-bin, above the entry's top sub_bits - gbits bits
+    int gbits = 0;
     // several launches feeding ONE K2 pass (a pass cut into sub-chunks so that K1's scratch is reused, kct_consume.hip): this
     // launch's writers are slots writer0 .. writer0 + writers - 1 of the wtot regions every block has (0 = writers)
     int writer0 = 0, wtot = 0;

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     T *my_out = reinterpret_cast<T *>(a.out) + (((u64)s << a.sub_bits) * Wt + wslot) * a.out_cap;
     const u64 bin_stride = (u64)Wt * a.out_cap;
     u64 *my_ovf = a.ovf + (u64)blockIdx.x * a.ovf_cap;
-    const u64 ovf_hi = kCompact ? (((u64)(s + a.bin0) << 32) | (1ULL << 63)) : 0ULL;
+    const int gbits = kCompact ? a.gbits : 0, lowbits = a.sub_bits - gbits, per_bin = a.nseg >> gbits;  // (regions per first-level bin)
+    const u64 ovf_hi = kCompact ? (((u64)(((u32)s << gbits) + a.bin0) << 32) | (1ULL << 63)) : 0ULL;
     auto overflow_one = [&](u64 h) {
         const u32 i = atomicAdd(&ovf_n, 1u);
         if (i < a.ovf_cap) my_ovf[i] = h;
@@ -83,14 +84,18 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     };
     auto flush_lines = [&](bool drain) {
         if constexpr (kPair) return ring_flush<2048u, T>(ring, cur, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_pair, bin_stride, 0ULL, a.min_lines);
-        else return ring_flush<2048u, T>(ring, cur, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_one, bin_stride, ovf_hi, a.min_lines);
+        else return ring_flush<2048u, T>(ring, cur, flist, &fcount, P2, D, my_out, a.out_cap, drain, overflow_one, bin_stride, ovf_hi, a.min_lines, (u32)lowbits);
     };
     // A wave owns the input regions seg = 16 w + wave, + 16 W, ...; work unit = a slab of 64 lanes x 64 bytes.  Every wave
     // runs the same number of rounds so that the flush barriers line up.
-    const u32 *counts = a.in_count + (u64)s * a.nseg;
+    // (grouped super-bins: region `seg` is workgroup seg >> gbits of first-level bin (s << gbits) + (seg & (2^gbits - 1)) -- neighbouring
+    // regions, which the sixteen waves read at the same time, belong to DIFFERENT bins, so that the appends of a moment spread over all
+    // the sub-bins; taken bin by bin they would all land in a quarter (or less) of the ring and overflow it)
+    const u32 *counts0 = a.in_count + (u64)s * a.nseg;
+    auto count_of = [&](int seg) -> u32 { return gbits ? counts0[(u64)(seg & ((1 << gbits) - 1)) * per_bin + (seg >> gbits)] : counts0[seg]; };
     u32 my_slabs = 0;
     const int seg0 = w * (kPartThreads / 64) + wave, seg_step = W * (kPartThreads / 64);
-    for (int seg = seg0; seg < a.nseg; seg += seg_step) my_slabs += (counts[seg] + kSlab - 1) / kSlab;
+    for (int seg = seg0; seg < a.nseg; seg += seg_step) my_slabs += (count_of(seg) + kSlab - 1) / kSlab;
     if (lane == 0) atomicMax(&rounds, my_slabs);
     __syncthreads();
     const u32 nrounds = rounds;
@@ -100,13 +105,15 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
         if constexpr (kPair) return v.x != 0;
         else return v != 0;
     };
-    auto load_slab = [&](T (&v)[kLoads]) {
+    auto load_slab = [&](T (&v)[kLoads], u32 &binlow) {  // binlow: which of the super-bin's first-level bins the slab's region belongs to
 #pragma unroll
         for (int j = 0; j < kLoads; ++j) v[j] = zero;
-        while (seg < a.nseg && off >= counts[seg]) { seg += seg_step; off = 0; }  // next non-empty region
+        while (seg < a.nseg && off >= count_of(seg)) { seg += seg_step; off = 0; }  // next non-empty region
         if (seg < a.nseg) {
-            const u32 cnt = counts[seg];
-            const T *src = reinterpret_cast<const T *>(a.in) + (a.in_off ? a.in_off[(u64)s * a.nseg + seg] : ((u64)seg * a.nbins + s) * a.in_cap) + off;
+            const u32 cnt = count_of(seg);
+            binlow = gbits ? (u32)seg & ((1u << gbits) - 1u) : 0u;
+            const u64 region = gbits ? ((u64)(seg >> gbits) * a.nbins + ((u64)s << gbits) + binlow) : ((u64)seg * a.nbins + s);
+            const T *src = reinterpret_cast<const T *>(a.in) + (a.in_off ? a.in_off[(u64)s * a.nseg + seg] : region * a.in_cap) + off;
             const u32 left = cnt - off;
 #pragma unroll
             for (int j = 0; j < kLoads; ++j) { const u32 i = lane + 64 * j; if (i < left) v[j] = src[i]; }
@@ -114,28 +121,30 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
         }
     };
     T va[kLoads], vb[kLoads];
-    if (nrounds) load_slab(va);
+    u32 bla = 0, blb = 0;
+    if (nrounds) load_slab(va, bla);
     for (u32 r = 0; r < nrounds; ++r) {
-        if (r + 1 < nrounds) load_slab(vb);
+        if (r + 1 < nrounds) load_slab(vb, blb);
 #pragma unroll
         for (int j = 0; j < kLoads; ++j) {
             const T e = va[j];
             if (is_set(e)) {
                 u32 b;
                 if constexpr (kPair) b = (u32)(e.x >> a.block_bits) & (u32)(P2 - 1);
-                else if constexpr (kCompact) b = e >> (32 - a.sub_bits);
+                else if constexpr (kCompact) b = (bla << lowbits) | (lowbits ? e >> (32 - lowbits) : 0u);
                 else b = (u32)(e >> a.block_bits) & (u32)(P2 - 1);
                 const u64 cw = atomicAdd(&cur[b], 1ULL);
                 const u32 pos = (u32)cw;
                 if (pos - (u32)(cw >> 32) < D) ring[(b << dshift) + (pos & dmask)] = e;
                 else if constexpr (kPair) overflow_pair(e.x, e.y);
-                else if constexpr (kCompact) overflow_one(ovf_hi | e);
+                else if constexpr (kCompact) overflow_one((ovf_hi + ((u64)bla << 32)) | e);
                 else overflow_one(e);
             }
             if ((j % kFlushEvery) == kFlushEvery - 1) flush_lines(false);
         }
 #pragma unroll
         for (int j = 0; j < kLoads; ++j) va[j] = vb[j];
+        bla = blb;
     }
     while (flush_lines(true)) {}
     for (int b = threadIdx.x; b < P2; b += kPartThreads) {
@@ -663,9 +672,15 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
     constexpr int kPairs = kRingEntries / 2;  // 8192 pairs = 128 KiB
     __shared__ __attribute__((aligned(16))) ulonglong2 ring[kPairs];
     __shared__ u64 cur[1024];  // per bin: fill (low half) | flushed (high half)
-    __shared__ u32 flist[2048];
+    constexpr u32 kListCap = COMPACT ? 1024 : 2048;  // (the compact variant's lane-compaction queues want the room)
+    __shared__ u32 flist[kListCap];
     __shared__ u32 fcount;
     __shared__ u32 ascii4[256];
+    // compact shadow: the slots with a pending count are gathered per wave (key | count << 32, and the block they came from) and hashed
+    // 64 at a time -- a shadow is 10-50 % occupied, and hashing a row in place left that share of the lanes working
+    constexpr u32 kQueue = 96;
+    __shared__ u64 qv[COMPACT ? (kPartThreads / 64) * kQueue : 1];
+    __shared__ unsigned short qb[COMPACT ? (kPartThreads / 64) * kQueue : 1];
     fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
     const int P = 1 << a.pbits;
     const u32 D = (u32)(kPairs >> a.pbits), dmask = D - 1;
@@ -680,7 +695,7 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
         if (i < a.ovf_cap) { a.ovf[2 * i] = h; a.ovf[2 * i + 1] = c; }  // (cap = every pending k-mer: cannot be exceeded)
     };
     auto flush_lines = [&](bool drain) {
-        return ring_flush<2048u, ulonglong2>(ring, cur, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_pair);
+        return ring_flush<kListCap, ulonglong2>(ring, cur, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_pair);
     };
     // this workgroup's share of the shadow: whole blocks, kBlocksPerWg of them, one row of 1024 slots per step
     constexpr u32 S = 1u << kBlockBitsMax;
@@ -724,8 +739,71 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
 #pragma unroll
     for (u32 j = 0; j < kAhead; ++j) {
         cq[j] = 0; kq[j] = 0;
-        if (j < nrows) { const W *cp = count_ptr(j); cq[j] = *cp; kq[j] = *(cp - S); }
+        if (!COMPACT && j < nrows) { const W *cp = count_ptr(j); cq[j] = *cp; kq[j] = *(cp - S); }
     }
+    auto emit_pair = [&](u64 h, u64 c) {
+        if (h) {  // lib.rs:589: hash 0 is skipped
+            const u32 b = (u32)(h >> a.table_block_bits) & (u32)(P - 1);
+            const u64 cw = atomicAdd(&cur[b], 1ULL);
+            const u32 pos = (u32)cw;
+            if (pos - (u32)(cw >> 32) < D) ring[(b << dshift) + (pos & dmask)] = make_ulonglong2(h, c);
+            else overflow_pair(h, c);
+        }
+    };
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    u32 qn = 0;  // entries in this wave's queue (wave-uniform)
+    auto hash_queued = [&](u32 take) {  // the queue's last `take` entries, one per lane
+        qn -= take;
+        if (lane < take) {
+            const u64 e = qv[wave * kQueue + qn + lane];
+            const u32 sb = sb0 + qb[wave * kQueue + qn + lane];
+            emit_pair(hash_of_mixed<2>(((u64)(a.shadow_bin0 + (sb >> (a.shadow_sbits - 10))) << 32) | (e & 0xFFFFFFFFULL), k, ascii4), e >> 32);
+        }
+    };
+    if constexpr (COMPACT) {
+        // The compact shadow is walked 4096 slots a step: every lane takes FOUR neighbouring counts and keys with 16-byte loads (a
+        // block is two steps), four steps in flight -- 128 KiB per workgroup: the 4-byte-per-lane walk below left the kernel bound by
+        // its few bytes in flight, not by hashing.  A lane's four slots are queued one after the other (four ballots per step).
+        (void)cq; (void)kq;
+        constexpr u32 kStepsPerBlock = S / (4 * kPartThreads);
+        const u32 nsteps = sb1 > sb0 ? (sb1 - sb0) * kStepsPerBlock : 0u;
+        auto count4_ptr = [&](u32 st) -> uint4 * {
+            const u32 sb = sb0 + st / kStepsPerBlock, part = st % kStepsPerBlock;
+            return reinterpret_cast<uint4 *>(base + ((u64)sb << (kBlockBitsMax + 1)) + S + part * (4 * kPartThreads)) + threadIdx.x;
+        };
+        uint4 c4[kAhead], k4[kAhead];
+#pragma unroll
+        for (u32 j = 0; j < kAhead; ++j) {
+            c4[j] = make_uint4(0, 0, 0, 0); k4[j] = make_uint4(0, 0, 0, 0);
+            if (j < nsteps) { const uint4 *cp = count4_ptr(j); c4[j] = *cp; k4[j] = *(cp - S / 4); }
+        }
+        for (u32 s0 = 0; s0 < nsteps; s0 += kAhead) {
+#pragma unroll
+            for (u32 j = 0; j < kAhead; ++j) {
+                const u32 st = s0 + j;
+                if (st >= nsteps) break;
+                const uint4 cc = c4[j], kk = k4[j];
+                if (st + kAhead < nsteps) { const uint4 *cp = count4_ptr(st + kAhead); c4[j] = *cp; k4[j] = *(cp - S / 4); }
+                if (cc.x | cc.y | cc.z | cc.w) *count4_ptr(st) = make_uint4(0, 0, 0, 0);
+                const u32 cs[4] = {cc.x, cc.y, cc.z, cc.w}, ks[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u64 has = __ballot(cs[q] != 0);
+                    const u32 n = (u32)__popcll(has);
+                    if (qn + n > kQueue) hash_queued(qn < 64u ? qn : 64u);
+                    if (cs[q]) {
+                        const u32 at = wave * kQueue + qn + __builtin_amdgcn_mbcnt_hi((u32)(has >> 32), __builtin_amdgcn_mbcnt_lo((u32)has, 0u));
+                        qv[at] = (u64)ks[q] | ((u64)cs[q] << 32);
+                        qb[at] = (unsigned short)(st / kStepsPerBlock);
+                    }
+                    qn += n;
+                    if (qn >= 64u) hash_queued(64u);
+                    if (q & 1) flush_lines(false);  // ~1000 pairs per half step over up to 1024 bins of 8
+                }
+            }
+        }
+        while (qn) hash_queued(qn < 64u ? qn : 64u);
+    } else {
     for (u32 r0 = 0; r0 < nrows; r0 += kAhead) {
 #pragma unroll
         for (u32 j = 0; j < kAhead; ++j) {
@@ -733,21 +811,10 @@ __global__ __launch_bounds__(kPartThreads) void flush_partition_kernel(FlushPart
             if (r >= nrows) break;
             const W c = cq[j], key = kq[j];
             if (r + kAhead < nrows) { const W *cp = count_ptr(r + kAhead); cq[j] = *cp; kq[j] = *(cp - S); }  // the row four ahead
-            if (c) {
-                *count_ptr(r) = 0;
-                const u32 sb = sb0 + r / kRowsPerBlock;
-                const u64 h = COMPACT ? hash_of_mixed<2>(((u64)(a.shadow_bin0 + (sb >> (a.shadow_sbits - 10))) << 32) | (u64)key, k, ascii4)
-                                      : hash_of_mixed<1>((u64)key, k, ascii4);
-                if (h) {  // lib.rs:589: hash 0 is skipped
-                    const u32 b = (u32)(h >> a.table_block_bits) & (u32)(P - 1);
-                    const u64 cw = atomicAdd(&cur[b], 1ULL);
-                    const u32 pos = (u32)cw;
-                    if (pos - (u32)(cw >> 32) < D) ring[(b << dshift) + (pos & dmask)] = make_ulonglong2(h, (u64)c);
-                    else overflow_pair(h, (u64)c);
-                }
-            }
+            if (c) { *count_ptr(r) = 0; emit_pair(hash_of_mixed<1>((u64)key, k, ascii4), (u64)c); }
             if ((r & 1) == 1) flush_lines(false);  // ~600 pairs per row over up to 1024 bins of 8: every second row
         }
+    }
     }
     while (flush_lines(true)) {}
     for (int b = threadIdx.x; b < P; b += kPartThreads) {

@@ -90,13 +90,19 @@ pu64 windows_per_pending_key(const T *t) { return partition_geometry_ok(t) && t-
 
 // The compact shadow (k <= 21): 2^sbits blocks x 8192 slots of u32 key + u32 count.  A block index is the TOP sbits bits
 // of the 42-bit mix42 value, an entry its low 32 bits, so sbits >= 10.  Beside a table of up to 1024 blocks it is the
-// fixed 1024-block (64 MiB) one and K1's bins are its blocks; beside a larger table it has as many blocks as the table
-// (at least 2^16, so that the second partition level has >= 64 bins per super-bin) and K1's 1024 bins are super-bins.
+// fixed 1024-block (64 MiB) one and K1's bins are its blocks; beside a larger table it has as many blocks as the table and K1's
+// 1024 bins are super-bins -- or, for shadows of fewer than 2^16 blocks, GROUPS of 2^(16 - sbits) of K1's bins are, so that the
+// second partition level still has 64 bins per super-bin (RepartitionArgs::gbits).  (Until round 4 such a shadow was rounded up to
+// 2^16 blocks -- 4 GiB beside a 2^24-slot table: K2 and the conversion then visit mostly empty blocks.)
 template <class T>
 int compact_sbits_for(const T *t) {
     const int bbits = policy_log2(t->cap >> t->block_bits);
-    return bbits <= 10 ? kCompactBlockBits : std::max(16, bbits);
+    return bbits <= 10 ? kCompactBlockBits : bbits;
 }
+// workgroups per second-level super-bin: one, unless there are too few super-bins to fill the chip (a writer's sixteen waves take one
+// input region each: no more writers than regions / 16)
+inline pu64 two_level_writers(pu64 nsuper, int nwg) { return std::max<pu64>(1, std::min<pu64>((pu64)nwg / std::max<pu64>(nsuper, 1), 16)); }
+inline int compact_group_bits(int sbits) { return sbits > kCompactBlockBits && sbits < 16 ? 16 - sbits : 0; }
 
 // A dedupe-first run also pays for its SHADOW, whatever the input: the first K2 pass stores every shadow block and the
 // conversion reads (and re-zeroes) every slot -- ~2.5 bytes of streaming per shadow byte at ~4.5 TB/s -- while a dedupe-first
@@ -183,6 +189,38 @@ inline double draws_per_distinct(double r) {
         if ((1.0 - std::exp(-mid)) / mid > r) lo = mid; else hi = mid;
     }
     return lo;
+}
+
+// The same from TWO depths of one sample -- f1 first sightings among the first n1 draws, f2 among all n2 -- under a model with one
+// more unknown: a share e of the draws are k-mers that never repeat (sequencing errors: a substituted base makes up to k new k-mers,
+// each seen once), the rest are uniform draws from D:  F(n) = e n + D (1 - exp(-(1 - e) n / D)).  Returns the k-mers per distinct
+// k-mer the model predicts for N draws, N / F(N).  With e = 0 this is draws_per_distinct's law; the one-depth estimate reads 1 % of
+// substitution errors at 30x coverage as "17 per distinct k-mer" where the truth is 4.5 (round 4: bench.py C2_sub1pct).
+inline double per_distinct_two_depths(double n1, double f1, double n2, double f2, double N) {
+    if (n2 <= 0 || f2 <= 0 || n1 <= 0 || n1 >= n2) return 1.0;
+    f1 = std::min(f1, n1); f2 = std::min(f2, n2);
+    // for a given e the second depth gives D (F is increasing in D); the first depth then picks e: F(n1; e, D(e)) falls as e grows
+    // (a straighter curve), so bisect on e
+    auto model = [](double n, double e, double D) { return e * n + D * (1.0 - std::exp(-(1.0 - e) * n / D)); };
+    auto solve_D = [&](double e) {
+        const double target = f2 - e * n2;               // D (1 - exp(-(1 - e) n2 / D)) = target, at most (1 - e) n2
+        if (target >= (1.0 - e) * n2 * 0.99995) return 1e30;   // every uniform draw was new: D is beyond the sample
+        if (target <= 0) return 1e-9;
+        double lo = 1.0, hi = 1e18;
+        for (int i = 0; i < 100; ++i) {
+            const double mid = std::sqrt(lo * hi);
+            if (mid * (1.0 - std::exp(-(1.0 - e) * n2 / mid)) < target) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    double elo = 0.0, ehi = std::min(0.999, f2 / n2);
+    for (int i = 0; i < 50; ++i) {
+        const double e = 0.5 * (elo + ehi);
+        if (model(n1, e, solve_D(e)) > f1) elo = e; else ehi = e;
+    }
+    const double e = 0.5 * (elo + ehi), D = solve_D(e);
+    const double FN = e * N + (D >= 1e29 ? (1.0 - e) * N : D * (1.0 - std::exp(-(1.0 - e) * N / D)));
+    return FN > 0 ? N / FN : 1e9;
 }
 
 // the probe's verdict: k-mers per distinct k-mer over the whole call (per_key), and a shadow the call can pay for

@@ -35,6 +35,7 @@ int policy_probe_wanted(const PolicyIn *in, uint64_t call_windows) { const FakeT
 int policy_probe_verdict(const PolicyIn *in, double per_key, uint64_t call_windows) { const FakeTable t = make(in); return kcth::probe_verdict(&t, per_key, call_windows) ? 1 : 0; }
 int policy_compact_sbits(const PolicyIn *in) { const FakeTable t = make(in); return kcth::compact_sbits_for(&t); }
 double policy_draws_per_distinct(double r) { return kcth::draws_per_distinct(r); }
+double policy_per_distinct_two_depths(double n1, double f1, double n2, double f2, double N) { return kcth::per_distinct_two_depths(n1, f1, n2, f2, N); }
 unsigned policy_region_capacity(double avg) { return kcth::region_capacity(avg); }
 unsigned policy_overflow_capacity(uint64_t per_wg) { return kcth::overflow_capacity(per_wg); }
 void policy_levels(int bbits, int nwg, int out[6]) {

@@ -27,6 +27,8 @@ def pol(tmp_path_factory):
     lib.policy_probe_verdict.argtypes = [C.POINTER(PolicyIn), C.c_double, C.c_uint64]
     lib.policy_draws_per_distinct.restype = C.c_double
     lib.policy_draws_per_distinct.argtypes = [C.c_double]
+    lib.policy_per_distinct_two_depths.restype = C.c_double
+    lib.policy_per_distinct_two_depths.argtypes = [C.c_double] * 5
     lib.policy_region_capacity.restype = C.c_uint
     lib.policy_region_capacity.argtypes = [C.c_double]
     lib.policy_overflow_capacity.restype = C.c_uint
@@ -73,14 +75,19 @@ def test_headline_shapes(pol):
 
 
 def test_a_shadow_must_be_paid_for(pol):
-    """Two-level tables: the compact shadow is >= 4 GiB, the 64-bit one table-sized -- 0.15 windows per shadow byte."""
+    """Two-level tables: the compact shadow is half the table's bytes (as many blocks as the table: since round 4 also below 2^16
+    blocks), the 64-bit one table-sized -- 0.15 windows per shadow byte."""
     choose = lambda t, n: pol.policy_choose_path(C.byref(t), n)  # noqa: E731
     sub1 = table(cap=1 << 26, dedupe_hint=1)                             # C2 with 1 % substitution errors: 2^26 slots
-    assert pol.policy_compact_sbits(C.byref(sub1)) == 16
-    assert choose(sub1, C2_WINDOWS) == PARTITIONED                       # 1.5x10^8 windows pay for neither 4 GiB nor 1 GiB of shadow
-    assert pol.policy_probe_wanted(C.byref(table(cap=1 << 26)), C2_WINDOWS) == 0
-    assert choose(table(cap=1 << 24, dedupe_hint=1), 90_000_000) == DEDUPE64   # 256 MiB of 64-bit shadow: paid by 4x10^7 windows
-    assert choose(table(cap=1 << 24, dedupe_hint=1, s32_dirty=1), 90_000_000) == COMPACT   # counts already pending: the shadow is paid for
+    assert pol.policy_compact_sbits(C.byref(sub1)) == 13                 # 8192 blocks, 512 MiB (it was rounded up to 2^16 blocks = 4 GiB)
+    assert choose(sub1, C2_WINDOWS) == COMPACT                           # 1.5x10^8 windows pay for 512 MiB of shadow ...
+    assert choose(sub1, 60_000_000) == PARTITIONED                       # ... 6x10^7 do not (nor for 1 GiB of 64-bit shadow)
+    assert pol.policy_probe_wanted(C.byref(table(cap=1 << 26)), C2_WINDOWS) == 1
+    assert pol.policy_compact_sbits(C.byref(table(cap=1 << 23))) == 10 and pol.policy_compact_sbits(C.byref(table(cap=1 << 24))) == 11
+    assert pol.policy_compact_sbits(C.byref(table(cap=1 << 30))) == 17
+    assert choose(table(cap=1 << 24, dedupe_hint=1), 90_000_000) == COMPACT    # 128 MiB of compact shadow: paid by 2x10^7 windows
+    assert choose(table(cap=1 << 24, dedupe_hint=1, compact_off=1), 90_000_000) == DEDUPE64   # 256 MiB of 64-bit shadow: by 4x10^7
+    assert choose(table(cap=1 << 26, dedupe_hint=1, s32_dirty=1), 60_000_000) == COMPACT   # counts already pending: the shadow is paid for
     ns = table(cap=1 << 30)                                              # the north-star run: 1.5x10^10 windows, 8 GiB of compact shadow
     assert pol.policy_probe_wanted(C.byref(ns), 15_100_000_000) == 1
     assert pol.policy_probe_verdict(C.byref(ns), 26.0, 15_100_000_000) == 1 and pol.policy_probe_verdict(C.byref(ns), 3.3, 15_100_000_000) == 0
@@ -116,3 +123,19 @@ def test_sizing_rules(pol):
     assert pol.policy_overflow_capacity(1000) == 4096 and pol.policy_overflow_capacity(1 << 20) == 1 << 17 and pol.policy_overflow_capacity(1 << 30) == 1 << 20
     assert pol.policy_min_lines(16384, 6, 8) == 4 and pol.policy_min_lines(16384, 8, 8) == 2 and pol.policy_min_lines(16384, 10, 8) == 1
     assert pol.policy_min_lines(32768, 7, 4) == 4 and pol.policy_min_lines(8192, 7, 16) == 4
+
+
+def test_two_depth_estimate_sees_never_repeating_k_mers(pol):
+    """The dry probe's estimator (two depths of one sample): uniform draws from D k-mers plus a share e of k-mers that never repeat
+    (sequencing errors).  On its own model it recovers N / F(N); with e = 0 it agrees with the one-depth law."""
+    import math
+
+    def F(n, e, D):
+        return e * n + D * (1.0 - math.exp(-(1.0 - e) * n / D))
+    n1, n2 = 2_000_000.0, 4_000_000.0
+    for e, D, N in ((0.0, 5e6, 1.5e8), (0.2, 5e6, 1.5e8), (0.25, 5e8, 3.3e9), (0.0, 5e8, 1.5e10), (0.02, 4e6, 1.5e8), (0.5, 1e6, 1e8)):
+        got = pol.policy_per_distinct_two_depths(n1, F(n1, e, D), n2, F(n2, e, D), N)
+        assert got == pytest.approx(N / F(N, e, D), rel=0.03), (e, D, N, got)
+    # C2 with 1 % substitutions (bench.py C2_sub1pct): the truth is 4.5 per distinct k-mer, not the one-depth estimate's 17
+    assert pol.policy_per_distinct_two_depths(n1, F(n1, 0.19, 5e6), n2, F(n2, 0.19, 5e6), 1.3e8) < 6.0
+    assert pol.policy_per_distinct_two_depths(n1, F(n1, 0.0, 5e6), n2, F(n2, 0.0, 5e6), 1.3e8) == pytest.approx(26.0, rel=0.02)
