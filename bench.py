@@ -49,7 +49,7 @@ same weak-scaled C2 job per rank + the late merge, and
 `roofline`: bound "hbm"; `achieved` = ALGORITHMIC bytes per step (k-mers x (L/(L-k+1) + 24) B) / the summed
 device time of every kernel of the step (HIP events on the table's stream, in an instrumented repetition of the job;
 `value` is taken with the events off); `traffic` / `measured_frac` = PMC-measured HBM bytes per step (profiles/
-pmc_r03.json, only if it was collected from THIS source tree -- stamped with a hash of the kernel sources -- else null);
+pmc_r04.json, only if it was collected from THIS source tree -- stamped with a hash of the kernel sources -- else null);
 `valu` = the ceiling that actually binds K1 (VALU instructions per window and issue-slot use from the same PMC file).
 `cpu_baseline`: the CPU restatement of the reference path (oracle/, "port") on this host: 1 thread (the reference's
 consume is single-threaded under the GIL), reads sharded over threads with a tree merge (reference-shaped "rayon"), and
@@ -129,9 +129,9 @@ def source_sha():
 
 
 def pmc_summary():
-    """profiles/pmc_r03.json if it was collected from this source tree, else {} (every PMC-derived field becomes null)."""
+    """profiles/pmc_r04.json if it was collected from this source tree, else {} (every PMC-derived field becomes null)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_r03.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_r04.json")) as f:
             d = json.load(f)
         return d if d.get("source_sha") == source_sha() else {}
     except (OSError, ValueError):
@@ -459,7 +459,7 @@ def main():
                     "measured_frac": (traffic_job / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_job and all_ms else None,
                     "basis": "achieved = algorithmic bytes per step (25.15 B/k-mer x k-mers) / summed device time of every kernel of the step (HIP "
                              "events, instrumented repetition); traffic = PMC HBM bytes per step and measured_frac = traffic / kernel time / peak, "
-                             "from profiles/pmc_r03.json when it matches this source tree (else null)",
+                             "from profiles/pmc_r04.json when it matches this source tree (else null)",
                     "alg_bytes_per_kmer": b_alg, "kmers_per_step": kmers_per_step, "kernels_total_ms_per_step": all_ms / args.steps,
                     "dominant_kernel_ms_per_step": ms / args.steps,
                     "frac_of_wall": kmers_per_step * b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
@@ -542,8 +542,9 @@ def main():
             assert ablate or ok
             del pc, pv
         if "k51_deep" in want:
-            # k > 32 with deep coverage of a small genome (1 M x 150 bp, k=51, genome 2 Mbp; steady-state steps as the headline's): the
-            # 128-bit dedupe-first variant (chosen from the second step on) against hashing every window
+            # k > 32 with deep coverage of a small genome (1 M x 150 bp, k=51, genome 2 Mbp; steady-state steps as the headline's): what the
+            # table chooses (hashing every window: the 128-bit dedupe-first variant left the automatic choice in round 4), hashing forced,
+            # and the 128-bit variant forced (set_path("dedupe"))
             Gk, kk = 2_000_000, 51
             gk = torch.empty(Gk, dtype=torch.uint8, device="cuda")
             rk = torch.empty(R * (L + 1), dtype=torch.uint8, device="cuda")
@@ -551,7 +552,7 @@ def main():
             assert lib.kct_synth_reads_device(rk.data_ptr(), gk.data_ptr(), Gk, 0, R, L, SEED_R, stream) == 0
             torch.cuda.synchronize()
             nk_step, res51 = R * (L - kk + 1), {}
-            for path in ("auto", "partitioned"):
+            for path in ("auto", "partitioned", "dedupe"):
                 t51 = KmerCountTable(kk, capacity=Gk)
                 t51.set_path(path)
 
@@ -566,12 +567,13 @@ def main():
                 res51[path] = (nk_step * args.steps / dt, dt, prof, (n, len(t51), t51.sum_counts) + t51.digest())
                 del t51
             rep, _ = kernel_report(res51["auto"][2], nk_step * args.steps, L / (L - kk + 1) + 24.0, None)
-            ok = res51["auto"][3] == res51["partitioned"][3] and res51["auto"][3][0] == nk_step * args.steps
+            ok = res51["auto"][3] == res51["partitioned"][3] == res51["dedupe"][3] and res51["auto"][3][0] == nk_step * args.steps
             configs["k51_deep"] = {"kmers_per_s": res51["auto"][0], "seconds": res51["auto"][1], "steps": args.steps,
                                    "partitioned_path_kmers_per_s": res51["partitioned"][0], "vs_partitioned": res51["auto"][0] / res51["partitioned"][0],
+                                   "forced_128bit_dedupe_kmers_per_s": res51["dedupe"][0], "forced_128bit_vs_partitioned": res51["dedupe"][0] / res51["partitioned"][0],
                                    "path_chosen": "128-bit dedupe-first" if any("raw128" in kn for kn in res51["auto"][2]) else "hash every window",
                                    "what": "1 M x 150 bp per step, k=51, genome 2 Mbp, steady state (event timing on)",
-                                   "gate": {"equals_partitioned_path": bool(ok)}, **rep}
+                                   "gate": {"auto_partitioned_and_forced_128bit_paths_agree": bool(ok)}, **rep}
             assert ablate or ok
             del gk, rk
         host = None

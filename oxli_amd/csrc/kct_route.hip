@@ -203,7 +203,7 @@ kct_status inbox_add(Route &r, Inbox &in, u64 base, const std::vector<u64> &recv
 }
 
 // everything in the inbox -> counted into this rank's table (`more` = windows later passes of the same call will still bring)
-kct_status inbox_count(Route &r, Inbox &in, u64 more, u64 *n_out) {
+kct_status inbox_count(Route &r, Inbox &in, u64 more, u64 *n_out, bool keep_room = false) {  // keep_room: a pass is arriving behind what is counted
     kct_table *t = r.t;
     *n_out = 0;
     kct_status st = KCT_OK;
@@ -221,7 +221,8 @@ kct_status inbox_count(Route &r, Inbox &in, u64 more, u64 *n_out) {
         st = consume_stream_runs(t, ri, in.groups, n_out);
         t->more_windows = 0;
     }
-    in.streams.clear(); in.groups = in.windows = 0; in.used = Inbox::kFront;
+    in.streams.clear(); in.groups = in.windows = 0;
+    if (!keep_room) in.used = Inbox::kFront;
     return st;
 }
 
@@ -276,12 +277,15 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const u64 inbox_target = std::min<u64>({(u64)((double)windows * (bases_per_window(k) / 4.0 + 0.125) * (solo ? 1.5 / world : 1.25)) + (8ULL << 20),
                                             (u64)(0.3 * (double)free_b), 30ULL << 30});
+    const u64 batches = ops && world <= 2 ? 3 : ops && world <= 4 ? 2 : 1;
+    const u64 batch_windows = std::max<u64>(1, windows / batches);   // (what arrives is about what this rank cuts)
+    u64 counted_upto = 0;                                            // passes already counted
     // count what the inbox holds (a local failure is kept in `status`, see cut)
-    auto count_inbox = [&](u64 more) {
+    auto count_inbox = [&](u64 more, bool keep_room = false) {
         const double t0 = now_ms();
         u64 n = 0;
-        if (status == KCT_OK) { status = inbox_count(r, inbox, more, &n); ++st_counts; }
-        else { inbox.streams.clear(); inbox.groups = inbox.windows = 0; inbox.used = Inbox::kFront; }
+        if (status == KCT_OK) { status = inbox_count(r, inbox, more, &n, keep_room); ++st_counts; }
+        else { inbox.streams.clear(); inbox.groups = inbox.windows = 0; if (!keep_room) inbox.used = Inbox::kFront; }
         owner_ms += now_ms() - t0;
         *n_out += n;
     };
@@ -323,7 +327,8 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
             }
         if (status != KCT_OK) st = status;
         if (st == KCT_OK && inbox.used + total + 64 > inbox.buf.cap) {
-            if (inbox.groups) count_inbox((passes - p) * (inbox.windows / std::max<u64>(1, p)));   // (every earlier pass has been waited for)
+            if (inbox.groups) count_inbox((passes - p) * (inbox.windows / std::max<u64>(1, p - counted_upto))), counted_upto = p;   // (every earlier pass has been waited for)
+            inbox.used = Inbox::kFront;   // (nothing is in flight: the whole buffer is free again)
             if (status == KCT_OK && Inbox::kFront + total + 64 > inbox.buf.cap) status = r.slab(inbox.buf, t->d_sk_inbox, std::max(total, inbox_target) + Inbox::kFront);
             st = status;
         }
@@ -362,6 +367,10 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
         }
         st_runs += po[b].runs; st_retries += po[b].retries;
         if (p + 1 < passes) job = post(p + 1);
+        // Few GPUs = few links in use = a long transfer (xGMI is point to point): the owner then counts what has arrived in two or
+        // three batches while the later passes are on the wire, instead of once at the end (every batch is a pass of the table's
+        // bulk path: K2 and the conversion visit every block once more -- with 8 GPUs the wire is short and one batch is cheaper).
+        if (job == KCT_OK && batches > 1 && p + 1 < passes && inbox.windows >= batch_windows) count_inbox((passes - 1 - p) * (inbox.windows / (p + 1 - counted_upto)), true), counted_upto = p + 1;
     }
     if (job == KCT_OK) count_inbox(0);
     if (status == KCT_OK) status = job;

@@ -156,7 +156,9 @@ bool compact_pays(const T *t, pu64 npos) {
 // 7.6 against 6.6, k = 64: 7.3 against 5.5; the hashing K1 has since become 8 % faster (rotl / tail tables: 7.2 at k = 51) -- chosen by
 // itself from k = 48 on, forced (set_path 3) at any k in 33..64.
 constexpr pu64 kShadow128Keys = (pu64)(0.6 * 1024 * 4096);
-constexpr int kDedupe128MinK = 48;
+// Round 4: OFF in the automatic choice (its gain over the hashing K1, which has since got 8 % faster, is 3 % on its showcase -- bench.py
+// k51_deep 1.03x -- for a second shadow layout and a conversion by atomics); kct_set_path(t, 3) still takes it at any k in 33..64.
+constexpr int kDedupe128MinK = 65;
 template <class T>
 bool dedupe128_pays(const T *t, pu64 npos) {
     if (t->k <= 32 || t->k > 64 || t->dedupe128_off || npos < (1ULL << 22)) return false;

@@ -143,8 +143,8 @@ def merge_across_ranks(table, group=None):
     table has to hold every k-mer its reads touch (close to the whole genome), but an owner's table holds 1/world of
     the key space (2^27 slots per GPU for C4 instead of 2^30).
 
-    A ``store_kmers`` table is refused: its hash -> k-mer map lives on the host of the rank that saw the k-mer, and this
-    exchange moves (hash, count) pairs only.
+    A ``store_kmers`` table's hash -> k-mer map (host side, as in the reference) follows its keys: the ranks' maps are gathered and
+    every rank keeps the entries of the keys it now owns -- ``add()`` merges ``hash_to_kmer`` the same way (lib.rs:810-828).
     """
     import ctypes as C
 
@@ -153,8 +153,10 @@ def merge_across_ranks(table, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return 0
-    if getattr(table, "store_kmers", False):
-        raise ValueError("merge_across_ranks moves (hash, count) pairs only: a store_kmers table would lose its hash -> k-mer map")
+    kmer_maps = None
+    if getattr(table, "store_kmers", False):   # (a host-side dict per rank: small tables only, like everything store_kmers does)
+        kmer_maps = [None] * world
+        dist.all_gather_object(kmer_maps, dict(table._hash_to_kmer or {}), group=group)
     dev = torch.device("cuda", torch.cuda.current_device())
     n = len(table)
     pairs = torch.empty((max(n, 1), 2), dtype=torch.int64, device=dev)
@@ -174,6 +176,11 @@ def merge_across_ranks(table, group=None):
     a, b = C.c_uint64(), C.c_uint64()
     table._check(table._lib.kct_merge_pairs_device(table._h, C.c_void_p(recv.data_ptr()), recv.shape[0], C.byref(a), C.byref(b)))
     table._check(table._lib.kct_add_consumed(table._h, consumed))
+    if kmer_maps is not None:
+        merged = {}
+        for m in kmer_maps:
+            merged.update(m)
+        table._hash_to_kmer = {int(h): merged[int(h)] for h in table.hashes if int(h) in merged}
     return recv.shape[0]
 
 

@@ -36,6 +36,9 @@ def main():
     if route.startswith("early"):
         early(route.split(":")[1], k, per_rank, G, L, rank, world, genome, reads, dev_reads)
         return
+    if route == "late:store_kmers":
+        late_store_kmers(k, per_rank, L, rank, world, reads)
+        return
     t = KmerCountTable(k, capacity=G)
     n = t.consume_device(dev_reads.data_ptr(), dev_reads.numel(), per_rank * L)
     assert n == per_rank * (L - k + 1)
@@ -68,6 +71,43 @@ def main():
         assert np.array_equal(gk[order], rk) and np.array_equal(gc[order], rc), "union of the owner tables differs from the oracle"
         del ref
         print(f"DIST_GPU_OK world={world} distinct={rk.size}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def late_store_kmers(k, per_rank, L, rank, world, reads):
+    """store_kmers tables through the late route: the hash -> k-mer map follows the keys to their owners (lib.rs:810-828)."""
+    import oracle
+    from oxli_amd import KmerCountTable
+    from oxli_amd.distributed import global_scalar_sum, merge_across_ranks, owner_of
+
+    t = KmerCountTable(k, store_kmers=True)
+    for r in reads:
+        t.consume(bytes(r[:L]).decode())
+    merge_across_ranks(t)
+    keys, counts = t.dump_arrays(1)
+    assert np.all(owner_of(torch.from_numpy(keys.view(np.int64).copy()), world).numpy() == rank)
+    pairs = t.dump_kmers(sortkeys=True)                      # [(k-mer, count)]: every owned key has its k-mer, with the global count
+    assert len(pairs) == keys.size and set(t._hash_to_kmer) == set(keys.tolist())
+    for kmer, c in pairs[:: max(1, len(pairs) // 200)]:
+        assert t.hash_kmer(kmer) in t._hash_to_kmer and t.get(kmer) == c and t.unhash(t.hash_kmer(kmer)) == kmer
+    parts = [None] * world
+    dist.all_gather_object(parts, pairs)
+    if rank == 0:
+        ref = oracle.OracleTable(k)
+        allreads = oracle.synth_reads(oracle.synth_genome(int(sys.argv[3]), 42), 0, world * per_rank, L, 1337)
+        for r in allreads:
+            ref.consume(bytes(r[:L]).decode())
+        rk, rc = ref.dump_arrays()
+        got = {}
+        for p in parts:
+            for kmer, c in p:
+                h = ref.hash_kmer(kmer)
+                assert h not in got
+                got[h] = c
+        assert got == dict(zip(rk.tolist(), rc.tolist()))
+        print(f"DIST_GPU_OK world={world} distinct={rk.size} route=late:store_kmers")
+    assert global_scalar_sum(t.sum_counts, "cpu") == world * per_rank * (L - k + 1)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -150,6 +150,31 @@ def test_serialize_save_load(KCT, tmp_path, capfd):
         t.save(str(tmp_path / "noexist" / "save.json"))
 
 
+def test_load_of_a_hand_assembled_reference_format_file(KCT, capfd):
+    """tests/golden/reference_format_save.json.gz: a file in the REFERENCE's save() format (lib.rs:274-292: serde_json of the struct at
+    lib.rs:31-39, gzip as niffler / flate2 write it at Level::One), assembled by tests/golden/make_reference_save_fixture.py from the
+    format's description -- unsorted HashMap order, a u64::MAX count, store_kmers with its hash -> k-mer map -- not by this repository's
+    writer.  load() must take it; the hashes in it are the reference's own known answers (reference_kats.json)."""
+    import os
+    from oxli_amd import VERSION
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    raw = open(os.path.join(here, "reference_format_save.json.gz"), "rb").read()
+    assert raw[:10] == bytes.fromhex("1f8b0800" "00000000" "04ff")       # no name, no time stamp, XFL "fastest", OS unknown
+    t = KCT.load(os.path.join(here, "reference_format_save.json.gz"))
+    want = {"AACC": 3, "AAAA": 1, "ACGT": 2 ** 64 - 1, "ATAA": 2, "CCCC": 7, "AACG": 40, "AAAC": 5}
+    assert t.ksize == 4 and len(t) == 7 and t.consumed == 123456789012 and t.version == VERSION and t.store_kmers is True
+    for kmer, c in want.items():
+        assert t.get(kmer) == c
+        assert t.unhash(t.hash_kmer(kmer)) == kmer
+    assert t.get("TTAT") == 2 and t.get("GGGG") == 7                      # reverse complements of ATAA / CCCC
+    assert t.count("AACC") == 4 and t.count("GGTT") == 5                  # a loaded table goes on counting (GGTT = revcomp of AACC)
+    assert sorted(t.hashes) == sorted(t.hash_kmer(k_) for k_ in want)
+    capfd.readouterr()
+    u = KCT.load(os.path.join(here, "reference_format_save_old_version.json"))   # uncompressed, older version, hash_to_kmer null
+    assert "Version mismatch: loaded version is 0.2.9, but current version is " + VERSION in capfd.readouterr().err
+    assert u.store_kmers is False and len(u) == 7 and u.get("ACGT") == 2 ** 64 - 1 and u.sum_counts == (sum(want.values())) % 2 ** 64
+
+
 # ---- dunders / attributes (test_dunders.py, test_attr.py) ------------------------------------------------------
 def test_consume_into_a_loaded_table(KCT, tmp_path):
     """load() then consume(): a loaded table takes every consume route (the per-record call glue included) and counts on

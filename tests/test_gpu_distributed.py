@@ -47,3 +47,14 @@ def test_ranks_sharing_one_gpu_early_route_equals_the_oracle_table(world, k, per
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-6000:]
     assert f"DIST_GPU_OK world={world}" in out.stdout and f"route=early:{path}" in out.stdout, out.stdout[-2000:]
+
+
+def test_store_kmers_tables_merge_with_their_k_mer_maps():
+    """The late route with store_kmers tables (lib.rs:810-828: add() merges hash_to_kmer): after merge_across_ranks every rank can
+    unhash exactly the keys it owns, with the global counts."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "21", "300", "20000", "late:store_kmers"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-6000:]
+    assert "DIST_GPU_OK world=2" in out.stdout and "route=late:store_kmers" in out.stdout, out.stdout[-2000:]

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of bench.py, per workload.
-# Usage: tools/collect_r03.sh [tag]   -> writes gpurun_out/prof_<tag>/<workload>/{stats,pmc_fetch,pmc_write,pmc_sq[,pmc_tcc]}
+# Usage: tools/collect_r04.sh [tag]   -> writes gpurun_out/prof_<tag>/<workload>/{stats,pmc_fetch,pmc_write,pmc_sq[,pmc_tcc]}
 # Every rocprofv3 line profiles `python3 bench.py` directly (no shell/env hop after `--`); --pmc passes never share a
 # run with a trace.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
@@ -26,6 +26,13 @@ run C3 --configs C3 --no-headline
 run C5_shard --configs C5_shard --no-headline
 run C4_shard --configs C4_shard --no-headline
 run C2_sub1pct --configs C2_sub1pct --no-headline
+# the early multi-GPU route's stages on this one GPU (tools/route_profile.py: the split for 8 owners, one owner's share of the job)
+mkdir -p $O/route_C4
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/route_C4/stats -- python3 /root/repo/tools/route_profile.py NS --owners 8 --skip-loopback --skip-plain > $O/route_C4/stats.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/route_C4/pmc_sq -- python3 /root/repo/tools/route_profile.py C4 --owners 8 --skip-loopback --skip-plain > $O/route_C4/pmc_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/route_C4/pmc_fetch -- python3 /root/repo/tools/route_profile.py C4 --owners 8 --skip-loopback --skip-plain > $O/route_C4/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/route_C4/pmc_write -- python3 /root/repo/tools/route_profile.py C4 --owners 8 --skip-loopback --skip-plain > $O/route_C4/pmc_write.log 2>&1
+echo "route_C4 done"
 # the direct path's L2-atomic counters (north_star: "L2-atomic counters")
 mkdir -p $O/C2_direct
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/C2_direct/stats -- $B --configs none --steps 5 --warmup 2 --max-repeats 3 --path direct > $O/C2_direct/stats.log 2>&1

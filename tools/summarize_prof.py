@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/prof_<tag>/ (made by tools/collect_r03.sh on the GPU box) into the small, committed files under profiles/:
+"""Turns gpurun_out/prof_<tag>/ (made by tools/collect_r04.sh on the GPU box) into the small, committed files under profiles/:
 
   profiles/<tag>_<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of that workload
   profiles/<tag>_pmc_full.json                 per workload, per kernel: launches, mean of every PMC counter, derived figures
@@ -24,12 +24,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 on_box = "--on-box" in sys.argv
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 
-STREAMING = ("partition_windows_kernel", "aggregate_blocks", "repartition_kernel", "flush_partition_kernel", "aggregate_pairs_kernel")
+STREAMING = ("partition_windows_kernel", "aggregate_blocks", "repartition_kernel", "flush_partition_kernel", "aggregate_pairs_kernel", "split_superkmers_kernel", "gather_units_kernel", "stage_stream_kernel")
 CLOCK_HZ, SIMDS = 2.4e9, 256 * 4
 
 
@@ -37,9 +37,15 @@ def short(name):
     n = name.split("(")[0].replace("void ", "").replace("kct::", "").replace("(anonymous namespace)::", "").strip()
     base = n.split("<")[0].strip()
     targs = n[n.index("<") + 1:n.rindex(">")] if "<" in n else ""
-    if base == "partition_windows_kernel":
-        mode = targs.split(",")[-1].strip() if targs else "0"
-        return base + {"0": "", "1": "<raw>", "true": "<raw>", "2": "<compact>"}.get(mode, "")
+    if base == "partition_windows_kernel":   # <KW, KC, MODE, RUNS>
+        ta = [x.strip() for x in targs.split(",")] if targs else []
+        mode = ta[2] if len(ta) > 2 else "0"
+        runs = len(ta) > 3 and ta[3] in ("true", "1")
+        tagm = {"0": "", "1": "raw", "true": "raw", "2": "compact", "3": "raw128"}.get(mode, "")
+        inner = ", ".join(x for x in (tagm, "runs" if runs else "") if x)
+        return base + (f"<{inner}>" if inner else "")
+    if base == "split_superkmers_kernel":
+        return base
     if base == "repartition_kernel":
         targs = targs.strip()
         return base + ("<pairs>" if "HIP_vector_type" in targs or "ulonglong2" in targs else "<compact>" if targs.startswith("unsigned int") else "")
@@ -63,7 +69,7 @@ def summarize(wdir):
             e["calls"] += int(row["Calls"]); e["total_ns"] += float(row["TotalDurationNs"])
     out = {}
     for k, counters in pmc.items():
-        if not (k.startswith(("partition", "aggregate", "repartition", "flush", "merge", "count_windows", "shadow"))):
+        if not (k.startswith(("partition", "aggregate", "repartition", "flush", "merge", "count_windows", "shadow", "split_superkmers", "gather_units", "run_directory", "stage_stream"))):
             continue
         mean = {c: sum(v) / len(v) for c, v in counters.items()}
         e = {"launches_seen": max(len(v) for v in counters.values()), "mean": mean}
@@ -106,7 +112,7 @@ def main():
         if on_box:
             json.dump(full, open(os.path.join(src, "summary.json"), "w"))
             for wdir in glob.glob(os.path.join(src, "*")):
-                for sub in ("stats", "pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
+                for sub in ("stats", "pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):  # (the raw per-dispatch files stay on the box)
                     shutil.rmtree(os.path.join(wdir, sub), ignore_errors=True)
             return
     from bench import source_sha
@@ -116,7 +122,7 @@ def main():
         json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
     except Exception as e:  # noqa: BLE001
         print("no bench.json:", e)
-    json.dump({"_how": "tools/collect_r03.sh + tools/summarize_prof.py; FETCH_SIZE/WRITE_SIZE in KiB, separate passes; x2 on streaming reads",
+    json.dump({"_how": "tools/collect_r04.sh + tools/summarize_prof.py; FETCH_SIZE/WRITE_SIZE in KiB, separate passes; x2 on streaming reads",
                "source_sha": source_sha(), "workloads": full}, open(os.path.join(dst, f"{tag}_pmc_full.json"), "w"), indent=1)
     windows = {"C2": 1.3e8, "C2_hashing": 1.3e8, "cold_C2": 1.3e8}  # k-mers of a launch
     small = {"source_sha": source_sha(), "_how": f"profiles/{tag}_pmc_full.json condensed for bench.py"}
