@@ -208,7 +208,7 @@ KCT_API kct_status kct_set_packed_upload(kct_table *t, int on);
  * hash(minimiser) * world >> 16, the minimiser being the smallest (in a scrambled order) canonical 8-mer inside the k-mer -- the same
  * for a k-mer and its reverse complement, and mostly the same for consecutive windows of a read.  Each rank cuts ITS records into
  * maximal runs of good windows with one owner and sends every run as 2-bit bases plus one start bit per window (~1 byte per window at
- * k = 21, ~0.45 at k = 51); every owner counts what it receives with the table's ordinary bulk path.  The ranks' tables end up a
+ * k = 21, ~0.9 at k = 51); every owner counts what it receives with the table's ordinary bulk path.  The ranks' tables end up a
  * disjoint partition of the key space: len / sum_counts of the global table are sums over ranks.  k <= 64.
  *
  * The library runs the whole call -- passes, pipelining (pass p + 1 is cut while pass p is on the wire, and is on the wire while pass

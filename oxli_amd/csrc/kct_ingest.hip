@@ -17,7 +17,10 @@ using namespace kcth;
 //     starts at the first record start at or after its segment's first byte and stops at the first record
 //     start at or after the segment's end, so every record is parsed by exactly one thread.  Records are
 //     independent, so the chunks can be counted in any order;
-//   * gzip files are inflated and parsed by the calling thread (inflate is the bottleneck).
+//   * gzip files are inflated by threads of their own into a ring of text slots that the calling thread parses: ONE inflater
+//     for a plain gzip stream (zlib's inflate, ~0.4 GB/s of text, is then the bound -- but no longer inflate PLUS parse), SEVERAL
+//     for BGZF (bgzip's blocked gzip: every member announces its compressed size in an extra field and its text size in its
+//     trailer, so blocks are found without inflating and land in order).
 // A record longer than a chunk is cut with a (k-1)-base overlap, which keeps every window counted
 // exactly once.
 namespace {
@@ -101,24 +104,97 @@ struct ChunkWriter {
     }
 };
 
-// Byte sources: a gzip (or plain) stream read through zlib, or a mapped file.
-struct GzSource {
-    gzFile f = nullptr;
-    std::vector<unsigned char> buf;
-    size_t pos = 0, end = 0;
+// Byte sources: a ring of inflated text (gzip input), or a mapped file.
+// ---- gzip input: inflater threads fill a ring of text slots in order, the parser reads them in order -------------------------------
+struct TextRing {
+    struct Slot { std::vector<unsigned char> buf; size_t used = 0; bool full = false; };
+    std::vector<Slot> slots;
+    std::mutex mu;
+    std::condition_variable cv;
+    u64 consumed = 0;      // slots the parser has finished with (slot seq is free once seq < consumed + slots.size())
+    u64 end_seq = ~0ULL;   // sequence number one past the last slot (set by the producer that meets the end of the input)
+    bool failed = false;
+    std::string msg;
+    TextRing(size_t n, size_t bytes) : slots(n) { for (auto &sl : slots) sl.buf.resize(bytes); }
+    // producer: the slot for sequence number seq, once the parser has released it (nullptr: the job was abandoned)
+    Slot *acquire(u64 seq) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return failed || seq < consumed + slots.size(); });
+        return failed ? nullptr : &slots[seq % slots.size()];
+    }
+    void publish(Slot *sl, size_t used) {
+        { std::lock_guard<std::mutex> lk(mu); sl->used = used; sl->full = true; }
+        cv.notify_all();
+    }
+    void finish(u64 seq_end) {
+        { std::lock_guard<std::mutex> lk(mu); end_seq = std::min(end_seq, seq_end); }
+        cv.notify_all();
+    }
+    void fail(const char *m) {
+        { std::lock_guard<std::mutex> lk(mu); if (!failed) { failed = true; msg = m; } }
+        cv.notify_all();
+    }
+    // parser: the next full slot in order (nullptr at the end of the input or on failure)
+    Slot *next(u64 seq) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return failed || seq >= end_seq || slots[seq % slots.size()].full; });
+        if (failed || seq >= end_seq) return nullptr;
+        return &slots[seq % slots.size()];
+    }
+    void release(u64 seq) {
+        { std::lock_guard<std::mutex> lk(mu); slots[seq % slots.size()].full = false; consumed = seq + 1; }
+        cv.notify_all();
+    }
+};
+
+struct RingSource {
+    TextRing *ring;
+    TextRing::Slot *cur = nullptr;
+    u64 seq = 0;
+    size_t pos = 0;
     bool eof = false;
     bool fill() {
         if (eof) return false;
-        int n = gzread(f, buf.data(), (unsigned)buf.size());
-        if (n <= 0) { eof = true; return false; }
-        pos = 0; end = (size_t)n;
-        return true;
+        if (cur) { ring->release(seq); ++seq; cur = nullptr; }
+        for (;;) {
+            cur = ring->next(seq);
+            if (!cur) { eof = true; return false; }
+            pos = 0;
+            if (cur->used) return true;
+            ring->release(seq); ++seq; cur = nullptr;   // (an empty slot: BGZF's end-of-file block)
+        }
     }
-    int peek() { if (pos >= end && !fill()) return -1; return buf[pos]; }
-    bool span(const unsigned char *&b, size_t &avail) { if (pos >= end && !fill()) return false; b = buf.data() + pos; avail = end - pos; return true; }
+    int peek() { if ((!cur || pos >= cur->used) && !fill()) return -1; return cur->buf[pos]; }
+    bool span(const unsigned char *&b, size_t &avail) { if ((!cur || pos >= cur->used) && !fill()) return false; b = cur->buf.data() + pos; avail = cur->used - pos; return true; }
     void advance(size_t n) { pos += n; }
     size_t offset() const { return 0; }  // unused: one parser, no segment end
 };
+
+// BGZF (SAM specification 4.1): gzip members of at most 64 KiB with FEXTRA holding the subfield 'B' 'C' = (member size - 1)
+struct BgzfBlock { size_t off, csize; unsigned isize; };
+bool bgzf_scan(const unsigned char *p, size_t size, std::vector<BgzfBlock> &out) {
+    size_t off = 0;
+    while (off < size) {
+        if (size - off < 28 || p[off] != 0x1f || p[off + 1] != 0x8b || p[off + 2] != 8 || !(p[off + 3] & 4)) return false;
+        const size_t xlen = p[off + 10] | ((size_t)p[off + 11] << 8);
+        size_t x = off + 12, bsize = 0;
+        const size_t xend = x + xlen;
+        if (xend > size) return false;
+        while (x + 4 <= xend) {
+            const size_t slen = p[x + 2] | ((size_t)p[x + 3] << 8);
+            if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2 && x + 6 <= xend) bsize = (p[x + 4] | ((size_t)p[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize || off + bsize > size || bsize < 12 + xlen + 8 || (p[off + 3] & ~4)) return false;   // (other header flags: not bgzip's output)
+        BgzfBlock b;
+        b.off = off; b.csize = bsize;
+        memcpy(&b.isize, p + off + bsize - 4, 4);
+        if (b.isize > 65536) return false;
+        out.push_back(b);
+        off += bsize;
+    }
+    return !out.empty();
+}
 
 struct MemSource {
     const unsigned char *base, *p, *end;
@@ -320,12 +396,87 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
             for (auto &th : pool) th.join();
         }
     } else {
-        GzSource src;
-        src.f = gzopen(path, "rb");
-        if (!src.f) { set_err("cannot open %s", path); st = KCT_ERR_ARG; }
-        else {
-            gzbuffer(src.f, 1 << 20);
-            src.buf.resize(1 << 22);
+        // gzip: inflater threads -> a ring of text slots -> this thread's parser (see the top of the file)
+        size_t slot_bytes = (size_t)4 << 20;
+        if (const char *e = getenv("KCT_FILE_SLOT")) slot_bytes = std::max<size_t>(65536, (size_t)atoll(e));  // tests shrink it: records across slots
+        Mapping gzmap;
+        std::vector<BgzfBlock> blocks;
+        {
+            const int fd = open(path, O_RDONLY);
+            struct stat sb;
+            if (fd >= 0 && fstat(fd, &sb) == 0 && sb.st_size > 0) {
+                void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) { gzmap.p = (const unsigned char *)m; gzmap.size = (size_t)sb.st_size; }
+            }
+            if (fd >= 0) close(fd);
+        }
+        const bool bgzf = gzmap.p && bgzf_scan(gzmap.p, gzmap.size, blocks);
+        size_t ninfl = 1;
+        if (bgzf) ninfl = std::max<size_t>(1, std::min<size_t>({(size_t)16, hw ? hw / 2 : 1, blocks.size()}));
+        if (const char *e = getenv("KCT_FILE_THREADS")) ninfl = bgzf ? std::max<size_t>(1, std::min<size_t>(64, (size_t)atoll(e))) : 1;
+        TextRing ring(2 * ninfl + 2, slot_bytes);
+        std::vector<std::thread> inflaters;
+        std::vector<size_t> task_first;   // (outlives the inflater threads, which read it)
+        if (bgzf) {
+            // tasks = runs of blocks whose text fits a slot, numbered in file order; inflater i takes tasks i, i + n, ...
+            {
+                size_t text = 0;
+                for (size_t i = 0; i < blocks.size(); ++i) {
+                    if (i == 0 || text + blocks[i].isize > slot_bytes) { task_first.push_back(i); text = 0; }
+                    text += blocks[i].isize;
+                }
+                task_first.push_back(blocks.size());
+            }
+            const size_t ntasks = task_first.size() - 1;
+            for (size_t w = 0; w < ninfl; ++w)
+                inflaters.emplace_back([&, w, ntasks] {   // (ntasks by value: it is local to this block, the threads outlive it)
+                    z_stream zs;
+                    memset(&zs, 0, sizeof zs);
+                    if (inflateInit2(&zs, -15) != Z_OK) { ring.fail("inflateInit2 failed"); return; }
+                    for (size_t task = w; task < ntasks; task += ninfl) {
+                        TextRing::Slot *sl = ring.acquire(task);
+                        if (!sl) break;
+                        size_t used = 0;
+                        bool ok = true;
+                        for (size_t i = task_first[task]; ok && i < task_first[task + 1]; ++i) {
+                            const BgzfBlock &b = blocks[i];
+                            const unsigned char *hdr = gzmap.p + b.off;
+                            const size_t xlen = hdr[10] | ((size_t)hdr[11] << 8), data = 12 + xlen;
+                            inflateReset(&zs);
+                            zs.next_in = const_cast<unsigned char *>(hdr + data); zs.avail_in = (unsigned)(b.csize - data - 8);
+                            zs.next_out = sl->buf.data() + used; zs.avail_out = (unsigned)(sl->buf.size() - used);
+                            const int rc = inflate(&zs, Z_FINISH);
+                            unsigned crc;
+                            memcpy(&crc, hdr + b.csize - 8, 4);
+                            ok = rc == Z_STREAM_END && zs.total_out == b.isize && (unsigned)crc32(0L, sl->buf.data() + used, b.isize) == crc;
+                            used += b.isize;
+                        }
+                        if (!ok) { ring.fail("corrupt BGZF block"); break; }
+                        ring.publish(sl, used);
+                    }
+                    inflateEnd(&zs);
+                    if (w == 0) ring.finish(ntasks);   // (the sequence ends at ntasks whoever gets there first)
+                });
+        } else {
+            inflaters.emplace_back([&] {
+                gzFile f = gzopen(path, "rb");
+                if (!f) { ring.fail("cannot open the gzip stream"); return; }
+                gzbuffer(f, 1 << 20);
+                u64 seq = 0;
+                for (;;) {
+                    TextRing::Slot *sl = ring.acquire(seq);
+                    if (!sl) break;
+                    const int n = gzread(f, sl->buf.data(), (unsigned)sl->buf.size());
+                    if (n < 0) { ring.fail("gzread failed (corrupt gzip stream)"); break; }
+                    if (n == 0) { ring.finish(seq); break; }
+                    ring.publish(sl, (size_t)n);
+                    ++seq;
+                }
+                gzclose(f);
+            });
+        }
+        {
+            RingSource src{&ring};
             int c;
             while ((c = src.peek()) >= 0 && (c == '\n' || c == '\r' || c == ' ' || c == '\t')) src.advance(1);
             if (c >= 0 && c != '>' && c != '@') { set_err("%s: neither FASTA nor FASTQ (starts with 0x%02x)", path, c); st = KCT_ERR_ARG; }
@@ -335,8 +486,10 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
                 w.finish();
                 records = w.records; bases = w.bases;
             }
-            gzclose(src.f);
+            if (st == KCT_OK && ring.failed) { set_err("%s: %s", path, ring.msg.c_str()); st = KCT_ERR_ARG; }
         }
+        ring.fail("the parser is done");   // (lets inflaters go that still wait for a slot: the parser stopped early, or the input is read)
+        for (auto &th : inflaters) th.join();
     }
     { std::lock_guard<std::mutex> lk(queue.mu); queue.done = true; }
     queue.cv.notify_all();

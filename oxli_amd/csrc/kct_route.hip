@@ -1,5 +1,5 @@
 // kct_route.hip -- the multi-GPU "early" route: every k-mer is counted by the GPU that OWNS it, at the input's full
-// coverage, and what crosses xGMI is SUPER-K-MERS -- about one byte per window at k = 21, half a byte at k = 51 -- not one entry per
+// coverage, and what crosses xGMI is SUPER-K-MERS -- about one byte per window at k = 21, 0.9 at k = 51 -- not one entry per
 // window.
 //
 //   every rank      split_superkmers_kernel over its own records: owner(k-mer) = hash(minimiser) * world >> 16, maximal runs of good

@@ -4,8 +4,8 @@
 // partitioned).  Sending one 4- or 8-byte entry per window makes the job xGMI-bound.  Consecutive windows of a read
 // overlap in k - 1 bases, so the route sends BASES instead: the owner of a k-mer is a function of its MINIMISER -- the smallest (in a
 // scrambled order) canonical m-mer inside it, m = 8 -- which consecutive windows mostly share; a maximal run of windows with one owner
-// travels as n + k - 1 bases at 2 bits each plus one start bit per window: ~1 byte per window at k = 21 instead of 4, ~0.45 at k = 51
-// instead of 8.  The minimiser is taken over canonical m-mers, so a k-mer and its reverse complement (the same key, lib.rs:576-584 via
+// travels as n + k - 1 bases at 2 bits each plus one start bit per window: ~1 byte per window at k = 21 instead of 4, ~0.9 at k = 51
+// instead of 8 (a run is longer there, but drags k - 1 bases along: ~3 bases per window at every k).  The minimiser is taken over canonical m-mers, so a k-mer and its reverse complement (the same key, lib.rs:576-584 via
 // sourmash's canonical min) have the same owner whatever strand a read shows.
 //
 //   split_superkmers_kernel<K>   persistent, one 1024-thread workgroup per CU, tiles of 16,384 window starts (as K1):

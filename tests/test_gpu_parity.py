@@ -862,6 +862,26 @@ def test_consume_file_example_fa(KCT, kats):
         assert t.last_file_records == 1 and t.consumed == 349930
 
 
+def _bgzf(data, rng):
+    """`data` as BGZF (SAM specification 4.1): gzip members of random sizes up to 64 KiB of text, each with the 'BC' extra subfield
+    holding its compressed size - 1, and the 28-byte end-of-file block."""
+    import struct
+    import zlib
+    out, pos = bytearray(), 0
+    while pos <= len(data):
+        n = min(len(data) - pos, rng.choice([1, 100, 5000, 30000, 65280]))
+        piece = data[pos: pos + n]
+        comp = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = comp.compress(piece) + comp.flush()
+        bsize = 18 + len(body) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += body + struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, n)
+        if n == 0:
+            break        # (the empty block marks the end)
+        pos += n
+    return bytes(out)
+
+
 def test_consume_file_formats_match_oracle(KCT, tmp_path, monkeypatch):
     import gzip
     rng = random.Random(31)
@@ -875,11 +895,35 @@ def test_consume_file_formats_match_oracle(KCT, tmp_path, monkeypatch):
     with open(fq, "w") as f:
         for i, s in enumerate(recs):
             f.write(f"@r{i}\n{s}\n+\n{'I' * len(s)}\n")
-    for path in (fa, fagz, fq):
+    # BGZF (bgzip's blocked gzip: members of <= 64 KiB announcing their size -- inflated by several threads) and a plain multi-member
+    # gzip file (members found only by inflating: one inflater thread)
+    fabgz, fqmm = tmp_path / "a.bgz.fa.gz", tmp_path / "a.multi.fq.gz"
+    text = open(fa, "rb").read()
+    with open(fabgz, "wb") as f:
+        f.write(_bgzf(text, rng))
+    with open(fqmm, "wb") as f:
+        fqtext = open(fq, "rb").read()
+        cut = len(fqtext) // 3
+        for part in (fqtext[:cut], fqtext[cut: 2 * cut], fqtext[2 * cut:]):
+            f.write(gzip.compress(part, 1))
+    for path in (fa, fagz, fq, fabgz, fqmm):
         dev = KCT(k)
         assert dev.consume_file(str(path)) == n_ref, path
         assert dev.last_file_records == len(recs)
         assert_same_table(dev, ref)
+    monkeypatch.setenv("KCT_FILE_SLOT", "65536")   # text slots of 64 KiB: records (up to 25 kbp) and lines across slot boundaries
+    for path, threads in ((fagz, "1"), (fabgz, "1"), (fabgz, "5"), (fqmm, "1")):
+        monkeypatch.setenv("KCT_FILE_THREADS", threads)
+        dev = KCT(k)
+        assert dev.consume_file(str(path)) == n_ref, (path, threads)
+        assert dev.last_file_records == len(recs)
+        assert_same_table(dev, ref)
+    monkeypatch.delenv("KCT_FILE_SLOT"); monkeypatch.delenv("KCT_FILE_THREADS")
+    bad = bytearray(open(fabgz, "rb").read())
+    bad[len(bad) // 2] ^= 0x55                      # a corrupt block: an error, not a short count
+    (tmp_path / "bad.fa.gz").write_bytes(bytes(bad))
+    with pytest.raises((RuntimeError, ValueError, OSError)):
+        KCT(k).consume_file(str(tmp_path / "bad.fa.gz"))
     # records longer than a staging chunk are cut with a (k-1)-base overlap: force tiny chunks
     monkeypatch.setenv("KCT_FILE_CHUNK", "4096")
     dev = KCT(k)
