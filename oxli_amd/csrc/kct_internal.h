@@ -335,6 +335,7 @@ kct_status consume_stream_runs(kct_table *t, const kct::RunsInput &in, u64 ngrou
 // kct_runs.hip: K1's super-k-mer instantiations and the early route's own kernels
 void launch_partition_runs(kct_table *t, int mode, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa);
 void launch_split(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 ntiles, const kct::SplitArgs &sa);
+inline int split_streams(const kct_table *t) { return t->num_cus; }   // workgroups of the split = streams a rank sends to every owner
 void launch_gather_units(kct_table *t, const void *src, const du64 *src_off, const du64 *dst_off, const unsigned int *n, unsigned int count, void *dst);
 void launch_run_directory(kct_table *t, const kct::RunStream *streams, unsigned int nstreams, const du64 *starts, kct::RunGroup *groups);
 void launch_expand_runs(kct_table *t, const kct::RunsInput &in, u64 ngroups, unsigned char *out);

@@ -102,8 +102,8 @@ kct_status split_pass(Route &r, const unsigned char *d_stream, u64 nbytes, Slab 
     out.windows_out = out.runs = out.bytes = 0;
     const u64 npos = nbytes >= (u64)k ? nbytes - k + 1 : 0;
     if (!npos) return KCT_OK;
-    const u64 ntiles = (npos + kct::kPartTile - 1) / kct::kPartTile, tiles_per_wg = (ntiles + nwg - 1) / nwg;
-    const double per_stream = (double)(tiles_per_wg * kct::kPartTile) / world;
+    const u64 ntiles = (npos + kct::kSkTile - 1) / kct::kSkTile, tiles_per_wg = (ntiles + nwg - 1) / nwg;
+    const double per_stream = (double)(tiles_per_wg * kct::kSkTile) / world;
     u64 cap_units = (u64)(per_stream * bases_per_window(k) * 1.3 / 64.0) + 16, cap_sunits = (u64)(per_stream * 1.3 / 128.0) + 16;
     std::vector<unsigned int> meta(4 * nstreams);
     for (;;) {
@@ -236,7 +236,7 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     if (ops && (!ops->alloc || !ops->exchange_sizes || !ops->start || !ops->wait)) { set_err("kct_exchange_ops needs alloc, exchange_sizes, start and wait"); return KCT_ERR_ARG; }
     const bool solo = !ops && world > 1;   // no exchange: of this rank's OWN records, count the k-mers it owns (what its peers own is dropped)
     if (k > 64) { set_err("the early route takes k <= 64"); return KCT_ERR_ARG; }
-    Route r{t, world, rank, ops, t->num_cus};
+    Route r{t, world, rank, ops, split_streams(t)};
     // ---- passes: as many as the tightest rank needs (HBM: regions, two send and two receive slabs, the owner's scratch), at least
     // four for a long stream so that the wire hides behind the kernels
     const u64 windows = nbytes >= (u64)k ? nbytes - k + 1 : 0;
@@ -419,7 +419,7 @@ extern "C" kct_status kct_superkmer_split_device(kct_table *t, const void *d_str
     if (!d_parts || !part_off || !part_bytes || !dir || (!d_stream && nbytes)) { set_err("null argument"); return KCT_ERR_ARG; }
     if (world < 1 || world > kct::kSkMaxWorld || t->k > 64) { set_err("bad world, or k > 64"); return KCT_ERR_ARG; }
     if (((uintptr_t)d_stream & 15) != 0) { set_err("d_stream must be 16-byte aligned"); return KCT_ERR_ARG; }
-    Route r{t, world, 0, nullptr, t->num_cus};
+    Route r{t, world, 0, nullptr, split_streams(t)};
     Slab send;
     PassOut po;
     KCT_TRY(split_pass(r, (const unsigned char *)d_stream, nbytes, send, t->d_sk_send, po));
@@ -429,4 +429,4 @@ extern "C" kct_status kct_superkmer_split_device(kct_table *t, const void *d_str
     return KCT_OK;
 }
 
-extern "C" uint32_t kct_superkmer_streams(const kct_table *t) { return t ? (uint32_t)t->num_cus : 0; }
+extern "C" uint32_t kct_superkmer_streams(const kct_table *t) { return t ? (uint32_t)split_streams(t) : 0; }

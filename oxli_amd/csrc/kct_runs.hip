@@ -19,7 +19,7 @@ void k1_runs(kct_table *t, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs
 template <int K>
 struct SplitByK {
     static void run(int k, hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, u64 ntiles, const kct::SplitArgs &sa) {
-        if (k == K) hipLaunchKernelGGL(kct::split_superkmers_kernel<K>, dim3(grid), dim3(kct::kPartThreads), 0, s, stream, nbytes, ntiles, sa);
+        if (k == K) hipLaunchKernelGGL(kct::split_superkmers_kernel<K>, dim3(grid), dim3(kct::kSkThreads), 0, s, stream, nbytes, ntiles, sa);
         else SplitByK<K - 1>::run(k, s, grid, stream, nbytes, ntiles, sa);
     }
 };
@@ -53,7 +53,7 @@ void launch_partition_runs(kct_table *t, int mode, u64 chunk_bytes, u64 ntiles, 
 
 void launch_split(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 ntiles, const kct::SplitArgs &sa) {
     ProfScope ps(t, "split_superkmers_kernel");
-    SplitByK<64>::run(t->k, t->stream, t->num_cus, d_stream, nbytes, ntiles, sa);
+    SplitByK<64>::run(t->k, t->stream, split_streams(t), d_stream, nbytes, ntiles, sa);
 }
 
 void launch_gather_units(kct_table *t, const void *src, const du64 *src_off, const du64 *dst_off, const unsigned int *n, unsigned int count, void *dst) {

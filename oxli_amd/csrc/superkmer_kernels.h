@@ -92,17 +92,17 @@ __device__ __forceinline__ u32 sk_gather4(u32 f) { return (((f >> 7) * 0x0020408
 __device__ __forceinline__ u32 sk_nonzero_bytes(u32 d) { return (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u; }
 
 template <int K>
-__global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const unsigned char *__restrict__ stream, u64 nbytes, u64 ntiles, SplitArgs a) {
+__global__ __launch_bounds__(kSkThreads) void split_superkmers_kernel(const unsigned char *__restrict__ stream, u64 nbytes, u64 ntiles, SplitArgs a) {
     constexpr int M = K < kSkM ? K : kSkM, W = K - M + 1;
     constexpr u32 MM = (1u << (2 * M)) - 1u;
     constexpr int NV = 16 + W - 1, NP = (NV + 1) / 2;
     constexpr int HT = (W - 1 + 15) / 16;                       // threads that also scramble the halo's m-mers
-    constexpr int kMmWords = kPartTile / 2 + 8 * HT + 8;
-    __shared__ u32 tc[1 + kPartThreads + 16 + 2];               // tile codes behind one zero word (a copy may look 32 bits to the left)
-    __shared__ unsigned short tv[kPartThreads + 16];
+    constexpr int kMmWords = kSkTile / 2 + 8 * HT + 8;
+    __shared__ u32 tc[1 + kSkThreads + 16 + 2];               // tile codes behind one zero word (a copy may look 32 bits to the left)
+    __shared__ unsigned short tv[kSkThreads + 16];
     __shared__ __attribute__((aligned(16))) u32 mm[kMmWords];   // scrambled canonical m-mers, 16 bits each
-    __shared__ __attribute__((aligned(16))) unsigned char own[kPartTile + 16];
-    __shared__ unsigned short emask[kPartThreads + 1];
+    __shared__ __attribute__((aligned(16))) unsigned char own[kSkTile + 16];
+    __shared__ unsigned short emask[kSkThreads + 1];
     __shared__ __attribute__((aligned(16))) u32 sb[kSkStageWords];      // outgoing bases, [world][capBw]
     __shared__ __attribute__((aligned(16))) u32 ss[kSkStageWords / 2];  // outgoing start bits, [world][capBw / 2]
     __shared__ u64 cur[kSkMaxWorld];       // per owner: windows (low half) | bases (high half) staged, carry included
@@ -118,11 +118,11 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
     // a sub-tile of g windows always fits: at most g / 2 runs of one owner (+ the few that kSkMaxRun cuts), K bases each, behind a
     // carry of < 64 bases.  gsafe = the largest power of two g with (g / 2) K + 16 K + 64 <= capB (16 holds for every world <= 64)
     u32 gsafe = 16;
-    while (gsafe < (u32)kPartTile && (u64)gsafe * K + 16 * K + 64 <= capB) gsafe <<= 1;
-    for (u32 i = t; i < (u32)kSkStageWords; i += kPartThreads) sb[i] = 0;
-    for (u32 i = t; i < (u32)kSkStageWords / 2; i += kPartThreads) ss[i] = 0;
+    while (gsafe < (u32)kSkTile && (u64)gsafe * K + 16 * K + 64 <= capB) gsafe <<= 1;
+    for (u32 i = t; i < (u32)kSkStageWords; i += kSkThreads) sb[i] = 0;
+    for (u32 i = t; i < (u32)kSkStageWords / 2; i += kSkThreads) ss[i] = 0;
     if (t < kSkMaxWorld) { cur[t] = 0; cur0[t] = 0; filledB[t] = 0; filledS[t] = 0; carryB[t] = make_uint4(0, 0, 0, 0); carryS[t] = make_uint4(0, 0, 0, 0); }
-    if (t == 0) { tc[0] = 0; emask[kPartThreads] = 0xFFFF; s_over = 0; s_runs = 0; }
+    if (t == 0) { tc[0] = 0; emask[kSkThreads] = 0xFFFF; s_over = 0; s_runs = 0; }
     uint4 *my_bases = a.bases_out + (u64)blockIdx.x * world * a.cap_units;
     uint4 *my_starts = a.starts_out + (u64)blockIdx.x * world * a.cap_sunits;
     u32 my_runs = 0;
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
     };
     uint4 pre_main = make_uint4(0, 0, 0, 0), pre_halo = make_uint4(0, 0, 0, 0);
     if (blockIdx.x < ntiles) {
-        pre_main = load_chunk((u64)blockIdx.x * kPartTile, t);
-        if (t < 16) pre_halo = load_chunk((u64)blockIdx.x * kPartTile, kPartThreads + t);
+        pre_main = load_chunk((u64)blockIdx.x * kSkTile, t);
+        if (t < 16) pre_halo = load_chunk((u64)blockIdx.x * kSkTile, kSkThreads + t);
     }
     __syncthreads();
     for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -163,16 +163,16 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
             tc[1 + t] = c; tv[t] = (unsigned short)v;
             if (t < 16) {
                 if (a.pcodes) { c = pre_halo.x; v = pre_halo.y; } else encode16(pre_halo, c, v);
-                tc[1 + kPartThreads + t] = c; tv[kPartThreads + t] = (unsigned short)v;
+                tc[1 + kSkThreads + t] = c; tv[kSkThreads + t] = (unsigned short)v;
             }
-            if (t == 0) { tc[1 + kPartThreads + 16] = 0; tc[1 + kPartThreads + 17] = 0; }
+            if (t == 0) { tc[1 + kSkThreads + 16] = 0; tc[1 + kSkThreads + 17] = 0; }
         }
         __syncthreads();
         {
             const u64 next = tile + gridDim.x;
             if (next < ntiles) {
-                pre_main = load_chunk(next * kPartTile, t);
-                if (t < 16) pre_halo = load_chunk(next * kPartTile, kPartThreads + t);
+                pre_main = load_chunk(next * kSkTile, t);
+                if (t < 16) pre_halo = load_chunk(next * kSkTile, kSkThreads + t);
             }
         }
         // ---- every m-mer of the tile, canonical and scrambled: out8[i] = value 2 i | value 2 i + 1 << 16 -----------------------------
@@ -218,9 +218,9 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
             reinterpret_cast<uint4 *>(mm)[2 * t] = make_uint4(o8[0], o8[1], o8[2], o8[3]);
             reinterpret_cast<uint4 *>(mm)[2 * t + 1] = make_uint4(o8[4], o8[5], o8[6], o8[7]);
             if ((int)t < HT) {  // the halo: m-mers that start beyond the tile's last window start
-                scramble16(tc[1 + kPartThreads + t], tc[2 + kPartThreads + t], o8);
-                reinterpret_cast<uint4 *>(mm)[2 * (kPartThreads + t)] = make_uint4(o8[0], o8[1], o8[2], o8[3]);
-                reinterpret_cast<uint4 *>(mm)[2 * (kPartThreads + t) + 1] = make_uint4(o8[4], o8[5], o8[6], o8[7]);
+                scramble16(tc[1 + kSkThreads + t], tc[2 + kSkThreads + t], o8);
+                reinterpret_cast<uint4 *>(mm)[2 * (kSkThreads + t)] = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+                reinterpret_cast<uint4 *>(mm)[2 * (kSkThreads + t) + 1] = make_uint4(o8[4], o8[5], o8[6], o8[7]);
             }
         }
         __syncthreads();
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
         }
         __syncthreads();
         // ---- runs: maximal stretches of good windows with one owner, cut every `cut` windows (cut >= 16, a power of two) ---------------
-        const u32 prev_o = t ? own[16 * t - 1] : 0xFFu, next_o = t + 1 < kPartThreads ? own[16 * t + 16] : 0xFFu;
+        const u32 prev_o = t ? own[16 * t - 1] : 0xFFu, next_o = t + 1 < kSkThreads ? own[16 * t + 16] : 0xFFu;
         u32 smask = 0;
         auto build_masks = [&](u32 cut) {
             u32 em = 0;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
         };
         // whole 16-byte units leave for this workgroup's regions; the partial ones move to the front for the next tile
         auto flush = [&]() {
-            for (u32 u = t; u < world * capU; u += kPartThreads) {
+            for (u32 u = t; u < world * capU; u += kSkThreads) {
                 const u32 o = __umulhi(u, invU), ul = u - o * capU;
                 if (ul < (u32)(cur[o] >> 32) / kSkUnitBases) {
                     uint4 *src = reinterpret_cast<uint4 *>(sb) + u;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
                     if (at < a.cap_units) my_bases[(u64)o * a.cap_units + at] = v;
                 }
             }
-            for (u32 u = t; u < world * capSU; u += kPartThreads) {
+            for (u32 u = t; u < world * capSU; u += kSkThreads) {
                 const u32 o = __umulhi(u, invSU), ul = u - o * capSU;
                 if (ul < (u32)cur[o] / kSkUnitWindows) {
                     uint4 *src = reinterpret_cast<uint4 *>(ss) + u;
@@ -364,15 +364,15 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
         build_masks(kSkMaxRun);
         __syncthreads();
         my_runs += (u32)__builtin_popcount(smask);
-        for_runs(0, kPartTile, emit);
+        for_runs(0, kSkTile, emit);
         __syncthreads();
         if (s_over == 0) flush();
         else {
             // (rare: far more runs than random sequence gives, or nearly all for one owner) -- the staging goes back to what the tile
             // found, and the tile goes out in pieces that cannot overflow it
             __syncthreads();
-            for (u32 i = t; i < (u32)kSkStageWords; i += kPartThreads) sb[i] = 0;
-            for (u32 i = t; i < (u32)kSkStageWords / 2; i += kPartThreads) ss[i] = 0;
+            for (u32 i = t; i < (u32)kSkStageWords; i += kSkThreads) sb[i] = 0;
+            for (u32 i = t; i < (u32)kSkStageWords / 2; i += kSkThreads) ss[i] = 0;
             if (t == 0) s_over = 0;
             __syncthreads();
             if (t < world) {
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kPartThreads) void split_superkmers_kernel(const un
             build_masks(gsafe < kSkMaxRun ? gsafe : kSkMaxRun);
             __syncthreads();
             my_runs += (u32)__builtin_popcount(smask);
-            for (u32 first = 0; first < (u32)kPartTile; first += gsafe) {
+            for (u32 first = 0; first < (u32)kSkTile; first += gsafe) {
                 for_runs(first, first + gsafe, emit);
                 __syncthreads();
                 flush();

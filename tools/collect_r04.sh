@@ -8,7 +8,7 @@ TAG=${1:-r04}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python3 /root/repo/bench.py --no-cpu-baseline --no-verify"
+B="python3 /root/repo/bench.py --no-cpu-baseline --no-verify --no-second-process"
 run() {  # name, bench arguments...
   local name=$1; shift
   mkdir -p $O/$name

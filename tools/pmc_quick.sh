@@ -4,7 +4,7 @@ P=${1:-auto}
 O=$GRAFT_REPO_ROOT/gpurun_out/pmcq_$P
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python3 /root/repo/bench.py --no-cpu-baseline --configs none --path $P --steps 3 --warmup 2"
+B="python3 /root/repo/bench.py --no-cpu-baseline --no-second-process --configs none --path $P --steps 3 --warmup 2"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/sq -- $B > $O/sq.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/lds -- $B > $O/lds.log 2>&1
 python3 - "$O" <<'PY'
