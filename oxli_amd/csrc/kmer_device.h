@@ -233,6 +233,9 @@ __device__ __forceinline__ u64 hash_packed(const Packed<KW> &a, int k, const u32
                                            const u64 *tmul = nullptr) {
     Murmur m;
     const int nblocks = k >> 4, rem = k & 15;
+#ifdef KCT_DEBUG_ZERO_KMER  // `make zero` (tests only): one chosen k-mer hashes to 0, the value consume skips (lib.rs:589)
+    if (k == KCT_DEBUG_ZERO_K && a.w[0] == KCT_DEBUG_ZERO_KMER) return 0;
+#endif
 #pragma unroll
     for (int b = 0; b < 2 * KW; ++b) {
         if (b * 16 < k) {

@@ -281,7 +281,7 @@ def _as_i64(values):
     return np.array(values, dtype=np.uint64).view(np.int64)
 
 
-def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, max_windows=0):
+def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, max_windows=0, exchange_when_alone=False):
     """Counts this rank's device-resident record stream by the EARLY route (``kct_consume_device_routed``): every k-mer is counted by
     the rank that owns it -- owner = hash(minimiser) -- and what travels is super-k-mers: runs of consecutive windows with one owner as
     2-bit bases + a start bit per window.  Every rank must call it.  The owner side is the table's ordinary bulk path (``set_path``
@@ -290,7 +290,9 @@ def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, ma
     stats dict).
 
     Afterwards the ranks' tables are a disjoint partition of the key space: ``global_scalar_sum`` of ``len`` / ``sum_counts`` gives the
-    global table's, and no ``merge_across_ranks`` is needed.  A failure on any rank raises on every rank."""
+    global table's, and no ``merge_across_ranks`` is needed.  A failure on any rank raises on every rank.
+    ``exchange_when_alone``: a group of ONE rank goes through the collectives too (everything is sent to itself) -- how the test suite
+    runs the RCCL branch of the exchange on a one-GPU box."""
     import ctypes as C
 
     world = dist.get_world_size(group)
@@ -298,7 +300,7 @@ def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, ma
     if getattr(table, "store_kmers", False):
         raise ValueError("the early route moves packed bases only: a store_kmers table would lose its hash -> k-mer map")
     dev = torch.device("cuda", torch.cuda.current_device())
-    ex = _Exchanger(group, dev) if world > 1 else None
+    ex = _Exchanger(group, dev) if world > 1 or exchange_when_alone else None
     n, stats = C.c_uint64(), (C.c_uint64 * 16)()
     st = table._lib.kct_consume_device_routed(table._h, C.c_void_p(int(data_ptr)), int(nbytes), int(consumed_bytes), world, rank,
                                               ex.ptr if ex else None, int(max_windows), C.byref(n), stats)

@@ -25,6 +25,9 @@ def main():
     L = int(sys.argv[5]) if len(sys.argv) > 5 else 150
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
+    if route == "rccl-alone":
+        rccl_alone(k, per_rank, G, L)
+        return
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle
     from oxli_amd import KmerCountTable
@@ -72,6 +75,35 @@ def main():
         del ref
         print(f"DIST_GPU_OK world={world} distinct={rk.size}")
     dist.barrier()
+    dist.destroy_process_group()
+
+
+def rccl_alone(k, per_rank, G, L):
+    """ONE rank with the nccl back end (= RCCL; a one-GPU box cannot hold more): the device-tensor, asynchronous branches of the
+    exchanges -- the size all-to-all on device int64, the payload all-to-all on device bytes with the library counting on another
+    stream meanwhile, exchange_pairs' uneven all-to-all -- run through a real communicator, everything sent to itself."""
+    import oracle
+    from oxli_amd import KmerCountTable
+    from oxli_amd.distributed import consume_device_early, exchange_pairs, exchange_route
+
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    genome = oracle.synth_genome(G, 42)
+    reads = oracle.synth_reads(genome, 0, per_rank, L, 1337)
+    dev_reads = torch.from_numpy(reads.reshape(-1)).cuda()
+    tab, _, _ = oracle.baseline_consume(reads, L, k, min(8, len(os.sched_getaffinity(0))), native=False)
+    rk, rc = tab.dump_arrays()
+    t = KmerCountTable(k, capacity=G)
+    n, st = consume_device_early(t, dev_reads.data_ptr(), dev_reads.numel(), per_rank * L, max_windows=1 << 22, exchange_when_alone=True)
+    assert n == per_rank * (L - k + 1) and st["passes"] > 1 and st["runs"] > 0 and st["windows_sent"] == 0, st   # (sent = to OTHER ranks)
+    keys, counts = t.dump_arrays(1)
+    assert np.array_equal(keys, rk) and np.array_equal(counts, rc)
+    # the late route's exchange: pairs on the device through all_to_all_single with uneven splits
+    assert exchange_route() == "all_to_all"
+    pairs = torch.stack([torch.from_numpy(keys.view(np.int64).copy()), torch.from_numpy(counts.view(np.int64).copy())], dim=1).cuda()
+    got, zero = exchange_pairs(pairs, torch.tensor([pairs.shape[0]], dtype=torch.int64), zero_count=7)
+    torch.cuda.synchronize()
+    assert zero == 7 and got.device.type == "cuda" and torch.equal(got, pairs)
+    print(f"DIST_GPU_OK world=1 distinct={rk.size} route=rccl-alone passes={st['passes']}")
     dist.destroy_process_group()
 
 

@@ -58,3 +58,15 @@ def test_store_kmers_tables_merge_with_their_k_mer_maps():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-6000:]
     assert "DIST_GPU_OK world=2" in out.stdout and "route=late:store_kmers" in out.stdout, out.stdout[-2000:]
+
+
+def test_one_rank_through_a_real_rccl_communicator():
+    """torch.distributed's nccl back end IS RCCL on this box: a group of one rank runs the exchanges' device-side, asynchronous branches
+    (what 8 ranks run over xGMI) through a real communicator -- the early route's size / payload all-to-alls under pipelined passes and
+    the late route's pair exchange; table == oracle."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "21", "200000", "2000000", "rccl-alone"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-6000:]
+    assert "DIST_GPU_OK world=1" in out.stdout and "route=rccl-alone" in out.stdout, out.stdout[-2000:]
