@@ -2,6 +2,7 @@
 #include "kct_internal.h"
 
 #include <deque>
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -17,10 +18,13 @@ using namespace kcth;
 //     starts at the first record start at or after its segment's first byte and stops at the first record
 //     start at or after the segment's end, so every record is parsed by exactly one thread.  Records are
 //     independent, so the chunks can be counted in any order;
-//   * gzip files are inflated by threads of their own into a ring of text slots that the calling thread parses: ONE inflater
-//     for a plain gzip stream (zlib's inflate, ~0.4 GB/s of text, is then the bound -- but no longer inflate PLUS parse), SEVERAL
-//     for BGZF (bgzip's blocked gzip: every member announces its compressed size in an extra field and its text size in its
-//     trailer, so blocks are found without inflating and land in order).
+//   * a plain gzip stream is inflated by ONE thread of its own into a ring of text slots that the calling thread parses (zlib's
+//     inflate, ~0.4 GB/s of text, is then the bound -- but no longer inflate PLUS parse);
+//   * BGZF (bgzip's blocked gzip: every member announces its compressed size in an extra field and its text size in its trailer, so
+//     blocks are found without inflating) is cut into slots of whole blocks that SEVERAL threads take in turn: a thread inflates
+//     its slot (libdeflate when the system has it, else zlib) and parses the records that start AND end inside it; what lies before
+//     the slot's first record start and from its last record start on goes, in slot order, to the calling thread, which parses
+//     that stream of fragments -- one record per slot boundary, or all of it when records are longer than slots.
 // A record longer than a chunk is cut with a (k-1)-base overlap, which keeps every window counted
 // exactly once.
 namespace {
@@ -263,29 +267,130 @@ bool parse_records(Src &s, ChunkWriter &w, int fmt, size_t stop, ChunkQueue &que
     return true;
 }
 
+// Is the line that starts at `ls` a record header?  FASTQ: '@' may also open a quality line.  A header is followed by a sequence
+// line and a '+' line; a quality line is followed by the next header and ITS sequence line, which never starts with '+'.
+// (Undecidable -- the two following lines are not all there -- counts as no.)
+inline bool is_record_start(const unsigned char *ls, const unsigned char *end, int fmt) {
+    if (ls >= end || *ls != (unsigned char)fmt) return false;
+    if (fmt == '>') return true;
+    auto line_end = [&](const unsigned char *q) { const unsigned char *nl = (const unsigned char *)memchr(q, '\n', (size_t)(end - q)); return nl ? nl : end; };
+    const unsigned char *l1 = line_end(ls);                       // end of the candidate header
+    const unsigned char *l2 = l1 < end ? line_end(l1 + 1) : end;  // end of the sequence line
+    return l2 < end && l2 + 1 < end && l2[1] == '+';
+}
+
 // First record start at or after `from` in a mapped file (file size if there is none).
 size_t find_record_start(const unsigned char *base, size_t size, size_t from, int fmt) {
     if (from == 0) return 0;
     if (from >= size) return size;
     // line starts at or after `from`: one after every '\n' at or after from - 1
     const unsigned char *p = base + from - 1, *end = base + size;
-    auto line_end = [&](const unsigned char *q) { const unsigned char *nl = (const unsigned char *)memchr(q, '\n', (size_t)(end - q)); return nl ? nl : end; };
     while (p < end) {
         const unsigned char *nl = (const unsigned char *)memchr(p, '\n', (size_t)(end - p));
         if (!nl || nl + 1 >= end) return size;
         const unsigned char *ls = nl + 1;
-        if (*ls == (unsigned char)fmt) {
-            if (fmt == '>') return (size_t)(ls - base);
-            // FASTQ: '@' may also open a quality line.  A header is followed by a sequence line and a '+' line;
-            // a quality line is followed by the next header and ITS sequence line, which never starts with '+'.
-            const unsigned char *l1 = line_end(ls);                       // end of the candidate header
-            const unsigned char *l2 = l1 < end ? line_end(l1 + 1) : end;  // end of the sequence line
-            if (l2 < end && l2 + 1 < end && l2[1] == '+') return (size_t)(ls - base);
-        }
+        if (is_record_start(ls, end, fmt)) return (size_t)(ls - base);
         p = ls;
     }
     return size;
 }
+
+// Last record start at or after `lo` (itself a record start) in base[0, size).
+size_t find_last_record_start(const unsigned char *base, size_t size, size_t lo, int fmt) {
+    const unsigned char *end = base + size, *q = end;
+    while (q > base + lo) {
+        const unsigned char *nl = (const unsigned char *)memrchr(base + lo, '\n', (size_t)(q - (base + lo)));
+        if (!nl) break;
+        if (is_record_start(nl + 1, end, fmt)) return (size_t)(nl + 1 - base);
+        q = nl;
+    }
+    return lo;
+}
+
+// ---- BGZF: what the slot parsers leave for the stitching parser, in slot order --------------------------------------------------
+struct Fragments {
+    struct Piece { std::vector<unsigned char> head, tail; bool ready = false; };
+    std::vector<Piece> ring;
+    std::mutex mu;
+    std::condition_variable cv;
+    u64 consumed = 0, end_seq;
+    bool failed = false;
+    std::string msg;
+    Fragments(size_t n, u64 nslots) : ring(n), end_seq(nslots) {}
+    bool may_start(u64 seq) {   // a slot thread: not more than ring.size() slots ahead of the stitcher
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return failed || seq < consumed + ring.size(); });
+        return !failed;
+    }
+    void publish(u64 seq, const unsigned char *h, size_t nh, const unsigned char *t, size_t nt) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            Piece &p = ring[seq % ring.size()];
+            p.head.assign(h, h + nh); p.tail.assign(t, t + nt); p.ready = true;
+        }
+        cv.notify_all();
+    }
+    void fail(const char *m) {
+        { std::lock_guard<std::mutex> lk(mu); if (!failed) { failed = true; msg = m; } }
+        cv.notify_all();
+    }
+    Piece *next(u64 seq) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return failed || seq >= end_seq || ring[seq % ring.size()].ready; });
+        return failed || seq >= end_seq ? nullptr : &ring[seq % ring.size()];
+    }
+    void release(u64 seq) {
+        { std::lock_guard<std::mutex> lk(mu); ring[seq % ring.size()].ready = false; consumed = seq + 1; }
+        cv.notify_all();
+    }
+};
+
+struct FragmentSource {   // head 0, tail 0, head 1, tail 1, ... as one byte stream
+    Fragments *f;
+    Fragments::Piece *cur = nullptr;
+    u64 seq = 0;
+    int part = 0;
+    size_t pos = 0;
+    bool eof = false;
+    const std::vector<unsigned char> &buf() const { return part ? cur->tail : cur->head; }
+    bool fill() {
+        for (;;) {
+            if (eof) return false;
+            if (!cur) {
+                cur = f->next(seq);
+                if (!cur) { eof = true; return false; }
+                part = 0; pos = 0;
+            }
+            if (pos < buf().size()) return true;
+            if (part == 0) { part = 1; pos = 0; continue; }
+            f->release(seq); ++seq; cur = nullptr;
+        }
+    }
+    int peek() { if ((!cur || pos >= buf().size()) && !fill()) return -1; return buf()[pos]; }
+    bool span(const unsigned char *&b, size_t &avail) { if ((!cur || pos >= buf().size()) && !fill()) return false; b = buf().data() + pos; avail = buf().size() - pos; return true; }
+    void advance(size_t n) { pos += n; }
+    size_t offset() const { return 0; }
+};
+
+// libdeflate (whole-buffer inflate, 2-3x zlib's rate) when the system has the shared library; its four entry points are declared here
+// because the image carries no header for it.  Absent: zlib.
+struct Deflate {
+    void *(*alloc)() = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*free_)(void *) = nullptr;
+    unsigned (*crc)(unsigned, const void *, size_t) = nullptr;
+    Deflate() {
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        free_ = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        crc = (unsigned (*)(unsigned, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        if (!alloc || !decompress || !free_ || !crc) alloc = nullptr;
+    }
+    bool ok() const { return alloc != nullptr; }
+};
+const Deflate &deflate_lib() { static Deflate d; return d; }
 
 struct Mapping {
     const unsigned char *p = nullptr;
@@ -325,14 +430,46 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
         close(fd);
     }
     const size_t k = t->k;
-    size_t chunk_cap = (size_t)16 << 20;  // stream bytes per chunk
+    // gzip: BGZF or a plain stream?
+    Mapping gzmap;
+    std::vector<BgzfBlock> blocks;
+    if (gz) {
+        const int fd = open(path, O_RDONLY);
+        struct stat sb;
+        if (fd >= 0 && fstat(fd, &sb) == 0 && sb.st_size > 0) {
+            void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) { gzmap.p = (const unsigned char *)m; gzmap.size = (size_t)sb.st_size; }
+        }
+        if (fd >= 0) close(fd);
+    }
+    const bool bgzf = gzmap.p && bgzf_scan(gzmap.p, gzmap.size, blocks);
+    size_t chunk_cap = (size_t)(bgzf ? 8 : 16) << 20;  // stream bytes per chunk
     if (const char *e = getenv("KCT_FILE_CHUNK")) chunk_cap = std::max<size_t>(1024, (size_t)atoll(e));  // tests shrink it to exercise record splitting
     size_t segment = (size_t)8 << 20;     // file bytes a parser thread takes at a time
     if (const char *e = getenv("KCT_FILE_SEGMENT")) segment = std::max<size_t>(64, (size_t)atoll(e));
+    size_t slot_bytes = (size_t)(bgzf ? 2 : 4) << 20;   // inflated text per slot
+    if (const char *e = getenv("KCT_FILE_SLOT")) slot_bytes = std::max<size_t>(65536, (size_t)atoll(e));  // tests shrink it: records across slots
     const unsigned hw = std::thread::hardware_concurrency();
-    size_t nparsers = 1;
+    // BGZF tasks = runs of blocks whose text fits a slot, numbered in file order
+    std::vector<size_t> task_first;
+    if (bgzf) {
+        size_t text = 0;
+        for (size_t i = 0; i < blocks.size(); ++i) {
+            if (i == 0 || text + blocks[i].isize > slot_bytes) { task_first.push_back(i); text = 0; }
+            text += blocks[i].isize;
+        }
+        task_first.push_back(blocks.size());
+    }
+    const size_t ntasks = bgzf ? task_first.size() - 1 : 0;
+    size_t nparsers = 1, nslot_threads = 0;
     if (map.p) nparsers = std::max<size_t>(1, std::min<size_t>({(size_t)8, hw ? hw : 1, (map.size + segment - 1) / segment}));
-    if (const char *e = getenv("KCT_FILE_THREADS")) nparsers = map.p ? std::max<size_t>(1, std::min<size_t>(64, (size_t)atoll(e))) : 1;
+    if (bgzf) nslot_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, hw ? hw / 2 : 1, ntasks}));
+    if (const char *e = getenv("KCT_FILE_THREADS")) {
+        const size_t want = std::max<size_t>(1, std::min<size_t>(64, (size_t)atoll(e)));
+        if (map.p) nparsers = want;
+        if (bgzf) nslot_threads = want;
+    }
+    if (bgzf) nparsers = nslot_threads + 1;   // (+ the calling thread, which parses the fragments between the slots)
 
     // chunk buffers stay with the table: pinning memory costs more than parsing a small file
     if (t->h_file.size() < 2 * nparsers) t->h_file.resize(2 * nparsers);
@@ -395,86 +532,120 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
             parser(0);
             for (auto &th : pool) th.join();
         }
-    } else {
-        // gzip: inflater threads -> a ring of text slots -> this thread's parser (see the top of the file)
-        size_t slot_bytes = (size_t)4 << 20;
-        if (const char *e = getenv("KCT_FILE_SLOT")) slot_bytes = std::max<size_t>(65536, (size_t)atoll(e));  // tests shrink it: records across slots
-        Mapping gzmap;
-        std::vector<BgzfBlock> blocks;
+    } else if (bgzf) {
+        // the file's first byte of text says FASTA or FASTQ (the slot threads need to know before they meet it)
+        int fmt = -1;
         {
-            const int fd = open(path, O_RDONLY);
-            struct stat sb;
-            if (fd >= 0 && fstat(fd, &sb) == 0 && sb.st_size > 0) {
-                void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-                if (m != MAP_FAILED) { gzmap.p = (const unsigned char *)m; gzmap.size = (size_t)sb.st_size; }
+            std::vector<unsigned char> first(65536);
+            for (size_t i = 0; i < blocks.size() && fmt < 0 && st == KCT_OK; ++i) {
+                const BgzfBlock &b = blocks[i];
+                const unsigned char *hdr = gzmap.p + b.off;
+                const size_t data = 12 + (hdr[10] | ((size_t)hdr[11] << 8));
+                z_stream zs;
+                memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, -15) != Z_OK) { set_err("inflateInit2 failed"); st = KCT_ERR_ARG; break; }
+                zs.next_in = const_cast<unsigned char *>(hdr + data); zs.avail_in = (unsigned)(b.csize - data - 8);
+                zs.next_out = first.data(); zs.avail_out = (unsigned)first.size();
+                const int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END || zs.total_out != b.isize) { set_err("%s: corrupt BGZF block", path); st = KCT_ERR_ARG; break; }
+                for (size_t j = 0; j < b.isize && fmt < 0; ++j)
+                    if (first[j] != '\n' && first[j] != '\r' && first[j] != ' ' && first[j] != '\t') fmt = first[j];
             }
-            if (fd >= 0) close(fd);
+            if (st == KCT_OK && fmt >= 0 && fmt != '>' && fmt != '@') { set_err("%s: neither FASTA nor FASTQ (starts with 0x%02x)", path, fmt); st = KCT_ERR_ARG; }
         }
-        const bool bgzf = gzmap.p && bgzf_scan(gzmap.p, gzmap.size, blocks);
-        size_t ninfl = 1;
-        if (bgzf) ninfl = std::max<size_t>(1, std::min<size_t>({(size_t)16, hw ? hw / 2 : 1, blocks.size()}));
-        if (const char *e = getenv("KCT_FILE_THREADS")) ninfl = bgzf ? std::max<size_t>(1, std::min<size_t>(64, (size_t)atoll(e))) : 1;
-        TextRing ring(2 * ninfl + 2, slot_bytes);
-        std::vector<std::thread> inflaters;
-        std::vector<size_t> task_first;   // (outlives the inflater threads, which read it)
-        if (bgzf) {
-            // tasks = runs of blocks whose text fits a slot, numbered in file order; inflater i takes tasks i, i + n, ...
-            {
-                size_t text = 0;
-                for (size_t i = 0; i < blocks.size(); ++i) {
-                    if (i == 0 || text + blocks[i].isize > slot_bytes) { task_first.push_back(i); text = 0; }
-                    text += blocks[i].isize;
-                }
-                task_first.push_back(blocks.size());
-            }
-            const size_t ntasks = task_first.size() - 1;
-            for (size_t w = 0; w < ninfl; ++w)
-                inflaters.emplace_back([&, w, ntasks] {   // (ntasks by value: it is local to this block, the threads outlive it)
-                    z_stream zs;
-                    memset(&zs, 0, sizeof zs);
-                    if (inflateInit2(&zs, -15) != Z_OK) { ring.fail("inflateInit2 failed"); return; }
-                    for (size_t task = w; task < ntasks; task += ninfl) {
-                        TextRing::Slot *sl = ring.acquire(task);
-                        if (!sl) break;
-                        size_t used = 0;
-                        bool ok = true;
-                        for (size_t i = task_first[task]; ok && i < task_first[task + 1]; ++i) {
-                            const BgzfBlock &b = blocks[i];
-                            const unsigned char *hdr = gzmap.p + b.off;
-                            const size_t xlen = hdr[10] | ((size_t)hdr[11] << 8), data = 12 + xlen;
+        if (st == KCT_OK && fmt >= 0) {
+            Fragments frags(2 * nslot_threads + 2, ntasks);
+            std::atomic<size_t> next_task{0};
+            std::mutex tally_mu;
+            auto slot_thread = [&](size_t id) {
+                ChunkWriter w(&queue, &t->h_file[2 * id], &t->h_file[2 * id + 1], chunk_cap, k);
+                std::vector<unsigned char> text(slot_bytes + 65536 + 16);
+                const Deflate &ld = deflate_lib();
+                void *dec = ld.ok() && !getenv("KCT_NO_LIBDEFLATE") ? ld.alloc() : nullptr;   // (the switch: tests run zlib's inflate too)
+                z_stream zs;
+                memset(&zs, 0, sizeof zs);
+                if (!dec && inflateInit2(&zs, -15) != Z_OK) { frags.fail("inflateInit2 failed"); return; }
+                for (;;) {
+                    const size_t task = next_task.fetch_add(1);
+                    if (task >= ntasks || !frags.may_start(task)) break;
+                    if (queue.failed()) { frags.fail("counting failed"); break; }
+                    size_t used = 0;
+                    bool ok = true;
+                    for (size_t i = task_first[task]; ok && i < task_first[task + 1]; ++i) {
+                        const BgzfBlock &b = blocks[i];
+                        const unsigned char *hdr = gzmap.p + b.off;
+                        const size_t data = 12 + (hdr[10] | ((size_t)hdr[11] << 8));
+                        unsigned crc, got;
+                        memcpy(&crc, hdr + b.csize - 8, 4);
+                        if (dec) {
+                            size_t n_out = 0;
+                            ok = ld.decompress(dec, hdr + data, b.csize - data - 8, text.data() + used, b.isize, &n_out) == 0 && n_out == b.isize;
+                            got = ok ? ld.crc(0, text.data() + used, b.isize) : 0;
+                        } else {
                             inflateReset(&zs);
                             zs.next_in = const_cast<unsigned char *>(hdr + data); zs.avail_in = (unsigned)(b.csize - data - 8);
-                            zs.next_out = sl->buf.data() + used; zs.avail_out = (unsigned)(sl->buf.size() - used);
-                            const int rc = inflate(&zs, Z_FINISH);
-                            unsigned crc;
-                            memcpy(&crc, hdr + b.csize - 8, 4);
-                            ok = rc == Z_STREAM_END && zs.total_out == b.isize && (unsigned)crc32(0L, sl->buf.data() + used, b.isize) == crc;
-                            used += b.isize;
+                            zs.next_out = text.data() + used; zs.avail_out = (unsigned)b.isize;
+                            ok = inflate(&zs, Z_FINISH) == Z_STREAM_END && zs.total_out == b.isize;
+                            got = ok ? (unsigned)crc32(0L, text.data() + used, b.isize) : 0;
                         }
-                        if (!ok) { ring.fail("corrupt BGZF block"); break; }
-                        ring.publish(sl, used);
+                        ok = ok && got == crc;
+                        used += b.isize;
                     }
-                    inflateEnd(&zs);
-                    if (w == 0) ring.finish(ntasks);   // (the sequence ends at ntasks whoever gets there first)
-                });
-        } else {
-            inflaters.emplace_back([&] {
-                gzFile f = gzopen(path, "rb");
-                if (!f) { ring.fail("cannot open the gzip stream"); return; }
-                gzbuffer(f, 1 << 20);
-                u64 seq = 0;
-                for (;;) {
-                    TextRing::Slot *sl = ring.acquire(seq);
-                    if (!sl) break;
-                    const int n = gzread(f, sl->buf.data(), (unsigned)sl->buf.size());
-                    if (n < 0) { ring.fail("gzread failed (corrupt gzip stream)"); break; }
-                    if (n == 0) { ring.finish(seq); break; }
-                    ring.publish(sl, (size_t)n);
-                    ++seq;
+                    if (!ok) { frags.fail("corrupt BGZF block"); break; }
+                    const unsigned char *tx = text.data();
+                    size_t lo = 0;
+                    if (task == 0) { while (lo < used && (tx[lo] == '\n' || tx[lo] == '\r' || tx[lo] == ' ' || tx[lo] == '\t')) ++lo; }  // the file's first record
+                    else lo = find_record_start(tx, used, 1, fmt);
+                    if (lo >= used) { frags.publish(task, tx, used, nullptr, 0); continue; }   // no record starts in this slot
+                    const size_t hi = find_last_record_start(tx, used, lo, fmt);
+                    if (hi > lo) {
+                        MemSource src{tx, tx + lo, tx + hi};
+                        if (!parse_records(src, w, fmt, hi, queue, path)) { queue.fail(KCT_ERR_ARG, g_err); frags.fail(g_err); break; }
+                    }
+                    frags.publish(task, tx, lo, tx + hi, used - hi);
                 }
-                gzclose(f);
-            });
+                if (dec) ld.free_(dec); else inflateEnd(&zs);
+                w.finish();
+                std::lock_guard<std::mutex> lk(tally_mu);
+                records += w.records; bases += w.bases;
+            };
+            std::vector<std::thread> pool;
+            for (size_t i = 1; i <= nslot_threads; ++i) pool.emplace_back(slot_thread, i);
+            {
+                FragmentSource fsrc{&frags};
+                ChunkWriter w0(&queue, &t->h_file[0], &t->h_file[1], chunk_cap, k);
+                if (!parse_records(fsrc, w0, fmt, ~(size_t)0, queue, path)) st = KCT_ERR_ARG;
+                w0.finish();
+                std::lock_guard<std::mutex> lk(tally_mu);
+                records += w0.records; bases += w0.bases;
+            }
+            bool slot_failed;
+            std::string slot_msg;
+            { std::lock_guard<std::mutex> lk(frags.mu); slot_failed = frags.failed; slot_msg = frags.msg; }
+            frags.fail("the parser is done");   // (lets slot threads go that still wait for their turn: the parser stopped early)
+            for (auto &th : pool) th.join();
+            if (st == KCT_OK && slot_failed) { set_err("%s: %s", path, slot_msg.c_str()); st = KCT_ERR_ARG; }
         }
+    } else {
+        // a plain gzip stream: one inflater thread -> a ring of text slots -> this thread's parser (see the top of the file)
+        TextRing ring(4, slot_bytes);
+        std::thread inflater([&] {
+            gzFile f = gzopen(path, "rb");
+            if (!f) { ring.fail("cannot open the gzip stream"); return; }
+            gzbuffer(f, 1 << 20);
+            u64 seq = 0;
+            for (;;) {
+                TextRing::Slot *sl = ring.acquire(seq);
+                if (!sl) break;
+                const int n = gzread(f, sl->buf.data(), (unsigned)sl->buf.size());
+                if (n < 0) { ring.fail("gzread failed (corrupt gzip stream)"); break; }
+                if (n == 0) { ring.finish(seq); break; }
+                ring.publish(sl, (size_t)n);
+                ++seq;
+            }
+            gzclose(f);
+        });
         {
             RingSource src{&ring};
             int c;
@@ -488,8 +659,8 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
             }
             if (st == KCT_OK && ring.failed) { set_err("%s: %s", path, ring.msg.c_str()); st = KCT_ERR_ARG; }
         }
-        ring.fail("the parser is done");   // (lets inflaters go that still wait for a slot: the parser stopped early, or the input is read)
-        for (auto &th : inflaters) th.join();
+        ring.fail("the parser is done");   // (lets the inflater go if it still waits for a slot: the parser stopped early, or the input is read)
+        inflater.join();
     }
     { std::lock_guard<std::mutex> lk(queue.mu); queue.done = true; }
     queue.cv.notify_all();

@@ -919,6 +919,30 @@ def test_consume_file_formats_match_oracle(KCT, tmp_path, monkeypatch):
         assert dev.last_file_records == len(recs)
         assert_same_table(dev, ref)
     monkeypatch.delenv("KCT_FILE_SLOT"); monkeypatch.delenv("KCT_FILE_THREADS")
+    # BGZF slots are inflated AND parsed by several threads, the records across slot boundaries by the caller's thread: FASTQ whose
+    # quality lines begin with '@' or '+' (a header is only a header when a '+' line follows its sequence line), empty records, CRLF,
+    # and records far longer than a slot (no record start in most slots: everything goes through the stitching parser)
+    recs2 = [rand_dna(rng, rng.choice([0, 1, 21, 60, 150, 151, 3000]), "ACGTACGTACGTNacgt") for _ in range(3000)] + [rand_dna(rng, 300_000, "ACGT")]
+    rng.shuffle(recs2)
+    ref2 = OracleTable(k)
+    n_ref2 = sum(ref2.consume(r) for r in recs2)
+    fq2, fa2 = tmp_path / "b.fq.gz", tmp_path / "b.fa.gz"
+    qual = lambda i, n: (("@" if i % 3 == 0 else "+" if i % 3 == 1 else "I") + "@+I" * n)[:n]   # noqa: E731
+    eol = lambda i: "\r\n" if i % 7 == 0 else "\n"                                              # noqa: E731
+    fq2.write_bytes(_bgzf("".join(f"@r{i} x{eol(i)}{s}{eol(i)}+{'r%d' % i if i % 2 else ''}{eol(i)}{qual(i, len(s))}{eol(i)}" for i, s in enumerate(recs2)).encode(), rng))
+    fa2.write_bytes(_bgzf("".join(f">r{i}\n" + "".join(s[j: j + 70] + "\n" for j in range(0, len(s), 70)) for i, s in enumerate(recs2)).encode(), rng))
+    for slot, threads, nolib in (("65536", "1", False), ("65536", "7", False), ("131072", "3", True), (None, None, False)):
+        if slot:
+            monkeypatch.setenv("KCT_FILE_SLOT", slot); monkeypatch.setenv("KCT_FILE_THREADS", threads)
+        if nolib:
+            monkeypatch.setenv("KCT_NO_LIBDEFLATE", "1")      # (zlib's inflate: what a system without libdeflate.so.0 runs)
+        for path in (fq2, fa2):
+            dev = KCT(k)
+            assert dev.consume_file(str(path)) == n_ref2, (path, slot, threads)
+            assert dev.last_file_records == len(recs2)
+            assert_same_table(dev, ref2)
+        for v in ("KCT_FILE_SLOT", "KCT_FILE_THREADS", "KCT_NO_LIBDEFLATE"):
+            monkeypatch.delenv(v, raising=False)
     bad = bytearray(open(fabgz, "rb").read())
     bad[len(bad) // 2] ^= 0x55                      # a corrupt block: an error, not a short count
     (tmp_path / "bad.fa.gz").write_bytes(bytes(bad))

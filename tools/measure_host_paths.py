@@ -84,8 +84,17 @@ with open(fa, "rb") as src, open(fabgz, "wb") as dst:
             break
 def run_bgz():
     t.clear(); assert t.consume_file(fabgz) == kmers
-s = best(run_bgz, reps=2)
+s = best(run_bgz, reps=4)
 out["consume_file_fasta_bgzf"] = {"seconds": s, "kmers_per_s": kmers / s, "file_bytes": os.path.getsize(fabgz)}
+for th in (4, 8, 16, 24):                      # slot threads (inflate + parse); the default is min(16, half the host's threads)
+    os.environ["KCT_FILE_THREADS"] = str(th)
+    s = best(run_bgz, reps=3)
+    out["consume_file_fasta_bgzf"][f"threads_{th}"] = kmers / s
+del os.environ["KCT_FILE_THREADS"]
+os.environ["KCT_NO_LIBDEFLATE"] = "1"          # zlib's inflate instead of libdeflate's
+s = best(run_bgz, reps=3)
+out["consume_file_fasta_bgzf"]["zlib_inflate"] = kmers / s
+del os.environ["KCT_NO_LIBDEFLATE"]
 
 n = len(t)
 for order, name in ((0, "dump_unsorted"), (1, "dump_sorted_by_hash"), (2, "dump_sorted_by_count_hash")):
