@@ -912,13 +912,25 @@ def test_consume_file_formats_match_oracle(KCT, tmp_path, monkeypatch):
         assert dev.last_file_records == len(recs)
         assert_same_table(dev, ref)
     monkeypatch.setenv("KCT_FILE_SLOT", "65536")   # text slots of 64 KiB: records (up to 25 kbp) and lines across slot boundaries
+    monkeypatch.setenv("KCT_GZIP_WHOLE_MAX", "0")  # (a small single-member file is otherwise inflated in one piece: here the streaming reader)
     for path, threads in ((fagz, "1"), (fabgz, "1"), (fabgz, "5"), (fqmm, "1")):
         monkeypatch.setenv("KCT_FILE_THREADS", threads)
         dev = KCT(k)
         assert dev.consume_file(str(path)) == n_ref, (path, threads)
         assert dev.last_file_records == len(recs)
         assert_same_table(dev, ref)
-    monkeypatch.delenv("KCT_FILE_SLOT"); monkeypatch.delenv("KCT_FILE_THREADS")
+    monkeypatch.delenv("KCT_FILE_SLOT"); monkeypatch.delenv("KCT_FILE_THREADS"); monkeypatch.delenv("KCT_GZIP_WHOLE_MAX")
+    monkeypatch.setenv("KCT_FILE_SEGMENT", "4096")   # the one-piece inflate's text, parsed by several threads in tiny segments
+    monkeypatch.setenv("KCT_FILE_THREADS", "4")
+    dev = KCT(k)
+    assert dev.consume_file(str(fagz)) == n_ref and dev.last_file_records == len(recs)
+    assert_same_table(dev, ref)
+    monkeypatch.delenv("KCT_FILE_SEGMENT"); monkeypatch.delenv("KCT_FILE_THREADS")
+    badgz = bytearray(open(fagz, "rb").read())
+    badgz[len(badgz) // 2] ^= 0x55                  # a corrupt single-member file: an error from whichever reader meets it
+    (tmp_path / "bad1.fa.gz").write_bytes(bytes(badgz))
+    with pytest.raises((RuntimeError, ValueError, OSError)):
+        KCT(k).consume_file(str(tmp_path / "bad1.fa.gz"))
     # BGZF slots are inflated AND parsed by several threads, the records across slot boundaries by the caller's thread: FASTQ whose
     # quality lines begin with '@' or '+' (a header is only a header when a '+' line follows its sequence line), empty records, CRLF,
     # and records far longer than a slot (no record start in most slots: everything goes through the stitching parser)
