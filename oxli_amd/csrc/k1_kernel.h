@@ -113,6 +113,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     __shared__ __attribute__((aligned(16))) unsigned char lds[kTileBytes];
     __shared__ u32 tcodes[kTileWords];
     __shared__ unsigned short tvalid[kTileWords];
+    __shared__ __attribute__((aligned(16))) RunGroup tdesc[RUNS ? kPartTile / 64 : 1];  // RUNS: the tile's group descriptors
     __shared__ u32 ascii4[(KW == 0 || MODE != 0) ? 1 : 256];  // four packed bases -> four ASCII bytes (only the hashing mode needs it)
     if constexpr (KW != 0 && MODE == 0) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
     // MurmurHash3's first multiply of every whole 16-base block comes out of pre-multiplied tables (kmer_device.h):
@@ -186,7 +187,16 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         return v;
     };
     auto load_any = [&](u64 tile_base, int c) -> uint4 { return packed ? load_group(tile_base, c) : load_chunk(tile_base, c); };
+    // super-k-mer input: what is staged per tile is its 256 group descriptors (16 bytes each, one per thread of the first four waves)
+    const u64 ngroups = RUNS ? (nbytes - (u64)k + 1 + 63) >> 6 : 0;
+    auto load_desc = [&](u64 tile) -> uint4 {
+        const u64 g = tile * (kPartTile / 64) + threadIdx.x;
+        uint4 v = make_uint4(0, 0, 0, 0);   // (no group: no windows)
+        if (threadIdx.x < kPartTile / 64 && g < ngroups) v = reinterpret_cast<const uint4 *>(a.runs.groups)[g];
+        return v;
+    };
     uint4 pre_main = make_uint4(0, 0, 0, 0), pre_halo = make_uint4(0, 0, 0, 0);
+    if (RUNS && blockIdx.x < ntiles) pre_main = load_desc(blockIdx.x);
     if (!RUNS && blockIdx.x < ntiles) {
         pre_main = load_any((u64)blockIdx.x * kPartTile, threadIdx.x);
         if (threadIdx.x < 16) pre_halo = load_any((u64)blockIdx.x * kPartTile, kPartThreads + threadIdx.x);
@@ -194,6 +204,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();  // the previous tile's readers are done with `lds`; ring/fill init is visible
         if constexpr (RUNS) {
+            if (threadIdx.x < kPartTile / 64) reinterpret_cast<uint4 *>(tdesc)[threadIdx.x] = pre_main;
         } else if constexpr (KW == 0) {
             reinterpret_cast<uint4 *>(lds)[threadIdx.x] = pre_main;
             if (threadIdx.x < 16) reinterpret_cast<uint4 *>(lds)[kPartThreads + threadIdx.x] = pre_halo;
@@ -208,8 +219,9 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
                 tcodes[kPartThreads + threadIdx.x] = c; tvalid[kPartThreads + threadIdx.x] = (unsigned short)v;
             }
         }
-        if constexpr (!RUNS) __syncthreads();
+        __syncthreads();
         const u64 next = tile + gridDim.x;
+        if (RUNS && next < ntiles) pre_main = load_desc(next);
         if (!RUNS && next < ntiles) {
             pre_main = load_any(next * kPartTile, threadIdx.x);
             if (threadIdx.x < 16) pre_halo = load_any(next * kPartTile, kPartThreads + threadIdx.x);
@@ -252,7 +264,7 @@ if constexpr (MODE == 2) pend_b = (u32)(h >> 32) & 1023u;
                 flush_lines(false);
             }
         };
-        if constexpr (RUNS) walk_windows_runs<KW, KC, true, MODE, kPre>(a.runs, tile * (kPartTile / 64), (nbytes - (u64)k + 1 + 63) >> 6, k, sink, ascii4, pm1, pm2, &aux_y, ptm);
+        if constexpr (RUNS) walk_windows_runs<KW, KC, true, MODE, kPre>(a.runs, tdesc, k, sink, ascii4, pm1, pm2, &aux_y, ptm);
         else if constexpr (KW == 0) walk_windows<0, 0, kPartWPT>(lds, k, sink);
         else walk_windows_encoded<KW, KC, true, MODE, kPre>(tcodes, tvalid, k, sink, ascii4, pm1, pm2, &aux_y, ptm);
         commit();

@@ -188,23 +188,24 @@ __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const uns
 // between a step and its k-mer (the group's descriptor -- wave-uniform -- then the bases), so the loop is software-pipelined: the
 // descriptor of step j + 3 and the bases of step j + 2 are requested before window j is hashed.
 template <int KW, int KC, bool LUT = false, int RAW = 0, int PRE = 0, class Sink>
-__device__ __forceinline__ void walk_windows_runs(const RunsInput &in, u64 group0, u64 ngroups, int k_rt, Sink &&sink, const u32 *lut = nullptr,
+__device__ __forceinline__ void walk_windows_runs(const RunsInput &in, const RunGroup *tdesc, int k_rt, Sink &&sink, const u32 *lut = nullptr,
                                                   const u64 *mul1 = nullptr, const u64 *mul2 = nullptr, u64 *aux = nullptr, const u64 *tmul = nullptr) {
     constexpr int WPT = 16, NX = 2 * KW + 1;  // words that hold 2k bits at any 2-bit offset
     const int k = KC > 0 ? KC : k_rt;
     const u32 lane = threadIdx.x & 63u;
-    const u64 g0 = group0 + (u64)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: the descriptor loads can be scalar)
-    constexpr u64 kStep = kPartThreads / 64;
+    const u32 wave = threadIdx.x >> 6;
+    constexpr u32 kStep = kPartThreads / 64;
     struct Fetch { u32 x[NX]; u32 sh; bool good; };
-    // (the directory is written by an earlier kernel and only read here: loads through the constant address space are scalar -- one
-    // s_load_dwordx4 per wave and step, the descriptor arithmetic on the scalar unit)
-    typedef const RunGroup __attribute__((address_space(4))) *ConstGroups;
-    const ConstGroups cgroups = (ConstGroups)(unsigned long long)in.groups;
+    // The tile's 256 descriptors sit in LDS (`tdesc`, staged by the kernel: group wave + 16 j of the tile is step j of this wave; groups
+    // past the end are zeros = no windows).  One broadcast ds_read_b128 + four v_readfirstlane make a descriptor wave-uniform, so its
+    // arithmetic runs on the scalar unit.  (Scalar LOADS of the descriptors -- s_load_dwordx4 through the constant address space, the
+    // first version -- share the lgkm counter with the append's LDS atomics and return out of order: every wait for an LDS result became
+    // lgkmcnt(0) and exposed a scalar-cache round trip per step.)
     auto describe = [&](int j) -> RunGroup {
+        const uint4 q = reinterpret_cast<const uint4 *>(tdesc)[wave + kStep * (u32)j];
         RunGroup d;
-        d.base_nvalid = 0; d.starts = 0;
-        const u64 g = g0 + kStep * (u64)j;
-        if (g < ngroups) { d.base_nvalid = cgroups[g].base_nvalid; d.starts = cgroups[g].starts; }
+        d.base_nvalid = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)q.y) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)q.x);
+        d.starts = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)q.w) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)q.z);
         return d;
     };
     // (no branches: a lane without a window -- the tail of a stream's last group, groups past the end -- reads the group's first word
