@@ -119,6 +119,7 @@ kct_status split_pass(Route &r, const unsigned char *d_stream, u64 nbytes, Slab 
         unsigned int *m = (unsigned int *)t->d_sk_meta.p;
         sa.nwin = m; sa.nunits = m + nstreams; sa.nsunits = m + 2 * nstreams; sa.nruns = m + 3 * nstreams;
         sa.overflow = d_overflow;
+        sa.ablate = (unsigned int)t->ablate;
         sa.pcodes = nullptr; sa.pvalid = nullptr;
         launch_split(t, d_stream, std::min<u64>(nbytes, npos + k - 1), ntiles, sa);
         HIP_TRY(hipGetLastError());

@@ -39,6 +39,7 @@ struct SplitArgs {
     u32 *nruns;            // [nwg][world] runs (statistics)
     u64 *overflow;
     const u32 *pcodes; const unsigned short *pvalid;  // packed input (PartitionArgs::pcodes) instead of ASCII
+    u32 ablate;            // KCT_ABLATE of a -DKCT_DEBUG_ENV build (tools/pmc_ablate.sh): phases skipped, results INVALID; 0 otherwise
 };
 
 // One received stream: its bases begin at bit bit0 of bases[], its start bits at starts[word0], it holds nwin windows, and its groups

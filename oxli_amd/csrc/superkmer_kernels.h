@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kSkThreads) void split_superkmers_kernel(const unsi
     __shared__ u32 tc[1 + kSkThreads + 16 + 2];               // tile codes behind one zero word (a copy may look 32 bits to the left)
     __shared__ unsigned short tv[kSkThreads + 16];
     __shared__ __attribute__((aligned(16))) u32 mm[kMmWords];   // scrambled canonical m-mers, 16 bits each
-    __shared__ __attribute__((aligned(16))) unsigned char own[kSkTile + 16];
+    __shared__ unsigned short edge[kSkThreads];                 // a thread's first | last << 8 owner byte: what its neighbours need of it
     __shared__ unsigned short emask[kSkThreads + 1];
     __shared__ __attribute__((aligned(16))) u32 sb[kSkStageWords];      // outgoing bases, [world][capBw]
     __shared__ __attribute__((aligned(16))) u32 ss[kSkStageWords / 2];  // outgoing start bits, [world][capBw / 2]
@@ -259,11 +259,11 @@ __global__ __launch_bounds__(kSkThreads) void split_superkmers_kernel(const unsi
                 const u32 ok = ((((good >> (4 * w)) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;                                    // 0xFF per good window
                 ow[w] = o | ~ok;
             }
-            reinterpret_cast<uint4 *>(own)[t] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            edge[t] = (unsigned short)((ow[0] & 0xFFu) | ((ow[3] >> 24) << 8));
         }
         __syncthreads();
         // ---- runs: maximal stretches of good windows with one owner, cut every `cut` windows (cut >= 16, a power of two) ---------------
-        const u32 prev_o = t ? own[16 * t - 1] : 0xFFu, next_o = t + 1 < kSkThreads ? own[16 * t + 16] : 0xFFu;
+        const u32 prev_o = t ? (u32)edge[t - 1] >> 8 : 0xFFu, next_o = t + 1 < kSkThreads ? (u32)edge[t + 1] & 0xFFu : 0xFFu;
         u32 smask = 0;
         auto build_masks = [&](u32 cut) {
             u32 em = 0;
@@ -311,18 +311,26 @@ __global__ __launch_bounds__(kSkThreads) void split_superkmers_kernel(const unsi
             const u32 wpos = (u32)cw, bpos = (u32)(cw >> 32);
             if (bpos + L > capB) { s_over = 1u; return; }
             atomicOr(&ss[o * (capBw / 2) + (wpos >> 5)], 1u << (wpos & 31u));
-            // L bases from tile bit 2 (16 t + j) to staging bit 2 bpos (both MSB-first), one destination word at a time
+            // L bases from tile bit 2 (16 t + j) to staging bit 2 bpos (both MSB-first), one destination word at a time.  Every step moves
+            // 32 bits on in BOTH streams, so the source's bit offset inside its words is the same for every word of the run: one LDS
+            // read and one v_alignbit per word (the previous read is the next word's high half); only the first and the last word
+            // are masked.  (The first version recomputed the offset and read two words per step: the copy was 36 % of the kernel.)
             u32 *dst = sb + o * capBw;
-            const u32 dbit = 2 * bpos, sbit = 32 + 2 * (16 * t + j), nbits = 2 * L;
-            const u32 dw1 = (dbit + nbits - 1) >> 5;
-            for (u32 dw = dbit >> 5; dw <= dw1; ++dw) {
-                const int rel = (int)(dw << 5) - (int)dbit;          // this word's first bit, counted from the run's first bit
-                const u32 sp = (u32)((int)sbit + rel);               // >= 1: tc[0] is a zero word
-                const u32 wi = sp >> 5, sh = sp & 31u;
-                u32 val = (u32)(((((u64)tc[wi] << 32) | tc[wi + 1]) << sh) >> 32);
-                if (rel < 0) val &= 0xFFFFFFFFu >> (u32)(-rel);
-                const int past = rel + 32 - (int)nbits;
-                if (past > 0) val &= 0xFFFFFFFFu << (u32)past;
+            const u32 dbit = 2 * bpos, nbits = 2 * L;
+            const u32 dw0 = dbit >> 5, dw1 = (dbit + nbits - 1) >> 5;
+            const u32 sp = 32u + 2u * (16u * t + j) - (dbit & 31u);   // source bit of the first destination word's bit 0 (>= 1: tc[0] is a zero word)
+            const u32 sh = sp & 31u;
+            u32 wi = (sp >> 5) - (sh == 0u ? 1u : 0u);                // v_alignbit(hi, lo, 0) = lo: an aligned source is read one word late
+            const u32 shift = (32u - sh) & 31u;
+            const u32 m0 = 0xFFFFFFFFu >> (dbit & 31u);               // the run's bits of its first word ...
+            const u32 m1 = 0xFFFFFFFFu << (31u - ((dbit + nbits - 1u) & 31u));   // ... and of its last
+            u32 hi = tc[wi];
+            for (u32 dw = dw0; dw <= dw1; ++dw) {
+                const u32 lo = tc[++wi];
+                u32 val = __builtin_amdgcn_alignbit(hi, lo, shift);
+                hi = lo;
+                if (dw == dw0) val &= m0;
+                if (dw == dw1) val &= m1;
                 atomicOr(&dst[dw], val);
             }
         };
@@ -364,8 +372,15 @@ __global__ __launch_bounds__(kSkThreads) void split_superkmers_kernel(const unsi
         build_masks(kSkMaxRun);
         __syncthreads();
         my_runs += (u32)__builtin_popcount(smask);
+#ifdef KCT_DEBUG_ENV   // (timing experiments, tools/pmc_ablate.sh: 0x100 no emit, 0x200 cursors only, 0x400 no flush)
+        if (a.ablate & 0x200u) for_runs(0, kSkTile, [&](u32, u32 n, u32 o) { atomicAdd(&cur[o], (u64)n | ((u64)(n + K - 1) << 32)); });
+        else if (!(a.ablate & 0x100u))
+#endif
         for_runs(0, kSkTile, emit);
         __syncthreads();
+#ifdef KCT_DEBUG_ENV
+        if (a.ablate & 0x600u) { if (t < world) cur[t] = cur0[t] = 0; __syncthreads(); continue; }
+#endif
         if (s_over == 0) flush();
         else {
             // (rare: far more runs than random sequence gives, or nearly all for one owner) -- the staging goes back to what the tile

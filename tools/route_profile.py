@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--max-windows", type=int, default=0)
     ap.add_argument("--skip-plain", action="store_true")
     ap.add_argument("--skip-loopback", action="store_true")
+    ap.add_argument("--split-only", action="store_true", help="the sender's split alone (tools/split_ablate.sh; no checks: an ablated build loses windows)")
     args = ap.parse_args()
     import torch
 
@@ -71,11 +72,14 @@ def main():
                 per_owner[o] += w
                 tot_win += w
     prof = t.profile_read()
-    assert tot_win == n_expect, (tot_win, n_expect)
+    assert args.split_only or tot_win == n_expect, (tot_win, n_expect)
     out["split"] = {"kernels_ms": {kk: round(v[1], 3) for kk, v in prof.items()}, "wire_bytes": tot_bytes, "bytes_per_window": tot_bytes / tot_win,
                     "owner_share_min_max": [min(per_owner) / tot_win * W, max(per_owner) / tot_win * W]}
     t.release_scratch()
     del t
+    if args.split_only:
+        print(json.dumps(out))
+        return
 
     # ---- ONE OWNER's share: rank 0 of `owners`, counting what it owns of ALL these records (world > 1 without an exchange): its table,
     # its passes, its kernels are those of a rank in a job of `owners` GPUs whose reads, all together, are this input ---------------------
