@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kSkThreads) void split_superkmers_kernel(const unsi
     __shared__ u64 cur0[kSkMaxWorld];      // ... as it stood when the tile began (the carry alone)
     __shared__ __attribute__((aligned(16))) uint4 carryB[kSkMaxWorld], carryS[kSkMaxWorld];  // the carried partial units, for a tile that has to be redone
     __shared__ u32 filledB[kSkMaxWorld], filledS[kSkMaxWorld];
-    __shared__ u32 s_over, s_runs;
+    __shared__ u32 s_over, s_runs, nlist;   // nlist: runs of the current tile in the run list (below)
     const u32 world = a.world, t = threadIdx.x;
     const u32 capBw = (u32)(kSkStageWords / world) & ~7u;      // staging words per owner (whole 16-byte units of bases AND of start bits)
     const u32 capB = capBw * 16u;                              // ... in bases, and as many window bits
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kSkThreads) void split_superkmers_kernel(const unsi
                 if (a.pcodes) { c = pre_halo.x; v = pre_halo.y; } else encode16(pre_halo, c, v);
                 tc[1 + kSkThreads + t] = c; tv[kSkThreads + t] = (unsigned short)v;
             }
-            if (t == 0) { tc[1 + kSkThreads + 16] = 0; tc[1 + kSkThreads + 17] = 0; }
+            if (t == 0) { tc[1 + kSkThreads + 16] = 0; tc[1 + kSkThreads + 17] = 0; nlist = 0; }
         }
         __syncthreads();
         {
@@ -305,20 +305,20 @@ __global__ __launch_bounds__(kSkThreads) void split_superkmers_kernel(const unsi
             }
         };
         // a run takes its place in its owner's staging with ONE ds_add_rtn_u64 and is copied there; a run that would not fit raises s_over
-        auto emit = [&](u32 j, u32 n, u32 o) {
+        auto emit = [&](u32 pos, u32 n, u32 o) {   // pos: the run's first window in the tile
             const u32 L = n + K - 1;
             const u64 cw = atomicAdd(&cur[o], (u64)n | ((u64)L << 32));
             const u32 wpos = (u32)cw, bpos = (u32)(cw >> 32);
             if (bpos + L > capB) { s_over = 1u; return; }
             atomicOr(&ss[o * (capBw / 2) + (wpos >> 5)], 1u << (wpos & 31u));
-            // L bases from tile bit 2 (16 t + j) to staging bit 2 bpos (both MSB-first), one destination word at a time.  Every step moves
+            // L bases from tile bit 2 pos to staging bit 2 bpos (both MSB-first), one destination word at a time.  Every step moves
             // 32 bits on in BOTH streams, so the source's bit offset inside its words is the same for every word of the run: one LDS
             // read and one v_alignbit per word (the previous read is the next word's high half); only the first and the last word
             // are masked.  (The first version recomputed the offset and read two words per step: the copy was 36 % of the kernel.)
             u32 *dst = sb + o * capBw;
             const u32 dbit = 2 * bpos, nbits = 2 * L;
             const u32 dw0 = dbit >> 5, dw1 = (dbit + nbits - 1) >> 5;
-            const u32 sp = 32u + 2u * (16u * t + j) - (dbit & 31u);   // source bit of the first destination word's bit 0 (>= 1: tc[0] is a zero word)
+            const u32 sp = 32u + 2u * pos - (dbit & 31u);   // source bit of the first destination word's bit 0 (>= 1: tc[0] is a zero word)
             const u32 sh = sp & 31u;
             u32 wi = (sp >> 5) - (sh == 0u ? 1u : 0u);                // v_alignbit(hi, lo, 0) = lo: an aligned source is read one word late
             const u32 shift = (32u - sh) & 31u;
@@ -376,7 +376,33 @@ __global__ __launch_bounds__(kSkThreads) void split_superkmers_kernel(const unsi
         if (a.ablate & 0x200u) for_runs(0, kSkTile, [&](u32, u32 n, u32 o) { atomicAdd(&cur[o], (u64)n | ((u64)(n + K - 1) << 32)); });
         else if (!(a.ablate & 0x100u))
 #endif
-        for_runs(0, kSkTile, emit);
+        {
+            // A thread finds 1.9 run starts among its 16 windows on average and 5-6 at worst in a wave: emitted where they are found, the
+            // wave's lanes idle two thirds of the copy.  So the runs first go on a LIST (in `mm`, which is dead by now) -- a wave reserves
+            // its stretch with ONE atomic: the lanes' counts are summed bit by bit with ballots, no cross-lane traffic -- and then every
+            // thread emits list entries t, t + 1024, ...: two rounds with all lanes busy.
+            const u32 cnt = (u32)__builtin_popcount(smask), lane = t & 63u;
+            u32 before = 0, total = 0;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                const u64 m = __ballot((cnt >> b) & 1u);
+                before += __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)) << b;
+                total += (u32)__popcll(m) << b;
+            }
+            u32 base = 0;
+            if (lane == 0 && total) base = atomicAdd(&nlist, total);
+            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + total <= (u32)kMmWords) {
+                u32 slot = base + before;
+                for_runs(0, kSkTile, [&](u32 j, u32 n, u32 o) { mm[slot++] = (16u * t + j) | ((n - 1u) << 14) | (o << 24); });
+            } else {   // (more runs than the list holds: this wave's go out directly, what it reserved of the list says "no run")
+                for (u32 x = base + lane; x < (u32)kMmWords; x += 64u) mm[x] = 0xFFFFFFFFu;
+                for_runs(0, kSkTile, [&](u32 j, u32 n, u32 o) { emit(16u * t + j, n, o); });
+            }
+            __syncthreads();
+            const u32 nl = nlist < (u32)kMmWords ? nlist : (u32)kMmWords;
+            for (u32 i = t; i < nl; i += kSkThreads) { const u32 e = mm[i]; if (e != 0xFFFFFFFFu) emit(e & 0x3FFFu, ((e >> 14) & 0x3FFu) + 1u, e >> 24); }
+        }
         __syncthreads();
 #ifdef KCT_DEBUG_ENV
         if (a.ablate & 0x600u) { if (t < world) cur[t] = cur0[t] = 0; __syncthreads(); continue; }
@@ -400,7 +426,7 @@ __global__ __launch_bounds__(kSkThreads) void split_superkmers_kernel(const unsi
             __syncthreads();
             my_runs += (u32)__builtin_popcount(smask);
             for (u32 first = 0; first < (u32)kSkTile; first += gsafe) {
-                for_runs(first, first + gsafe, emit);
+                for_runs(first, first + gsafe, [&](u32 j, u32 n, u32 o) { emit(16u * t + j, n, o); });
                 __syncthreads();
                 flush();
             }

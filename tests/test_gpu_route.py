@@ -78,12 +78,16 @@ def runs_of(stream, k):
     return out
 
 
-@pytest.mark.parametrize("k,world", [(21, 1), (21, 8), (31, 3), (51, 8), (64, 2), (13, 4), (5, 2), (33, 64)])
-def test_split_wire_format_decodes_to_the_input_k_mers(gpu, k, world):
+@pytest.mark.parametrize("k,world,R", [(21, 1, 12_000), (21, 8, 12_000), (31, 3, 12_000), (51, 8, 12_000), (64, 2, 12_000), (13, 4, 12_000), (5, 2, 12_000),
+                                       (33, 64, 12_000),
+                                       # k < 8: every window is its own minimiser, the owner changes from window to window -- full tiles
+                                       # (50,000 reads: 30,000 window starts per workgroup) then hold more runs than the kernel's run list
+                                       (7, 16, 50_000)])
+def test_split_wire_format_decodes_to_the_input_k_mers(gpu, k, world, R):
     """Every good window of the input travels exactly once, to ONE owner that depends on the canonical k-mer only: the oracle's table of
     the decoded runs equals its table of the records, and the owners' key sets are disjoint."""
     torch, KCT = gpu
-    G, R, L = 300_000, 12_000, 150
+    G, L = 300_000, 150
     genome = oracle.synth_genome(G, 7)
     reads = oracle.synth_reads_ex(genome, 0, R, L, 3, n_ppm=3_000)
     dev = torch.from_numpy(reads.reshape(-1)).cuda()
