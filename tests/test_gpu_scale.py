@@ -208,7 +208,8 @@ def test_C2_with_sequencing_errors_equals_the_oracle_table(gpu, model):
 def test_128_bit_dedupe_first_at_C2_size_equals_the_oracle_table(gpu, k):
     """33 <= k <= 64, deep coverage of a 2 Mbp genome (1 M x 150 bp): K1 partitions mix128 pairs of the two packed words (16-byte
     entries), aggregate_blocks128_kernel counts them into the 1024 x 4096-slot shadow (two-word keys claimed by CAS + flag),
-    the conversion hashes each distinct k-mer once.  Forced and automatic (second pass), against the oracle's table pair by pair."""
+    the conversion hashes each distinct k-mer once.  Forced (set_path("dedupe")) against the oracle's table pair by pair; the automatic
+    choice hashes every window at these k and must give the same table."""
     torch, KCT, _ = gpu
     G, R, L = 2_000_000, 1_000_000, 150
     g, r = synth(gpu, G, R, L, seed_g=7, seed_r=8)
@@ -226,11 +227,11 @@ def test_128_bit_dedupe_first_at_C2_size_equals_the_oracle_table(gpu, k):
     assert "shadow128_flush_kernel" in t.profile_read()
     assert dk.size == d["len"] and ss.mismatches(dk, dc) == 0
     assert_digest_equal(t, ss, n)
-    a = KCT(k, capacity=G)                     # automatic: the first pass hashes every window, the second knows 2 M k-mers at 50 windows each
+    a = KCT(k, capacity=G)                     # automatic: both passes hash every window
     assert a.consume_device(r.data_ptr(), r.numel(), R * L) == n
     a.profile(True)
     assert a.consume_device(r.data_ptr(), r.numel(), R * L) == n
-    assert ("aggregate_blocks128_kernel" in a.profile_read()) == (k >= 48), a.profile_read()   # (slower than hashing below k = 48: not chosen)
+    assert "aggregate_blocks128_kernel" not in a.profile_read(), a.profile_read()   # (1.0x over hashing on its showcase: never chosen by itself since round 4)
     ak, ac = a.dump_arrays(1)
     assert np.array_equal(ak, dk) and np.array_equal(ac, 2 * dc)
 
