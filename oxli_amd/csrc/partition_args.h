@@ -25,7 +25,7 @@ struct RunsInput {
 };
 
 // ---- the early route's sender (superkmer_kernels.h) ----
-constexpr int kSkThreads = 1024;   // threads of a split workgroup (one per CU; 512 x 2 per CU measured no faster: the kernel is VALU-bound); its tile = 16 window starts per thread
+constexpr int kSkThreads = 1024;   // threads of a split workgroup, one per CU (two of 512 threads per CU: +3 %, two of 1024 at 64 VGPRs: +5 %, measured twice); its tile = 16 window starts per thread
 constexpr int kSkTile = 16 * kSkThreads;
 constexpr u32 kSkMaxWorld = 64;   // owners a split can address (one byte per window in LDS, per-owner LDS staging)
 struct SplitArgs {

@@ -93,13 +93,28 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     // the sub-bins; taken bin by bin they would all land in a quarter (or less) of the ring and overflow it)
     const u32 *counts0 = a.in_count + (u64)s * a.nseg;
     auto count_of = [&](int seg) -> u32 { return gbits ? counts0[(u64)(seg & ((1 << gbits) - 1)) * per_bin + (seg >> gbits)] : counts0[seg]; };
-    u32 my_slabs = 0;
     const int seg0 = w * (kPartThreads / 64) + wave, seg_step = W * (kPartThreads / 64);
-    for (int seg = seg0; seg < a.nseg; seg += seg_step) my_slabs += (count_of(seg) + kSlab - 1) / kSlab;
+    // The sizes of this wave's regions (its r-th region is seg0 + r seg_step) sit in ONE register, lane r holding region r's: a slab's
+    // loads then start from a v_readlane instead of behind a global load of the size -- a round trip that every wave of the workgroup
+    // paid at the same moment (the flush barriers keep them in step), once per slab.  (More than 64 regions per wave: loaded as before.)
+    const int nreg = seg0 < a.nseg ? (a.nseg - seg0 + seg_step - 1) / seg_step : 0;
+    const bool in_lanes = nreg <= 64;
+    u32 lane_cnt = 0;
+    if (in_lanes && lane < nreg) lane_cnt = count_of(seg0 + lane * seg_step);
+    auto region_count = [&](int r) -> u32 {   // r: wave-uniform
+        return in_lanes ? (u32)__builtin_amdgcn_readlane((int)lane_cnt, __builtin_amdgcn_readfirstlane(r)) : count_of(seg0 + r * seg_step);
+    };
+    u32 my_slabs = 0;
+    if (in_lanes) {
+        u32 v = (lane_cnt + kSlab - 1) / kSlab;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+        my_slabs = v;
+    } else for (int r = 0; r < nreg; ++r) my_slabs += (region_count(r) + kSlab - 1) / kSlab;
     if (lane == 0) atomicMax(&rounds, my_slabs);
     __syncthreads();
     const u32 nrounds = rounds;
-    int seg = seg0;
+    int reg = 0;
     u32 off = 0;
     auto is_set = [](const T &v) -> bool {
         if constexpr (kPair) return v.x != 0;
@@ -108,9 +123,10 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
     auto load_slab = [&](T (&v)[kLoads], u32 &binlow) {  // binlow: which of the super-bin's first-level bins the slab's region belongs to
 #pragma unroll
         for (int j = 0; j < kLoads; ++j) v[j] = zero;
-        while (seg < a.nseg && off >= count_of(seg)) { seg += seg_step; off = 0; }  // next non-empty region
-        if (seg < a.nseg) {
-            const u32 cnt = count_of(seg);
+        u32 cnt = reg < nreg ? region_count(reg) : 0u;
+        while (reg < nreg && off >= cnt) { ++reg; off = 0; cnt = reg < nreg ? region_count(reg) : 0u; }  // next non-empty region
+        if (reg < nreg) {
+            const int seg = seg0 + reg * seg_step;
             binlow = gbits ? (u32)seg & ((1u << gbits) - 1u) : 0u;
             const u64 region = gbits ? ((u64)(seg >> gbits) * a.nbins + ((u64)s << gbits) + binlow) : ((u64)seg * a.nbins + s);
             const T *src = reinterpret_cast<const T *>(a.in) + (a.in_off ? a.in_off[(u64)s * a.nseg + seg] : region * a.in_cap) + off;
