@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     __shared__ __attribute__((aligned(16))) unsigned char lds[kTileBytes];
     __shared__ u32 tcodes[kTileWords];
     __shared__ unsigned short tvalid[kTileWords];
-    __shared__ __attribute__((aligned(16))) RunGroup tdesc[RUNS ? kPartTile / 64 : 1];  // RUNS: the tile's group descriptors
+    __shared__ __attribute__((aligned(16))) RunGroup tdesc[RUNS ? 2 * (kPartTile / 64) : 1];  // RUNS: the group descriptors of this tile and the next (two buffers, taking turns)
     __shared__ u32 ascii4[(KW == 0 || MODE != 0) ? 1 : 256];  // four packed bases -> four ASCII bytes (only the hashing mode needs it)
     if constexpr (KW != 0 && MODE == 0) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
     // MurmurHash3's first multiply of every whole 16-base block comes out of pre-multiplied tables (kmer_device.h):
@@ -196,7 +196,11 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         return v;
     };
     uint4 pre_main = make_uint4(0, 0, 0, 0), pre_halo = make_uint4(0, 0, 0, 0);
-    if (RUNS && blockIdx.x < ntiles) pre_main = load_desc(blockIdx.x);
+    // (pre_main: the descriptors of the workgroup's NEXT tile -- they go into the buffer that the current tile's walk reads its last
+    // steps' prefetches from; pre_halo, first iteration only: the first tile's own)
+    if (RUNS && blockIdx.x < ntiles) { pre_halo = load_desc(blockIdx.x); pre_main = load_desc((u64)blockIdx.x + gridDim.x); }
+    RunsPipe<(KW > 0 ? KW : 1)> pipe;
+    u32 iter = 0;
     if (!RUNS && blockIdx.x < ntiles) {
         pre_main = load_any((u64)blockIdx.x * kPartTile, threadIdx.x);
         if (threadIdx.x < 16) pre_halo = load_any((u64)blockIdx.x * kPartTile, kPartThreads + threadIdx.x);
@@ -204,7 +208,10 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();  // the previous tile's readers are done with `lds`; ring/fill init is visible
         if constexpr (RUNS) {
-            if (threadIdx.x < kPartTile / 64) reinterpret_cast<uint4 *>(tdesc)[threadIdx.x] = pre_main;
+            if (threadIdx.x < kPartTile / 64) {
+                if (iter == 0) reinterpret_cast<uint4 *>(tdesc)[threadIdx.x] = pre_halo;
+                reinterpret_cast<uint4 *>(tdesc)[((iter + 1) & 1u) * (kPartTile / 64) + threadIdx.x] = pre_main;   // (that buffer's readers finished a tile ago)
+            }
         } else if constexpr (KW == 0) {
             reinterpret_cast<uint4 *>(lds)[threadIdx.x] = pre_main;
             if (threadIdx.x < 16) reinterpret_cast<uint4 *>(lds)[kPartThreads + threadIdx.x] = pre_halo;
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         }
         __syncthreads();
         const u64 next = tile + gridDim.x;
-        if (RUNS && next < ntiles) pre_main = load_desc(next);
+        if (RUNS) pre_main = load_desc(next + gridDim.x);   // (zeros beyond the last tile)
         if (!RUNS && next < ntiles) {
             pre_main = load_any(next * kPartTile, threadIdx.x);
             if (threadIdx.x < 16) pre_halo = load_any(next * kPartTile, kPartThreads + threadIdx.x);
@@ -264,7 +271,11 @@ if constexpr (MODE == 2) pend_b = (u32)(h >> 32) & 1023u;
                 flush_lines(false);
             }
         };
-        if constexpr (RUNS) walk_windows_runs<KW, KC, true, MODE, kPre>(a.runs, tdesc, k, sink, ascii4, pm1, pm2, &aux_y, ptm);
+        if constexpr (RUNS) {
+            walk_windows_runs<KW, KC, true, MODE, kPre>(a.runs, tdesc + (iter & 1u) * (kPartTile / 64), tdesc + ((iter + 1) & 1u) * (kPartTile / 64), pipe, iter == 0, k, sink,
+                                                        ascii4, pm1, pm2, &aux_y, ptm);
+            ++iter;
+        }
         else if constexpr (KW == 0) walk_windows<0, 0, kPartWPT>(lds, k, sink);
         else walk_windows_encoded<KW, KC, true, MODE, kPre>(tcodes, tvalid, k, sink, ascii4, pm1, pm2, &aux_y, ptm);
         commit();

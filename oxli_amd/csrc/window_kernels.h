@@ -186,9 +186,22 @@ __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const uns
 // window is assembled from its run's packed bases (no rolling: there is no "previous window" to roll from at a run start, and
 // assembling costs what rolling does); the lanes of a wave read overlapping words, which the L1 serves.  Two dependent loads stand
 // between a step and its k-mer (the group's descriptor -- wave-uniform -- then the bases), so the loop is software-pipelined: the
-// descriptor of step j + 3 and the bases of step j + 2 are requested before window j is hashed.
+// descriptor of step j + 3 and the bases of step j + 2 are requested before window j is hashed -- across tiles too (RunsPipe).
+// What the walk keeps in flight from one tile to the next: the descriptors of the next tile's first three steps and the bases of its
+// first two are requested during the current tile's last steps, so that a tile does not start with two dependent round trips (LDS, then
+// HBM) that all sixteen waves would sit out together behind the tile's barrier.
+constexpr int kRunsFetchAhead = 2;   // steps between requesting a window's bases and using them (its descriptor: one more; 3: no faster)
+template <int KW>
+struct RunsPipe {
+    RunGroup d[kRunsFetchAhead + 1];
+    u32 x[kRunsFetchAhead][2 * KW + 1];
+    u32 sh[kRunsFetchAhead];
+    bool good[kRunsFetchAhead];
+};
+
 template <int KW, int KC, bool LUT = false, int RAW = 0, int PRE = 0, class Sink>
-__device__ __forceinline__ void walk_windows_runs(const RunsInput &in, const RunGroup *tdesc, int k_rt, Sink &&sink, const u32 *lut = nullptr,
+__device__ __forceinline__ void walk_windows_runs(const RunsInput &in, const RunGroup *tdesc, const RunGroup *tdesc_next, RunsPipe<KW> &pipe, bool first,
+                                                  int k_rt, Sink &&sink, const u32 *lut = nullptr,
                                                   const u64 *mul1 = nullptr, const u64 *mul2 = nullptr, u64 *aux = nullptr, const u64 *tmul = nullptr) {
     constexpr int WPT = 16, NX = 2 * KW + 1;  // words that hold 2k bits at any 2-bit offset
     const int k = KC > 0 ? KC : k_rt;
@@ -197,12 +210,12 @@ __device__ __forceinline__ void walk_windows_runs(const RunsInput &in, const Run
     constexpr u32 kStep = kPartThreads / 64;
     struct Fetch { u32 x[NX]; u32 sh; bool good; };
     // The tile's 256 descriptors sit in LDS (`tdesc`, staged by the kernel: group wave + 16 j of the tile is step j of this wave; groups
-    // past the end are zeros = no windows).  One broadcast ds_read_b128 + four v_readfirstlane make a descriptor wave-uniform, so its
-    // arithmetic runs on the scalar unit.  (Scalar LOADS of the descriptors -- s_load_dwordx4 through the constant address space, the
-    // first version -- share the lgkm counter with the append's LDS atomics and return out of order: every wait for an LDS result became
-    // lgkmcnt(0) and exposed a scalar-cache round trip per step.)
-    auto describe = [&](int j) -> RunGroup {
-        const uint4 q = reinterpret_cast<const uint4 *>(tdesc)[wave + kStep * (u32)j];
+    // past the end are zeros = no windows; `tdesc_next`: the following tile's).  One broadcast ds_read_b128 + four v_readfirstlane make
+    // a descriptor wave-uniform, so its arithmetic runs on the scalar unit.  (Scalar LOADS of the descriptors -- s_load_dwordx4 through
+    // the constant address space, the first version -- share the lgkm counter with the append's LDS atomics and return out of order:
+    // every wait for an LDS result became lgkmcnt(0) and exposed a scalar-cache round trip per step.)
+    auto describe = [&](int j) -> RunGroup {   // j >= WPT: step j - WPT of the next tile
+        const uint4 q = reinterpret_cast<const uint4 *>(j < WPT ? tdesc : tdesc_next)[wave + kStep * (u32)(j < WPT ? j : j - WPT)];
         RunGroup d;
         d.base_nvalid = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)q.y) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)q.x);
         d.starts = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)q.w) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)q.z);
@@ -227,14 +240,28 @@ __device__ __forceinline__ void walk_windows_runs(const RunsInput &in, const Run
         f.sh = rel & 31u;
         return f;
     };
-    RunGroup D[WPT + 3];
-    Fetch F[WPT + 2];
-    D[0] = describe(0); D[1] = describe(1); D[2] = describe(2);
-    F[0] = fetch(D[0]); F[1] = fetch(D[1]);
+    constexpr int FA = kRunsFetchAhead, DA = FA + 1;
+    RunGroup D[WPT + DA];
+    Fetch F[WPT + FA];
+    if (first) {   // (workgroup-uniform: the workgroup's first tile)
+#pragma unroll
+        for (int i = 0; i < DA; ++i) D[i] = describe(i);
+#pragma unroll
+        for (int i = 0; i < FA; ++i) F[i] = fetch(D[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < DA; ++i) D[i] = pipe.d[i];
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+#pragma unroll
+            for (int w = 0; w < NX; ++w) F[i].x[w] = pipe.x[i][w];
+            F[i].sh = pipe.sh[i]; F[i].good = pipe.good[i];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
-        if (j + 3 < WPT) D[j + 3] = describe(j + 3);
-        if (j + 2 < WPT) F[j + 2] = fetch(D[j + 2]);
+        D[j + DA] = describe(j + DA);
+        F[j + FA] = fetch(D[j + FA]);
         const Fetch &cur = F[j];
         u64 h;
         {
@@ -271,6 +298,14 @@ __device__ __forceinline__ void walk_windows_runs(const RunsInput &in, const Run
             }
         }
         sink(j, cur.good, h);
+    }
+#pragma unroll
+    for (int i = 0; i < DA; ++i) pipe.d[i] = D[WPT + i];
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+#pragma unroll
+        for (int w = 0; w < NX; ++w) pipe.x[i][w] = F[WPT + i].x[w];
+        pipe.sh[i] = F[WPT + i].sh; pipe.good[i] = F[WPT + i].good;
     }
 }
 
