@@ -239,7 +239,7 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     if (k > 64) { set_err("the early route takes k <= 64"); return KCT_ERR_ARG; }
     Route r{t, world, rank, ops, split_streams(t)};
     // ---- passes: as many as the tightest rank needs (HBM: regions, two send and two receive slabs, the owner's scratch), at least
-    // four for a long stream so that the wire hides behind the kernels
+    // four (eight with more than four ranks) for a long stream so that the wire hides behind the kernels
     const u64 windows = nbytes >= (u64)k ? nbytes - k + 1 : 0;
     if (!max_windows) {
         size_t free_b = 0, total_b = 0;
@@ -247,7 +247,8 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
         const double held = (double)(t->d_scratch.cap + t->d_scratch2.cap + t->d_sk_bases.cap + t->d_sk_starts.cap);
         const double per_window = 6.0 * bases_per_window(k) / 4.0 + 24.0;
         max_windows = (u64)std::max(1.0 * (1 << 24), 0.6 * ((double)free_b + held) / per_window);
-        if (windows >= (1ULL << 28)) max_windows = std::min<u64>(max_windows, std::max<u64>(1ULL << 26, windows / 4));
+        // (what no pass can hide is the first cut and the last transfer: with many peers the wire is short and eight passes expose half as much)
+        if (windows >= (1ULL << 28)) max_windows = std::min<u64>(max_windows, std::max<u64>(1ULL << 26, windows / (world > 4 ? 8 : 4)));
     }
     max_windows = std::max<u64>(1 << 16, max_windows & ~0xFFFFULL);
     std::vector<u64> sz(world * 2), rz;
