@@ -129,8 +129,8 @@ KCT_API kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint
  * `nbytes` bytes in which records are separated by at least one non-ACGT byte (e.g. '\n');
  * skip_bad semantics.  `consumed` grows by `consumed_bytes` (the caller knows the record
  * lengths).  Runs on the table's stream; the caller's buffer is free again when the call returns.
- * A call that is SMALL for the table (fewer than 4 window starts per slot) is, in deferred mode (the default, kct_set_deferred),
- * copied behind the earlier ones in HBM and counted with them -- when anything else touches the table, when 32 window starts per
+ * A call that is SMALL for the table (fewer than 4 window starts per slot; fewer than 1 if it is the first call into an empty
+ * table) is, in deferred mode (the default, kct_set_deferred), copied behind the earlier ones in HBM and counted with them -- when anything else touches the table, when 32 window starts per
  * slot have gathered or the staging buffer (<= 32 GiB, a quarter of the free HBM) is full -- so that an input fed in pieces is
  * counted in the passes, and on the path, of ONE large call; *n_total then comes from the copy kernel's own validity scan (the
  * all-ACGT rule of lib.rs:586-600; it differs from the reference's n only if a window's true hash is 0, probability 2^-64). */

@@ -1044,6 +1044,7 @@ kct_status consume_stream(kct_table *t, const unsigned char *d_stream, u64 nbyte
     KCT_DBG(t, "consume_stream: %llu window starts (+ %llu announced), chunk limit %llu, table %llu slots\n", (unsigned long long)here,
             (unsigned long long)t->more_windows, (unsigned long long)chunk_limit, (unsigned long long)t->cap);
     bool probe = probe_wanted(t, call_windows);
+    if (!probe && mostly_new_expected(t, call_windows)) t->expect_new_keys = true;
     if (here > chunk_limit) {  // passes of equal size
         const u64 passes = (here + chunk_limit - 1) / chunk_limit;
         chunk_limit = std::min(chunk_limit, (((here + passes - 1) / passes) + 0xFFFF) & ~(u64)0xFFFF);

@@ -514,8 +514,12 @@ kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes,
     if (((uintptr_t)d_stream & 15) != 0) { set_err("d_stream must be 16-byte aligned"); return KCT_ERR_ARG; }
     // A call that is small for the table is staged behind the earlier ones and counted with them (kct_internal.h defer_device): the
     // table then sees ONE large pass -- its two-level paths, its dedupe probe -- where a caller feeds a large input in pieces.
+    // (Not the FIRST call into an empty table if it brings a window start per slot or more: whoever makes one large call and then reads
+    // the table should not pay a copy for the calls that might have followed -- 4 % of such a call; a stream of calls of that size has
+    // its first one counted by itself and the rest together.)
     const u64 npos = nbytes >= (u64)t->k ? (u64)nbytes - t->k + 1 : 0;
-    if (t->defer_device && t->k <= 255 && npos && npos < 4 * t->cap) {
+    const bool untouched = t->n_keys == 0 && !t->defer_used && !t->shadow_dirty && !t->s32_dirty && !t->s128_dirty;
+    if (t->defer_device && t->k <= 255 && npos && npos < 4 * t->cap && !(untouched && npos >= t->cap)) {
         const u64 padded = (((u64)nbytes + 15) & ~15ULL) + 16;   // (the stream, separators up to a 16-byte boundary, one unit of separators)
         size_t free_b = 0, total_b = 0;
         u64 limit = 32ULL << 30;

@@ -176,9 +176,19 @@ template <class T>
 bool probe_wanted(const T *t, pu64 call_windows) {
     return t->force_path == 0 && t->k <= 32 && !t->dedupe_off && !t->dedupe_hint && !t->auto_sized &&
            std::max({(pu64)t->n_keys, (pu64)t->shadow_keys, (pu64)t->s32_keys}) == 0 && call_windows >= 8 * kProbeWindows &&
+           call_windows >= 4 * (pu64)t->cap &&   // (a table its owner sized holds its k-mers at a load of 0.3-0.6: fewer than 4 window starts
+                                                  // per slot are fewer than ~10 per distinct k-mer -- hashing, no need to look)
            t->cap >= kProbeShadowSlots && partition_geometry_ok(t) && partition_pays(t, call_windows) &&
            ((t->k <= 21 && !t->compact_off && shadow_amortises(t, true, t->windows_since_read + call_windows)) ||
             shadow_amortises(t, false, t->windows_since_read + call_windows));
+}
+
+// No probe because the call is small for the table its owner sized (above): then it is mostly first sightings -- fewer than 2.5
+// window starts per slot are fewer than ~6 per distinct k-mer -- and the hashing K2 of an empty table runs the variant whose fast path
+// claims slots itself (what a probe's "fewer than six per distinct k-mer" sets too).
+template <class T>
+bool mostly_new_expected(const T *t, pu64 call_windows) {
+    return !t->auto_sized && std::max({(pu64)t->n_keys, (pu64)t->shadow_keys, (pu64)t->s32_keys}) == 0 && 2 * call_windows < 5 * (pu64)t->cap;
 }
 
 // From the share r of a uniform sample's n draws that were first sightings: x = n / D solves r = (1 - e^-x) / x.

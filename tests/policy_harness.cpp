@@ -32,6 +32,7 @@ static FakeTable make(const PolicyIn *in) {
 
 int policy_choose_path(const PolicyIn *in, uint64_t npos) { const FakeTable t = make(in); return (int)kcth::choose_path(&t, npos); }
 int policy_probe_wanted(const PolicyIn *in, uint64_t call_windows) { const FakeTable t = make(in); return kcth::probe_wanted(&t, call_windows) ? 1 : 0; }
+int policy_mostly_new_expected(const PolicyIn *in, uint64_t call_windows) { const FakeTable t = make(in); return kcth::mostly_new_expected(&t, call_windows) ? 1 : 0; }
 int policy_probe_verdict(const PolicyIn *in, double per_key, uint64_t call_windows) { const FakeTable t = make(in); return kcth::probe_verdict(&t, per_key, call_windows) ? 1 : 0; }
 int policy_compact_sbits(const PolicyIn *in) { const FakeTable t = make(in); return kcth::compact_sbits_for(&t); }
 double policy_draws_per_distinct(double r) { return kcth::draws_per_distinct(r); }

@@ -24,6 +24,7 @@ def pol(tmp_path_factory):
     lib = C.CDLL(so)
     lib.policy_choose_path.argtypes = [C.POINTER(PolicyIn), C.c_uint64]
     lib.policy_probe_wanted.argtypes = [C.POINTER(PolicyIn), C.c_uint64]
+    lib.policy_mostly_new_expected.argtypes = [C.POINTER(PolicyIn), C.c_uint64]
     lib.policy_probe_verdict.argtypes = [C.POINTER(PolicyIn), C.c_double, C.c_uint64]
     lib.policy_draws_per_distinct.restype = C.c_double
     lib.policy_draws_per_distinct.argtypes = [C.c_double]
@@ -82,7 +83,14 @@ def test_a_shadow_must_be_paid_for(pol):
     assert pol.policy_compact_sbits(C.byref(sub1)) == 13                 # 8192 blocks, 512 MiB (it was rounded up to 2^16 blocks = 4 GiB)
     assert choose(sub1, C2_WINDOWS) == COMPACT                           # 1.5x10^8 windows pay for 512 MiB of shadow ...
     assert choose(sub1, 60_000_000) == PARTITIONED                       # ... 6x10^7 do not (nor for 1 GiB of 64-bit shadow)
-    assert pol.policy_probe_wanted(C.byref(table(cap=1 << 26)), C2_WINDOWS) == 1
+    assert pol.policy_probe_wanted(C.byref(table(cap=1 << 26)), C2_WINDOWS) == 0    # 2.2 window starts per slot: mostly distinct k-mers, no need to look
+    assert pol.policy_probe_wanted(C.byref(table(cap=1 << 25)), C2_WINDOWS) == 1    # 4.5 per slot: look
+    # ... and a call of fewer than 2.5 per slot into an empty table its owner sized is taken for mostly first sightings (K2 claims slots)
+    assert pol.policy_mostly_new_expected(C.byref(table(cap=1 << 26)), C2_WINDOWS) == 1
+    assert pol.policy_mostly_new_expected(C.byref(table(cap=1 << 30)), 1_900_000_000) == 1       # C4's shard
+    assert pol.policy_mostly_new_expected(C.byref(table(cap=1 << 25)), C2_WINDOWS) == 0
+    assert pol.policy_mostly_new_expected(C.byref(table(cap=1 << 26, n_keys=1)), C2_WINDOWS) == 0
+    assert pol.policy_mostly_new_expected(C.byref(table(cap=1 << 26, auto_sized=1)), C2_WINDOWS) == 0
     assert pol.policy_compact_sbits(C.byref(table(cap=1 << 23))) == 10 and pol.policy_compact_sbits(C.byref(table(cap=1 << 24))) == 11
     assert pol.policy_compact_sbits(C.byref(table(cap=1 << 30))) == 17
     assert choose(table(cap=1 << 24, dedupe_hint=1), 90_000_000) == COMPACT    # 128 MiB of compact shadow: paid by 2x10^7 windows
