@@ -552,10 +552,11 @@ __global__ __launch_bounds__(kPartThreads, 8) void aggregate_blocks32_kernel(Agg
     };
     u32 *myq = wq + wave * kWaveQueue32;
     u32 qn = 0;
+    // (qn is the same in every lane: kept on the scalar unit -- v_readfirstlane -- its tests are s_cmp + s_cbranch, no exec-mask regions)
     auto drain = [&](u32 keep_below) {
         while (qn > keep_below) {
             const u32 take = qn < 64 ? qn : 64;
-            qn -= take;
+            qn = (u32)__builtin_amdgcn_readfirstlane((int)(qn - take));
             if ((u32)lane < take) insert(myq[qn + lane]);
         }
     };
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(kPartThreads, 8) void aggregate_blocks32_kernel(Agg
         if (m) {
             const u32 pos = qn + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
             if (miss) myq[pos] = e;
-            qn += (u32)__popcll(m);
+            qn = (u32)__builtin_amdgcn_readfirstlane((int)(qn + (u32)__popcll(m)));
             if (qn > kWaveQueue32 - 64) drain(31);
         }
     };
