@@ -550,8 +550,10 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
         ra.min_lines = repartition_min_lines(t, kct::kRingEntries * 2, sub_bits, 4);
         {
             ProfScope ps(t, "repartition_kernel<compact>");
-            // (one flush per slab, as the 64-bit variant does, was measured: K1b -5 %, but more overflow entries: no gain overall)
-            hipLaunchKernelGGL((kct::repartition_kernel<unsigned int, false>), dim3((unsigned)n2), dim3(kct::kPartThreads), 0, t->stream, ra);
+            // One flush per slab (16 appends per thread) where a sub-bin's stretch of the ring is deep enough for it: up to 128 sub-bins,
+            // 256 entries each -- an interval brings 128 on average; K1b -5 %.  With shallower stretches the overflow entries eat the gain.
+            if (sub_bits <= 7) hipLaunchKernelGGL((kct::repartition_kernel<unsigned int, true>), dim3((unsigned)n2), dim3(kct::kPartThreads), 0, t->stream, ra);
+            else hipLaunchKernelGGL((kct::repartition_kernel<unsigned int, false>), dim3((unsigned)n2), dim3(kct::kPartThreads), 0, t->stream, ra);
         }
         HIP_TRY(hipGetLastError());
         aa.scratch = (const unsigned int *)t->d_scratch2.p; aa.seg_stride = out_cap; aa.block_stride = W2 * out_cap;
