@@ -17,6 +17,7 @@ Cheaper invariants beside them:
 
 Smaller inputs into tables of more than 1024 blocks are compared with the oracle's table bit for bit.
 """
+import json
 import os
 
 import numpy as np
@@ -81,8 +82,28 @@ def oracle_shardset(gpu, g, r, R, L, k, **model):
     return oracle.ShardSet(k, L, genome=genome, nreads=R, seed_r=SEED_R, expect_keys=min(len(genome), R * (L - k + 1)), **model)
 
 
+GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_digests.json")))
+DIGEST_KEYS = ("sum_hc", "xor_hc", "sum_sq", "len", "sum_counts", "min", "max", "n", "consumed")
+# test name -> entry of tests/golden/config_digests.json (the CPU oracle's digests of the same input, made once on the GPU box's host
+# by tests/golden/make_config_digests.py).  KCT_FULL_ORACLE=1 rebuilds the oracle's table on the spot instead (minutes per config).
+GOLDEN_OF = {"C3": "C3", "C4-shard": "C4_shard", "C5-shard": "C5_shard", "NS-k21": "north_star_k21"}
+
+
+def golden_digest(name, **expect):
+    d = GOLDEN[name]
+    for key, v in expect.items():   # the entry really is this input
+        assert d[key] == v, (name, key, d[key], v)
+    assert (d["seed_g"], d["seed_r"]) == (SEED_G, SEED_R)
+    return d
+
+
+def table_digest(t, n):
+    lo, hi, _ = t._count_stats()
+    return dict(zip(("sum_hc", "xor_hc", "sum_sq"), t.digest()), len=len(t), sum_counts=t.sum_counts, min=lo, max=hi, n=n, consumed=t.consumed)
+
+
 def assert_digest_equal(t, ss, n):
-    d = ss.digest()
+    d = ss if isinstance(ss, dict) else ss.digest()
     lo, hi, _ = t._count_stats()
     got = dict(zip(("sum_hc", "xor_hc", "sum_sq"), t.digest()), len=len(t), sum_counts=t.sum_counts, min=lo, max=hi, n=n, consumed=t.consumed)
     assert got == {k_: d[k_] for k_ in got}, (got, d)
@@ -122,16 +143,24 @@ def test_full_size_config(gpu, name):
     # a sample of keys: the slice's keys plus keys that are absent
     sample = np.concatenate([rk, rk ^ np.uint64(0x5555555555555555)])
     sample_counts = np.array(t.get_hash_array(sample), dtype=np.uint64)
-    # THE ORACLE'S TABLE OF THE WHOLE INPUT: digests equal, and every sampled key's count equal
-    ss = oracle_shardset(gpu, g, r, R, L, k)
+    # THE ORACLE'S TABLE OF THE WHOLE INPUT: its committed digests (tests/golden/config_digests.json) must equal the device table's;
+    # every key of the slice is there with at least the slice's count.  C4's shard -- and every config under KCT_FULL_ORACLE=1 --
+    # rebuilds the oracle's table on this host: digests, every sampled key's count, and (C4's shard, 4.8x10^8 pairs) the whole
+    # dump pair by pair.
+    gold = golden_digest(GOLDEN_OF[name], reads=R, read_len=L, k=k, genome=G)
+    assert_digest_equal(t, gold, n)
+    assert np.all(sample_counts[: rk.size] >= rc) and not sample_counts[rk.size:].any()
+    if name == "C4-shard" or os.environ.get("KCT_FULL_ORACLE") == "1":
+        ss = oracle_shardset(gpu, g, r, R, L, k)
+        assert ss.digest() == {k_: gold[k_] for k_ in ss.digest()}, "the committed digest is not the oracle's"
+        assert_digest_equal(t, ss, n)
+        assert sample_counts.tolist() == [ss.get_hash(int(h)) for h in sample.tolist()]
+        if name == "C4-shard":
+            dk, dc = t.dump_arrays(0)
+            assert dk.size == ss.digest()["len"] and ss.mismatches(dk, dc) == 0
+            del dk, dc
+        del ss
     del g
-    assert_digest_equal(t, ss, n)
-    assert sample_counts.tolist() == [ss.get_hash(int(h)) for h in sample.tolist()]
-    if name == "C4-shard":  # 4.8x10^8 pairs: the whole dump, pair by pair
-        dk, dc = t.dump_arrays(0)
-        assert dk.size == ss.digest()["len"] and ss.mismatches(dk, dc) == 0
-        del dk, dc
-    del ss
     # the same stream again: every count doubles, no key is new
     assert t.consume_device(r.data_ptr(), r.numel(), R * L) == n_expect
     d2, total2, lo2, hi2, sq2 = stats(t)
@@ -149,6 +178,93 @@ def test_full_size_config(gpu, name):
     assert (dd, dtotal, dlo, dhi) == (distinct, n_expect, lo, hi)
     assert dsq == pytest.approx(sq, rel=1e-12)
     assert np.array_equal(np.array(d.get_hash_array(sample), dtype=np.uint64), sample_counts)
+
+
+def test_whole_C5_on_one_gpu_equals_the_oracle_digest(gpu):
+    """BASELINE.json configs[4] at its OWN size on one MI355X: 10 M x 10 kbp reads of a 3.1 Gbp genome, k = 51 -- 9.95x10^10 k-mers,
+    3.1x10^9 distinct, into ONE 2^33-slot table (128 GiB).  The 100 GB of reads do not sit beside that table and its scratch, so they
+    are generated on the device in eight pieces (the multi-GPU job's eight rank shards, in rank order) and fed to the same table call
+    after call, as a file reader would.  The table must equal the CPU oracle's table of the whole input: its committed digests
+    (tests/golden/config_digests.json "C5", 13 host-minutes on 64 threads; lib.rs:545-607 per record, 778-837 for the union)."""
+    torch, KCT, lib = gpu
+    gold = golden_digest("C5")
+    R, L, k, G = gold["reads"], gold["read_len"], gold["k"], gold["genome"]
+    assert (R, L, k, G) == (10_000_000, 10_000, 51, 3_100_000_000)
+    free, _total = torch.cuda.mem_get_info()
+    if free < 250 * (1 << 30):
+        pytest.skip("needs a whole MI355X (250 GiB of free HBM)")
+    pieces = 8
+    per = R // pieces
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.empty(G, dtype=torch.uint8, device="cuda")
+    assert lib.kct_synth_genome_device(g.data_ptr(), G, SEED_G, stream) == 0
+    r = torch.empty(per * (L + 1), dtype=torch.uint8, device="cuda")
+    genome_host = g.cpu().numpy()
+    t = KCT(k, capacity=G)
+    assert t.capacity == 1 << 33
+    t.profile(True)
+    n = 0
+    for p in range(pieces):
+        assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), G, p * per, per, L, SEED_R, stream) == 0
+        torch.cuda.synchronize()
+        if p in (0, pieces - 1):   # the host generator makes the same bytes (what the oracle's digest was made from)
+            dev = r[: 3 * (L + 1)].cpu().numpy().reshape(3, L + 1)
+            assert np.array_equal(dev, oracle.synth_reads_ex(genome_host, p * per, 3, L, SEED_R)), "host and device generators differ"
+        n += t.consume_device(r.data_ptr(), r.numel(), per * L)
+    assert n == R * (L - k + 1)
+    prof = t.profile_read()
+    assert "count_windows_kernel" not in prof and "repartition_kernel" in prof, prof   # two partition levels carried it, no per-k-mer atomics
+    assert_digest_equal(t, gold, n)
+    # an oracle slice: the first 40 reads' keys are there with at least the slice's counts
+    sub = oracle.synth_reads_ex(genome_host, 0, 40, L, SEED_R)
+    ref = OracleTable(k)
+    for i in range(40):
+        ref.consume(sub[i, :L])
+    rk, rc = ref.dump_arrays()
+    got = np.array(t.get_hash_array(rk), dtype=np.uint64)
+    assert np.all(got >= rc)
+
+
+@pytest.mark.parametrize("route_k", [21])
+def test_C4_through_the_early_route_eight_owners_in_turn(gpu, route_k):
+    """BASELINE.json configs[3] (100 M x 150 bp, k = 21, 8 GPUs) through the EARLY multi-GPU route at full size, the one GPU playing the
+    eight owners in turn: ``kct_consume_device_routed(world=8, rank=r, ops=NULL)`` cuts the WHOLE input into super-k-mers and counts
+    what rank r owns into r's own table (kct_route.hip's owned-only mode: the sender's split kernel and the owner's K1-over-runs at
+    full size, no wire).  The owners' tables are a partition of the key space: their union must equal the oracle's table of the whole
+    input -- sums (xor) over owners of the digests == tests/golden/config_digests.json "north_star_k21"."""
+    import ctypes as C
+    torch, KCT, lib = gpu
+    gold = golden_digest("north_star_k21", k=route_k)
+    R, L, k, G = gold["reads"], gold["read_len"], gold["k"], gold["genome"]
+    free, _total = torch.cuda.mem_get_info()
+    if free < 100 * (1 << 30):
+        pytest.skip("needs 100 GiB of free HBM")
+    g, r = synth(gpu, G, R, L)
+    del g
+    world = 8
+    M = (1 << 64) - 1
+    tot = dict(sum_hc=0, xor_hc=0, sum_sq=0, len=0, sum_counts=0, n=0)
+    lo_all, hi_all, shares = M, 0, []
+    for rank in range(world):
+        t = KCT(k, capacity=G // world)
+        nn, stats = C.c_uint64(), (C.c_uint64 * 16)()
+        t._check(lib.kct_consume_device_routed(t._h, C.c_void_p(r.data_ptr()), r.numel(), R * L if rank == 0 else 0, world, rank, None, 0,
+                                               C.byref(nn), stats))
+        s_hc, x_hc, s_sq = t.digest()
+        lo, hi, _ = t._count_stats()
+        tot["sum_hc"] = (tot["sum_hc"] + s_hc) & M
+        tot["xor_hc"] ^= x_hc
+        tot["sum_sq"] = (tot["sum_sq"] + s_sq) & M
+        tot["len"] += len(t)
+        tot["sum_counts"] += t.sum_counts
+        tot["n"] += nn.value
+        tot["consumed"] = tot.get("consumed", 0) + t.consumed
+        lo_all, hi_all = min(lo_all, lo), max(hi_all, hi)
+        shares.append(nn.value)
+        del t
+    tot.update(min=lo_all, max=hi_all)
+    assert tot == {k_: gold[k_] for k_ in tot}, (tot, gold)
+    assert max(shares) < 1.1 * sum(shares) / world and min(shares) > 0.9 * sum(shares) / world, shares   # owners' shares are even
 
 
 def test_full_C2_table_equals_the_oracle_table(gpu):
