@@ -42,6 +42,11 @@ same weak-scaled C2 job per rank + the late merge, and
                  config_digests.json at full size; computed on rank 0's host for the reduced sizes).  Ranks that SHARE a GPU
                  (--backend gloo on a one-GPU box) run a reduced size and say so.  C5 runs only when named (--configs C4,C5): its late
                  route needs a 128 GiB private table per rank.
+  C5_whole       BASELINE.json configs[4] at its OWN size on ONE GPU: 10 M x 10 kbp, k=51, genome 3.1 Gbp -- 9.95x10^10 k-mers into one
+                 2^33-slot (128 GiB) table.  The 100 GB of reads do not fit beside the table and its scratch, so they are generated on
+                 the device in 8 pieces (the multi-GPU job's rank shards) and consumed call after call; `seconds` = the summed wall time of
+                 the eight consume calls + the final sync (each piece resident in HBM when its call starts; generation untimed); gated on
+                 the CPU oracle's committed digests of the whole input (tests/golden/config_digests.json "C5").
   north_star_streamed   the north-star run's 100 M reads fed the way a caller feeds them: 20 calls of 5 M reads and 100 calls of 1 M
                  reads into ONE table that starts empty and hint-free (one conversion at the end); rate against the one-call run,
                  the path every call took, gated on the oracle's digests.
@@ -90,7 +95,9 @@ MULTI = {
     "C4": (100_000_000, 150, 21, 500_000_000),
     "C5": (10_000_000, 10_000, 51, 3_100_000_000),
 }
-ALL_CONFIGS = ["cold_C2", "packed_C2", "e2e_C2", "per_record", "k51_deep"] + list(BIG) + ["north_star_streamed"] + list(ERR) + list(MULTI)
+# BASELINE.json configs[4] WHOLE on one GPU: the 100 GB of reads are generated on the device in PIECES and fed call after call
+C5_WHOLE = (10_000_000, 10_000, 51, 3_100_000_000, 8)   # reads, read length, k, genome, pieces
+ALL_CONFIGS = ["cold_C2", "packed_C2", "e2e_C2", "per_record", "k51_deep"] + list(BIG) + ["north_star_streamed", "C5_whole"] + list(ERR) + list(MULTI)
 
 
 def parse():
@@ -236,7 +243,7 @@ def compact(res):
             if "feeds" in c:
                 e["vs_one_call"] = r(c["vs_one_call"], 3)
                 e["feeds"] = {kk: {"kmers_per_s": r(vv["kmers_per_s"], 0), "counting_launches": vv["counting_launches"]} for kk, vv in c["feeds"].items()}
-            for k in ("path_chosen", "world", "best_route", "note", "reads_total", "oracle_digests"):
+            for k in ("path_chosen", "world", "best_route", "note", "reads_total", "oracle_digests", "pieces", "table_slots"):
                 if k in c:
                     e[k] = c[k]
             if "partitioned_path_kmers_per_s" in c:
@@ -761,6 +768,64 @@ def main():
             log(f"north_star_streamed: 1 call {base:.3g}, 20 calls {entry['feeds']['20']['kmers_per_s']:.3g}, 100 calls {entry['feeds']['100']['kmers_per_s']:.3g} k-mers/s, gate {gate}")
             assert ablate or all(gate.values()), gate
             del r
+            torch.cuda.empty_cache()
+    # ------------------------------------------------------------------------------------------ C5 whole, one GPU, fed in pieces
+    if rank == 0 and world == 1 and "C5_whole" in want:
+        Rb, Lb, kb, Gb, pieces = C5_WHOLE
+        free, _tot = torch.cuda.mem_get_info()
+        if free < 250 * (1 << 30):
+            configs["C5_whole"] = {"skipped": f"needs a whole MI355X: {free >> 30} GiB free"}
+        else:
+            per = Rb // pieces
+            n_exp = Rb * (Lb - kb + 1)
+            balg = Lb / (Lb - kb + 1) + 24.0
+            g = torch.empty(Gb, dtype=torch.uint8, device="cuda")
+            assert lib.kct_synth_genome_device(g.data_ptr(), Gb, SEED_G, stream) == 0
+            r = torch.empty(per * (Lb + 1), dtype=torch.uint8, device="cuda")
+            t = KmerCountTable(kb, capacity=Gb)
+            t.set_path(args.path)
+
+            def whole(profile):
+                t.clear()
+                t.set_path(args.path)
+                t.profile(profile)
+                t.profile_reset()
+                n_, secs = 0, 0.0
+                for p_ in range(pieces):
+                    assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), Gb, p_ * per, per, Lb, SEED_R, stream) == 0
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    n_ += t.consume_device(r.data_ptr(), r.numel(), per * Lb)
+                    if p_ == pieces - 1:
+                        t.sync()
+                    torch.cuda.synchronize()
+                    secs += time.perf_counter() - t0
+                prof_ = t.profile_read() if profile else {}
+                t.profile(False)
+                return secs, n_, prof_
+            t0 = time.perf_counter()
+            first = whole(False)            # every allocation (128 GiB of table, ~100 GB of scratch)
+            wall_first = time.perf_counter() - t0
+            runs = [whole(False) for _ in range(2)]
+            dt, n = min(runs, key=lambda x: x[0])[:2]
+            _dtp, n_p, prof = whole(True)   # per-kernel device times: the same job with event timing on
+            rep, _ = kernel_report(prof, n_exp, balg, pmc.get("C5_whole"))
+            mine = table_digest(t)
+            gd = golden.get("C5", {})
+            same_input = bool(gd) and (gd["reads"], gd["read_len"], gd["k"], gd["genome"]) == (Rb, Lb, kb, Gb)
+            gate = {"n": bool(n == n_exp == first[1] == n_p and all(x[1] == n_exp for x in runs)),
+                    "equals_oracle_digests": bool(same_input and all(mine[f_] == gd[f_] for f_ in DIGEST_FIELDS) and n == gd["n"] and t.consumed == gd["consumed"])}
+            entry = {"kmers": n_exp, "kmers_per_s": n_exp / dt, "seconds": dt, "seconds_runs": [round(x[0], 4) for x in runs], "seconds_first_run_with_allocations": first[0],
+                     "wall_first_run_with_generation": wall_first, "pieces": pieces, "table_slots": t.capacity, "distinct": mine["len"],
+                     "launches": {kn: v[0] for kn, v in prof.items()},
+                     "what": f"{Rb} x {Lb} bp, k={kb}, genome {Gb} bp on ONE GPU: {pieces} device-generated pieces consumed call after call into one "
+                             f"2^33-slot table; seconds = the consume calls + final sync (generation untimed); best of 2 after an allocating run",
+                     "gate": gate, **rep}
+            configs["C5_whole"] = entry
+            log(f"C5_whole: {entry['kmers_per_s']:.3g} k-mers/s in {dt:.3f} s, gate {gate}")
+            assert ablate or all(gate.values()), ("C5_whole", gate, mine)
+            t.release_scratch()
+            del t, r, g
             torch.cuda.empty_cache()
     # ------------------------------------------------------------------------------------------ inputs with sequencing errors
     if rank == 0 and world == 1:
