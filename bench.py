@@ -121,6 +121,11 @@ def parse():
     p.add_argument("--verbose", action="store_true", help="print the full record instead of the compact line")
     p.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"), help="where the full record is written")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo lets several ranks share one GPU for debugging")
+    p.add_argument("--exchange", choices=["auto", "native", "torch", "both"], default="auto",
+                   help="N > 1: who moves the data between ranks -- libkct_rccl.so (native: ncclSend / ncclRecv groups inside the library, what a Rust "
+                        "caller links; needs --backend nccl, one rank per GPU) or torch.distributed.  auto = native for the headline's merge where "
+                        "possible, and BOTH side by side in configs.C4 / C5")
+    p.add_argument("--job-timeout", type=float, default=3000.0, help="N > 1 self-launch: seconds after which the parent kills the ranks (a hung collective) and exits 124")
     p.add_argument("--no-second-process", action="store_true", help="skip the headline's second sample from another cold-started process")
     p.add_argument("--headline-sample", action="store_true", help=argparse.SUPPRESS)   # (the child of the above: headline only, prints its value)
     return p.parse_args()
@@ -249,7 +254,7 @@ def compact(res):
             if "partitioned_path_kmers_per_s" in c:
                 e["partitioned_path_kmers_per_s"] = r(c["partitioned_path_kmers_per_s"], 0)
             if "routes" in c:
-                e["routes"] = {rn: {"kmers_per_s": r(rv["kmers_per_s"], 0), "seconds": r(rv["seconds"], 5), "mode": rv["mode"],
+                e["routes"] = {rn: {"kmers_per_s": r(rv["kmers_per_s"], 0), "seconds": r(rv["seconds"], 5), "mode": rv["mode"], "exchange": rv.get("exchange"),
                                     "rank0": {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in (rv["per_rank"][0] or {}).items()}}
                                for rn, rv in c["routes"].items()}
             if "kernels_ms" in c:
@@ -307,8 +312,10 @@ def cpu_baseline(args, log):
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process -- before
-    anything in this process has touched the GPU -- and exit with its code."""
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process group -- before
+    anything in this process has touched the GPU -- and exit with its code.  Hang guard: a job that has not finished after
+    --job-timeout seconds (a collective some rank never joined) has its whole process group killed and the parent exits 124."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as sock:
@@ -317,7 +324,22 @@ def self_launch(args):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd, env=env))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)   # its own process group: the exact group we may have to kill
+    try:
+        raise SystemExit(child.wait(timeout=args.job_timeout))
+    except subprocess.TimeoutExpired:
+        print(f"[bench] the {args.gpus}-rank job did not finish in {args.job_timeout:.0f} s: killing its process group", file=sys.stderr, flush=True)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        raise SystemExit(124)
 
 
 def second_process_sample(args):
@@ -366,6 +388,17 @@ def main():
     def log(msg):
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    # who moves data between the ranks: libkct_rccl.so's own communicator (bootstrapped over the torch group) and / or torch.distributed
+    native = None
+    if world > 1 and args.exchange != "torch":
+        can = args.backend == "nccl" and world <= torch.cuda.device_count()
+        if can:
+            from oxli_amd.distributed import NativeRccl
+            native = NativeRccl()
+        elif args.exchange == "native":
+            raise SystemExit("--exchange native needs --backend nccl and one rank per GPU (RCCL refuses two ranks on one device)")
+    exchanges = ([("native", native)] if native is not None else []) + ([("torch", None)] if native is None or args.exchange in ("both", "auto") else [])
 
     lib = _lib.load()
     L, k, R, G = args.read_len, args.k, args.reads, args.genome
@@ -433,7 +466,7 @@ def main():
         for s in range(args.steps):
             n += step(s)
         t_merge = time.perf_counter()
-        recv = merge_across_ranks(table) if world > 1 else 0
+        recv = merge_across_ranks(table, native=native) if world > 1 else 0
         table.sync()  # counts still pending in the dedupe-first path's shadow table are converted inside the timed region
         torch.cuda.synchronize()
         merge_ms = (time.perf_counter() - t_merge) * 1e3
@@ -450,7 +483,7 @@ def main():
         for s in range(args.warmup):
             step(s)
         if world > 1 and args.warmup:
-            merge_across_ranks(table)  # warm the collective and the merge kernels too
+            merge_across_ranks(table, native=native)  # warm the collective and the merge kernels too
         first = job()  # (also teaches a fresh table that the dedupe-first path pays: the steady state)
         repeats = int(min(args.max_repeats, max(5 if world == 1 else 3, math.ceil(1.15 * args.min_seconds / max(first[0], 1e-6)))))
         if world > 1:  # every rank must run the same number of jobs
@@ -504,7 +537,8 @@ def main():
                        "reads_per_gpu": R, "read_len": L, "k": k, "genome": G, "distinct_kmers": distinct, "distinct_batches_per_gpu": nb,
                        "job": f"{args.steps} steps into an empty table + conversion of pending counts" +
                               (f" + one RCCL owner all-to-all merge ({med([r[2] for r in runs]):.3f} ms on rank 0, {runs[-1][3]} pairs received)" if world > 1 else ""),
-                       "world": world, "backend": args.backend if world > 1 else None},
+                       "world": world, "backend": args.backend if world > 1 else None,
+                       "exchange": None if world == 1 else "libkct_rccl.so (kct_rccl_merge_across_ranks)" if native is not None else "torch.distributed (all_to_all_single)"},
             "roofline": roofline,
         })
         if other is not None:
@@ -917,13 +951,19 @@ def main():
             torch.cuda.synchronize()
             del g
             distinct_global = min(Gb, n_exp_total)
-            routes = {"late": None, "early": "super-k-mers"}
+            # both routes, each through every exchange there is: "late" / "early" = libkct_rccl.so where it can run, else torch.distributed;
+            # "late_torch" / "early_torch" = torch.distributed beside the native one
+            routes = {}
+            for xi, (xname, xobj) in enumerate(exchanges):
+                suffix = "" if xi == 0 else "_" + xname
+                routes["late" + suffix] = ("late", None, xname, xobj)
+                routes["early" + suffix] = ("early", "super-k-mers", xname, xobj)
             entry = {"world": world, "reads_total": per * world, "reads_per_rank": per, "read_len": Lb, "k": kb, "genome": Gb, "kmers": n_exp_total,
                      "scaling": "strong", "routes": {}}
             if note:
                 entry["note"] = note
             digests = {}
-            for route, mode in routes.items():
+            for rname, (route, mode, xname, xobj) in routes.items():
                 # late: a rank's private table meets k-mers from all over the genome; early: an owner holds 1 / world of the key space
                 distinct_rank = min(Gb, per * (Lb - kb + 1)) if route == "late" else distinct_global // world + (1 << 16)
                 t = KmerCountTable(kb, capacity=max(distinct_rank, 400_000), device=local)
@@ -939,10 +979,10 @@ def main():
                     if route == "late":
                         n = t.consume_device(r.data_ptr(), r.numel(), per * Lb)
                         t_x = time.perf_counter()
-                        stats["pairs_received"] = merge_across_ranks(t)
+                        stats["pairs_received"] = merge_across_ranks(t, native=xobj)
                         stats["merge_ms"] = (time.perf_counter() - t_x) * 1e3
                     else:
-                        n, st_ = consume_device_early(t, r.data_ptr(), r.numel(), per * Lb)
+                        n, st_ = consume_device_early(t, r.data_ptr(), r.numel(), per * Lb, native=xobj)
                         stats.update(st_)
                         stats["bytes_sent_per_window"] = st_["bytes_sent"] / max(1, st_["windows_sent"])
                     t.sync()        # the dedupe-first modes' conversion is part of the job
@@ -964,8 +1004,9 @@ def main():
                 for d in dg:
                     gx ^= d[3]
                 gsq = sum(d[4] for d in dg) & ((1 << 64) - 1)
-                digests[route] = (glen, gsum, gshc, gx, gsq)
-                entry["routes"][route] = {"kmers_per_s": n_exp_total / dt, "seconds": dt, "seconds_min_max": [runs[0][0], runs[-1][0]], "mode": mode,
+                digests[rname] = (glen, gsum, gshc, gx, gsq)
+                entry["routes"][rname] = {"kmers_per_s": n_exp_total / dt, "seconds": dt, "seconds_min_max": [runs[0][0], runs[-1][0]], "mode": mode,
+                                          "exchange": "libkct_rccl.so" if xobj is not None else f"torch.distributed ({args.backend})",
                                           "n": n_all, "distinct_global": glen, "per_rank": per_rank_stats}
                 t.release_scratch()
                 del t
@@ -1032,6 +1073,8 @@ def main():
         except OSError:
             pass
         print(json.dumps(result if args.verbose else compact(result), separators=(",", ":") if not args.verbose else None), flush=True)
+    if native is not None:
+        native.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -106,7 +106,12 @@ KCT_API kct_status kct_set_hash(kct_table *t, uint64_t hash, uint64_t count);
  * consume(seq, skip_bad_kmers=true) -> n                                     lib.rs:545-607
  * *n_out = k-mers counted (valid windows whose hash is not 0).  With skip_bad == 0 and a bad
  * window present: returns KCT_ERR_BAD_KMER, *n_out = k-mers counted before it (they stay
- * counted), `consumed` unchanged -- the message is "bad k-mer encountered at position {n}". */
+ * counted), `consumed` unchanged -- the message is "bad k-mer encountered at position {n}".
+ * DEVIATION in *n_out (every bulk entry point below shares it): the reference leaves a window whose MurmurHash3 value is exactly 0
+ * out of n (lib.rs:589).  Passes that hash as they read do the same; DEFERRED calls (the default for skip_bad != 0: n comes from a
+ * host-side validity scan), device-side STAGED calls and DEDUPE-FIRST passes (the hash is only computed at conversion time) count
+ * such a window in n -- the table itself never receives key 0 on any path, so its contents are the reference's.  Probability
+ * 2^-64 per distinct k-mer; demonstrated on every path by the `make zero` build (tests/test_gpu_zero_hash.py). */
 KCT_API kct_status kct_consume(kct_table *t, const char *seq, size_t len, int skip_bad, uint64_t *n_out);
 
 /* 1 if kct_consume(t, seq of `len` bytes, skip_bad) would only APPEND to deferred mode's buffer (no device work, ~60 ns), 0 if it
@@ -205,7 +210,7 @@ KCT_API kct_status kct_set_packed_upload(kct_table *t, int on);
 
 /* ---- multi-GPU "early" route: every k-mer is counted by the GPU that owns it; SUPER-K-MERS cross the wire ---------
  * Independent records (README.md:96-98) and per-key sums (add(), lib.rs:778-837) let the key space be partitioned: owner(k-mer) =
- * hash(minimiser) * world >> 16, the minimiser being the smallest (in a scrambled order) canonical 8-mer inside the k-mer -- the same
+ * (hash16(minimiser) >> 6) * world >> 10 (the top ten bits of a 16-bit hash spread over world <= 64 ranks), the minimiser being the smallest (in a scrambled order) canonical 8-mer inside the k-mer -- the same
  * for a k-mer and its reverse complement, and mostly the same for consecutive windows of a read.  Each rank cuts ITS records into
  * maximal runs of good windows with one owner and sends every run as 2-bit bases plus one start bit per window (~1 byte per window at
  * k = 21, ~0.9 at k = 51); every owner counts what it receives with the table's ordinary bulk path.  The ranks' tables end up a

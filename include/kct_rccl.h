@@ -9,7 +9,8 @@
  *
  *   rank 0:      kct_rccl_unique_id(id)            -> 128 bytes, handed to every rank out of band (file, socket, MPI, env)
  *   every rank:  kct_rccl_create(id, world, rank, device, &x)
- *                kct_consume_device_routed(table, ..., world, rank, kct_rccl_ops(x), 0, &n, stats)
+ *                kct_consume_device_routed(table, ..., world, rank, kct_rccl_ops(x), 0, &n, stats)        (the EARLY route)
+ *          or    kct_consume_device(table, own records ...); kct_rccl_merge_across_ranks(x, table, &got)  (the LATE route)
  *                kct_rccl_destroy(x)
  */
 #ifndef KCT_RCCL_H
@@ -31,6 +32,17 @@ int kct_rccl_create(const void *id128, int world, int rank, int device, kct_rccl
 const kct_exchange_ops *kct_rccl_ops(kct_rccl *x);
 void kct_rccl_destroy(kct_rccl *x);
 const char *kct_rccl_last_error(void);
+/* The LATE route's collective -- BASELINE.json north_star's "final RCCL reduce of per-bucket counts"; the reference's add(),
+ * lib.rs:778-837 (per-key sum of counts), applied across ranks.  Every rank has counted its OWN records into its own table; every rank
+ * calls this; afterwards rank r's table holds exactly the keys of hash slice r -- owner(hash) = floor(hi32(hash) * world / 2^32) --
+ * with their global counts, resized for that slice; the global table is the disjoint union over ranks (its len / sum_counts /
+ * consumed are sums over ranks; `consumed` of each table stays that rank's own share).  One size round (status, pair counts, the count
+ * of key 0 -- kept beside the device table -- to its owner, rank 0), one status round once every rank has room, one ncclSend /
+ * ncclRecv group of 16-byte {hash, count} pairs.  A failure on any rank before the payload ends the call on EVERY rank with the
+ * tables unchanged.  *pairs_received (may be NULL) = pairs this rank received, its own included.  A world of one returns at once
+ * unless kct_rccl_merge_when_alone(x, 1) asks for the collectives anyway (tests on a one-GPU box). */
+int kct_rccl_merge_across_ranks(kct_rccl *x, kct_table *t, uint64_t *pairs_received);
+void kct_rccl_merge_when_alone(kct_rccl *x, int on);
 /* bytes this communicator has sent to / received from OTHER ranks, and seconds spent blocked in wait() (statistics) */
 void kct_rccl_stats(const kct_rccl *x, uint64_t *bytes_sent, uint64_t *bytes_received, double *wait_seconds);
 

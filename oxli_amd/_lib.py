@@ -101,7 +101,39 @@ class ExchangeOps(C.Structure):
     _fields_ = [("user", C.c_void_p), ("alloc", ALLOC), ("release", RELEASE), ("exchange_sizes", SIZES), ("start", START), ("wait", WAIT)]
 
 
+# include/kct_rccl.h (libkct_rccl.so: the exchange and the late route's merge over RCCL)
+RCCL_LIB_PATH = os.path.join(HERE, "csrc", "libkct_rccl.so")
+RCCL_ID_BYTES = 128
+RCCL_SIGNATURES = {
+    "kct_rccl_unique_id": (ci, [vp]),
+    "kct_rccl_create": (ci, [vp, ci, ci, ci, C.POINTER(vp)]),
+    "kct_rccl_ops": (vp, [vp]),
+    "kct_rccl_destroy": (None, [vp]),
+    "kct_rccl_last_error": (cp, []),
+    "kct_rccl_stats": (None, [vp, u64p, u64p, C.POINTER(C.c_double)]),
+    "kct_rccl_merge_across_ranks": (ci, [vp, vp, u64p]),
+    "kct_rccl_merge_when_alone": (None, [vp, ci]),
+}
+
 _lib = None
+_rccl = None
+
+
+def load_rccl():
+    """ctypes handle of libkct_rccl.so (optional: built when the RCCL headers are there).  libkct_hip.so is loaded first, so that the
+    helper's dependency on it resolves to the SAME copy; in a process that carries PyTorch, RCCL resolves to PyTorch's librccl.so.1."""
+    global _rccl
+    if _rccl is None:
+        load()
+        if not os.path.exists(RCCL_LIB_PATH):
+            raise ImportError(f"{RCCL_LIB_PATH} is missing (built by `make -C oxli_amd/csrc` when /opt/rocm/include/rccl/rccl.h exists)")
+        lib = C.CDLL(RCCL_LIB_PATH)
+        for name, (res, args) in RCCL_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _rccl = lib
+    return _rccl
 
 
 def load():
@@ -112,7 +144,7 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  oxli_amd has no CPU fallback.")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)   # (global: libkct_rccl.so binds to this copy's kct_* symbols)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library does not export what kct.h declares
             fn.restype = res

@@ -4,6 +4,10 @@
 // asynchronous all-to-all of byte ranges.  Here they are hipMalloc, and ncclSend / ncclRecv pairs inside one group on a stream that
 // belongs to the communicator -- the payload moves while the library's kernels run on the table's stream; wait() is a
 // hipStreamSynchronize of that stream.  xGMI is point to point: a group of world - 1 sends and receives uses every link at once.
+//
+// kct_rccl_merge_across_ranks is the LATE route's collective in the same library: private tables -> owner-bucketed {hash, count} pairs
+// (kct_export_by_owner_device) -> one size round + one payload group over the same communicator -> every owner folds what arrives into
+// a table resized for its slice (kct_merge_pairs_device); add()'s semantics, lib.rs:778-837.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -40,6 +44,7 @@ struct kct_rccl {
     size_t sizes_cap = 0;
     uint64_t sent = 0, received = 0;
     double wait_s = 0;
+    bool merge_when_alone = false;   // a world of one goes through the merge's collectives too (tests on a one-GPU box)
     kct_exchange_ops ops;
 };
 
@@ -142,6 +147,65 @@ void kct_rccl_stats(const kct_rccl *x, uint64_t *bytes_sent, uint64_t *bytes_rec
     if (bytes_received) *bytes_received = x->received;
     if (wait_seconds) *wait_seconds = x->wait_s;
 }
+
+// The late route (BASELINE.json north_star: "a final RCCL reduce of per-bucket counts"): every rank has counted its own records into its
+// own table; afterwards rank r holds every key of hash slice r -- owner(hash) = floor(hi32(hash) * world / 2^32) -- with its GLOBAL
+// count: add() (lib.rs:778-837: per-key sum) applied across ranks.  `consumed` stays this rank's own share; len / sum_counts / consumed
+// of the global table are sums over ranks.  Collective: every rank must call it; a failure on any rank is learnt by all in the size
+// round (slot 0 = status) or the second one-word round, before any payload moves.  *pairs_received (may be NULL) = pairs this rank
+// received, its own included.
+int kct_rccl_merge_across_ranks(kct_rccl *x, kct_table *t, uint64_t *pairs_received) {
+    if (!x || !t) { set_err("null argument"); return 1; }
+    if (pairs_received) *pairs_received = 0;
+    const int world = x->world;
+    if (world == 1 && !x->merge_when_alone) return 0;
+    uint64_t status = 0;    // this rank's own failure so far (it stays in step until every rank has learnt of it)
+    auto fail = [&](const char *what) { if (!status) { set_err("%s: %s", what, kct_last_error()); status = 1; } };
+    uint64_t n = 0, zero = 0, consumed = 0, got = 0;
+    if (kct_len(t, &n) != KCT_OK || kct_get_hash(t, 0, &zero) != KCT_OK || kct_consumed(t, &consumed) != KCT_OK) fail("reading the table");
+    std::vector<uint64_t> part(world, 0), send((size_t)world * 3, 0), recv((size_t)world * 3, 0);
+    void *d_send = nullptr, *d_recv = nullptr;
+    if (!status && n) {
+        d_send = x_alloc(x, n * 16);
+        if (!d_send) status = 1;
+        else if (kct_export_by_owner_device(t, (uint32_t)world, d_send, n, part.data(), &got) != KCT_OK) fail("kct_export_by_owner_device");
+    }
+    // round 1: [status, pairs for that owner, this rank's count of key 0 (kept beside the device table: 0 is its EMPTY sentinel) -> owner 0]
+    for (int r = 0; r < world; ++r) { send[3 * r] = status; send[3 * r + 1] = status ? 0 : part[r]; send[3 * r + 2] = r == 0 && !status ? zero : 0; }
+    if (x_sizes(x, send.data(), 3, recv.data()) != 0) { if (d_send) x_release(x, d_send); return 1; }   // (the collective itself failed: nothing to agree through)
+    uint64_t total = 0, zero_total = 0, failed = status;
+    for (int r = 0; r < world; ++r) { failed |= recv[3 * r]; total += recv[3 * r + 1]; zero_total += recv[3 * r + 2]; }
+    if (!failed && total) { d_recv = x_alloc(x, total * 16); if (!d_recv) status = 1; }
+    // round 2: has every rank room for what it is to receive?
+    std::vector<uint64_t> s1(world, status | failed), r1(world, 0);
+    if (x_sizes(x, s1.data(), 1, r1.data()) != 0) { if (d_send) x_release(x, d_send); if (d_recv) x_release(x, d_recv); return 1; }
+    for (int r = 0; r < world; ++r) failed |= r1[r];
+    if (failed) {
+        if (!status) set_err("the merge failed on another rank before any pair moved: this rank's table is unchanged");
+        if (d_send) x_release(x, d_send);
+        if (d_recv) x_release(x, d_recv);
+        return 1;
+    }
+    std::vector<uint64_t> soff(world), sbytes(world), roff(world), rbytes(world);
+    uint64_t so = 0, ro = 0;
+    for (int r = 0; r < world; ++r) { soff[r] = so; sbytes[r] = part[r] * 16; so += sbytes[r]; roff[r] = ro; rbytes[r] = recv[3 * r + 1] * 16; ro += rbytes[r]; }
+    int rc = x_start(x, d_send, soff.data(), sbytes.data(), d_recv, roff.data(), rbytes.data());
+    if (rc == 0) rc = x_wait(x);
+    // the owner's table: cleared, sized for its slice of the key space (2^27 slots per GPU for C4 instead of 2^30), refilled
+    uint64_t a = 0, b = 0;
+    const uint64_t zk = 0;
+    if (rc == 0 && (kct_clear(t) != KCT_OK || kct_resize(t, total) != KCT_OK || (zero_total && kct_merge_host(t, &zk, &zero_total, 1, &a, &b) != KCT_OK) ||
+                    (total && kct_merge_pairs_device(t, d_recv, total, &a, &b) != KCT_OK) || kct_add_consumed(t, consumed) != KCT_OK || kct_sync(t) != KCT_OK)) {
+        set_err("folding the received pairs: %s", kct_last_error());
+        rc = 1;
+    }
+    if (d_send) x_release(x, d_send);
+    if (d_recv) x_release(x, d_recv);
+    if (pairs_received) *pairs_received = total;
+    return rc;
+}
+
+void kct_rccl_merge_when_alone(kct_rccl *x, int on) { if (x) x->merge_when_alone = on != 0; }
 
 void kct_rccl_destroy(kct_rccl *x) {
     if (!x) return;

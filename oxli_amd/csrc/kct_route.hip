@@ -2,7 +2,7 @@
 // coverage, and what crosses xGMI is SUPER-K-MERS -- about one byte per window at k = 21, 0.9 at k = 51 -- not one entry per
 // window.
 //
-//   every rank      split_superkmers_kernel over its own records: owner(k-mer) = hash(minimiser) * world >> 16, maximal runs of good
+//   every rank      split_superkmers_kernel over its own records: owner(k-mer) = sk_owner(minimiser, world), maximal runs of good
 //                   windows with one owner as 2-bit bases + one start bit per window (superkmer_kernels.h); gather_units_kernel makes one
 //                   contiguous part per owner
 //   exchange        through the caller's kct_exchange_ops (RCCL over xGMI: csrc/kct_rccl.cpp; torch.distributed: oxli_amd/distributed.py):
@@ -252,11 +252,16 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     }
     max_windows = std::max<u64>(1 << 16, max_windows & ~0xFFFFULL);
     std::vector<u64> sz(world * 2), rz;
-    for (unsigned p = 0; p < world; ++p) { sz[2 * p] = 0; sz[2 * p + 1] = windows ? (windows + max_windows - 1) / max_windows : 1; }
-    KCT_TRY(r.sizes(sz, 2, rz));
+    // (the first round also carries every rank's stream count: the per-pass size messages and the stream directories are laid out by it,
+    // so ranks with different CU counts -- mixed SKUs, partition modes, CU masks -- must not go on)
+    for (unsigned p = 0; p < world; ++p) { sz[2 * p] = (u64)r.nwg; sz[2 * p + 1] = windows ? (windows + max_windows - 1) / max_windows : 1; }
+    KCT_TRY(r.sizes(sz, 2, rz));   // (the first collective: if IT fails there is nothing to agree through)
     u64 passes = 1;
     for (unsigned p = 0; p < world; ++p) passes = std::max(passes, rz[2 * p + 1]);
+    // every rank reads the same rz columns, so these two verdicts fall alike everywhere
     if (passes > (1u << 20)) { set_err("a rank asked for %llu passes", (unsigned long long)passes); return KCT_ERR_ARG; }
+    for (unsigned p = 0; p < world; ++p)
+        if (rz[2 * p] != rz[0]) { set_err("ranks disagree on the number of super-k-mer streams (%llu on rank 0, %llu on rank %u): the early route needs GPUs with the same CU count", (unsigned long long)rz[0], (unsigned long long)rz[2 * p], p); return KCT_ERR_ARG; }
     const u64 step = windows ? (((windows + passes - 1) / passes) + 0xFFFF) & ~0xFFFFULL : 0;  // window starts per pass (16-byte aligned cuts)
     auto pass_range = [&](u64 p, u64 *off, u64 *len) {
         *off = std::min(p * step, nbytes);
@@ -273,10 +278,13 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     for (int b = 0; b < 2; ++b) { po[b].part_off.assign(world, 0); po[b].part_bytes.assign(world, 0); po[b].dir.assign((size_t)r.nwg * world, 0); }
     u64 st_windows_out = 0, st_windows_in = 0, st_bytes_out = 0, st_bytes_in = 0, st_runs = 0, st_retries = 0, st_counts = 0;
     double split_ms = 0, owner_ms = 0;
+    // From here on the ranks are inside a protocol of collectives: NO early return.  A local failure is kept in `status` -- the rank stays
+    // in step, announces it in its next size message (or the final agree()) and every rank ends the call with an error; the exchange's
+    // slabs are released on every way out.
     kct_status status = KCT_OK;
     // the inbox: room for the whole call where HBM allows (what arrives is about what leaves), at most 30 GiB (the directory's offsets)
     size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { set_err("hipMemGetInfo failed inside the early route"); status = KCT_ERR_HIP; free_b = 0; }
     const u64 inbox_target = std::min<u64>({(u64)((double)windows * (bases_per_window(k) / 4.0 + 0.125) * (solo ? 1.5 / world : 1.25)) + (8ULL << 20),
                                             (u64)(0.3 * (double)free_b), 30ULL << 30});
     const u64 batches = ops && world <= 2 ? 3 : ops && world <= 4 ? 2 : 1;
@@ -339,14 +347,21 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
         if (st != KCT_OK) return st;
         inbox.used += total;
         char *dst = (char *)inbox.buf.p + recv_base[b];
-        if (!ops) {   // loop-back: what this rank cut for itself is what it receives
+        if (!ops) {   // loop-back: what this rank cut for itself is what it receives (no peers: a failure simply ends the job)
             for (unsigned q = 0; q < world; ++q)
-                if (recv_bytes[b][q]) HIP_TRY(hipMemcpyAsync(dst + recv_off[b][q], (const char *)send[b].p + po[b].part_off[solo ? rank : q], recv_bytes[b][q], hipMemcpyDeviceToDevice, t->stream));
+                if (recv_bytes[b][q] && hipMemcpyAsync(dst + recv_off[b][q], (const char *)send[b].p + po[b].part_off[solo ? rank : q], recv_bytes[b][q], hipMemcpyDeviceToDevice, t->stream) != hipSuccess) {
+                    set_err("the loop-back copy of pass %llu failed", (unsigned long long)p);
+                    status = KCT_ERR_HIP;
+                    return status;
+                }
             return KCT_OK;
         }
         if (ops->start(ops->user, send[b].p, po[b].part_off.data(), po[b].part_bytes.data(), dst, recv_off[b].data(), recv_bytes[b].data()) != 0) {
-            set_err("the exchange failed to start");   // (every rank's collective fails with it)
-            return KCT_ERR_HIP;
+            // A start() that fails on THIS rank only: the rank must not walk away -- its peers would sit in the next collective for ever.
+            // It stays in step (wait() has nothing to wait for), announces the failure in the next size message or the final agree(),
+            // and the call then ends on every rank.
+            set_err("the exchange failed to start pass %llu", (unsigned long long)p);
+            if (status == KCT_OK) status = KCT_ERR_HIP;
         }
         return KCT_OK;
     };
@@ -376,7 +391,10 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     }
     if (job == KCT_OK) count_inbox(0);
     if (status == KCT_OK) status = job;
-    HIP_TRY(hipStreamSynchronize(t->stream));
+    if (hipStreamSynchronize(t->stream) != hipSuccess && status == KCT_OK) {   // (an asynchronous kernel fault surfaces here)
+        set_err("the table's stream failed at the end of the early route: %s", hipGetErrorString(hipGetLastError()));
+        status = KCT_ERR_HIP;
+    }
     if (world > 1) status = r.agree(status);   // (the last owner pass may have failed somewhere)
     if (ops && ops->release) {
         for (int b = 0; b < 2; ++b)

@@ -10,7 +10,7 @@
 //
 //   split_superkmers_kernel<K>   persistent, one 1024-thread workgroup per CU, tiles of 16,384 window starts (as K1):
 //        encode the tile (2-bit codes + validity), scramble every canonical m-mer into LDS, sliding minimum over the k - m + 1 m-mers of
-//        every window (packed 16-bit minima, log steps), owner = hash(minimiser) * world >> 16, runs = maximal stretches of good
+//        every window (packed 16-bit minima, log steps), owner = (hash(minimiser) >> 6) * world >> 10 (sk_owner), runs = maximal stretches of good
 //        windows with one owner; every run gets its place in its owner's LDS staging by ONE ds_add_rtn_u64 (windows | bases << 32) and
 //        is copied there with a few ds_or_b32; whole 16-byte units leave for this workgroup's private region of the owner (no global
 //        atomics), the partial unit stays in LDS for the next tile.
@@ -36,7 +36,9 @@ __device__ __host__ __forceinline__ u32 sk_scramble(u32 x) {
     return x;
 }
 // minima crowd near 0: spread them over the owners with one more odd multiply
-__device__ __host__ __forceinline__ u32 sk_owner(u32 minimiser, u32 world) { return (((minimiser * 0x9E37u) & 0xFFFFu) * world) >> 16; }
+// owner of a scrambled minimiser: the top TEN bits of its 16-bit hash spread over the ranks (world <= 64, so the product fits the 16-bit lanes
+// of sk_pk_owner, which is this function on both halves of a word: the kernel's rule and the documented one are the same arithmetic)
+__device__ __host__ __forceinline__ u32 sk_owner(u32 minimiser, u32 world) { return ((((minimiser * 0x9E37u) & 0xFFFFu) >> 6) * world) >> 10; }
 
 __device__ __forceinline__ u32 sk_pkmin(u32 a, u32 b) {
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));

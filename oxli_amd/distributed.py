@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["owner_of", "partition_by_owner", "exchange_route", "exchange_pairs", "merge_across_ranks", "global_scalar_sum",
-           "consume_device_early", "ROUTE_STATS"]
+           "consume_device_early", "ROUTE_STATS", "NativeRccl"]
 
 
 def owner_of(hashes_i64: torch.Tensor, world: int) -> torch.Tensor:
@@ -127,7 +127,66 @@ def global_scalar_sum(value: int, device, group=None) -> int:
     return int(t.item())
 
 
-def merge_across_ranks(table, group=None):
+class NativeRccl:
+    """A communicator of libkct_rccl.so (include/kct_rccl.h) for this process: what a Rust or C caller of the C ABI uses -- the early
+    route's ``kct_exchange_ops`` and the late route's ``kct_rccl_merge_across_ranks``, ncclSend / ncclRecv groups on a stream of the
+    helper's own, no Python between the collectives.  The 128-byte ``ncclUniqueId`` is made on rank 0 and handed round through the
+    ``torch.distributed`` group that is already up (any back end: it is 128 bytes, once).  One rank per GPU (RCCL refuses two ranks on
+    one device); in a process that carries PyTorch the helper binds to PyTorch's own librccl.so.1 -- one copy of RCCL per process."""
+
+    def __init__(self, group=None, device=None):
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+        self._lib = _lib.load_rccl()
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        dev = torch.cuda.current_device() if device is None else int(device)
+        ident = np.zeros(_lib.RCCL_ID_BYTES, dtype=np.uint8)
+        if rank == 0 and self._lib.kct_rccl_unique_id(ident.ctypes.data) != 0:
+            raise RuntimeError(self.last_error())
+        if world > 1:
+            box = [ident.tobytes()]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = np.frombuffer(box[0], dtype=np.uint8).copy()
+        h = C.c_void_p()
+        if self._lib.kct_rccl_create(ident.ctypes.data, world, rank, dev, C.byref(h)) != 0:
+            raise RuntimeError(self.last_error())
+        self._h, self.world, self.rank = h, world, rank
+        self.ops = C.c_void_p(self._lib.kct_rccl_ops(h))
+
+    def last_error(self):
+        return (self._lib.kct_rccl_last_error() or b"").decode("utf-8", "replace")
+
+    def merge_when_alone(self, on=True):
+        self._lib.kct_rccl_merge_when_alone(self._h, 1 if on else 0)
+
+    def merge_across_ranks(self, table):
+        """The late route's collective, natively (``kct_rccl_merge_across_ranks``).  Returns the pairs this rank received."""
+        import ctypes as C
+        got = C.c_uint64()
+        if self._lib.kct_rccl_merge_across_ranks(self._h, table._h, C.byref(got)) != 0:
+            raise RuntimeError("kct_rccl_merge_across_ranks: " + self.last_error())
+        return got.value
+
+    def stats(self):
+        import ctypes as C
+        a, b, w = C.c_uint64(), C.c_uint64(), C.c_double()
+        self._lib.kct_rccl_stats(self._h, C.byref(a), C.byref(b), C.byref(w))
+        return {"bytes_sent": a.value, "bytes_received": b.value, "wait_seconds": w.value}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.kct_rccl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def merge_across_ranks(table, group=None, native=None):
     """Turns per-rank tables into the owner-partitioned global table, in place.
 
     After the call ``table`` on rank r holds every key of hash-slice r with its global count;
@@ -150,6 +209,8 @@ def merge_across_ranks(table, group=None):
 
     import numpy as np
 
+    if native is not None and not getattr(table, "store_kmers", False):   # the whole exchange inside libkct_rccl.so (``NativeRccl``)
+        return native.merge_across_ranks(table)
     world = dist.get_world_size(group)
     if world == 1:
         return 0
@@ -204,6 +265,10 @@ class _Exchanger:
         self.world = dist.get_world_size(group)
         self.host = dist.get_backend(group) != "nccl"
         self.keep = {}       # device address -> tensor
+        self._size_bufs = {}
+        self.host_s = 0.0    # seconds inside the callbacks OUTSIDE the collectives and staging copies (marshalling, bookkeeping)
+        self.coll_s = 0.0    # seconds inside the collectives themselves (and, host-staged, their copies)
+        self.calls = 0
         self.work = None
         self.pending = None  # (received host tensor, destination) of a host-staged exchange
         self.error = None
@@ -231,15 +296,37 @@ class _Exchanger:
 
     def sizes(self, _user, send, nvals, recv):
         def go():
+            import time
+
+            import numpy as np
+            t0 = time.perf_counter()
             n = self.world * int(nvals)
-            src = torch.from_numpy(_as_i64([int(send[i]) for i in range(n)]))   # (uint64 values travel as int64 bit patterns)
-            if not self.host:
-                src = src.to(self.dev)
-            out = torch.empty_like(src)
-            dist.all_to_all_single(out, src, group=self.group)
-            vals = out.cpu().numpy().view("uint64")
-            for i in range(n):
-                recv[i] = int(vals[i])
+            # (uint64 values travel as int64 bit patterns; the library's arrays are viewed in place, no per-element marshalling)
+            src_np = np.ctypeslib.as_array(send, shape=(n,)).view(np.int64)
+            key = (n, self.host)
+            if key not in self._size_bufs:   # staging tensors kept across passes
+                dev = "cpu" if self.host else self.dev
+                self._size_bufs[key] = (torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.int64, device=dev),
+                                        torch.empty(n, dtype=torch.int64, pin_memory=True) if not self.host else None)
+            src, out, pinned = self._size_bufs[key]
+            if self.host:
+                src.copy_(torch.from_numpy(src_np))
+                t1 = time.perf_counter()
+                dist.all_to_all_single(out, src, group=self.group)
+                t2 = time.perf_counter()
+                vals = out.numpy()
+            else:
+                pinned.copy_(torch.from_numpy(src_np))
+                t1 = time.perf_counter()
+                src.copy_(pinned, non_blocking=True)
+                dist.all_to_all_single(out, src, group=self.group)
+                pinned.copy_(out)          # (synchronises with the collective on the current stream)
+                t2 = time.perf_counter()
+                vals = pinned.numpy()
+            np.ctypeslib.as_array(recv, shape=(n,)).view(np.int64)[:] = vals
+            self.coll_s += t2 - t1
+            self.host_s += (t1 - t0) + (time.perf_counter() - t2)
+            self.calls += 1
             return 0
         return self._guard(go, 1)
 
@@ -251,11 +338,17 @@ class _Exchanger:
 
     def start(self, _user, d_send, send_off, send_bytes, d_recv, recv_off, recv_bytes):
         def go():
+            import time
+
+            import numpy as np
+            t0 = time.perf_counter()
             w = self.world
-            sb, rb = [int(send_bytes[i]) for i in range(w)], [int(recv_bytes[i]) for i in range(w)]
-            assert all(int(send_off[i]) == sum(sb[:i]) for i in range(w)) and all(int(recv_off[i]) == sum(rb[:i]) for i in range(w))
+            arr = lambda p_: np.ctypeslib.as_array(p_, shape=(w,))  # noqa: E731
+            sb, rb = arr(send_bytes).tolist(), arr(recv_bytes).tolist()
+            assert arr(send_off).tolist() == np.concatenate([[0], np.cumsum(sb)[:-1]]).tolist() and arr(recv_off).tolist() == np.concatenate([[0], np.cumsum(rb)[:-1]]).tolist()
             src = self._view(int(d_send or 0), sum(sb)) if sum(sb) else torch.empty(0, dtype=torch.uint8, device=self.dev)
             dst = self._view(int(d_recv or 0), sum(rb)) if sum(rb) else torch.empty(0, dtype=torch.uint8, device=self.dev)
+            t1 = time.perf_counter()
             if self.host:
                 got = torch.empty(sum(rb), dtype=torch.uint8)
                 dist.all_to_all_single(got, src.cpu(), output_split_sizes=rb, input_split_sizes=sb, group=self.group)
@@ -263,6 +356,9 @@ class _Exchanger:
                 torch.cuda.synchronize()
             else:
                 self.work = dist.all_to_all_single(dst, src, output_split_sizes=rb, input_split_sizes=sb, group=self.group, async_op=True)
+            t2 = time.perf_counter()
+            self.coll_s += t2 - t1
+            self.host_s += t1 - t0
             return 0
         return self._guard(go, 1)
 
@@ -281,7 +377,7 @@ def _as_i64(values):
     return np.array(values, dtype=np.uint64).view(np.int64)
 
 
-def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, max_windows=0, exchange_when_alone=False):
+def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, max_windows=0, exchange_when_alone=False, native=None):
     """Counts this rank's device-resident record stream by the EARLY route (``kct_consume_device_routed``): every k-mer is counted by
     the rank that owns it -- owner = hash(minimiser) -- and what travels is super-k-mers: runs of consecutive windows with one owner as
     2-bit bases + a start bit per window.  Every rank must call it.  The owner side is the table's ordinary bulk path (``set_path``
@@ -292,19 +388,30 @@ def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, ma
     Afterwards the ranks' tables are a disjoint partition of the key space: ``global_scalar_sum`` of ``len`` / ``sum_counts`` gives the
     global table's, and no ``merge_across_ranks`` is needed.  A failure on any rank raises on every rank.
     ``exchange_when_alone``: a group of ONE rank goes through the collectives too (everything is sent to itself) -- how the test suite
-    runs the RCCL branch of the exchange on a one-GPU box."""
+    runs the RCCL branch of the exchange on a one-GPU box.  ``native``: a ``NativeRccl`` -- the exchange is then libkct_rccl.so's
+    (ncclSend / ncclRecv groups on its own stream, sizes marshalled in C), not ``torch.distributed``'s."""
     import ctypes as C
 
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     if getattr(table, "store_kmers", False):
         raise ValueError("the early route moves packed bases only: a store_kmers table would lose its hash -> k-mer map")
+    n, stats = C.c_uint64(), (C.c_uint64 * 16)()
+    if native is not None:
+        st = table._lib.kct_consume_device_routed(table._h, C.c_void_p(int(data_ptr)), int(nbytes), int(consumed_bytes), native.world, native.rank,
+                                                  native.ops if native.world > 1 or exchange_when_alone else None, int(max_windows), C.byref(n), stats)
+        table._check(st)
+        return n.value, dict(zip(ROUTE_STATS, (int(v) for v in stats)))
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     dev = torch.device("cuda", torch.cuda.current_device())
     ex = _Exchanger(group, dev) if world > 1 or exchange_when_alone else None
-    n, stats = C.c_uint64(), (C.c_uint64 * 16)()
     st = table._lib.kct_consume_device_routed(table._h, C.c_void_p(int(data_ptr)), int(nbytes), int(consumed_bytes), world, rank,
                                               ex.ptr if ex else None, int(max_windows), C.byref(n), stats)
     if ex is not None and ex.error is not None:
         raise ex.error
     table._check(st)
-    return n.value, dict(zip(ROUTE_STATS, (int(v) for v in stats)))
+    out = dict(zip(ROUTE_STATS, (int(v) for v in stats)))
+    if ex is not None:   # the Python glue's own cost: per size exchange, outside the collectives
+        out["glue_host_us_per_exchange"] = round(ex.host_s * 1e6 / max(1, ex.calls), 1)
+        out["glue_collective_us"] = round(ex.coll_s * 1e6, 1)
+        out["glue_size_exchanges"] = ex.calls
+    return n.value, out

@@ -1,6 +1,7 @@
 /* A plain-C caller of the early multi-GPU route with the RCCL exchange (include/kct_rccl.h), world = 1: the communicator, the size
  * all-to-all, the asynchronous payload all-to-all (ncclSend / ncclRecv to itself on the helper's stream) and the owner-side count all
- * run as they do on N GPUs -- only the peers are missing.  Prints the digests of the routed table and of a table that counted the same
+ * run as they do on N GPUs -- only the peers are missing; then the LATE route's kct_rccl_merge_across_ranks on the directly counted
+ * table.  Prints the digests of the routed table and of a table that counted the same
  * reads directly; tests/test_gpu_api.py compares them (and both with the CPU oracle's).
  *
  *   c_rccl_example <k> <reads> <read length> <genome> <passes>
@@ -57,6 +58,21 @@ int main(int argc, char **argv) {
     kct_rccl_stats(x, &sent, &received, &wait_s);
     printf("passes %llu runs %llu counts %llu sent_to_others %llu\n", (unsigned long long)stats[5], (unsigned long long)stats[4], (unsigned long long)stats[11],
            (unsigned long long)sent);
+    /* the LATE route's collective (kct_rccl_merge_across_ranks) on the directly counted table: with one rank every pair is sent to
+     * itself through the size rounds and the ncclSend / ncclRecv group, the table is cleared, resized and refilled -- same digests */
+    uint64_t got = 0, len_before = 0, consumed_before = 0, consumed_after = 0;
+    CHECK(kct_len(plain, &len_before));
+    CHECK(kct_count_hash(plain, 0, &got));            /* key 0 lives beside the device table and rides on the size round */
+    CHECK(kct_consumed(plain, &consumed_before));
+    kct_rccl_merge_when_alone(x, 1);
+    CHECK(kct_rccl_merge_across_ranks(x, plain, &got));
+    CHECK(kct_consumed(plain, &consumed_after));
+    uint64_t zero_count = 0;
+    CHECK(kct_get_hash(plain, 0, &zero_count));
+    printf("merge pairs_received %llu len_before %llu zero %llu consumed_kept %d\n", (unsigned long long)got, (unsigned long long)len_before,
+           (unsigned long long)zero_count, consumed_before == consumed_after);
+    CHECK(kct_remove_hash(plain, 0, &got));
+    if (report("merged", plain, n)) return 1;
     kct_destroy(routed);
     kct_destroy(plain);
     kct_rccl_destroy(x);

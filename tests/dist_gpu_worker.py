@@ -103,7 +103,27 @@ def rccl_alone(k, per_rank, G, L):
     got, zero = exchange_pairs(pairs, torch.tensor([pairs.shape[0]], dtype=torch.int64), zero_count=7)
     torch.cuda.synchronize()
     assert zero == 7 and got.device.type == "cuda" and torch.equal(got, pairs)
-    print(f"DIST_GPU_OK world=1 distinct={rk.size} route=rccl-alone passes={st['passes']}")
+    # libkct_rccl.so IN THIS PROCESS, beside PyTorch (it binds to PyTorch's own librccl.so.1: one copy of RCCL): its own communicator
+    # bootstrapped over the torch group, the early route through its kct_exchange_ops and the late route's kct_rccl_merge_across_ranks
+    from oxli_amd.distributed import NativeRccl, merge_across_ranks
+    rccl_maps = [ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln]
+    nat = NativeRccl()
+    assert len({os.path.realpath(p_) for p_ in rccl_maps + [ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln]}) == 1, "two copies of RCCL in one process"
+    t2 = KmerCountTable(k, capacity=G)
+    n2, st2 = consume_device_early(t2, dev_reads.data_ptr(), dev_reads.numel(), per_rank * L, max_windows=1 << 22, exchange_when_alone=True, native=nat)
+    assert n2 == n and st2["passes"] == st["passes"] and st2["runs"] == st["runs"], (st, st2)
+    k2, c2 = t2.dump_arrays(1)
+    assert np.array_equal(k2, rk) and np.array_equal(c2, rc)
+    t2.count_hash(0); t2.count_hash(0)            # key 0 lives beside the device table and must survive the merge
+    nat.merge_when_alone(True)
+    cap_before, consumed_before = t2.capacity, t2.consumed
+    assert merge_across_ranks(t2, native=nat) == rk.size
+    assert t2.get_hash(0) == 2 and t2.consumed == consumed_before and t2.capacity <= cap_before
+    t2.drop_hash(0)
+    k3, c3 = t2.dump_arrays(1)
+    assert np.array_equal(k3, rk) and np.array_equal(c3, rc)
+    nat.close()
+    print(f"DIST_GPU_OK world=1 distinct={rk.size} route=rccl-alone passes={st['passes']} native=ok")
     dist.destroy_process_group()
 
 

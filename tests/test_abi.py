@@ -54,13 +54,15 @@ def test_rccl_exchange_library_exports_its_header(lib, tmp_path):
     import ctypes
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "kct_rccl.h")).read(), flags=re.S)
     declared = set(re.findall(r"\b(kct_rccl_[a-z_0-9]+)\s*\(", text))
-    assert {"kct_rccl_unique_id", "kct_rccl_create", "kct_rccl_ops", "kct_rccl_destroy"} <= declared
+    assert {"kct_rccl_unique_id", "kct_rccl_create", "kct_rccl_ops", "kct_rccl_destroy", "kct_rccl_merge_across_ranks"} <= declared
     path = os.path.join(ROOT, "oxli_amd", "csrc", "libkct_rccl.so")
     out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l} - {"_init", "_fini"}
     assert exported == declared
     handle = ctypes.CDLL(path)
     assert all(hasattr(handle, n) for n in declared)
+    from oxli_amd import _lib as L_
+    assert set(L_.RCCL_SIGNATURES) == declared      # the ctypes table mirrors the header
     needed = subprocess.run(["readelf", "-d", lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
     assert "rccl" not in needed.lower()
     src = tmp_path / "t.c"

@@ -331,9 +331,13 @@ def test_c_program_routes_through_rccl_with_a_world_of_one(tmp_path, k, R, L, G,
                     f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
     run = subprocess.run([str(exe), str(k), str(R), str(L), str(G), str(passes)], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout + run.stderr
-    out = [ln for ln in run.stdout.splitlines() if ln.startswith(("plain ", "routed ", "passes "))]   # (RCCL prints a banner of its own)
-    plain, routed, tail = out[0].split(), out[1].split(), out[2].split()
+    out = [ln for ln in run.stdout.splitlines() if ln.startswith(("plain ", "routed ", "passes ", "merge ", "merged "))]   # (RCCL prints a banner of its own)
+    plain, routed, tail, merge, merged = (ln.split() for ln in out)
     assert plain[0] == "plain" and routed[0] == "routed" and plain[1:] == routed[1:]
+    # the late route's collective (kct_rccl_merge_across_ranks) through the same communicator: every pair sent (to itself), key 0's count
+    # delivered to its owner, consumed kept, the refilled table's digests unchanged
+    assert merged[0] == "merged" and merged[1:] == plain[1:]
+    assert merge[2] == merge[4] == plain[4] and merge[6] == "1" and merge[8] == "1"
     ss = oracle.ShardSet(k, L, genome=oracle.synth_genome(G, 42), nreads=R, seed_r=1337, threads=8)
     d = ss.digest()
     assert [int(v) for v in routed[2::2][:3]] == [d["n"], d["len"], d["sum_counts"]]

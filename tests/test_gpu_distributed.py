@@ -69,4 +69,4 @@ def test_one_rank_through_a_real_rccl_communicator():
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "21", "200000", "2000000", "rccl-alone"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-6000:]
-    assert "DIST_GPU_OK world=1" in out.stdout and "route=rccl-alone" in out.stdout, out.stdout[-2000:]
+    assert "DIST_GPU_OK world=1" in out.stdout and "route=rccl-alone" in out.stdout and "native=ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
