@@ -149,6 +149,11 @@ KCT_API kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t
  * sequence bytes read (`consumed` grows by *n_bases).  Out-parameters other than n_total may be NULL. */
 KCT_API kct_status kct_consume_file(kct_table *t, const char *path, int skip_bad, uint64_t *n_total, uint64_t *n_records,
                             uint64_t *n_bases);
+/* Which inflater kct_consume_file uses for gzip / BGZF input in this process: "libdeflate" (the system's libdeflate.so.0, found at
+ * run time: whole-buffer inflate at 2-3x zlib's rate, several threads for BGZF blocks) or "zlib" (the fallback linked into the
+ * library: one streaming inflater thread for a plain gzip file -- a single deflate stream cannot be inflated in parallel).  What
+ * bench.py records beside its file-input entries. */
+KCT_API const char *kct_inflater_name(void);
 
 /* ---- table attributes ---------------------------------------------------------------------
  * __len__ lib.rs:665-667; sum_counts lib.rs:536-539; consumed lib.rs:530-533; ksize lib.rs:34 */

@@ -51,6 +51,7 @@ SIGNATURES = {
     "kct_superkmer_split_device": (ci, [vp, vp, sz, C.c_uint32, C.POINTER(vp), u64p, u64p, u64p]),
     "kct_superkmer_streams": (C.c_uint32, [vp]),
     "kct_consume_file": (ci, [vp, cp, ci, u64p, u64p, u64p]),
+    "kct_inflater_name": (cp, []),
     "kct_len": (ci, [vp, u64p]),
     "kct_sum_counts": (ci, [vp, u64p]),
     "kct_consumed": (ci, [vp, u64p]),

@@ -394,6 +394,7 @@ struct Deflate {
     bool ok() const { return alloc != nullptr; }
 };
 const Deflate &deflate_lib() { static Deflate d; return d; }
+bool libdeflate_disabled() { return getenv("KCT_NO_LIBDEFLATE") != nullptr; }   // (the switch: tests and bench run zlib's inflate too)
 
 struct Mapping {
     const unsigned char *p = nullptr;
@@ -402,6 +403,8 @@ struct Mapping {
 };
 
 }  // namespace
+
+extern "C" const char *kct_inflater_name(void) { return deflate_lib().ok() && !libdeflate_disabled() ? "libdeflate" : "zlib"; }
 
 extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_bad, uint64_t *n_total, uint64_t *n_records,
                                        uint64_t *n_bases) {
