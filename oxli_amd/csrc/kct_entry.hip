@@ -37,6 +37,8 @@ kct_status unpack_stream(kct_table *t, const unsigned int *d_codes, const unsign
 
 // ---- host packer: ASCII -> 2-bit codes + validity bits (the host twin of kmer_device.h encode16) -----------------------
 #include <tmmintrin.h>
+#include <immintrin.h>
+// [host-packer-begin]  (tests/test_host_packer.py compiles this block alone and checks the SIMD encoders against the scalar one)
 static inline void encode16_scalar(const unsigned char *p, unsigned int *codes, unsigned short *valid) {
     unsigned int c = 0, v = 0;
     for (int i = 0; i < 16; ++i) {
@@ -62,11 +64,42 @@ __attribute__((target("ssse3"))) static inline void encode16_ssse3(const unsigne
     *codes = (unsigned int)_mm_cvtsi128_si32(sh);                         // bases 0-3 in the top byte
     *valid = (unsigned short)(__builtin_bitreverse16((unsigned short)_mm_movemask_epi8(ok)));
 }
+// whole runs of groups, the loop INSIDE the function that carries the target attribute (a target("...") function is not inlined into a
+// caller without it: one call per 16 bases otherwise)
+__attribute__((target("ssse3"))) static void encode_run_ssse3(const unsigned char *p, size_t ngroups, unsigned int *codes, unsigned short *valid) {
+    for (size_t g = 0; g < ngroups; ++g) encode16_ssse3(p + 16 * g, codes + g, valid + g);
+}
+// 32 bases per step: the same arithmetic on two 128-bit lanes
+__attribute__((target("avx2"))) static void encode_run_avx2(const unsigned char *p, size_t ngroups, unsigned int *codes, unsigned short *valid) {
+    const __m256i lower = _mm256_set1_epi8(0x20), ca = _mm256_set1_epi8('a'), cc = _mm256_set1_epi8('c'), cg = _mm256_set1_epi8('g'), ct = _mm256_set1_epi8('t');
+    const __m256i three = _mm256_set1_epi8(3), one = _mm256_set1_epi8(1), m2 = _mm256_set1_epi16(0x0104), m4 = _mm256_set1_epi32(0x00010010);
+    const __m256i pick = _mm256_set_epi8(-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12);
+    size_t g = 0;
+    for (; g + 2 <= ngroups; g += 2) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)(p + 16 * g)), up = _mm256_or_si256(v, lower);
+        const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(up, ca), _mm256_cmpeq_epi8(up, cc)), _mm256_or_si256(_mm256_cmpeq_epi8(up, cg), _mm256_cmpeq_epi8(up, ct)));
+        __m256i x = _mm256_and_si256(_mm256_srli_epi16(v, 1), three);
+        x = _mm256_xor_si256(x, _mm256_and_si256(_mm256_srli_epi16(x, 1), one));
+        x = _mm256_and_si256(x, ok);
+        const __m256i sh = _mm256_shuffle_epi8(_mm256_madd_epi16(_mm256_maddubs_epi16(x, m2), m4), pick);
+        codes[g] = (unsigned int)_mm256_extract_epi32(sh, 0);
+        codes[g + 1] = (unsigned int)_mm256_extract_epi32(sh, 4);
+        // (one 32-bit reversal: the first group's sixteen bits come out in the upper half.  Two __builtin_bitreverse16 of the halves
+        // were miscompiled by this clang at -O2 -- the halves came out swapped; enc unit test in tests/test_host_packer.py)
+        const unsigned int rv = __builtin_bitreverse32((unsigned int)_mm256_movemask_epi8(ok));
+        valid[g] = (unsigned short)(rv >> 16);
+        valid[g + 1] = (unsigned short)rv;
+    }
+    for (; g < ngroups; ++g) encode16_scalar(p + 16 * g, codes + g, valid + g);
+}
 static void encode_groups(const unsigned char *p, size_t ngroups, unsigned int *codes, unsigned short *valid) {
-    static const bool ssse3 = __builtin_cpu_supports("ssse3");
-    if (ssse3) for (size_t g = 0; g < ngroups; ++g) encode16_ssse3(p + 16 * g, codes + g, valid + g);
+    static const int level = __builtin_cpu_supports("avx2") ? 2 : __builtin_cpu_supports("ssse3") ? 1 : 0;
+    if (level == 2) encode_run_avx2(p, ngroups, codes, valid);
+    else if (level == 1) encode_run_ssse3(p, ngroups, codes, valid);
     else for (size_t g = 0; g < ngroups; ++g) encode16_scalar(p + 16 * g, codes + g, valid + g);
 }
+
+// [host-packer-end]
 
 // host bytes -> pinned staging -> device stream buffer (padded with '\n' to a multiple of 16)
 kct_status upload_stream(kct_table *t, size_t nbytes) {
@@ -336,34 +369,31 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
         std::atomic<size_t> next_item{0};
         WorkerPool &pool = WorkerPool::instance();
         pool.start(nthreads, [&](size_t) {
-            constexpr size_t kBuf = 4096;
-            unsigned char buf[kBuf + 16];
+            // A record's groups are encoded STRAIGHT from the caller's memory wherever sixteen stream bytes lie inside one record (nine of
+            // ten groups of a 150 bp read); only the group across a record boundary -- the record's tail, its separator, the next record's
+            // head -- is assembled in a 16-byte carry.  (Until round 5 every byte went through a 4 KiB line buffer first: a second pass over
+            // the data, and one call per group into the SIMD encoder.)
+            unsigned char carry[16];
             for (;;) {
                 const size_t it = next_item.fetch_add(1, std::memory_order_relaxed);
                 if (it >= nitems) break;
                 size_t g = pos[it] >> 4, fill = 0;
-                auto drain = [&](bool all) {  // encode the buffer's whole groups (all: pad the rest with separators first)
-                    if (all) while (fill & 15) buf[fill++] = '\n';
-                    const size_t n = fill >> 4;
-                    encode_groups(buf, n, h_codes + g, h_valid + g);
-                    g += n;
-                    const size_t rest = fill - 16 * n;
-                    if (rest) memmove(buf, buf + 16 * n, rest);
-                    fill = rest;
-                };
                 for (size_t r = cut[it]; r < cut[it + 1]; ++r) {
                     const unsigned char *src = (const unsigned char *)bytes + offsets[r];
                     size_t n = (size_t)(offsets[r + 1] - offsets[r]);
-                    while (n) {
-                        const size_t take = std::min(n, kBuf - fill);
-                        memcpy(buf + fill, src, take);
+                    if (fill) {   // finish the group the previous record (and its separator) began
+                        const size_t take = std::min(n, 16 - fill);
+                        memcpy(carry + fill, src, take);
                         fill += take; src += take; n -= take;
-                        if (fill == kBuf) drain(false);
+                        if (fill == 16) { encode_groups(carry, 1, h_codes + g, h_valid + g); ++g; fill = 0; }
                     }
-                    buf[fill++] = '\n';
-                    if (fill == kBuf) drain(false);
+                    const size_t whole = n >> 4;
+                    if (whole) { encode_groups(src, whole, h_codes + g, h_valid + g); g += whole; src += 16 * whole; n -= 16 * whole; }
+                    if (n) { memcpy(carry + fill, src, n); fill += n; }   // (fill is 0 here unless the record ended inside the carried group)
+                    carry[fill++] = '\n';
+                    if (fill == 16) { encode_groups(carry, 1, h_codes + g, h_valid + g); ++g; fill = 0; }
                 }
-                drain(true);
+                if (fill) { while (fill < 16) carry[fill++] = '\n'; encode_groups(carry, 1, h_codes + g, h_valid + g); ++g; }
                 for (; g < (pos[it + 1] >> 4); ++g) { h_codes[g] = 0; h_valid[g] = 0; }  // (never: a part's groups are exactly its bytes, padded)
                 packed[it / parts].fetch_add(1, std::memory_order_release);
             }
