@@ -247,7 +247,8 @@ def compact(res):
             g = c.get("gate", {})
             e = {"kmers_per_s": r(c["kmers_per_s"], 0), "seconds": r(c["seconds"], 5),
                  "gate": "ok" if all(v for kk, v in g.items() if kk != "sampled_keys") else [kk for kk, v in g.items() if not v]}
-            for k in ("alg_frac", "measured_frac", "hbm_bytes_per_kmer", "kmers_per_s_warm", "us_per_call", "us_per_call_loop_only", "vs_partitioned"):
+            for k in ("alg_frac", "measured_frac", "hbm_bytes_per_kmer", "kmers_per_s_warm", "us_per_call", "us_per_call_loop_only", "vs_partitioned",
+                      "K1_ms_per_step", "ascii_same_timing_K1_ms_per_step", "vs_ascii_same_timing"):
                 if k in c:
                     e[k] = r(c[k], 0 if k == "kmers_per_s_warm" else 4)
             if "feeds" in c:
@@ -604,13 +605,25 @@ def main():
                 for _s in range(args.steps):
                     n_ += table.consume_device_packed(pc.data_ptr(), pv.data_ptr(), reads0.numel(), R * L)
                 return n_
+            def ascii_job():   # the SAME batch as ASCII bytes under the SAME timing (events on, one batch repeated): the like-for-like comparison
+                n_ = 0
+                for _s in range(args.steps):
+                    n_ += table.consume_device(reads0.data_ptr(), reads0.numel(), R * L)
+                return n_
             timed_call(table, packed_job, False)
             runs = [timed_call(table, packed_job, False) for _ in range(9)]
             dt, n, prof = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
             ok = all(r[1] == kmers_per_step * args.steps for r in runs) and table.sum_counts == kmers_per_step * args.steps
             rep, _ = kernel_report(prof, kmers_per_step * args.steps, b_alg, None)
+            timed_call(table, ascii_job, False)
+            aruns = [timed_call(table, ascii_job, False) for _ in range(9)]
+            adt, _an, aprof = sorted(aruns, key=lambda r: r[0])[len(aruns) // 2]
+            k1_of = lambda pr: sum(v[1] for kn, v in pr.items() if kn.startswith("partition_windows_kernel")) / args.steps  # noqa: E731
             configs["packed_C2"] = {"kmers_per_s": kmers_per_step * args.steps / dt, "seconds": dt, "runs": len(runs), "steps": args.steps,
-                                    "what": "the headline's steps with the batch resident as packed base arrays (0.375 B per base), event timing on",
+                                    "what": "the headline's steps with the batch resident as packed base arrays (0.375 B per base), event timing on; "
+                                            "ascii_same_timing = the same batch as ASCII bytes through the same loop under the same timing",
+                                    "K1_ms_per_step": round(k1_of(prof), 4), "ascii_same_timing_kmers_per_s": kmers_per_step * args.steps / adt,
+                                    "ascii_same_timing_K1_ms_per_step": round(k1_of(aprof), 4), "vs_ascii_same_timing": adt / dt,
                                     "gate": {"n_and_sum_counts": bool(ok)}, **rep}
             assert ablate or ok
             del pc, pv

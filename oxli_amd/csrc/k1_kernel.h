@@ -92,10 +92,15 @@ __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *f
 // every eight windows instead of four); a value whose low half is 0 -- the hole marker -- takes the overflow route.
 // RUNS: the input is a stream of super-k-mers (PartitionArgs::runs, the multi-GPU early route's wire format) -- the tile walk is
 // replaced by walk_windows_runs, everything behind the sink is the same.
-template <int KW, int KC, int MODE = 0, bool RUNS = false>
+// PACKED: the input is packed base arrays (PartitionArgs::pcodes / pvalid, 16-byte aligned) and the tile's words are fetched SIXTEEN BYTES per
+// lane -- 256 lanes take four code words each, 128 lanes eight validity halves, six more the halo -- straight into the places of tcodes /
+// tvalid they land in anyway: one wide load per lane of six waves instead of a 4-byte and a 2-byte load per lane of all sixteen.  (An
+// instantiation without PACKED still reads packed arrays when pcodes is set, with the two narrow loads: k without a PACKED instantiation.)
+template <int KW, int KC, int MODE = 0, bool RUNS = false, bool PACKED = false>
 __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
                                                                          u64 ntiles, PartitionArgs a) {
     static_assert(!RUNS || KW != 0, "super-k-mer input needs k <= 64");
+    static_assert(!PACKED || (KW != 0 && !RUNS), "packed base arrays: k <= 64, not super-k-mers");
     // MODE 3 (33 <= k <= 64, dedupe-first): mix128 values of the two packed words as 16-byte {x, y} entries: bins and slots come from x.
     using T = typename std::conditional<MODE == 2, u32, typename std::conditional<MODE == 3, ulonglong2, u64>::type>::type;
     using PH = typename std::conditional<MODE == 3, u64, T>::type;  // the pending append's (first) word
@@ -111,8 +116,8 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     constexpr int kTileBytes = KW == 0 ? kPartTile + kHaloMax + 16 : 16;
     constexpr int kTileWords = (KW == 0 || RUNS) ? 4 : kPartThreads + 16;
     __shared__ __attribute__((aligned(16))) unsigned char lds[kTileBytes];
-    __shared__ u32 tcodes[kTileWords];
-    __shared__ unsigned short tvalid[kTileWords];
+    __shared__ __attribute__((aligned(16))) u32 tcodes[kTileWords];
+    __shared__ __attribute__((aligned(16))) unsigned short tvalid[kTileWords];
     __shared__ __attribute__((aligned(16))) RunGroup tdesc[RUNS ? 2 * (kPartTile / 64) : 1];  // RUNS: the group descriptors of this tile and the next (two buffers, taking turns)
     __shared__ u32 ascii4[(KW == 0 || MODE != 0) ? 1 : 256];  // four packed bases -> four ASCII bytes (only the hashing mode needs it)
     if constexpr (KW != 0 && MODE == 0) fill_ascii4_lut(ascii4, threadIdx.x, kPartThreads);
@@ -187,6 +192,35 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         return v;
     };
     auto load_any = [&](u64 tile_base, int c) -> uint4 { return packed ? load_group(tile_base, c) : load_chunk(tile_base, c); };
+    // PACKED: this lane's 16-byte piece of a tile's packed words (zeros where the stream has ended; lanes without a piece: zeros).  The
+    // piece's place: code words [4 t, 4 t + 4) for t < 256, validity halves [8 (t - 256), + 8) for t < 384, then the halo's sixteen groups
+    // (t = 384..387: code words, 388..389: halves).
+    const u64 pk_ng = (nbytes + 15) >> 4;   // groups this launch's arrays hold
+    auto load_piece = [&](u64 tile_base) -> uint4 {
+        const u32 t = threadIdx.x;
+        const u64 g0 = tile_base >> 4;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t < 256u || (t >= 384u && t < 388u)) {
+            const u64 g = g0 + (t < 256u ? 4u * t : 1024u + 4u * (t - 384u));
+            if (g + 4 <= pk_ng) v = *reinterpret_cast<const uint4 *>(a.pcodes + g);
+            else if (g < pk_ng) { v.x = a.pcodes[g]; if (g + 1 < pk_ng) v.y = a.pcodes[g + 1]; if (g + 2 < pk_ng) v.z = a.pcodes[g + 2]; }
+        } else if (t < 390u) {
+            const u64 g = g0 + (t < 384u ? 8u * (t - 256u) : 1024u + 8u * (t - 388u));
+            if (g + 8 <= pk_ng) v = *reinterpret_cast<const uint4 *>(a.pvalid + g);
+            else if (g < pk_ng) {
+                u32 w[4] = {0, 0, 0, 0};
+                for (int j = 0; j < 8; ++j) if (g + j < pk_ng) w[j >> 1] |= (u32)a.pvalid[g + j] << (16 * (j & 1));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            // the stream's last group is cut to nbytes (bases at or beyond it do not exist)
+            if ((nbytes & 15) && g < pk_ng && g + 8 >= pk_ng) {
+                const u32 j = (u32)(pk_ng - 1 - g), m = ~((1u << (16 - (u32)(nbytes & 15))) - 1u) & 0xFFFFu;
+                const u32 keep = (j & 1) ? ((m << 16) | 0xFFFFu) : (0xFFFF0000u | m);
+                if ((j >> 1) == 0) v.x &= keep; else if ((j >> 1) == 1) v.y &= keep; else if ((j >> 1) == 2) v.z &= keep; else v.w &= keep;
+            }
+        }
+        return v;
+    };
     // super-k-mer input: what is staged per tile is its 256 group descriptors (16 bytes each, one per thread of the first four waves)
     const u64 ngroups = RUNS ? (nbytes - (u64)k + 1 + 63) >> 6 : 0;
     auto load_desc = [&](u64 tile) -> uint4 {
@@ -201,7 +235,8 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     if (RUNS && blockIdx.x < ntiles) { pre_halo = load_desc(blockIdx.x); pre_main = load_desc((u64)blockIdx.x + gridDim.x); }
     RunsPipe<(KW > 0 ? KW : 1)> pipe;
     u32 iter = 0;
-    if (!RUNS && blockIdx.x < ntiles) {
+    if (PACKED && blockIdx.x < ntiles) pre_main = load_piece((u64)blockIdx.x * kPartTile);
+    if (!RUNS && !PACKED && blockIdx.x < ntiles) {
         pre_main = load_any((u64)blockIdx.x * kPartTile, threadIdx.x);
         if (threadIdx.x < 16) pre_halo = load_any((u64)blockIdx.x * kPartTile, kPartThreads + threadIdx.x);
     }
@@ -215,6 +250,12 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         } else if constexpr (KW == 0) {
             reinterpret_cast<uint4 *>(lds)[threadIdx.x] = pre_main;
             if (threadIdx.x < 16) reinterpret_cast<uint4 *>(lds)[kPartThreads + threadIdx.x] = pre_halo;
+        } else if constexpr (PACKED) {
+            const u32 t = threadIdx.x;
+            if (t < 256u) reinterpret_cast<uint4 *>(tcodes)[t] = pre_main;
+            else if (t < 384u) reinterpret_cast<uint4 *>(tvalid)[t - 256u] = pre_main;
+            else if (t < 388u) reinterpret_cast<uint4 *>(tcodes + kPartThreads)[t - 384u] = pre_main;
+            else if (t < 390u) reinterpret_cast<uint4 *>(tvalid + kPartThreads)[t - 388u] = pre_main;
         } else {
             u32 c, v;
             if (packed) { c = pre_main.x; v = pre_main.y; }
@@ -229,7 +270,8 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         __syncthreads();
         const u64 next = tile + gridDim.x;
         if (RUNS) pre_main = load_desc(next + gridDim.x);   // (zeros beyond the last tile)
-        if (!RUNS && next < ntiles) {
+        if (PACKED && next < ntiles) pre_main = load_piece(next * kPartTile);
+        if (!RUNS && !PACKED && next < ntiles) {
             pre_main = load_any(next * kPartTile, threadIdx.x);
             if (threadIdx.x < 16) pre_halo = load_any(next * kPartTile, kPartThreads + threadIdx.x);
         }

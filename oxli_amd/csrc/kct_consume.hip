@@ -70,17 +70,14 @@ template <>
 struct PartitionCompactByK<0> {
     static void run(int, hipStream_t, int, const unsigned char *, u64, u64, const kct::PartitionArgs &) {}
 };
-// the 128-bit dedupe-first variant (33 <= k <= 64): mix128 pairs, 16-byte entries
-template <int K>
-struct PartitionRaw128ByK {
+// the 128-bit dedupe-first variant (33 <= k <= 64): mix128 pairs, 16-byte entries.  Reachable only through kct_set_path(t, 3) since round 4
+// (1.0x over hashing on its showcase), so it no longer gets an instantiation per k (32 copies of K1, a quarter of this file's compile time):
+// k = 51 at compile time, every other k at run time.
+struct PartitionRaw128 {
     static void run(int k, hipStream_t s, int grid, const unsigned char *stream, u64 nbytes, u64 ntiles, const kct::PartitionArgs &a) {
-        if (k == K) hipLaunchKernelGGL((kct::partition_windows_kernel<2, K, 3>), dim3(grid), dim3(kct::kPartThreads), 0, s, stream, nbytes, k, ntiles, a);
-        else PartitionRaw128ByK<K - 1>::run(k, s, grid, stream, nbytes, ntiles, a);
+        if (k == 51) hipLaunchKernelGGL((kct::partition_windows_kernel<2, 51, 3>), dim3(grid), dim3(kct::kPartThreads), 0, s, stream, nbytes, k, ntiles, a);
+        else hipLaunchKernelGGL((kct::partition_windows_kernel<2, 0, 3>), dim3(grid), dim3(kct::kPartThreads), 0, s, stream, nbytes, k, ntiles, a);
     }
-};
-template <>
-struct PartitionRaw128ByK<32> {
-    static void run(int, hipStream_t, int, const unsigned char *, u64, u64, const kct::PartitionArgs &) {}
 };
 template <>
 struct PartitionByK<0> {
@@ -89,10 +86,38 @@ struct PartitionByK<0> {
     }
 };
 
+// K1 over PACKED base arrays, the popular k (and run-time k for the rest of k <= 32 / <= 64 where the mode allows): the instantiations that
+// fetch a tile's words sixteen bytes per lane (k1_kernel.h PACKED).  false: no such instantiation (or misaligned arrays) -- the ordinary
+// instantiation reads the arrays with its two narrow loads per lane.
+template <int KW, int KC, int MODE>
+static void k1_packed(kct_table *t, int nwg, u64 chunk_bytes, int k, u64 ntiles, const kct::PartitionArgs &pa) {
+    hipLaunchKernelGGL((kct::partition_windows_kernel<KW, KC, MODE, false, true>), dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, (const unsigned char *)nullptr, chunk_bytes, k, ntiles, pa);
+}
+static bool launch_partition_packed(kct_table *t, int mode, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa) {
+    const int k = t->k, nwg = t->num_cus;
+    if ((((uintptr_t)pa.pcodes | (uintptr_t)pa.pvalid) & 15) != 0 || k > 64) return false;
+    if (mode == 2) {
+        if (k == 21) k1_packed<1, 21, 2>(t, nwg, chunk_bytes, k, ntiles, pa);
+        else k1_packed<1, 0, 2>(t, nwg, chunk_bytes, k, ntiles, pa);
+    } else if (mode == 1) {
+        if (k == 21) k1_packed<1, 21, 1>(t, nwg, chunk_bytes, k, ntiles, pa);
+        else if (k == 31) k1_packed<1, 31, 1>(t, nwg, chunk_bytes, k, ntiles, pa);
+        else k1_packed<1, 0, 1>(t, nwg, chunk_bytes, k, ntiles, pa);
+    } else if (mode == 0) {
+        if (k == 21) k1_packed<1, 21, 0>(t, nwg, chunk_bytes, k, ntiles, pa);
+        else if (k == 31) k1_packed<1, 31, 0>(t, nwg, chunk_bytes, k, ntiles, pa);
+        else if (k == 51) k1_packed<2, 51, 0>(t, nwg, chunk_bytes, k, ntiles, pa);
+        else if (k <= 32) k1_packed<1, 0, 0>(t, nwg, chunk_bytes, k, ntiles, pa);
+        else k1_packed<2, 0, 0>(t, nwg, chunk_bytes, k, ntiles, pa);
+    } else return false;
+    return true;
+}
+
 void launch_partition(kct_table *t, int mode, const unsigned char *d_stream, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa) {
     const int k = t->k, nwg = t->num_cus;
     if (pa.runs.groups) { launch_partition_runs(t, mode, chunk_bytes, ntiles, pa); return; }  // received super-k-mers (kct_runs.hip)
     ProfScope ps(t, mode == 2 ? "partition_windows_kernel<compact>" : mode == 1 ? "partition_windows_kernel<raw>" : "partition_windows_kernel");
+    if (pa.pcodes && launch_partition_packed(t, mode, chunk_bytes, ntiles, pa)) return;
     if (mode == 2) PartitionCompactByK<21>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
     else if (mode == 1) PartitionRawByK<32>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
     else PartitionByK<64>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
@@ -705,7 +730,7 @@ kct_status consume_raw128(kct_table *t, const unsigned char *d_stream, u64 chunk
     packed_args(t, d_stream, &pa);
     {
         ProfScope ps(t, "partition_windows_kernel<raw128>");
-        PartitionRaw128ByK<64>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
+        PartitionRaw128::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
     }
     HIP_TRY(hipGetLastError());
     kct::Aggregate128Args aa;
