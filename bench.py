@@ -58,7 +58,7 @@ same weak-scaled C2 job per rank + the late merge, and
 `roofline`: bound "hbm"; `achieved` = ALGORITHMIC bytes per step (k-mers x (L/(L-k+1) + 24) B) / the summed
 device time of every kernel of the step (HIP events on the table's stream, in an instrumented repetition of the job;
 `value` is taken with the events off); `traffic` / `measured_frac` = PMC-measured HBM bytes per step (profiles/
-pmc_r04.json, only if it was collected from THIS source tree -- stamped with a hash of the kernel sources -- else null);
+pmc_r05.json, only if it was collected from THIS source tree -- stamped with a hash of the kernel sources -- else null);
 `valu` = the ceiling that actually binds K1 (VALU instructions per window and issue-slot use from the same PMC file).
 `cpu_baseline`: the CPU restatement of the reference path (oracle/, "port") on this host: 1 thread (the reference's
 consume is single-threaded under the GIL), reads sharded over threads with a tree merge (reference-shaped "rayon"), and
@@ -148,9 +148,9 @@ def source_sha():
 
 
 def pmc_summary():
-    """profiles/pmc_r04.json if it was collected from this source tree, else {} (every PMC-derived field becomes null)."""
+    """profiles/pmc_r05.json (tools/collect_r05.sh) if it was collected from this source tree, else {} (every PMC-derived field becomes null)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_r04.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_r05.json")) as f:
             d = json.load(f)
         return d if d.get("source_sha") == source_sha() else {}
     except (OSError, ValueError):
@@ -530,7 +530,7 @@ def main():
                     "measured_frac": (traffic_job / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_job and all_ms else None,
                     "basis": "achieved = algorithmic bytes per step (25.15 B/k-mer x k-mers) / summed device time of every kernel of the step (HIP "
                              "events, instrumented repetition); traffic = PMC HBM bytes per step and measured_frac = traffic / kernel time / peak, "
-                             "from profiles/pmc_r04.json when it matches this source tree (else null)",
+                             "from profiles/pmc_r05.json when it matches this source tree (else null)",
                     "alg_bytes_per_kmer": b_alg, "kmers_per_step": kmers_per_step, "kernels_total_ms_per_step": all_ms / args.steps,
                     "dominant_kernel_ms_per_step": ms / args.steps,
                     "frac_of_wall": kmers_per_step * b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,

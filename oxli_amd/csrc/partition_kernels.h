@@ -131,8 +131,29 @@ __global__ __launch_bounds__(kPartThreads) void repartition_kernel(RepartitionAr
             const u64 region = gbits ? ((u64)(seg >> gbits) * a.nbins + ((u64)s << gbits) + binlow) : ((u64)seg * a.nbins + s);
             const T *src = reinterpret_cast<const T *>(a.in) + (a.in_off ? a.in_off[(u64)s * a.nseg + seg] : region * a.in_cap) + off;
             const u32 left = cnt - off;
+            if constexpr (!kPair) {
+                // SIXTEEN bytes per lane and load (kVec entries: regions are whole 64-byte lines, so a piece is never cut): a slab is the
+                // same 64 bytes per lane in a quarter (u32) or half (u64) of the load instructions -- K1b is bound by the requests a CU keeps
+                // in flight, and a request of 1 KiB per wave carries what four of 256 bytes did.  (Which lane appends which entry is immaterial.)
+                constexpr int kVec = 16 / sizeof(T);
+                if (a.in_off == nullptr) {
 #pragma unroll
-            for (int j = 0; j < kLoads; ++j) { const u32 i = lane + 64 * j; if (i < left) v[j] = src[i]; }
+                    for (int p = 0; p < kLoads / kVec; ++p) {
+                        const u32 i = kVec * (lane + 64 * p);
+                        if (i < left) {
+                            const uint4 w = *reinterpret_cast<const uint4 *>(src + i);
+                            if constexpr (kCompact) { v[kVec * p] = w.x; v[kVec * p + 1] = w.y; v[kVec * p + 2] = w.z; v[kVec * p + 3] = w.w; }
+                            else { v[kVec * p] = ((u64)w.y << 32) | w.x; v[kVec * p + 1] = ((u64)w.w << 32) | w.z; }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kLoads; ++j) { const u32 i = lane + 64 * j; if (i < left) v[j] = src[i]; }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < kLoads; ++j) { const u32 i = lane + 64 * j; if (i < left) v[j] = src[i]; }
+            }
             off += kSlab;
         }
     };
@@ -218,8 +239,12 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
         if (seg >= a.nregions) return false;
         const u32 s0 = (g - sbase) * kSlab, left = cnt - s0;
         const u64 *src = a.scratch + (u64)seg * a.seg_stride + (u64)b * a.block_stride + s0;
+        // (sixteen bytes -- two entries -- per lane and load: regions are whole 64-byte lines)
 #pragma unroll
-        for (int j = 0; j < kInFlight; ++j) { const u32 i = lane + 64 * j; if (i < left) v[j] = src[i]; }
+        for (int p = 0; p < kInFlight / 2; ++p) {
+            const u32 i = 2 * (lane + 64 * p);
+            if (i < left) { const uint4 w = *reinterpret_cast<const uint4 *>(src + i); v[2 * p] = ((u64)w.y << 32) | w.x; v[2 * p + 1] = ((u64)w.w << 32) | w.z; }
+        }
         g += kWaves;
         return true;
     };
@@ -336,7 +361,12 @@ __global__ __launch_bounds__(kPartThreads) void aggregate_blocks_kernel(Aggregat
     auto do_slab = [&](const u64 *src, u32 left) {
         u64 v[kInFlight];
 #pragma unroll
-        for (int j = 0; j < kInFlight; ++j) { const u32 i = lane + 64 * j; v[j] = i < left ? src[i] : 0ULL; }
+        for (int p = 0; p < kInFlight / 2; ++p) {   // (sixteen bytes -- two entries -- per lane and load)
+            const u32 i = 2 * (lane + 64 * p);
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (i < left) w = *reinterpret_cast<const uint4 *>(src + i);
+            v[2 * p] = ((u64)w.y << 32) | w.x; v[2 * p + 1] = ((u64)w.w << 32) | w.z;
+        }
         if (a.ablate & 16) {
 #pragma unroll
             for (int j = 0; j < kInFlight; ++j) counted += (u32)v[j];

@@ -24,7 +24,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 on_box = "--on-box" in sys.argv
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
@@ -122,7 +122,7 @@ def main():
         json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
     except Exception as e:  # noqa: BLE001
         print("no bench.json:", e)
-    json.dump({"_how": "tools/collect_r04.sh + tools/summarize_prof.py; FETCH_SIZE/WRITE_SIZE in KiB, separate passes; x2 on streaming reads",
+    json.dump({"_how": f"tools/collect_{tag}.sh + tools/summarize_prof.py; FETCH_SIZE/WRITE_SIZE in KiB, separate passes; x2 on streaming reads",
                "source_sha": source_sha(), "workloads": full}, open(os.path.join(dst, f"{tag}_pmc_full.json"), "w"), indent=1)
     windows = {"C2": 1.3e8, "C2_hashing": 1.3e8, "cold_C2": 1.3e8}  # k-mers of a launch
     small = {"source_sha": source_sha(), "_how": f"profiles/{tag}_pmc_full.json condensed for bench.py"}
