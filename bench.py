@@ -402,8 +402,23 @@ def main():
     if world > 1 and args.exchange != "torch":
         can = args.backend == "nccl" and world <= torch.cuda.device_count()
         if can:
-            from oxli_amd.distributed import NativeRccl
-            native = NativeRccl()
+            # (never run on more than one GPU before the driver's own 8-GPU run: a failure to come up on ANY rank -- agreed with one
+            # all-reduce -- sends every rank back to torch.distributed instead of ending the job)
+            try:
+                from oxli_amd.distributed import NativeRccl
+                native = NativeRccl()
+                ok_native = 1
+            except Exception as e:  # noqa: BLE001
+                log(f"libkct_rccl.so did not come up on rank {rank}: {e}")
+                native, ok_native = None, 0
+            flag = torch.tensor([ok_native], dtype=torch.int64, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if not int(flag.item()):
+                if native is not None:
+                    native.close()
+                native = None
+                if args.exchange == "native":
+                    raise SystemExit("--exchange native: libkct_rccl.so's communicator did not come up on every rank")
         elif args.exchange == "native":
             raise SystemExit("--exchange native needs --backend nccl and one rank per GPU (RCCL refuses two ranks on one device)")
     exchanges = ([("native", native)] if native is not None else []) + ([("torch", None)] if native is None or args.exchange in ("both", "auto") else [])

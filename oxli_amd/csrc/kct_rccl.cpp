@@ -45,6 +45,8 @@ struct kct_rccl {
     uint64_t sent = 0, received = 0;
     double wait_s = 0;
     bool merge_when_alone = false;   // a world of one goes through the merge's collectives too (tests on a one-GPU box)
+    void *m_send = nullptr, *m_recv = nullptr;   // the late route's pair buffers, kept between merges (grow-only: no hipMalloc / hipFree per job)
+    uint64_t m_send_cap = 0, m_recv_cap = 0;
     kct_exchange_ops ops;
 };
 
@@ -61,6 +63,16 @@ void x_release(void *user, void *p) {
     kct_rccl *x = (kct_rccl *)user;
     (void)hipStreamSynchronize(x->stream);
     (void)hipFree(p);
+}
+
+// a grow-only device buffer of the communicator (the merge's pair buffers)
+void *x_keep(kct_rccl *x, void **p, uint64_t *cap, uint64_t bytes) {
+    if (bytes <= *cap) return *p;
+    if (*p) { (void)hipStreamSynchronize(x->stream); (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    const uint64_t want = bytes + bytes / 8;
+    if (hipSetDevice(x->device) != hipSuccess || hipMalloc(p, want) != hipSuccess) { set_err("hipMalloc of %llu bytes failed", (unsigned long long)want); *p = nullptr; return nullptr; }
+    *cap = want;
+    return *p;
 }
 
 int x_sizes(void *user, const uint64_t *send, uint32_t nvals, uint64_t *recv) {
@@ -166,24 +178,22 @@ int kct_rccl_merge_across_ranks(kct_rccl *x, kct_table *t, uint64_t *pairs_recei
     std::vector<uint64_t> part(world, 0), send((size_t)world * 3, 0), recv((size_t)world * 3, 0);
     void *d_send = nullptr, *d_recv = nullptr;
     if (!status && n) {
-        d_send = x_alloc(x, n * 16);
+        d_send = x_keep(x, &x->m_send, &x->m_send_cap, n * 16);
         if (!d_send) status = 1;
         else if (kct_export_by_owner_device(t, (uint32_t)world, d_send, n, part.data(), &got) != KCT_OK) fail("kct_export_by_owner_device");
     }
     // round 1: [status, pairs for that owner, this rank's count of key 0 (kept beside the device table: 0 is its EMPTY sentinel) -> owner 0]
     for (int r = 0; r < world; ++r) { send[3 * r] = status; send[3 * r + 1] = status ? 0 : part[r]; send[3 * r + 2] = r == 0 && !status ? zero : 0; }
-    if (x_sizes(x, send.data(), 3, recv.data()) != 0) { if (d_send) x_release(x, d_send); return 1; }   // (the collective itself failed: nothing to agree through)
+    if (x_sizes(x, send.data(), 3, recv.data()) != 0) return 1;   // (the collective itself failed: nothing to agree through)
     uint64_t total = 0, zero_total = 0, failed = status;
     for (int r = 0; r < world; ++r) { failed |= recv[3 * r]; total += recv[3 * r + 1]; zero_total += recv[3 * r + 2]; }
-    if (!failed && total) { d_recv = x_alloc(x, total * 16); if (!d_recv) status = 1; }
+    if (!failed && total) { d_recv = x_keep(x, &x->m_recv, &x->m_recv_cap, total * 16); if (!d_recv) status = 1; }
     // round 2: has every rank room for what it is to receive?
     std::vector<uint64_t> s1(world, status | failed), r1(world, 0);
-    if (x_sizes(x, s1.data(), 1, r1.data()) != 0) { if (d_send) x_release(x, d_send); if (d_recv) x_release(x, d_recv); return 1; }
+    if (x_sizes(x, s1.data(), 1, r1.data()) != 0) return 1;
     for (int r = 0; r < world; ++r) failed |= r1[r];
     if (failed) {
         if (!status) set_err("the merge failed on another rank before any pair moved: this rank's table is unchanged");
-        if (d_send) x_release(x, d_send);
-        if (d_recv) x_release(x, d_recv);
         return 1;
     }
     std::vector<uint64_t> soff(world), sbytes(world), roff(world), rbytes(world);
@@ -199,8 +209,6 @@ int kct_rccl_merge_across_ranks(kct_rccl *x, kct_table *t, uint64_t *pairs_recei
         set_err("folding the received pairs: %s", kct_last_error());
         rc = 1;
     }
-    if (d_send) x_release(x, d_send);
-    if (d_recv) x_release(x, d_recv);
     if (pairs_received) *pairs_received = total;
     return rc;
 }
@@ -213,6 +221,8 @@ void kct_rccl_destroy(kct_rccl *x) {
     if (x->stream) (void)hipStreamSynchronize(x->stream);
     if (x->comm) (void)ncclCommDestroy(x->comm);
     if (x->d_sizes) (void)hipFree(x->d_sizes);
+    if (x->m_send) (void)hipFree(x->m_send);
+    if (x->m_recv) (void)hipFree(x->m_recv);
     if (x->stream) (void)hipStreamDestroy(x->stream);
     delete x;
 }
