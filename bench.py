@@ -48,8 +48,8 @@ same weak-scaled C2 job per rank + the late merge, and
                  route needs a 128 GiB private table per rank.
   C5_whole       BASELINE.json configs[4] at its OWN size on ONE GPU: 10 M x 10 kbp, k=51, genome 3.1 Gbp -- 9.95x10^10 k-mers into one
                  2^33-slot (128 GiB) table.  The 100 GB of reads do not fit beside the table and its scratch, so they are generated on
-                 the device in 8 pieces (the multi-GPU job's rank shards) and consumed call after call; `seconds` = the summed wall time of
-                 the eight consume calls + the final sync (each piece resident in HBM when its call starts; generation untimed); gated on
+                 the device in 12 pieces (each one pass beside that table) and consumed call after call; `seconds` = the summed wall time of
+                 the twelve consume calls + the final sync (each piece resident in HBM when its call starts; generation untimed); gated on
                  the CPU oracle's committed digests of the whole input (tests/golden/config_digests.json "C5").
   north_star_streamed   the north-star run's 100 M reads fed the way a caller feeds them: 20 calls of 5 M reads and 100 calls of 1 M
                  reads into ONE table that starts empty and hint-free (one conversion at the end); rate against the one-call run,
@@ -100,7 +100,9 @@ MULTI = {
     "C5": (10_000_000, 10_000, 51, 3_100_000_000),
 }
 # BASELINE.json configs[4] WHOLE on one GPU: the 100 GB of reads are generated on the device in PIECES and fed call after call
-C5_WHOLE = (10_000_000, 10_000, 51, 3_100_000_000, 8)   # reads, read length, k, genome, pieces
+# (12 pieces: a piece's 8.3x10^9 window starts are ONE pass beside the 128 GiB table -- a pass is bounded by its ~12.5 B of scratch per window
+# start -- and every pass re-reads and re-writes the whole table; with the multi-GPU job's 8 rank shards as pieces each takes two passes, 16 in all)
+C5_WHOLE = (10_000_000, 10_000, 51, 3_100_000_000, 12)   # reads, read length, k, genome, pieces
 FILES = ["file_fasta", "file_gz", "file_bgzf"]
 ALL_CONFIGS = ["cold_C2", "packed_C2", "e2e_C2", "per_record"] + FILES + ["k51_deep"] + list(BIG) + ["north_star_streamed", "C5_whole"] + list(ERR) + list(MULTI)
 
@@ -956,7 +958,7 @@ def main():
         if free < 250 * (1 << 30):
             configs["C5_whole"] = {"skipped": f"needs a whole MI355X: {free >> 30} GiB free"}
         else:
-            per = Rb // pieces
+            per = (Rb + pieces - 1) // pieces        # (the last piece is shorter)
             n_exp = Rb * (Lb - kb + 1)
             balg = Lb / (Lb - kb + 1) + 24.0
             g = torch.empty(Gb, dtype=torch.uint8, device="cuda")
@@ -972,10 +974,11 @@ def main():
                 t.profile_reset()
                 n_, secs = 0, 0.0
                 for p_ in range(pieces):
-                    assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), Gb, p_ * per, per, Lb, SEED_R, stream) == 0
+                    cnt_ = min(per, Rb - p_ * per)
+                    assert lib.kct_synth_reads_device(r.data_ptr(), g.data_ptr(), Gb, p_ * per, cnt_, Lb, SEED_R, stream) == 0
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    n_ += t.consume_device(r.data_ptr(), r.numel(), per * Lb)
+                    n_ += t.consume_device(r.data_ptr(), cnt_ * (Lb + 1), cnt_ * Lb)
                     if p_ == pieces - 1:
                         t.sync()
                     torch.cuda.synchronize()

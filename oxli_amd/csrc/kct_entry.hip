@@ -549,11 +549,21 @@ kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes,
     // its first one counted by itself and the rest together.)
     const u64 npos = nbytes >= (u64)t->k ? (u64)nbytes - t->k + 1 : 0;
     const bool untouched = t->n_keys == 0 && !t->defer_used && !t->shadow_dirty && !t->s32_dirty && !t->s128_dirty;
-    if (t->defer_device && t->k <= 255 && npos && npos < 4 * t->cap && !(untouched && npos >= t->cap)) {
+    // Nor a call that by itself fills the passes HBM has room for: a pass is bounded by its scratch (~12.5 B per window start on the 64-bit
+    // two-level path), so beside a table that takes most of the GPU -- whole C5's 128 GiB one -- gathering calls cannot make passes larger,
+    // and the copy's buffer would only take room from the scratch (every pass re-reads and re-writes the whole table: fewer passes matter).
+    bool fills_a_pass = false;
+    size_t free_b = 0, total_b = 0;
+    const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    if (have_mem && (t->cap >> t->block_bits) > 1024) {
+        const double avail = (double)free_b + (double)(t->d_scratch.cap + t->d_scratch2.cap + t->d_irr.cap + t->d_irr2.cap + t->d_defer.cap);
+        fills_a_pass = (double)npos * 12.5 >= 0.5 * 0.8 * avail;
+    }
+    if (fills_a_pass && t->defer_used) KCT_TRY(flush_deferred_device(t));
+    if (t->defer_device && t->k <= 255 && npos && npos < 4 * t->cap && !(untouched && npos >= t->cap) && !fills_a_pass) {
         const u64 padded = (((u64)nbytes + 15) & ~15ULL) + 16;   // (the stream, separators up to a 16-byte boundary, one unit of separators)
-        size_t free_b = 0, total_b = 0;
         u64 limit = 32ULL << 30;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) limit = std::min<u64>(limit, ((u64)free_b + t->d_defer.cap) / 4);
+        if (have_mem) limit = std::min<u64>(limit, ((u64)free_b + t->d_defer.cap) / 4);
         if (t->defer_used + padded > limit && t->defer_used) KCT_TRY(flush_deferred_device(t));
         if (padded <= limit) {
             KCT_TRY(t->d_defer.reserve_keep(t->defer_used + padded, t->defer_used, t->stream));
