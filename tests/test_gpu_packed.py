@@ -90,6 +90,42 @@ def test_packed_device_stream_equals_ascii_and_oracle(gpu, k, path):
         assert t.consumed == ref.consumed
 
 
+@pytest.mark.parametrize("k,path", [(21, "dedupe"), (21, "partitioned"), (31, "dedupe"), (51, "partitioned"), (25, "partitioned")])
+def test_packed_arrays_cut_mid_group_and_misaligned(gpu, k, path):
+    """K1's PACKED instantiations fetch a tile's words sixteen bytes per lane (k1_kernel.h): the stream's last group is cut to nbases
+    inside the loading lane, pieces that would reach past the arrays are fetched word by word, and arrays that are not 16-byte
+    aligned (here: the same arrays entered one group further in) go through the ordinary instantiation's narrow loads.  All of it
+    against the ASCII stream cut at the same byte and the oracle.  (k = 25: no PACKED instantiation of its own -- run-time k.)"""
+    torch, KCT, lib = gpu
+    rng = random.Random(500 + k)
+    body = "".join(rng.choice("ACGT") for _ in range(3_000_000))          # one long record: every cut lands among valid bases
+    stream = (body + "\n").encode()
+    dev = torch.frombuffer(bytearray(stream + b"\n" * ((-len(stream)) % 16) + b"\n" * 64), dtype=torch.uint8).cuda()
+    ng = (len(stream) + 15) // 16
+    codes = torch.zeros(ng + 4, dtype=torch.int32, device="cuda")
+    valid = torch.zeros(ng + 8, dtype=torch.int16, device="cuda")
+    assert lib.kct_pack_stream_device(dev.data_ptr(), len(stream), codes.data_ptr(), valid.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    for cut, skip in ((len(stream) - 7, 0), (len(stream) - 16 * 1000 - 3, 0), (16384 * 3 + 5, 0), (len(stream) - 9, 1), (16384 * 2 + 16 * 5 + 11, 3)):
+        # `skip` groups dropped in front: the arrays then start 4 * skip / 2 * skip bytes into their allocation (misaligned for 16-byte loads)
+        nb = cut - 16 * skip
+        text = body[16 * skip:cut]
+        ref = OracleTable(k)
+        n_ref = ref.consume(text)
+        rk, rc = ref.dump_arrays()
+        t = KCT(k, capacity=6_000_000)
+        t.set_path(path)
+        n = t.consume_device_packed(codes.data_ptr() + 4 * skip, valid.data_ptr() + 2 * skip, nb, nb)
+        assert n == n_ref, (cut, skip, n, n_ref)
+        dk, dc = t.dump_arrays(1)
+        assert np.array_equal(dk, rk) and np.array_equal(dc, rc), (cut, skip)
+        a = KCT(k, capacity=6_000_000)
+        a.set_path(path)
+        assert a.consume_device(dev.data_ptr() + 16 * skip, nb, nb) == n_ref
+        ak, ac = a.dump_arrays(1)
+        assert np.array_equal(ak, rk) and np.array_equal(ac, rc)
+
+
 @pytest.mark.parametrize("k", [21, 31, 51])
 def test_batch_packed_upload_equals_ascii_upload_and_oracle(gpu, k):
     """kct_consume_batch with >= 8 MiB of records: the host packers (16 pool threads, SSSE3) + packed H2D, against the ASCII
