@@ -17,6 +17,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+DEV, NATIVE = "cpu", None   # where the scalar all-reduces live; libkct_rccl.so's communicator when the run asks for it
 
 
 def main():
@@ -24,11 +25,22 @@ def main():
     route = sys.argv[4] if len(sys.argv) > 4 else "late"
     L = int(sys.argv[5]) if len(sys.argv) > 5 else 150
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
+    # KCT_DIST_BACKEND=nccl (a box with one GPU PER RANK: tests/test_gpu_distributed.py::test_two_gpus_over_rccl): RCCL between the ranks;
+    # with KCT_DIST_NATIVE=1 the exchanges are libkct_rccl.so's own (NativeRccl) instead of torch.distributed's
+    backend = os.environ.get("KCT_DIST_BACKEND", "gloo")
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
     if route == "rccl-alone":
         rccl_alone(k, per_rank, G, L)
         return
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    global DEV, NATIVE
+    DEV = "cuda" if backend == "nccl" else "cpu"
+    if backend == "nccl" and os.environ.get("KCT_DIST_NATIVE") == "1":
+        from oxli_amd.distributed import NativeRccl
+        NATIVE = NativeRccl()
     import oracle
     from oxli_amd import KmerCountTable
     from oxli_amd.distributed import global_scalar_sum, merge_across_ranks, owner_of
@@ -49,15 +61,15 @@ def main():
         for _ in range(3):
             t.count_hash(0)            # key 0 lives beside the device table; its owner is rank 0
     cap_private = t.capacity
-    recv = merge_across_ranks(t)
+    recv = merge_across_ranks(t, native=NATIVE)
     assert recv > 0
     keys, counts = t.dump_arrays(1)
     nz = keys != 0
     assert np.all(owner_of(torch.from_numpy(keys[nz].view(np.int64).copy()), world).numpy() == rank)   # only my slice of hash space
     assert t.capacity <= cap_private   # an owner's table is sized for its slice
-    total = global_scalar_sum(t.sum_counts, "cpu")
+    total = global_scalar_sum(t.sum_counts, DEV)
     assert total == world * per_rank * (L - k + 1) + 3, total
-    assert global_scalar_sum(t.consumed, "cpu") == world * per_rank * L
+    assert global_scalar_sum(t.consumed, DEV) == world * per_rank * L
     parts = [None] * world
     dist.all_gather_object(parts, (keys, counts))
     if rank == 0:
@@ -159,7 +171,7 @@ def late_store_kmers(k, per_rank, L, rank, world, reads):
                 got[h] = c
         assert got == dict(zip(rk.tolist(), rc.tolist()))
         print(f"DIST_GPU_OK world={world} distinct={rk.size} route=late:store_kmers")
-    assert global_scalar_sum(t.sum_counts, "cpu") == world * per_rank * (L - k + 1)
+    assert global_scalar_sum(t.sum_counts, DEV) == world * per_rank * (L - k + 1)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -176,17 +188,17 @@ def early(path, k, per_rank, G, L, rank, world, genome, reads, dev_reads):
     half = h * (L + 1)
     # (the first call is cut into passes of 2^22 window starts: several exchanges in flight beside the counting, windows across the
     # cuts -- inside a record for long reads -- counted once)
-    n1, s1 = consume_device_early(t, dev_reads.data_ptr(), half, h * L, max_windows=1 << 22)
+    n1, s1 = consume_device_early(t, dev_reads.data_ptr(), half, h * L, max_windows=1 << 22, native=NATIVE)
     assert s1["passes"] == -(-(half - k + 1) // (1 << 22)) > 1, s1
-    n2, s2 = consume_device_early(t, dev_reads.data_ptr() + half, dev_reads.numel() - half, (per_rank - h) * L)
+    n2, s2 = consume_device_early(t, dev_reads.data_ptr() + half, dev_reads.numel() - half, (per_rank - h) * L, native=NATIVE)
     assert s1["windows_sent"] > 0 and s1["windows_received"] > 0 and s1["bytes_sent"] > 0
     assert s1["bytes_sent"] < (0.75 if k < 30 else 0.5) * 4 * s1["windows_sent"], s1        # far fewer bytes than one 4-byte entry per window
-    total_n = global_scalar_sum(n1 + n2, "cpu")
+    total_n = global_scalar_sum(n1 + n2, DEV)
     expect = world * per_rank * (L - k + 1)
     assert total_n == expect, (total_n, expect)
     keys, counts = t.dump_arrays(1)          # (reading the table converts what the dedupe-first paths left pending)
-    assert global_scalar_sum(t.sum_counts, "cpu") == expect
-    assert global_scalar_sum(t.consumed, "cpu") == world * per_rank * L
+    assert global_scalar_sum(t.sum_counts, DEV) == expect
+    assert global_scalar_sum(t.consumed, DEV) == world * per_rank * L
     parts = [None] * world
     dist.all_gather_object(parts, (keys, counts))
     if rank == 0:

@@ -70,3 +70,23 @@ def test_one_rank_through_a_real_rccl_communicator():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-6000:]
     assert "DIST_GPU_OK world=1" in out.stdout and "route=rccl-alone" in out.stdout and "native=ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+@pytest.mark.parametrize("native", ["0", "1"], ids=["torch.distributed", "libkct_rccl.so"])
+@pytest.mark.parametrize("route", ["late", "early:auto"])
+def test_two_gpus_over_rccl(route, native):
+    """Both routes between TWO GPUs over RCCL / xGMI -- the cross-rank stream ordering, the self send / receive inside a group and the
+    error agreement that a world of one cannot show -- through torch.distributed's nccl back end and through libkct_rccl.so's own
+    communicator (NativeRccl); union of the owners' tables == the oracle's table.  Skipped on the one-GPU test boxes of this pool."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", KCT_DIST_BACKEND="nccl", KCT_DIST_NATIVE=native)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "21", "400000", "2000000", route]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-6000:]
+    assert "DIST_GPU_OK world=2" in out.stdout, out.stdout[-2000:]
