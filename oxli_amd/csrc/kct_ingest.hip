@@ -670,6 +670,12 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
             if (st == KCT_OK && slot_failed) { set_err("%s: %s", path, slot_msg.c_str()); st = KCT_ERR_ARG; }
         }
     } else {
+        // (said ONCE per process, loudly: without libdeflate.so.0 a gzip file is inflated by one zlib thread at ~0.4 GB/s of text -- below
+        // what the CPU reference path reads -- and nothing downstream can make up for it; bgzip the file, or install libdeflate)
+        static std::atomic<bool> said{false};
+        if (!(deflate_lib().ok() && !libdeflate_disabled()) && gzmap.size > (64u << 20) && !said.exchange(true))
+            fprintf(stderr, "kct_consume_file: libdeflate.so.0 not found -- %s is inflated by zlib on one thread (~0.4 GB/s of text); "
+                            "BGZF input (bgzip) is inflated on many threads, libdeflate doubles a single stream's rate\n", path);
         // a plain gzip stream: one inflater thread -> a ring of text slots -> this thread's parser (see the top of the file)
         TextRing ring(4, slot_bytes);
         std::thread inflater([&] {
