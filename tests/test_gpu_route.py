@@ -78,6 +78,25 @@ def runs_of(stream, k):
     return out
 
 
+def host_owner(kmer, world):
+    """The documented owner rule (include/kct.h, superkmer_kernels.h sk_scramble / sk_owner), restated on the host: the smallest scrambled
+    canonical m-mer (m = min(8, k)) inside the k-mer, its 16-bit hash's top ten bits spread over the ranks."""
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    m = min(8, len(kmer))
+    def scramble(x):
+        x = (x * 0x9E3B) & 0xFFFF; x ^= x >> 7
+        x = (x * 0x6A75) & 0xFFFF; x ^= x >> 9
+        return x
+    best = 1 << 20
+    for i in range(len(kmer) - m + 1):
+        f = r = 0
+        for j in range(m):
+            f = (f << 2) | code[kmer[i + j]]
+            r = (r << 2) | (3 - code[kmer[i + m - 1 - j]])
+        best = min(best, scramble(min(f, r)))
+    return ((((best * 0x9E37) & 0xFFFF) >> 6) * world) >> 10
+
+
 @pytest.mark.parametrize("k,world,R", [(21, 1, 12_000), (21, 8, 12_000), (31, 3, 12_000), (51, 8, 12_000), (64, 2, 12_000), (13, 4, 12_000), (5, 2, 12_000),
                                        (33, 64, 12_000),
                                        # k < 8: every window is its own minimiser, the owner changes from window to window -- full tiles
@@ -97,13 +116,17 @@ def test_split_wire_format_decodes_to_the_input_k_mers(gpu, k, world, R):
     n_ref = sum(ref.consume(bytes(r[:L]).decode()) for r in reads)
     rk, rc = ref.dump_arrays()
     tabs, n_dec, nruns, nbases = [], 0, 0, 0
-    for streams in owners:
+    rng = np.random.default_rng(k * 1000 + world)
+    for o, streams in enumerate(owners):
         tab = OracleTable(k)
         for st in streams:
             for run in runs_of(st, k):
                 n = tab.consume(run, False)            # every window of a run is good
                 assert n == len(run) - k + 1
                 n_dec += n; nruns += 1; nbases += len(run)
+                if rng.random() < 0.02:                # the DOCUMENTED owner rule, on a sample of windows (first, last and one inside the run)
+                    for w in {0, n - 1, int(rng.integers(0, n))}:
+                        assert host_owner(run[w: w + k], world) == o, (run[w: w + k], o)
         tabs.append(tab)
     assert n_dec == n_ref
     ks = [tb.dump_arrays() for tb in tabs]
