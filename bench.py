@@ -132,7 +132,7 @@ def parse():
                    help="N > 1: who moves the data between ranks -- libkct_rccl.so (native: ncclSend / ncclRecv groups inside the library, what a Rust "
                         "caller links; needs --backend nccl, one rank per GPU) or torch.distributed.  auto = native for the headline's merge where "
                         "possible, and BOTH side by side in configs.C4 / C5")
-    p.add_argument("--job-timeout", type=float, default=3000.0, help="N > 1 self-launch: seconds after which the parent kills the ranks (a hung collective) and exits 124")
+    p.add_argument("--job-timeout", type=float, default=1800.0, help="N > 1 self-launch: seconds after which the parent kills the ranks (a hung collective) and exits 124")
     p.add_argument("--no-second-process", action="store_true", help="skip the headline's second sample from another cold-started process")
     p.add_argument("--headline-sample", action="store_true", help=argparse.SUPPRESS)   # (the child of the above: headline only, prints its value)
     return p.parse_args()
@@ -507,6 +507,27 @@ def main():
     if not args.no_headline:
         for s in range(args.warmup):
             step(s)
+        if world > 1 and native is not None:
+            # libkct_rccl.so's merge has never run between real GPUs before the driver's own N-GPU run: a rank on which its FIRST call
+            # returns an error (an exception here, not a hang) sends every rank back to torch.distributed for the rest of the job
+            try:
+                merge_across_ranks(table, native=native)
+                ok_merge = 1
+            except Exception as e:  # noqa: BLE001
+                log(f"kct_rccl_merge_across_ranks failed on rank {rank}: {e}")
+                ok_merge = 0
+            flag = torch.tensor([ok_merge], dtype=torch.int64, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if not int(flag.item()):
+                if args.exchange == "native":
+                    raise SystemExit("--exchange native: kct_rccl_merge_across_ranks failed")
+                native.close()
+                native = None
+                exchanges = [("torch", None)]
+                table.clear()
+                table.resize(G)
+                for s in range(max(1, args.warmup)):
+                    step(s)
         if world > 1 and args.warmup:
             merge_across_ranks(table, native=native)  # warm the collective and the merge kernels too
         first = job()  # (also teaches a fresh table that the dedupe-first path pays: the steady state)
