@@ -335,21 +335,46 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     child = subprocess.Popen(cmd, env=env, start_new_session=True)   # its own process group: the exact group we may have to kill
-    try:
-        raise SystemExit(child.wait(timeout=args.job_timeout))
-    except subprocess.TimeoutExpired:
-        print(f"[bench] the {args.gpus}-rank job did not finish in {args.job_timeout:.0f} s: killing its process group", file=sys.stderr, flush=True)
+
+    def kill_group():
         for sig in (signal.SIGTERM, signal.SIGKILL):
             try:
                 os.killpg(child.pid, sig)
             except ProcessLookupError:
-                break
+                return
             try:
                 child.wait(timeout=10)
-                break
+                return
             except subprocess.TimeoutExpired:
                 continue
-        raise SystemExit(124)
+
+    # The ranks live in ANOTHER session, so a signal sent to this process (or to its process group: Ctrl-C, an outer `timeout`) does
+    # not reach them: SIGTERM / SIGINT / SIGHUP here are turned into an exception, and every way out of the wait -- those, the hang
+    # guard, any other error -- kills the ranks' group before this process exits.  (The parent has not touched the GPU: killing and
+    # exiting non-zero is all there is to do.)
+    class _Signalled(BaseException):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Signalled(signum)
+
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sg, on_signal)
+    code = None
+    try:
+        code = child.wait(timeout=args.job_timeout)
+    except subprocess.TimeoutExpired:
+        print(f"[bench] the {args.gpus}-rank job did not finish in {args.job_timeout:.0f} s: killing its process group", file=sys.stderr, flush=True)
+        code = 124
+    except _Signalled as e:
+        print(f"[bench] signal {e.args[0]}: killing the {args.gpus}-rank job's process group", file=sys.stderr, flush=True)
+        code = 128 + int(e.args[0])
+    finally:
+        if child.poll() is None:
+            for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+                signal.signal(sg, signal.SIG_IGN)   # (a second signal must not interrupt the clean-up)
+            kill_group()
+    raise SystemExit(code)
 
 
 def second_process_sample(args):

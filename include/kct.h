@@ -255,6 +255,21 @@ typedef struct kct_exchange_ops {
 KCT_API kct_status kct_consume_device_routed(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes, uint32_t world, uint32_t rank,
                                              const kct_exchange_ops *ops, uint64_t max_windows, uint64_t *n_owned, uint64_t *stats16);
 
+/* Fault injection for the early route's error agreement (tests/test_gpu_distributed.py::test_a_failing_rank_ends_the_early_route_on_every_rank;
+ * not in the reference): the NEXT kct_consume_device_routed call on this table fails once, on this rank only, at the named point --
+ *   1 the HBM query before the first collective     2 the split (cut) of pass `pass`       3 the next slab allocation
+ *   4 the start of pass `pass`'s payload             5 the wait for pass `pass`'s payload   6 the owner-side count
+ * -- as if the HIP call (or the caller's callback) there had failed; 0 disarms.  The contract under test is the one stated above:
+ * every rank of the job then returns an error from the same call, none is left inside a collective. */
+#define KCT_FAULT_NONE 0
+#define KCT_FAULT_MEMINFO 1
+#define KCT_FAULT_SPLIT 2
+#define KCT_FAULT_ALLOC 3
+#define KCT_FAULT_START 4
+#define KCT_FAULT_WAIT 5
+#define KCT_FAULT_COUNT 6
+KCT_API kct_status kct_debug_inject_fault(kct_table *t, int point, uint64_t pass);
+
 /* The sender half alone (tests, tools, a caller with its own transport): this rank's records cut into super-k-mers for `world` owners.
  * *d_parts (device memory owned by the table, valid until its next bulk call) holds owner o's part at part_off[o] .. + part_bytes[o]:
  * the 16-byte base units (64 bases: 2 bits each, first base in the most significant bits of the first 32-bit word) of its

@@ -38,11 +38,17 @@ const char *kct_rccl_last_error(void);
  * with their global counts, resized for that slice; the global table is the disjoint union over ranks (its len / sum_counts /
  * consumed are sums over ranks; `consumed` of each table stays that rank's own share).  One size round (status, pair counts, the count
  * of key 0 -- kept beside the device table -- to its owner, rank 0), one status round once every rank has room, one ncclSend /
- * ncclRecv group of 16-byte {hash, count} pairs.  A failure on any rank before the payload ends the call on EVERY rank with the
- * tables unchanged.  *pairs_received (may be NULL) = pairs this rank received, its own included.  A world of one returns at once
+ * ncclRecv group of 16-byte {hash, count} pairs, one status round after every rank's refill.  A failure on any rank before the payload
+ * ends the call on EVERY rank with the tables unchanged; a failure after it (the refill) ends it on every rank with the tables'
+ * contents UNDEFINED -- clear them.  (An RCCL call that fails on one rank once its peers may have enqueued their halves aborts that
+ * rank's communicator: every later call on it fails at once; the peers are ended by the launcher's hang guard.)  *pairs_received (may be NULL) = pairs this rank received, its own included.  A world of one returns at once
  * unless kct_rccl_merge_when_alone(x, 1) asks for the collectives anyway (tests on a one-GPU box). */
 int kct_rccl_merge_across_ranks(kct_rccl *x, kct_table *t, uint64_t *pairs_received);
 void kct_rccl_merge_when_alone(kct_rccl *x, int on);
+/* The merge keeps its two pair buffers (16 B per pair sent / received, + 1/8) between merges.  kct_rccl_release_buffers frees them now;
+ * kct_rccl_release_above(x, bytes) makes every merge free them afterwards when one has grown beyond `bytes` (default 4 GiB, 0 = never). */
+void kct_rccl_release_buffers(kct_rccl *x);
+void kct_rccl_release_above(kct_rccl *x, uint64_t bytes);
 /* bytes this communicator has sent to / received from OTHER ranks, and seconds spent blocked in wait() (statistics) */
 void kct_rccl_stats(const kct_rccl *x, uint64_t *bytes_sent, uint64_t *bytes_received, double *wait_seconds);
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "kct_consume_device_routed": (ci, [vp, vp, sz, u64, C.c_uint32, C.c_uint32, vp, u64, u64p, u64p]),
     "kct_superkmer_split_device": (ci, [vp, vp, sz, C.c_uint32, C.POINTER(vp), u64p, u64p, u64p]),
     "kct_superkmer_streams": (C.c_uint32, [vp]),
+    "kct_debug_inject_fault": (ci, [vp, ci, u64]),
     "kct_consume_file": (ci, [vp, cp, ci, u64p, u64p, u64p]),
     "kct_inflater_name": (cp, []),
     "kct_len": (ci, [vp, u64p]),
@@ -114,6 +115,8 @@ RCCL_SIGNATURES = {
     "kct_rccl_stats": (None, [vp, u64p, u64p, C.POINTER(C.c_double)]),
     "kct_rccl_merge_across_ranks": (ci, [vp, vp, u64p]),
     "kct_rccl_merge_when_alone": (None, [vp, ci]),
+    "kct_rccl_release_buffers": (None, [vp]),
+    "kct_rccl_release_above": (None, [vp, u64]),
 }
 
 _lib = None

@@ -10,6 +10,28 @@
 
 namespace kct {
 
+// ---- where a K1 wave's time goes (measurement builds, -DKCT_K1_STAMPS: tools/k1_stamps.sh) -------------------------------------
+// Every wave reads the shader clock (s_memtime) at the phase boundaries below and adds the cycles since its previous reading to the
+// phase that just ended; the sums leave through PartitionArgs::stamps.  A "barrier" phase runs from the reading in front of
+// __syncthreads() to the one behind it: the wave's own outstanding LDS / memory operations draining plus the wait for the slowest of
+// the other fifteen waves.  The shipped build compiles NoStamps: nothing.
+enum { ST_HASH = 0, ST_BAR_TILE, ST_STAGE, ST_BAR1, ST_LIST, ST_BAR2, ST_MOVE, ST_BAR3, ST_TAIL, kStampSlots };
+struct NoStamps { __device__ __forceinline__ void mark(int) {} };
+// -DKCT_ABLATE_FLUSH_BARRIERS (tools/k1_stamps.sh; results INVALID): ring_flush keeps its work and drops its three workgroup barriers --
+// what the barriers themselves cost, as opposed to the work between them
+#ifdef KCT_ABLATE_FLUSH_BARRIERS
+#define KCT_FLUSH_BARRIER() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#else
+#define KCT_FLUSH_BARRIER() __syncthreads()
+#endif
+#ifdef KCT_K1_STAMPS
+struct WaveStamps {
+    u64 last, acc[kStampSlots];
+    __device__ __forceinline__ void start() { for (int i = 0; i < kStampSlots; ++i) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void mark(int i) { const u64 now = __builtin_amdgcn_s_memtime(); acc[i] += now - last; last = now; }
+};
+#endif
+
 // ---- LDS write-combining ring shared by both partition levels ------------------------------------------
 // Bin b owns ring[b*D .. b*D+D).  Its cursor word cur[b] holds `fill` (positions handed out) in the low half and
 // `flushed` (positions that have left the ring) in the high half, so ONE 64-bit LDS add returns both.  An append takes
@@ -27,10 +49,10 @@ namespace kct {
 // upper half, 16 per line); a value handed to overflow_hash is always the full 64-bit one.
 // ovf_hi (u32 rings only): the upper half of a value handed to overflow_hash -- 0 = derive it from the bin (K1: the bin
 // IS the value's top 10 bits), otherwise a fixed word (K1b: the super-bin, the sub-bin bits are inside the entry).
-template <u32 LISTCAP, class T, class Overflow>
+template <u32 LISTCAP, class T, class Overflow, class St = NoStamps>
 __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *fcount, int P, u32 D,
                                            T *out_base, u32 out_cap, bool drain, Overflow &&overflow_hash, u64 bin_stride = 0, u64 ovf_hi = 0,
-                                           u32 min_lines = 1, u32 ovf_shift = 31) {
+                                           u32 min_lines = 1, u32 ovf_shift = 31, St *st = nullptr) {
     // ovf_shift (u32 rings, ovf_hi set): the bin's bits from ovf_shift up are added to the first-level bin in ovf_hi (K1b with grouped
     // super-bins: the sub-bin's top bits are the first-level bin's low bits)
     // min_lines: a bin's lines leave the ring only that many at a time (adjacent lane groups then store adjacent lines:
@@ -39,7 +61,9 @@ __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *f
     const u32 dmask = D - 1;
     if (bin_stride == 0) bin_stride = out_cap;  // distance between the regions of consecutive bins
     const int dshift = __builtin_ctz(D);  // D is a power of two: shifts instead of quarter-rate multiplies
-    __syncthreads();  // appends of this interval are in the ring; *fcount == 0
+    if (st) st->mark(ST_HASH);
+    KCT_FLUSH_BARRIER();  // appends of this interval are in the ring; *fcount == 0
+    if (st) st->mark(ST_BAR1);
     for (int b = threadIdx.x; b < P; b += kPartThreads) {
         const u64 cw = cur[b];
         const u32 f0 = (u32)(cw >> 32), top = (u32)cw;
@@ -53,7 +77,9 @@ __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *f
         }
         if (f != f0) atomicAdd(&cur[b], (u64)(f - f0) << 32);  // (appenders bump the low half concurrently)
     }
-    __syncthreads();
+    if (st) st->mark(ST_LIST);
+    KCT_FLUSH_BARRIER();
+    if (st) st->mark(ST_BAR2);
     const u32 listed = *fcount, nlist = listed < LISTCAP ? listed : LISTCAP;
     for (u32 item = threadIdx.x; item < 4 * nlist; item += kPartThreads) {
         const u32 e = flist[item >> 2], q = item & 3u, b = e & 1023u, f = (e >> 10) & 0x1FFFFFu;
@@ -80,7 +106,9 @@ __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *f
             if (v.w) overflow_hash(hi | v.w);
         }
     }
-    __syncthreads();
+    if (st) st->mark(ST_MOVE);
+    KCT_FLUSH_BARRIER();
+    if (st) st->mark(ST_BAR3);
     if (threadIdx.x == 0) *fcount = 0;
     return listed > LISTCAP;
 }
@@ -159,8 +187,15 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
             else my_ovf[i] = h;
         } else *a.overflow = 1ULL;
     };
+#ifdef KCT_K1_STAMPS
+    WaveStamps stamps;
+    stamps.start();
+    WaveStamps *stp = &stamps;
+#else
+    NoStamps *stp = nullptr;
+#endif
     auto flush_lines = [&](bool drain) {
-        return ring_flush<kListCap, T>(ring, cur, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_hash);
+        return ring_flush<kListCap, T>(ring, cur, flist, &fcount, P, D, my_scratch, a.region_cap, drain, overflow_hash, 0, 0, 1, 31, stp);
     };
 
     // A tile is kPartTile + k - 1 <= 1024 + 16 sixteen-byte chunks: one per thread plus a halo that
@@ -241,7 +276,9 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
         if (threadIdx.x < 16) pre_halo = load_any((u64)blockIdx.x * kPartTile, kPartThreads + threadIdx.x);
     }
     for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (stp) stp->mark(ST_HASH);
         __syncthreads();  // the previous tile's readers are done with `lds`; ring/fill init is visible
+        if (stp) stp->mark(ST_BAR_TILE);
         if constexpr (RUNS) {
             if (threadIdx.x < kPartTile / 64) {
                 if (iter == 0) reinterpret_cast<uint4 *>(tdesc)[threadIdx.x] = pre_halo;
@@ -268,6 +305,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
             }
         }
         __syncthreads();
+        if (stp) stp->mark(ST_STAGE);
         const u64 next = tile + gridDim.x;
         if (RUNS) pre_main = load_desc(next + gridDim.x);   // (zeros beyond the last tile)
         if (PACKED && next < ntiles) pre_main = load_piece(next * kPartTile);
@@ -329,6 +367,11 @@ if constexpr (MODE == 2) pend_b = (u32)(h >> 32) & 1023u;
     }
     __syncthreads();
     if (threadIdx.x == 0) a.ovf_count[blockIdx.x] = ovf_n < a.ovf_cap ? ovf_n : a.ovf_cap;
+#ifdef KCT_K1_STAMPS
+    stamps.mark(ST_TAIL);
+    if (a.stamps && (threadIdx.x & 63) == 0)
+        for (int i = 0; i < kStampSlots; ++i) a.stamps[((u64)blockIdx.x * (kPartThreads / 64) + (threadIdx.x >> 6)) * kStampSlots + i] = stamps.acc[i];
+#endif
 }
 
 }  // namespace kct

@@ -117,10 +117,47 @@ void launch_partition(kct_table *t, int mode, const unsigned char *d_stream, u64
     const int k = t->k, nwg = t->num_cus;
     if (pa.runs.groups) { launch_partition_runs(t, mode, chunk_bytes, ntiles, pa); return; }  // received super-k-mers (kct_runs.hip)
     ProfScope ps(t, mode == 2 ? "partition_windows_kernel<compact>" : mode == 1 ? "partition_windows_kernel<raw>" : "partition_windows_kernel");
-    if (pa.pcodes && launch_partition_packed(t, mode, chunk_bytes, ntiles, pa)) return;
-    if (mode == 2) PartitionCompactByK<21>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
-    else if (mode == 1) PartitionRawByK<32>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
-    else PartitionByK<64>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa);
+#ifdef KCT_K1_STAMPS
+    // measurement build (tools/k1_stamps.sh): every wave's cycles per phase come back after the launch (which is waited for) and one
+    // JSON line per launch goes to the file KCT_K1_STAMPS_OUT names
+    kct::PartitionArgs pas = pa;
+    const size_t nst = (size_t)nwg * (kct::kPartThreads / 64) * kct::kStampSlots;
+    du64 *d_st = nullptr;
+    if (hipMalloc((void **)&d_st, nst * 8) == hipSuccess) { (void)hipMemsetAsync(d_st, 0, nst * 8, t->stream); pas.stamps = d_st; }
+    const kct::PartitionArgs &pa_ = pas;
+    struct StampsOut {
+        kct_table *t; du64 *d; size_t n; int mode; u64 ntiles;
+        ~StampsOut() {
+            if (!d) return;
+            std::vector<u64> h(n);
+            if (hipMemcpyAsync(h.data(), d, n * 8, hipMemcpyDeviceToHost, t->stream) == hipSuccess && hipStreamSynchronize(t->stream) == hipSuccess) {
+                static const char *names[kct::kStampSlots] = {"hash", "bar_tile", "stage", "bar1", "list", "bar2", "move", "bar3", "tail"};
+                u64 sum[kct::kStampSlots] = {0}, wmin = ~0ULL, wmax = 0, tot = 0;
+                for (size_t w = 0; w < n / kct::kStampSlots; ++w) {
+                    u64 wt = 0;
+                    for (int i = 0; i < kct::kStampSlots; ++i) { sum[i] += h[w * kct::kStampSlots + i]; wt += h[w * kct::kStampSlots + i]; }
+                    if (wt) { wmin = std::min(wmin, wt); wmax = std::max(wmax, wt); }
+                    tot += wt;
+                }
+                if (const char *path = getenv("KCT_K1_STAMPS_OUT"))
+                    if (FILE *f = fopen(path, "a")) {
+                        fprintf(f, "{\"mode\": %d, \"k\": %d, \"tiles\": %llu, \"waves\": %zu, \"wave_cycles_min\": %llu, \"wave_cycles_max\": %llu, \"share\": {", mode, (int)t->k,
+                                (unsigned long long)ntiles, n / kct::kStampSlots, (unsigned long long)wmin, (unsigned long long)wmax);
+                        for (int i = 0; i < kct::kStampSlots; ++i) fprintf(f, "%s\"%s\": %.4f", i ? ", " : "", names[i], tot ? (double)sum[i] / (double)tot : 0.0);
+                        fprintf(f, "}}\n");
+                        fclose(f);
+                    }
+            }
+            (void)hipFree(d);
+        }
+    } stamps_out{t, d_st, nst, mode, ntiles};
+#else
+    const kct::PartitionArgs &pa_ = pa;
+#endif
+    if (pa_.pcodes && launch_partition_packed(t, mode, chunk_bytes, ntiles, pa_)) return;
+    if (mode == 2) PartitionCompactByK<21>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa_);
+    else if (mode == 1) PartitionRawByK<32>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa_);
+    else PartitionByK<64>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa_);
 }
 
 void launch_repartition(kct_table *t, int mode, unsigned grid, const kct::RepartitionArgs &ra, bool whole_slab) {

@@ -47,6 +47,7 @@ struct kct_rccl {
     bool merge_when_alone = false;   // a world of one goes through the merge's collectives too (tests on a one-GPU box)
     void *m_send = nullptr, *m_recv = nullptr;   // the late route's pair buffers, kept between merges (grow-only: no hipMalloc / hipFree per job)
     uint64_t m_send_cap = 0, m_recv_cap = 0;
+    uint64_t release_above = 4ULL << 30;         // a merge frees its pair buffers afterwards when one has grown beyond this (0 = never)
     kct_exchange_ops ops;
 };
 
@@ -75,9 +76,22 @@ void *x_keep(kct_rccl *x, void **p, uint64_t *cap, uint64_t bytes) {
     return *p;
 }
 
+// A collective that fails on THIS rank after its peers may have enqueued their halves cannot be agreed away (their receives from this
+// rank never complete): the open group is closed and the communicator ABORTED, so that every later call on it fails at once instead of
+// enqueueing behind a dead operation.  The peers' pending operations end when their own RCCL notices (or the launcher's hang guard
+// does); kct_consume_device_routed's "every rank returns an error" holds for failures the protocol can carry, not for this one.
+int x_broken(kct_rccl *x, bool group_open, const char *what, ncclResult_t r) {
+    set_err("%s: %s -- the communicator is aborted", what, ncclGetErrorString(r));
+    if (group_open) (void)ncclGroupEnd();
+    if (x->comm) { (void)ncclCommAbort(x->comm); x->comm = nullptr; }
+    return 1;
+}
+#define NCCL_GROUP(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) return x_broken(x, true, #expr, r_); } while (0)
+
 int x_sizes(void *user, const uint64_t *send, uint32_t nvals, uint64_t *recv) {
     kct_rccl *x = (kct_rccl *)user;
     const size_t n = (size_t)x->world * nvals;
+    if (!x->comm) { set_err("the communicator was aborted by an earlier failure"); return 1; }
     HIP_OK(hipSetDevice(x->device));
     if (2 * n > x->sizes_cap) {
         if (x->d_sizes) HIP_OK(hipFree(x->d_sizes));
@@ -86,12 +100,14 @@ int x_sizes(void *user, const uint64_t *send, uint32_t nvals, uint64_t *recv) {
         x->sizes_cap = 2 * n;
     }
     HIP_OK(hipMemcpyAsync(x->d_sizes, send, n * sizeof(uint64_t), hipMemcpyHostToDevice, x->stream));
-    NCCL_OK(ncclGroupStart());
+    ncclResult_t g = ncclGroupStart();
+    if (g != ncclSuccess) return x_broken(x, false, "ncclGroupStart", g);
     for (int r = 0; r < x->world; ++r) {
-        NCCL_OK(ncclSend(x->d_sizes + (size_t)r * nvals, nvals, ncclUint64, r, x->comm, x->stream));
-        NCCL_OK(ncclRecv(x->d_sizes + n + (size_t)r * nvals, nvals, ncclUint64, r, x->comm, x->stream));
+        NCCL_GROUP(ncclSend(x->d_sizes + (size_t)r * nvals, nvals, ncclUint64, r, x->comm, x->stream));
+        NCCL_GROUP(ncclRecv(x->d_sizes + n + (size_t)r * nvals, nvals, ncclUint64, r, x->comm, x->stream));
     }
-    NCCL_OK(ncclGroupEnd());
+    g = ncclGroupEnd();
+    if (g != ncclSuccess) return x_broken(x, false, "ncclGroupEnd", g);
     HIP_OK(hipMemcpyAsync(recv, x->d_sizes + n, n * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
     HIP_OK(hipStreamSynchronize(x->stream));
     return 0;
@@ -99,14 +115,17 @@ int x_sizes(void *user, const uint64_t *send, uint32_t nvals, uint64_t *recv) {
 
 int x_start(void *user, const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv, const uint64_t *recv_off, const uint64_t *recv_bytes) {
     kct_rccl *x = (kct_rccl *)user;
+    if (!x->comm) { set_err("the communicator was aborted by an earlier failure"); return 1; }
     HIP_OK(hipSetDevice(x->device));
-    NCCL_OK(ncclGroupStart());
+    ncclResult_t g = ncclGroupStart();
+    if (g != ncclSuccess) return x_broken(x, false, "ncclGroupStart", g);
     for (int r = 0; r < x->world; ++r) {
-        if (send_bytes[r]) NCCL_OK(ncclSend((const char *)d_send + send_off[r], send_bytes[r], ncclUint8, r, x->comm, x->stream));
-        if (recv_bytes[r]) NCCL_OK(ncclRecv((char *)d_recv + recv_off[r], recv_bytes[r], ncclUint8, r, x->comm, x->stream));
+        if (send_bytes[r]) NCCL_GROUP(ncclSend((const char *)d_send + send_off[r], send_bytes[r], ncclUint8, r, x->comm, x->stream));
+        if (recv_bytes[r]) NCCL_GROUP(ncclRecv((char *)d_recv + recv_off[r], recv_bytes[r], ncclUint8, r, x->comm, x->stream));
         if (r != x->rank) { x->sent += send_bytes[r]; x->received += recv_bytes[r]; }
     }
-    NCCL_OK(ncclGroupEnd());
+    g = ncclGroupEnd();
+    if (g != ncclSuccess) return x_broken(x, false, "ncclGroupEnd", g);
     return 0;
 }
 
@@ -164,8 +183,8 @@ void kct_rccl_stats(const kct_rccl *x, uint64_t *bytes_sent, uint64_t *bytes_rec
 // own table; afterwards rank r holds every key of hash slice r -- owner(hash) = floor(hi32(hash) * world / 2^32) -- with its GLOBAL
 // count: add() (lib.rs:778-837: per-key sum) applied across ranks.  `consumed` stays this rank's own share; len / sum_counts / consumed
 // of the global table are sums over ranks.  Collective: every rank must call it; a failure on any rank is learnt by all in the size
-// round (slot 0 = status) or the second one-word round, before any payload moves.  *pairs_received (may be NULL) = pairs this rank
-// received, its own included.
+// round (slot 0 = status) or the second one-word round, before any payload moves (tables unchanged), or in the third one-word round
+// after the refill (tables undefined: clear them).  *pairs_received (may be NULL) = pairs this rank received, its own included.
 int kct_rccl_merge_across_ranks(kct_rccl *x, kct_table *t, uint64_t *pairs_received) {
     if (!x || !t) { set_err("null argument"); return 1; }
     if (pairs_received) *pairs_received = 0;
@@ -210,8 +229,28 @@ int kct_rccl_merge_across_ranks(kct_rccl *x, kct_table *t, uint64_t *pairs_recei
         rc = 1;
     }
     if (pairs_received) *pairs_received = total;
+    // round 3: one word -- did every rank's refill succeed?  Every rank returns the same verdict; after a failure HERE (the payload has
+    // moved, tables were cleared) the tables' contents are undefined on every rank and must be cleared.  (A rank whose communicator was
+    // aborted cannot take part: x_sizes fails at once, it returns 1, and its peers wait for the launcher's hang guard -- see x_broken.)
+    std::vector<uint64_t> s2(world, (uint64_t)(rc != 0)), r2(world, 0);
+    if (x_sizes(x, s2.data(), 1, r2.data()) != 0) return 1;
+    for (int r = 0; r < world; ++r)
+        if (r2[r] && rc == 0) { set_err("the merge failed on rank %d after the pairs had moved: every rank's table must be cleared", r); rc = 1; }
+    if (x->release_above && (x->m_send_cap > x->release_above || x->m_recv_cap > x->release_above)) kct_rccl_release_buffers(x);
     return rc;
 }
+
+// The merge's pair buffers are kept between merges (no hipMalloc / hipFree per job) -- after a big table's merge that is tens of GB of
+// HBM held for the life of the communicator.  This gives them back; kct_rccl_release_above(x, bytes) makes every merge do so by itself
+// when a buffer has grown beyond `bytes` (default 4 GiB; 0 = keep everything).
+void kct_rccl_release_buffers(kct_rccl *x) {
+    if (!x) return;
+    (void)hipSetDevice(x->device);
+    if (x->stream) (void)hipStreamSynchronize(x->stream);
+    if (x->m_send) { (void)hipFree(x->m_send); x->m_send = nullptr; x->m_send_cap = 0; }
+    if (x->m_recv) { (void)hipFree(x->m_recv); x->m_recv = nullptr; x->m_recv_cap = 0; }
+}
+void kct_rccl_release_above(kct_rccl *x, uint64_t bytes) { if (x) x->release_above = bytes; }
 
 void kct_rccl_merge_when_alone(kct_rccl *x, int on) { if (x) x->merge_when_alone = on != 0; }
 

@@ -47,8 +47,16 @@ struct Route {
     int nwg;
     double wait_ms = 0;
 
+    // kct_debug_inject_fault: is the armed fault this point (of this pass)?  One shot.
+    bool fault(int point, u64 pass = 0) {
+        if (t->fault_point != point) return false;
+        if ((point == KCT_FAULT_SPLIT || point == KCT_FAULT_START || point == KCT_FAULT_WAIT) && t->fault_pass != pass) return false;
+        t->fault_point = KCT_FAULT_NONE;
+        return true;
+    }
     kct_status slab(Slab &s, DevBuf &own, u64 bytes) {
         bytes = std::max<u64>(bytes, 256) + 64;   // (K1 reads up to two words past a window's last base)
+        if (fault(KCT_FAULT_ALLOC)) { set_err("injected fault: no buffer of %llu bytes", (unsigned long long)bytes); return KCT_ERR_NOMEM; }
         if (bytes <= s.cap) return KCT_OK;
         if (!ops) {
             KCT_TRY(own.reserve(bytes + bytes / 8));
@@ -241,9 +249,13 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     // ---- passes: as many as the tightest rank needs (HBM: regions, two send and two receive slabs, the owner's scratch), at least
     // four (eight with more than four ranks) for a long stream so that the wire hides behind the kernels
     const u64 windows = nbytes >= (u64)k ? nbytes - k + 1 : 0;
+    // A failure of THIS rank from here on is kept in `status` and travels in its messages: the rank stays in step with its peers, every
+    // rank learns of it in the same collective and every rank ends the call there -- no return between the first collective and the last.
+    kct_status status = KCT_OK;
+    if (r.fault(KCT_FAULT_MEMINFO)) { set_err("injected fault: the HBM query before the first collective"); status = KCT_ERR_HIP; max_windows = 1ULL << 24; }
     if (!max_windows) {
         size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { set_err("hipMemGetInfo failed at the start of the early route"); status = KCT_ERR_HIP; free_b = 0; (void)hipGetLastError(); }
         const double held = (double)(t->d_scratch.cap + t->d_scratch2.cap + t->d_sk_bases.cap + t->d_sk_starts.cap);
         const double per_window = 6.0 * bases_per_window(k) / 4.0 + 24.0;
         max_windows = (u64)std::max(1.0 * (1 << 24), 0.6 * ((double)free_b + held) / per_window);
@@ -251,17 +263,22 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
         if (windows >= (1ULL << 28)) max_windows = std::min<u64>(max_windows, std::max<u64>(1ULL << 26, windows / (world > 4 ? 8 : 4)));
     }
     max_windows = std::max<u64>(1 << 16, max_windows & ~0xFFFFULL);
-    std::vector<u64> sz(world * 2), rz;
+    std::vector<u64> sz(world * 3), rz;
     // (the first round also carries every rank's stream count: the per-pass size messages and the stream directories are laid out by it,
-    // so ranks with different CU counts -- mixed SKUs, partition modes, CU masks -- must not go on)
-    for (unsigned p = 0; p < world; ++p) { sz[2 * p] = (u64)r.nwg; sz[2 * p + 1] = windows ? (windows + max_windows - 1) / max_windows : 1; }
-    KCT_TRY(r.sizes(sz, 2, rz));   // (the first collective: if IT fails there is nothing to agree through)
+    // so ranks with different CU counts -- mixed SKUs, partition modes, CU masks -- must not go on; and every rank's status so far)
+    for (unsigned p = 0; p < world; ++p) { sz[3 * p] = (u64)r.nwg; sz[3 * p + 1] = windows ? (windows + max_windows - 1) / max_windows : 1; sz[3 * p + 2] = (u64)status; }
+    KCT_TRY(r.sizes(sz, 3, rz));   // (the first collective: if IT fails there is nothing to agree through)
     u64 passes = 1;
-    for (unsigned p = 0; p < world; ++p) passes = std::max(passes, rz[2 * p + 1]);
-    // every rank reads the same rz columns, so these two verdicts fall alike everywhere
+    for (unsigned p = 0; p < world; ++p) passes = std::max(passes, rz[3 * p + 1]);
+    // every rank reads the same rz columns, so these three verdicts fall alike everywhere
+    for (unsigned p = 0; p < world; ++p)
+        if (rz[3 * p + 2] != 0) {
+            if (status == KCT_OK) set_err("the early route failed on rank %u (status %llu) before its first pass", p, (unsigned long long)rz[3 * p + 2]);
+            return status != KCT_OK ? status : KCT_ERR_HIP;
+        }
     if (passes > (1u << 20)) { set_err("a rank asked for %llu passes", (unsigned long long)passes); return KCT_ERR_ARG; }
     for (unsigned p = 0; p < world; ++p)
-        if (rz[2 * p] != rz[0]) { set_err("ranks disagree on the number of super-k-mer streams (%llu on rank 0, %llu on rank %u): the early route needs GPUs with the same CU count", (unsigned long long)rz[0], (unsigned long long)rz[2 * p], p); return KCT_ERR_ARG; }
+        if (rz[3 * p] != rz[0]) { set_err("ranks disagree on the number of super-k-mer streams (%llu on rank 0, %llu on rank %u): the early route needs GPUs with the same CU count", (unsigned long long)rz[0], (unsigned long long)rz[3 * p], p); return KCT_ERR_ARG; }
     const u64 step = windows ? (((windows + passes - 1) / passes) + 0xFFFF) & ~0xFFFFULL : 0;  // window starts per pass (16-byte aligned cuts)
     auto pass_range = [&](u64 p, u64 *off, u64 *len) {
         *off = std::min(p * step, nbytes);
@@ -278,10 +295,9 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     for (int b = 0; b < 2; ++b) { po[b].part_off.assign(world, 0); po[b].part_bytes.assign(world, 0); po[b].dir.assign((size_t)r.nwg * world, 0); }
     u64 st_windows_out = 0, st_windows_in = 0, st_bytes_out = 0, st_bytes_in = 0, st_runs = 0, st_retries = 0, st_counts = 0;
     double split_ms = 0, owner_ms = 0;
-    // From here on the ranks are inside a protocol of collectives: NO early return.  A local failure is kept in `status` -- the rank stays
-    // in step, announces it in its next size message (or the final agree()) and every rank ends the call with an error; the exchange's
-    // slabs are released on every way out.
-    kct_status status = KCT_OK;
+    // From here on the ranks are inside a protocol of per-pass collectives: NO early return.  A local failure is kept in `status` -- the
+    // rank stays in step, announces it in its next size message (or the final agree()) and every rank ends the call with an error; the
+    // exchange's slabs are released on every way out.
     // the inbox: room for the whole call where HBM allows (what arrives is about what leaves), at most 30 GiB (the directory's offsets)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { set_err("hipMemGetInfo failed inside the early route"); status = KCT_ERR_HIP; free_b = 0; }
@@ -294,6 +310,7 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
     auto count_inbox = [&](u64 more, bool keep_room = false) {
         const double t0 = now_ms();
         u64 n = 0;
+        if (status == KCT_OK && r.fault(KCT_FAULT_COUNT)) { set_err("injected fault: the owner-side count"); status = KCT_ERR_HIP; }
         if (status == KCT_OK) { status = inbox_count(r, inbox, more, &n, keep_room); ++st_counts; }
         else { inbox.streams.clear(); inbox.groups = inbox.windows = 0; if (!keep_room) inbox.used = Inbox::kFront; }
         owner_ms += now_ms() - t0;
@@ -306,6 +323,7 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
         u64 off, len;
         pass_range(p, &off, &len);
         const double t0 = now_ms();
+        if (status == KCT_OK && r.fault(KCT_FAULT_SPLIT, p)) { set_err("injected fault: the split of pass %llu", (unsigned long long)p); status = KCT_ERR_HIP; }
         if (status == KCT_OK) status = split_pass(r, d_stream + off, len, send[b], b ? t->d_sk_recv : t->d_sk_send, po[b]);
         split_ms += now_ms() - t0;
         if (status != KCT_OK) { po[b].part_off.assign(world, 0); po[b].part_bytes.assign(world, 0); po[b].dir.assign((size_t)r.nwg * world, 0); }
@@ -356,10 +374,15 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
                 }
             return KCT_OK;
         }
-        if (ops->start(ops->user, send[b].p, po[b].part_off.data(), po[b].part_bytes.data(), dst, recv_off[b].data(), recv_bytes[b].data()) != 0) {
-            // A start() that fails on THIS rank only: the rank must not walk away -- its peers would sit in the next collective for ever.
-            // It stays in step (wait() has nothing to wait for), announces the failure in the next size message or the final agree(),
-            // and the call then ends on every rank.
+        // A start() that reports a failure on THIS rank only: the rank does not walk away -- it stays in step, announces the failure in the
+        // next size message or the final agree(), and the call then ends on every rank.  That holds for a start() which has made its
+        // part of the collective before it reports (a failed copy behind it, a bookkeeping error: what the injected fault stands for); an
+        // implementation that fails BEFORE joining a blocking collective leaves its peers inside that collective, which no protocol
+        // above it can undo -- such a failure is fatal to the communicator (csrc/kct_rccl.cpp aborts it) and the launcher's hang guard
+        // (bench.py --job-timeout) is what ends the peers.
+        int start_rc = ops->start(ops->user, send[b].p, po[b].part_off.data(), po[b].part_bytes.data(), dst, recv_off[b].data(), recv_bytes[b].data());
+        if (start_rc == 0 && r.fault(KCT_FAULT_START, p)) start_rc = -1;
+        if (start_rc != 0) {
             set_err("the exchange failed to start pass %llu", (unsigned long long)p);
             if (status == KCT_OK) status = KCT_ERR_HIP;
         }
@@ -373,7 +396,9 @@ kct_status consume_routed(kct_table *t, const unsigned char *d_stream, u64 nbyte
         if (p + 1 < passes) cut(p + 1);
         if (ops) {
             const double t0 = now_ms();
-            if (ops->wait(ops->user) != 0 && status == KCT_OK) { set_err("the exchange failed"); status = KCT_ERR_HIP; }
+            int wait_rc = ops->wait(ops->user);
+            if (wait_rc == 0 && r.fault(KCT_FAULT_WAIT, p)) wait_rc = -1;
+            if (wait_rc != 0 && status == KCT_OK) { set_err("the exchange of pass %llu failed", (unsigned long long)p); status = KCT_ERR_HIP; }
             r.wait_ms += now_ms() - t0;
         }
         if (status == KCT_OK) status = inbox_add(r, inbox, recv_base[b], recv_off[b], recv_bytes[b], dirs[b]);
@@ -450,3 +475,10 @@ extern "C" kct_status kct_superkmer_split_device(kct_table *t, const void *d_str
 }
 
 extern "C" uint32_t kct_superkmer_streams(const kct_table *t) { return t ? (uint32_t)split_streams(t) : 0; }
+
+extern "C" kct_status kct_debug_inject_fault(kct_table *t, int point, uint64_t pass) {
+    KCT_BORROW(t);
+    if (point < KCT_FAULT_NONE || point > KCT_FAULT_COUNT) { set_err("unknown fault point %d", point); return KCT_ERR_ARG; }
+    t->fault_point = point; t->fault_pass = pass;
+    return KCT_OK;
+}

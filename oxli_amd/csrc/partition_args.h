@@ -72,6 +72,8 @@ struct PartitionArgs {
     // 2-bit bases with no separators, one start bit per window.  K1's RUNS instantiations walk the WINDOWS (64 per group), not
     // byte positions: `stream` / `nbytes` then only say how many (nbytes - k + 1 = 64 * groups of this launch).
     RunsInput runs;
+    // -DKCT_K1_STAMPS builds only (tools/k1_stamps.sh): [nwg][16 waves][kStampSlots] shader-clock cycles per phase of K1, summed per wave
+    u64 *stamps = nullptr;
 };
 
 struct RepartitionArgs {

@@ -404,6 +404,7 @@ def consume_device_early(table, data_ptr, nbytes, consumed_bytes, group=None, ma
     rank = dist.get_rank(group)
     dev = torch.device("cuda", torch.cuda.current_device())
     ex = _Exchanger(group, dev) if world > 1 or exchange_when_alone else None
+    consume_device_early.last_exchanger = ex   # (tests look at what it still holds after a failed call)
     st = table._lib.kct_consume_device_routed(table._h, C.c_void_p(int(data_ptr)), int(nbytes), int(consumed_bytes), world, rank,
                                               ex.ptr if ex else None, int(max_windows), C.byref(n), stats)
     if ex is not None and ex.error is not None:

@@ -48,6 +48,9 @@ def main():
     genome = oracle.synth_genome(G, 42)
     reads = oracle.synth_reads(genome, rank * per_rank, per_rank, L, 1337)
     dev_reads = torch.from_numpy(reads.reshape(-1)).cuda()
+    if route.startswith("fault"):
+        faults(k, per_rank, G, L, rank, world, dev_reads)
+        route = "early:auto"     # ... and then a clean job through the same processes and process group
     if route.startswith("early"):
         early(route.split(":")[1], k, per_rank, G, L, rank, world, genome, reads, dev_reads)
         return
@@ -174,6 +177,48 @@ def late_store_kmers(k, per_rank, L, rank, world, reads):
     assert global_scalar_sum(t.sum_counts, DEV) == world * per_rank * (L - k + 1)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def faults(k, per_rank, G, L, rank, world, dev_reads):
+    """include/kct.h's promise for the early route -- "a failure on any rank ends the call on EVERY rank with an error" -- under injected
+    faults (kct_debug_inject_fault): one rank fails at one point of the protocol (the HBM query before the first collective, the split of
+    pass 1, a slab allocation, the start / the wait of a payload, the owner-side count); every rank must come back from THAT call with
+    an error within 30 s, none left inside a collective, the exchange's slabs released.  The next scenario (and the clean job that
+    follows, checked against the oracle) runs through the same process group: a rank that had been left behind would hang it."""
+    import time
+
+    from oxli_amd import KmerCountTable, _lib
+    from oxli_amd.distributed import consume_device_early
+
+    lib = _lib.load()
+    MEMINFO, SPLIT, ALLOC, START, WAIT, COUNT = 1, 2, 3, 4, 5, 6
+    scenarios = [(SPLIT, 1, 2 % world), (MEMINFO, 0, 1 % world), (ALLOC, 0, 0), (START, 1, 3 % world), (WAIT, 2, 1 % world), (COUNT, 0, 2 % world), (START, 0, 0)]
+    for point, pas, bad in scenarios:
+        t = KmerCountTable(k, capacity=max(G // world, 400_000))
+        if rank == bad:
+            assert lib.kct_debug_inject_fault(t._h, point, pas) == 0
+        dist.barrier()
+        t0 = time.perf_counter()
+        failed, text = False, ""
+        try:
+            consume_device_early(t, dev_reads.data_ptr(), dev_reads.numel(), per_rank * L, max_windows=1 << 22)
+        except (RuntimeError, MemoryError) as e:
+            failed, text = True, str(e)
+        dt = time.perf_counter() - t0
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, (failed, round(dt, 2), text[:160]))
+        assert all(v[0] for v in verdicts), f"fault {point} at pass {pas} on rank {bad}: not every rank returned an error: {verdicts}"
+        assert max(v[1] for v in verdicts) < 30.0, verdicts
+        if rank != bad:
+            assert f"rank {bad}" in text, (point, pas, bad, text)     # the peers are told WHO failed
+        else:
+            assert "injected fault" in text or "failed to start" in text or "exchange of pass" in text, text
+        ex = consume_device_early.last_exchanger
+        assert ex is not None and len(ex.keep) == 0, f"{len(ex.keep)} exchange slabs still held after the failed call"
+        t.clear()
+        del t
+    if rank == 0:
+        print(f"FAULTS_OK world={world} scenarios={len(scenarios)}")
 
 
 def early(path, k, per_rank, G, L, rank, world, genome, reads, dev_reads):

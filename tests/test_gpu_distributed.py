@@ -49,6 +49,18 @@ def test_ranks_sharing_one_gpu_early_route_equals_the_oracle_table(world, k, per
     assert f"DIST_GPU_OK world={world}" in out.stdout and f"route=early:{path}" in out.stdout, out.stdout[-2000:]
 
 
+def test_a_failing_rank_ends_the_early_route_on_every_rank():
+    """Fault injection (kct_debug_inject_fault): 4 ranks sharing the GPU over gloo, ONE rank fails at one point of the early route's
+    protocol -- seven scenarios, among them rank 2 at the split of pass 1 -- and every rank must return an error from that call within
+    30 s with its slabs released; a clean job through the same processes then equals the oracle (dist_gpu_worker.py::faults)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "21", "150000", "2000000", "fault", "150"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-6000:]
+    assert "FAULTS_OK world=4 scenarios=7" in out.stdout and "DIST_GPU_OK world=4" in out.stdout, out.stdout[-2000:]
+
+
 def test_store_kmers_tables_merge_with_their_k_mer_maps():
     """The late route with store_kmers tables (lib.rs:810-828: add() merges hash_to_kmer): after merge_across_ranks every rank can
     unhash exactly the keys it owns, with the global counts."""
