@@ -755,15 +755,16 @@ def main():
             variants = {}
             for vname, make in (("one_thread", lambda: np.ascontiguousarray(src2d).reshape(-1)), ("spread", first_touch_spread)):
                 flat = make()
-                stage = []
+                stage, tls = [], []
 
                 def batch_job():
                     t0_ = time.perf_counter()
                     n_ = table.consume_batch((flat, offsets))
                     stage.append(time.perf_counter() - t0_)     # the call itself: pack + H2D + passes submitted (and mostly run)
+                    tls.append(table.batch_timeline())          # where inside the call (kct_batch_timeline)
                     return n_
                 timed_call(table, batch_job, False)
-                stage.clear()
+                stage.clear(); tls.clear()
                 runs = [timed_call(table, batch_job, False) for _ in range(7)]
                 order = sorted(range(len(runs)), key=lambda i: runs[i][0])
                 mid = order[len(order) // 2]
@@ -773,17 +774,22 @@ def main():
                 variants[vname] = {"kmers_per_s": kmers_per_step / dt, "seconds": dt, "seconds_min_max": [runs[order[0]][0], runs[order[-1]][0]],
                                    "call_ms": stage[mid] * 1e3, "sync_after_ms": (dt - stage[mid]) * 1e3, "kernels_ms_total": rep["kernel_ms_total"],
                                    "host_side_ms": stage[mid] * 1e3 - rep["kernel_ms_total"],
-                                   "source_GB_per_s_over_the_call": R * L / stage[mid] / 1e9, "ok": bool(ok), "rep": rep}
+                                   "source_GB_per_s_over_the_call": R * L / stage[mid] / 1e9, "ok": bool(ok), "rep": rep,
+                                   "timeline": {kk: round(vv, 3) for kk, vv in tls[mid].items()},
+                                   "packers_GB_per_s": round(tls[mid]["source_bytes"] / max(1e-9, (tls[mid]["last_packer_end_ms"] - tls[mid]["first_packer_start_ms"]) * 1e-3) / 1e9, 1),
+                                   "packer_GB_per_s_per_thread": round(tls[mid]["source_bytes"] / max(1e-9, tls[mid]["threads_busy_ms_sum"] * 1e-3) / 1e9, 2)}
                 del flat
             best = max(variants, key=lambda v_: variants[v_]["kmers_per_s"])
             v1 = variants["one_thread"]
             configs["e2e_C2"] = {"kmers_per_s": v1["kmers_per_s"], "seconds": v1["seconds"], "runs": 7,
-                                 "what": "kct_consume_batch from pageable host memory: 16 pool threads SIMD-pack the records to 0.375 B/base into pinned staging, "
+                                 "what": "kct_consume_batch from pageable host memory: 32 pool threads SIMD-pack the records to 0.375 B/base into pinned staging, "
                                          "H2D, count + conversion; `kmers_per_s` = the source array first-touched by one thread (as before); variants: see bench.py",
                                  "variants": {vn: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v_.items() if kk not in ("rep", "ok")} for vn, v_ in variants.items()},
                                  "best_variant": best, "kmers_per_s_best_variant": variants[best]["kmers_per_s"],
                                  "timeline": "call_ms = pack + H2D + kernels submitted; host_side_ms = call_ms - device kernel time: what the packers and PCIe cost; "
-                                             "source_GB_per_s_over_the_call = 150 MB / call_ms (the packers' read rate is at least this)",
+                                             "source_GB_per_s_over_the_call = 150 MB / call_ms; variants.*.timeline = kct_batch_timeline of the median call (ms since the "
+                                             "call began: argument checks, parts cut, first packer start, last packer end, last H2D enqueued, passes submitted; threads, their "
+                                             "busy time, bytes, minor faults, CPUs / NUMA nodes the packers ran on)",
                                  "gate": {"n_and_sum_counts": bool(all(v_["ok"] for v_ in variants.values()))}, **v1["rep"]}
             assert ablate or configs["e2e_C2"]["gate"]["n_and_sum_counts"]
         if any(f_ in want for f_ in FILES):

@@ -139,6 +139,16 @@ KCT_API kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint
  * slot have gathered or the staging buffer (<= 32 GiB, a quarter of the free HBM) is full -- so that an input fed in pieces is
  * counted in the passes, and on the path, of ONE large call; *n_total then comes from the copy kernel's own validity scan (the
  * all-ACGT rule of lib.rs:586-600; it differs from the reference's n only if a window's true hash is 0, probability 2^-64). */
+/* Where the last kct_consume_batch call of this table spent its time (a large skip_bad batch through the host packer; not in the
+ * reference): out[0..15], milliseconds since the call began unless said otherwise --
+ *   0 argument checks done             1 parts cut, staging reserved        2 first packer thread started its first part
+ *   3 last packer thread finished      4 last slice's H2D copy enqueued     5 the device pass(es) submitted: the call returns
+ *   6 packer threads used              7 sum of the threads' busy times     8 longest single thread's busy time
+ *   9 source bytes read                10 packed bytes uploaded             11 minor page faults during the call (getrusage)
+ *   12 distinct CPUs the packers ran on  13 distinct NUMA nodes of those CPUs  14 the calling thread's CPU  15 1 = packers pinned
+ * All zero when the last batch did not take the packed-upload route. */
+KCT_API kct_status kct_batch_timeline(kct_table *t, double *out16);
+
 KCT_API kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes,
                               uint64_t *n_total);
 

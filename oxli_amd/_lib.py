@@ -44,6 +44,7 @@ SIGNATURES = {
     "kct_consume_will_defer": (ci, [vp, sz, ci]),
     "kct_consume_batch": (ci, [vp, vp, vp, sz, ci, u64p, u64p, u64p]),
     "kct_consume_device": (ci, [vp, vp, sz, u64, u64p]),
+    "kct_batch_timeline": (ci, [vp, C.POINTER(C.c_double)]),
     "kct_consume_device_packed": (ci, [vp, vp, vp, sz, u64, u64p]),
     "kct_pack_stream_device": (ci, [vp, sz, vp, vp, vp]),
     "kct_set_packed_upload": (ci, [vp, ci]),

@@ -139,7 +139,22 @@ void launch_partition(kct_table *t, int mode, const unsigned char *d_stream, u64
                     if (wt) { wmin = std::min(wmin, wt); wmax = std::max(wmax, wt); }
                     tot += wt;
                 }
-                if (const char *path = getenv("KCT_K1_STAMPS_OUT"))
+                if (t->tune.k1_flushers > 0 && getenv("KCT_K1_STAMPS_OUT")) {   // the wave-specialised K1 writes raw per-wave figures (k1ws_kernel.h)
+                    if (FILE *f = fopen(getenv("KCT_K1_STAMPS_OUT"), "a")) {
+                        const int F = t->tune.k1_flushers, W = kct::kPartThreads / 64;
+                        double hs[2] = {0, 0}, fs[7] = {0, 0, 0, 0, 0, 0, 0};
+                        for (size_t w = 0; w < n / kct::kStampSlots; ++w) {
+                            const u64 *o = &h[w * kct::kStampSlots];
+                            if ((int)(w % W) < F) for (int i = 0; i < 7; ++i) fs[i] += (double)o[i];
+                            else { hs[0] += (double)o[0]; hs[1] += (double)o[1]; }
+                        }
+                        const double nf = (double)(n / kct::kStampSlots / W * F), nh = (double)(n / kct::kStampSlots / W * (W - F));
+                        fprintf(f, "{\"ws\": 1, \"mode\": %d, \"k\": %d, \"tiles\": %llu, \"hash_wave_cycles\": %.0f, \"pieces_per_hash_wave\": %.1f, \"flusher_cycles\": %.0f, \"sweeps\": %.1f, "
+                                   "\"lines_per_sweep\": %.2f, \"grace_share\": %.3f, \"list_cycles_per_sweep\": %.0f, \"move_cycles_per_sweep\": %.0f}\n", mode, (int)t->k, (unsigned long long)ntiles,
+                                hs[0] / nh, hs[1] / nh, fs[0] / nf, fs[1] / nf, fs[1] ? fs[2] / fs[1] : 0.0, fs[1] ? fs[3] / fs[1] : 0.0, fs[1] ? fs[4] / fs[1] : 0.0, fs[1] ? fs[5] / fs[1] : 0.0);
+                        fclose(f);
+                    }
+                } else if (const char *path = getenv("KCT_K1_STAMPS_OUT"))
                     if (FILE *f = fopen(path, "a")) {
                         fprintf(f, "{\"mode\": %d, \"k\": %d, \"tiles\": %llu, \"waves\": %zu, \"wave_cycles_min\": %llu, \"wave_cycles_max\": %llu, \"share\": {", mode, (int)t->k,
                                 (unsigned long long)ntiles, n / kct::kStampSlots, (unsigned long long)wmin, (unsigned long long)wmax);
@@ -154,6 +169,7 @@ void launch_partition(kct_table *t, int mode, const unsigned char *d_stream, u64
 #else
     const kct::PartitionArgs &pa_ = pa;
 #endif
+    if (mode != 3 && launch_partition_ws(t, mode, d_stream, chunk_bytes, ntiles, pa_)) return;   // the wave-specialised K1 (kct_k1ws.hip)
     if (pa_.pcodes && launch_partition_packed(t, mode, chunk_bytes, ntiles, pa_)) return;
     if (mode == 2) PartitionCompactByK<21>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa_);
     else if (mode == 1) PartitionRawByK<32>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa_);

@@ -53,7 +53,56 @@ WorkerPool &WorkerPool::instance() {
     return *pool;
 }
 
+// The CPUs of every NUMA node that this process may run on (/sys/devices/system/node/nodeN/cpulist); empty = one node, or unknown.
+static std::vector<cpu_set_t> numa_cpu_sets() {
+    std::vector<cpu_set_t> out;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
+    for (int nd = 0; nd < 64; ++nd) {
+        char path[96];
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", nd);
+        FILE *f = fopen(path, "r");
+        if (!f) break;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        char buf[4096];
+        if (fgets(buf, sizeof buf, f)) {
+            for (char *q = buf; *q && *q != '\n';) {   // "0-63,128-191"
+                char *e;
+                const long a_ = strtol(q, &e, 10);
+                if (e == q) break;
+                long b_ = a_;
+                if (*e == '-') { q = e + 1; b_ = strtol(q, &e, 10); }
+                for (long x = a_; x <= b_ && x < CPU_SETSIZE; ++x) if (x >= 0 && CPU_ISSET(x, &allowed)) CPU_SET(x, &set);
+                if (*e != ',') break;
+                q = e + 1;
+            }
+        }
+        fclose(f);
+        if (CPU_COUNT(&set) > 0) out.push_back(set);
+    }
+    if (out.size() < 2) out.clear();
+    return out;
+}
+
+int WorkerPool::nodes() const { return node_sets_.empty() ? 1 : (int)node_sets_.size(); }
+
+int WorkerPool::nodes_hint() {
+    std::unique_lock<std::mutex> lk(m_);
+    if (pid_ != (int)getpid() && !topo_read_) {   // (start() reads it again for a forked child)
+        const char *pin = getenv("KCT_PACK_PIN");
+        if (pin && atoi(pin) != 0) node_sets_ = numa_cpu_sets();
+        topo_read_ = true;
+    }
+    return node_sets_.empty() ? 1 : (int)node_sets_.size();
+}
+
 void WorkerPool::worker(size_t id) {
+    // KCT_PACK_PIN=1 (a measurement switch): worker i lives on NUMA node i % nodes (any CPU of it), and kct_consume_batch hands each node's
+    // share of a batch (move_pages in query mode) to that node's workers.  Round 6 measured it on the two-socket EPYC 9575F test boxes:
+    // 3.2-3.8 ms per C2 batch against 2.5-2.8 ms with the scheduler's own placement (tools/e2e_diag.py) -- so it is off by default.
+    if (!node_sets_.empty()) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &node_sets_[id % node_sets_.size()]);
     size_t seen = 0;
     std::unique_lock<std::mutex> lk(m_);
     for (;;) {
@@ -76,6 +125,11 @@ void WorkerPool::start(size_t n, std::function<void(size_t)> fn) {
         (void)gone;
         threads_.clear();
         pid_ = (int)getpid();
+        const char *pin = getenv("KCT_PACK_PIN");   // 1: bind the workers to NUMA nodes (measured SLOWER than the scheduler's placement on the two-socket test boxes: off by default)
+        pin_ = pin && atoi(pin) != 0;
+        node_sets_.clear();
+        if (pin_) node_sets_ = numa_cpu_sets();
+        pin_ = !node_sets_.empty();
     }
     fn_ = std::move(fn);
     want_ = n;
@@ -396,6 +450,7 @@ kct_status kct_create(uint8_t ksize, uint64_t capacity_hint, int device, kct_tab
     if (const char *e = getenv("KCT_SUB_CHUNKS")) t->tune.sub_chunks = std::max(1, std::min(15, atoi(e)));
 #endif
     if (const char *e = getenv("KCT_PACK_THREADS")) t->tune.pack_threads = std::max(1, atoi(e));
+    if (const char *e = getenv("KCT_K1_FLUSHERS")) { const int f = atoi(e); t->tune.k1_flushers = f == 2 || f == 4 ? f : 0; }
     t->ablate = t->tune.ablate;
     t->debug = getenv("KCT_DEBUG") != nullptr;
     if (hipStreamSynchronize(t->stream) != hipSuccess) { set_err("stream sync failed"); return fail(KCT_ERR_HIP); }

@@ -3,6 +3,10 @@
 #include "kct_internal.h"
 
 #include <emmintrin.h>
+#include <sched.h>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include "window_kernels.h"
 #include "stream_kernels.h"
 
@@ -90,7 +94,20 @@ __attribute__((target("avx2"))) static void encode_run_avx2(const unsigned char 
         valid[g] = (unsigned short)(rv >> 16);
         valid[g + 1] = (unsigned short)rv;
     }
-    for (; g < ngroups; ++g) encode16_scalar(p + 16 * g, codes + g, valid + g);
+    // the odd group at the end: the same arithmetic on one 128-bit lane.  (Until round 6 it went through encode16_scalar -- and so did every
+    // one-group call for the group that straddles a record boundary: two scalar groups per 150 bp read, more time than the read's
+    // other eight groups together.  kct_batch_timeline put the packers at 2.9-3.4 GB/s per thread.)
+    for (; g < ngroups; ++g) {
+        const __m128i v = _mm_loadu_si128((const __m128i *)(p + 16 * g)), up = _mm_or_si128(v, _mm256_castsi256_si128(lower));
+        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(up, _mm256_castsi256_si128(ca)), _mm_cmpeq_epi8(up, _mm256_castsi256_si128(cc))),
+                                        _mm_or_si128(_mm_cmpeq_epi8(up, _mm256_castsi256_si128(cg)), _mm_cmpeq_epi8(up, _mm256_castsi256_si128(ct))));
+        __m128i x = _mm_and_si128(_mm_srli_epi16(v, 1), _mm256_castsi256_si128(three));
+        x = _mm_xor_si128(x, _mm_and_si128(_mm_srli_epi16(x, 1), _mm256_castsi256_si128(one)));
+        x = _mm_and_si128(x, ok);
+        const __m128i sh = _mm_shuffle_epi8(_mm_madd_epi16(_mm_maddubs_epi16(x, _mm256_castsi256_si128(m2)), _mm256_castsi256_si128(m4)), _mm256_castsi256_si128(pick));
+        codes[g] = (unsigned int)_mm_cvtsi128_si32(sh);
+        valid[g] = (unsigned short)(__builtin_bitreverse32((unsigned int)_mm_movemask_epi8(ok)) >> 16);
+    }
 }
 static void encode_groups(const unsigned char *p, size_t ngroups, unsigned int *codes, unsigned short *valid) {
     static const int level = __builtin_cpu_supports("avx2") ? 2 : __builtin_cpu_supports("ssse3") ? 1 : 0;
@@ -315,7 +332,11 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
     *n_total = 0;
     if (bad_record) *bad_record = nrec;
     if (bad_position) *bad_position = 0;
+    for (double &v : t->batch_tl) v = 0;
     if (nrec == 0) return KCT_OK;
+    const double tl0 = now_ms();
+    struct rusage ru0;
+    getrusage(RUSAGE_SELF, &ru0);
     const u64 total = offsets[nrec] - offsets[0];
     const u64 stream_len = total + nrec;  // one '\n' after every record
     const size_t padded = (stream_len + 15) & ~(size_t)15;
@@ -326,9 +347,24 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
     u64 *rec_off = (u64 *)(dst + padded + 16);  // 16-aligned since padded is
     // Pack the records into the record stream: record r lands at (offsets[r] - offsets[0]) + r, one
     // separator behind it.  Positions are known up front, so large batches are packed by several threads.
-    for (size_t r = 0; r < nrec; ++r)
-        if (offsets[r + 1] < offsets[r]) { set_err("offsets must be non-decreasing"); return KCT_ERR_ARG; }
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t max_threads = (size_t)t->tune.pack_threads;
+    // (pack_threads PER NUMA NODE the pool's workers are bound to: a batch that lies on one node is packed by that node's workers)
+    const size_t pool_nodes = (size_t)WorkerPool::instance().nodes_hint();
+    const size_t nthreads = stream_len >= (8u << 20) ? std::min<size_t>({max_threads * pool_nodes, hw ? hw : 1, nrec}) : 1;
+    {
+        // (8 MB of offsets for a million records: 0.2 ms on one thread, cold -- a twentieth of the call; the pool does it in ~20 us)
+        std::atomic<int> bad{0};
+        auto check = [&](size_t r0, size_t r1) { for (size_t r = r0; r < r1; ++r) if (offsets[r + 1] < offsets[r]) { bad.store(1, std::memory_order_relaxed); break; } };
+        if (nthreads > 1) {
+            WorkerPool &pool = WorkerPool::instance();
+            pool.start(nthreads, [&](size_t tid) { check(nrec * tid / nthreads, nrec * (tid + 1) / nthreads); });
+            pool.wait();
+        } else check(0, nrec);
+        if (bad.load()) { set_err("offsets must be non-decreasing"); return KCT_ERR_ARG; }
+    }
     const u64 base0 = offsets[0];
+    const double tl_checked = now_ms() - tl0;
     auto pack_range = [&](size_t r0, size_t r1) {
         for (size_t r = r0; r < r1; ++r) {
             const u64 n = offsets[r + 1] - offsets[r], w = (offsets[r] - base0) + r;
@@ -338,9 +374,6 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
         }
     };
     KCT_TRY(t->d_stream.reserve(padded + 16));
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t max_threads = (size_t)t->tune.pack_threads;
-    const size_t nthreads = stream_len >= (8u << 20) ? std::min<size_t>({max_threads, hw ? hw : 1, nrec}) : 1;
     if (skip_bad && t->packed_upload && t->k <= 64 && nthreads > 1) {
         // PACKED upload: every part of the batch starts on a 16-base boundary of the stream (extra separator bytes in front of
         // it -- any number of invalid bases may sit between two records), so the packers can encode their parts independently:
@@ -366,17 +399,46 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
         unsigned short *h_valid = (unsigned short *)((char *)t->h_stage.p + valid_off);
         std::vector<std::atomic<int>> packed(nslices);
         for (auto &r : packed) r.store(0, std::memory_order_relaxed);
-        std::atomic<size_t> next_item{0};
+        // KCT_PACK_PIN=1 (measurement switch, kct_core.hip): the parts are listed per NUMA node of their source (move_pages in query
+        // mode, one page per part) and a worker takes from its own node's list first.  Off (one node, one list) by default.
+        const size_t nn = std::max<size_t>(1, pool_nodes);
+        std::vector<std::vector<unsigned int>> lists(nn);
+        {
+            std::vector<int> status(nitems, -1);
+            if (nn > 1) {
+                std::vector<void *> pages(nitems);
+                const long psz = sysconf(_SC_PAGESIZE);
+                for (size_t i = 0; i < nitems; ++i) pages[i] = (void *)((uintptr_t)(bytes + offsets[std::min(cut[i], nrec - 1)]) & ~(uintptr_t)(psz - 1));
+                if (syscall(SYS_move_pages, 0, (unsigned long)nitems, pages.data(), nullptr, status.data(), 0) != 0) std::fill(status.begin(), status.end(), -1);
+            }
+            for (size_t i = 0; i < nitems; ++i) lists[status[i] >= 0 && (size_t)status[i] < nn ? (size_t)status[i] : i % nn].push_back((unsigned int)i);
+        }
+        std::vector<std::atomic<size_t>> next_of(nn);
+        for (auto &a_ : next_of) a_.store(0, std::memory_order_relaxed);
+        // kct_batch_timeline: per packer thread its first start, last end, busy time and the CPU it ran on
+        struct ThreadLine { double first = 1e300, last = 0, busy = 0; int cpu = -1; char pad[36]; };
+        std::vector<ThreadLine> lines(nthreads);
+        const double tl_cut = now_ms() - tl0;
         WorkerPool &pool = WorkerPool::instance();
-        pool.start(nthreads, [&](size_t) {
+        pool.start(nthreads, [&](size_t tid) {
+            ThreadLine &ln = lines[tid];
+            ln.cpu = sched_getcpu();
             // A record's groups are encoded STRAIGHT from the caller's memory wherever sixteen stream bytes lie inside one record (nine of
             // ten groups of a 150 bp read); only the group across a record boundary -- the record's tail, its separator, the next record's
             // head -- is assembled in a 16-byte carry.  (Until round 5 every byte went through a 4 KiB line buffer first: a second pass over
             // the data, and one call per group into the SIMD encoder.)
             unsigned char carry[16];
             for (;;) {
-                const size_t it = next_item.fetch_add(1, std::memory_order_relaxed);
+                size_t it = nitems;
+                for (size_t d = 0; d < nn && it == nitems; ++d) {   // this worker's node first (worker i lives on node i % nn)
+                    const size_t nd = (tid + d) % nn;
+                    if (next_of[nd].load(std::memory_order_relaxed) >= lists[nd].size()) continue;
+                    const size_t ix = next_of[nd].fetch_add(1, std::memory_order_relaxed);
+                    if (ix < lists[nd].size()) it = lists[nd][ix];
+                }
                 if (it >= nitems) break;
+                const double it0 = now_ms() - tl0;
+                ln.first = std::min(ln.first, it0);
                 size_t g = pos[it] >> 4, fill = 0;
                 for (size_t r = cut[it]; r < cut[it + 1]; ++r) {
                     const unsigned char *src = (const unsigned char *)bytes + offsets[r];
@@ -395,6 +457,8 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
                 }
                 if (fill) { while (fill < 16) carry[fill++] = '\n'; encode_groups(carry, 1, h_codes + g, h_valid + g); ++g; }
                 for (; g < (pos[it + 1] >> 4); ++g) { h_codes[g] = 0; h_valid[g] = 0; }  // (never: a part's groups are exactly its bytes, padded)
+                ln.last = now_ms() - tl0;
+                ln.busy += ln.last - it0;
                 packed[it / parts].fetch_add(1, std::memory_order_release);
             }
         });
@@ -406,11 +470,37 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
             if (g1 > g0 && copy_err == hipSuccess) copy_err = hipMemcpyAsync(d_base + g0 * 4, h_codes + g0, (g1 - g0) * 4, hipMemcpyHostToDevice, t->stream);
             if (g1 > g0 && copy_err == hipSuccess) copy_err = hipMemcpyAsync(d_base + valid_off + g0 * 2, h_valid + g0, (g1 - g0) * 2, hipMemcpyHostToDevice, t->stream);
         }
+        const double tl_h2d = now_ms() - tl0;
         pool.wait();
         HIP_TRY(copy_err);
         KCT_DBG(t, "batch: packed upload of %llu bases enqueued\n", (unsigned long long)nbases);
         KCT_TRY(consume_stream_packed(t, (const unsigned int *)d_base, (const unsigned short *)(d_base + valid_off), nbases, n_total));
         t->consumed += total;
+        {
+            double *o = t->batch_tl;
+            struct rusage ru1;
+            getrusage(RUSAGE_SELF, &ru1);
+            double first = 1e300, last = 0, busy = 0, busy_max = 0;
+            std::vector<int> cpus, nodes;
+            for (const ThreadLine &ln : lines) {
+                if (ln.last == 0) continue;
+                first = std::min(first, ln.first); last = std::max(last, ln.last); busy += ln.busy; busy_max = std::max(busy_max, ln.busy);
+                if (std::find(cpus.begin(), cpus.end(), ln.cpu) == cpus.end()) cpus.push_back(ln.cpu);
+            }
+            for (int c : cpus) {   // the NUMA node of a CPU: the nodeN entry of its sysfs directory
+                int node = -1;
+                for (int nd = 0; nd < 16 && node < 0; ++nd) {
+                    char path[128];
+                    snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/node%d", c, nd);
+                    if (access(path, F_OK) == 0) node = nd;
+                }
+                if (std::find(nodes.begin(), nodes.end(), node) == nodes.end()) nodes.push_back(node);
+            }
+            o[0] = tl_checked; o[1] = tl_cut; o[2] = first < 1e299 ? first : 0; o[3] = last; o[4] = tl_h2d; o[5] = now_ms() - tl0;
+            o[6] = (double)cpus.size() ? (double)std::count_if(lines.begin(), lines.end(), [](const ThreadLine &l) { return l.last != 0; }) : 0; o[7] = busy; o[8] = busy_max;
+            o[9] = (double)total; o[10] = (double)(ng * 6); o[11] = (double)(ru1.ru_minflt - ru0.ru_minflt);
+            o[12] = (double)cpus.size(); o[13] = (double)nodes.size(); o[14] = (double)sched_getcpu(); o[15] = pool.pinned() ? 1 : 0;
+        }
         return KCT_OK;
     }
     if (nthreads <= 1) {
@@ -593,3 +683,10 @@ kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes,
 }
 
 }  // extern "C"
+
+extern "C" kct_status kct_batch_timeline(kct_table *t, double *out16) {
+    KCT_BORROW(t);
+    if (!out16) { set_err("null argument"); return KCT_ERR_ARG; }
+    for (int i = 0; i < 16; ++i) out16[i] = t->batch_tl[i];
+    return KCT_OK;
+}

@@ -15,6 +15,7 @@
 #include <functional>
 #include <mutex>
 #include <pthread.h>
+#include <sched.h>
 #include <new>
 #include <string>
 #include <thread>
@@ -39,6 +40,9 @@ class WorkerPool {
 public:
     static WorkerPool &instance();
     void start(size_t n, std::function<void(size_t)> fn);
+    bool pinned() const { return pin_; }
+    int nodes() const;                  // NUMA nodes the workers are spread over: worker i lives on node i % nodes() (1 = not bound)
+    int nodes_hint();                   // ... before the first job: reads the topology (and KCT_PACK_PIN) if that has not happened yet
     void wait();
 private:
     void worker(size_t id);
@@ -49,6 +53,9 @@ private:
     std::function<void(size_t)> fn_;
     size_t want_ = 0, generation_ = 0, running_ = 0;
     int pid_ = 0;
+    bool pin_ = false;                  // KCT_PACK_PIN=1: workers bound to NUMA nodes
+    std::vector<cpu_set_t> node_sets_;
+    bool topo_read_ = false;
 };
 #define KCT_DBG(t, ...) do { if ((t)->debug) { fprintf(stderr, "[kct %11.3f ms] ", kcth::now_ms()); fprintf(stderr, __VA_ARGS__); } } while (0)
 
@@ -141,7 +148,8 @@ struct Tuning {
     bool k1b_half = false;     // KCT_K1B_HALF: two ring flushes per slab in the 64-bit second level
     int sub_chunks = 0;        // KCT_SUB_CHUNKS: sub-chunks of a 64-bit two-level pass that does not fit in one (0 = the default, 4)
     int ablate = 0;            // KCT_ABLATE: skip work (results INVALID)
-    int pack_threads = 16;     // KCT_PACK_THREADS (operational, read in every build): host threads packing a batch
+    int pack_threads = 32;     // KCT_PACK_THREADS (operational, read in every build): host threads packing a batch (16 until round 6: with the encoder's scalar tails gone, 32 threads are as fast at their best and steadier from process to process: tools/e2e_diag.py)
+    int k1_flushers = 0;       // KCT_K1_FLUSHERS (operational, read in every build): 4 (or 2) = the wave-specialised K1 (k1ws_kernel.h) with that many flusher waves; 0 = the barrier-synchronised K1 (the default: DESIGN.md section 9, round 6)
 };
 
 struct ProfEntry { std::string name; u64 launches = 0; double ms = 0; };
@@ -249,6 +257,7 @@ struct kct_table {
         d_failed,  // K2: the numbers of the blocks it abandoned (partition_kernels.h FailedBlocks)
         d_prefix;  // error mode: the offending record's valid prefix (its own buffer: consume_stream reuses d_aux2 / d_spill)
     kcth::PinnedBuf h_stage;
+    double batch_tl[16] = {0};  // kct_batch_timeline: the last packed-upload batch
     std::vector<kcth::PinnedBuf> h_file;  // kct_consume_file's chunk buffers (two per parser thread), kept between calls
 
     bool prof_on = false;
@@ -336,6 +345,7 @@ kct_status unpack_stream(kct_table *t, const unsigned int *d_codes, const unsign
 kct_status consume_stream_runs(kct_table *t, const kct::RunsInput &in, u64 ngroups, u64 *n_out);  // received super-k-mers (kct_route.hip)
 // kct_runs.hip: K1's super-k-mer instantiations and the early route's own kernels
 void launch_partition_runs(kct_table *t, int mode, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa);
+bool launch_partition_ws(kct_table *t, int mode, const unsigned char *d_stream, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa);   // kct_k1ws.hip
 void launch_split(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 ntiles, const kct::SplitArgs &sa);
 inline int split_streams(const kct_table *t) { return t->num_cus; }   // workgroups of the split = streams a rank sends to every owner
 void launch_gather_units(kct_table *t, const void *src, const du64 *src_off, const du64 *dst_off, const unsigned int *n, unsigned int count, void *dst);

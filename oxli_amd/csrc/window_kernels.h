@@ -86,15 +86,23 @@ __device__ __forceinline__ void walk_windows_packed(const unsigned char *lds, in
 // the dedupe-first path counts k-mers first and hashes each distinct one once (partition_kernels.h).
 // RAW = 2 (k <= 21): mix42(packed canonical k-mer), a 42-bit value, with bit 63 set.
 // RAW = 3 (33 <= k <= 64): mix128 of the two packed words: the sink receives x, the companion word y is left in *aux.
+// walk_windows_words: the thread's NW = 2 KW + 1 code words (bases 0 .. 16 NW - 1 of its stretch) and their validity bits arrive in
+// registers -- vbits: validity of the first 64 bases, base n in bit 63 - n (KW = 1 needs 47, KW = 2 needs 79); vtail: bases 64..79 in
+// bits 15..0 (KW = 2 only).  walk_windows_encoded reads them from a staged tile; the wave-specialised K1 (k1ws_kernel.h) gets them
+// from its neighbouring lanes.
+template <int KW, int KC, bool LUT = false, int RAW = 0, int PRE = 0, class Sink>
+__device__ __forceinline__ void walk_windows_words(const u32 (&w)[2 * KW + 1], u64 vbits, u32 vtail, int k_rt, Sink &&sink,
+                                                   const u32 *lut = nullptr, const u64 *mul1 = nullptr, const u64 *mul2 = nullptr, u64 *aux = nullptr,
+                                                   const u64 *tmul = nullptr);
+
 template <int KW, int KC, bool LUT = false, int RAW = 0, int PRE = 0, class Sink>
 __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const unsigned short *valid, int k_rt, Sink &&sink,
                                                      const u32 *lut = nullptr, const u64 *mul1 = nullptr, const u64 *mul2 = nullptr, u64 *aux = nullptr,
                                                      const u64 *tmul = nullptr) {
-    constexpr int WPT = 16, NW = 2 * KW + 1;  // code words covering bases 0 .. 15 + k
-    const int k = KC > 0 ? KC : k_rt;
+    constexpr int NW = 2 * KW + 1;  // code words covering bases 0 .. 15 + k
     u32 w[NW];
-    u64 vbits = 0;  // validity of the first 64 bases, base n in bit 63 - n (KW = 1 needs 47, KW = 2 needs 79)
-    u32 vtail = 0;  // ... bases 64..79 in bits 15..0 (KW = 2 only)
+    u64 vbits = 0;
+    u32 vtail = 0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         w[i] = codes[threadIdx.x + i];
@@ -102,6 +110,14 @@ __device__ __forceinline__ void walk_windows_encoded(const u32 *codes, const uns
         if (i < 4) vbits |= v << (48 - 16 * i);
         else vtail = (u32)v;
     }
+    walk_windows_words<KW, KC, LUT, RAW, PRE>(w, vbits, vtail, k_rt, sink, lut, mul1, mul2, aux, tmul);
+}
+
+template <int KW, int KC, bool LUT, int RAW, int PRE, class Sink>
+__device__ __forceinline__ void walk_windows_words(const u32 (&w)[2 * KW + 1], u64 vbits, u32 vtail, int k_rt, Sink &&sink,
+                                                   const u32 *lut, const u64 *mul1, const u64 *mul2, u64 *aux, const u64 *tmul) {
+    constexpr int WPT = 16, NW = 2 * KW + 1;
+    const int k = KC > 0 ? KC : k_rt;
     // ---- window 0: bases 0 .. k-1
     Packed<KW> fw;
 #pragma unroll

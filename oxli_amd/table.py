@@ -274,6 +274,14 @@ class KmerCountTable:
         self._check(st)
         return n.value
 
+    def batch_timeline(self):
+        """Where the last large ``consume_batch`` call spent its time (``kct_batch_timeline``): a dict of milliseconds and counts."""
+        out = (C.c_double * 16)()
+        self._check(self._lib.kct_batch_timeline(self._h, out))
+        names = ("checked_ms", "cut_ms", "first_packer_start_ms", "last_packer_end_ms", "last_h2d_enqueued_ms", "submitted_ms", "threads", "threads_busy_ms_sum",
+                 "thread_busy_ms_max", "source_bytes", "packed_bytes", "minor_faults", "cpus", "numa_nodes", "caller_cpu", "pinned")
+        return dict(zip(names, (float(v) for v in out)))
+
     def consume_file(self, path, skip_bad_kmers=True):
         """``for record in screed.open(path): kct.consume(record.sequence)`` (README.md:89-99) for a FASTA
         or FASTQ file, plain or gzip.  Returns the total number of k-mers counted.  With

@@ -90,12 +90,13 @@ def test_packed_device_stream_equals_ascii_and_oracle(gpu, k, path):
         assert t.consumed == ref.consumed
 
 
-@pytest.mark.parametrize("k,path", [(21, "dedupe"), (21, "partitioned"), (31, "dedupe"), (51, "partitioned"), (25, "partitioned")])
+@pytest.mark.parametrize("k,path", [(21, "dedupe"), (21, "partitioned"), (31, "dedupe"), (51, "partitioned"), (25, "partitioned"), (25, "dedupe"), (15, "dedupe")])
 def test_packed_arrays_cut_mid_group_and_misaligned(gpu, k, path):
     """K1's PACKED instantiations fetch a tile's words sixteen bytes per lane (k1_kernel.h): the stream's last group is cut to nbases
     inside the loading lane, pieces that would reach past the arrays are fetched word by word, and arrays that are not 16-byte
     aligned (here: the same arrays entered one group further in) go through the ordinary instantiation's narrow loads.  All of it
-    against the ASCII stream cut at the same byte and the oracle.  (k = 25: no PACKED instantiation of its own -- run-time k.)"""
+    against the ASCII stream cut at the same byte and the oracle.  (k = 25: no PACKED instantiation of its own -- run-time k, the hashing
+    mode and the 64-bit dedupe-first mode k1_packed<1, 0, 1>; k = 15: the compact dedupe-first mode at run-time k, k1_packed<1, 0, 2>.)"""
     torch, KCT, lib = gpu
     rng = random.Random(500 + k)
     body = "".join(rng.choice("ACGT") for _ in range(3_000_000))          # one long record: every cut lands among valid bases
@@ -155,3 +156,40 @@ def test_batch_packed_upload_equals_ascii_upload_and_oracle(gpu, k):
             for r in recs:
                 r2.consume(r, skip_bad_kmers=False)
         assert str(e1.value) == str(e2.value)
+
+
+@pytest.mark.parametrize("k,flushers,cap", [(21, 4, 400_000), (21, 2, 400_000), (17, 4, 400_000), (21, 4, 40_000_000)])
+def test_wave_specialised_k1_equals_oracle(gpu, k, flushers, cap, monkeypatch):
+    """KCT_K1_FLUSHERS (k1ws_kernel.h): the compact dedupe-first K1 with hashing waves that never reach a workgroup barrier and flusher
+    waves that move complete lines out after a grace period -- not the default, but it must count exactly what partition_windows_kernel
+    counts: ASCII and packed input, messy records (holes, the overflow route: a homopolymer run hammers one bin), a one-level and a
+    two-level shadow (capacity 4x10^7: 2^26 slots), against the oracle."""
+    torch, KCT, lib = gpu
+    rng = random.Random(900 + k + flushers)
+    genome = "".join(rng.choice("ACGT") for _ in range(200_000))
+    recs = [genome[i:i + 150] for i in (rng.randrange(0, len(genome) - 150) for _ in range(40_000))] + messy_records(rng, 4000, 0, 300) + ["A" * 5000, "ACGT" * 2000, ""]
+    rng.shuffle(recs)
+    ref = OracleTable(k)
+    n_ref = sum(ref.consume(r) for r in recs)
+    rk, rc = ref.dump_arrays()
+    stream = "".join(r + "\n" for r in recs).encode()
+    dev = torch.frombuffer(bytearray(stream + b"\n" * ((-len(stream)) % 16) + b"\n" * 64), dtype=torch.uint8).cuda()
+    ng = (len(stream) + 15) // 16
+    codes = torch.zeros(ng + 4, dtype=torch.int32, device="cuda")
+    valid = torch.zeros(ng + 8, dtype=torch.int16, device="cuda")
+    assert lib.kct_pack_stream_device(dev.data_ptr(), len(stream), codes.data_ptr(), valid.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    monkeypatch.setenv("KCT_K1_FLUSHERS", str(flushers))   # (read by kct_create)
+    for packed in (False, True):
+        t = KCT(k, capacity=cap)
+        t.set_path("dedupe")
+        t.profile(True)
+        consumed = sum(len(r) for r in recs)
+        n = t.consume_device_packed(codes.data_ptr(), valid.data_ptr(), len(stream), consumed) if packed else t.consume_device(dev.data_ptr(), len(stream), consumed)
+        assert n == n_ref
+        n += t.consume_device(dev.data_ptr(), len(stream), consumed)     # a second pass meets a live shadow
+        dk, dc = t.dump_arrays(1)
+        prof = t.profile_read()
+        assert "partition_windows_kernel<compact>" in prof, prof
+        assert np.array_equal(dk, rk) and np.array_equal(dc, 2 * rc), (packed,)
+        assert t.sum_counts == 2 * n_ref
