@@ -220,6 +220,60 @@ kct_status hash_stream(kct_table *t, u64 nbytes, u64 nwin, u64 *first_bad) {
 
 }  // namespace kcth
 
+namespace kcth {
+
+// A device-resident piece of input that is small for the table is STAGED behind the earlier ones (kct_internal.h defer_device) and counted
+// with them: the table then sees ONE large pass -- its two-level paths, its dedupe probe -- where the input arrives in pieces
+// (kct_consume_device calls; the 8 / 16 MiB chunks of kct_consume_file, which until round 6 were counted one by one and flipped between
+// the policy's paths from chunk to chunk).  *n_total = the piece's good windows (counted on the way by the staging kernel).
+// (Not the FIRST piece into an empty table if it brings a window start per slot or more: whoever makes one large call and then reads
+// the table should not pay a copy for the calls that might have followed -- 4 % of such a call; a stream of calls of that size has
+// its first one counted by itself and the rest together.)
+kct_status consume_device_staged(kct_table *t, const unsigned char *d_stream, size_t nbytes, u64 *n_total) {
+    const u64 npos = nbytes >= (u64)t->k ? (u64)nbytes - t->k + 1 : 0;
+    const bool untouched = t->n_keys == 0 && !t->defer_used && !t->shadow_dirty && !t->s32_dirty && !t->s128_dirty;
+    // Nor a call that by itself fills the passes HBM has room for: a pass is bounded by its scratch (~12.5 B per window start on the 64-bit
+    // two-level path), so beside a table that takes most of the GPU -- whole C5's 128 GiB one -- gathering calls cannot make passes larger,
+    // and the copy's buffer would only take room from the scratch (every pass re-reads and re-writes the whole table: fewer passes matter).
+    bool fills_a_pass = false;
+    size_t free_b = 0, total_b = 0;
+    const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    if (have_mem && (t->cap >> t->block_bits) > 1024) {
+        const double avail = (double)free_b + (double)(t->d_scratch.cap + t->d_scratch2.cap + t->d_irr.cap + t->d_irr2.cap + t->d_defer.cap);
+        fills_a_pass = (double)npos * 12.5 >= 0.5 * 0.8 * avail;
+    }
+    if (fills_a_pass && t->defer_used) KCT_TRY(flush_deferred_device(t));
+    if (t->defer_device && t->k <= 255 && npos && npos < 4 * t->cap && !(untouched && npos >= t->cap) && !fills_a_pass) {
+        const u64 padded = (((u64)nbytes + 15) & ~15ULL) + 16;   // (the stream, separators up to a 16-byte boundary, one unit of separators)
+        u64 limit = 32ULL << 30;
+        if (have_mem) limit = std::min<u64>(limit, ((u64)free_b + t->d_defer.cap) / 4);
+        if (t->defer_used + padded > limit && t->defer_used) KCT_TRY(flush_deferred_device(t));
+        if (padded <= limit) {
+            KCT_TRY(t->d_defer.reserve_keep(t->defer_used + padded, t->defer_used, t->stream));
+            du64 *d_good = t->d_counters + kNumCounters + 2;   // scratch word 2
+            HIP_TRY(hipMemsetAsync(d_good, 0, 8, t->stream));
+            {
+                ProfScope ps(t, "stage_stream_kernel");
+                const u64 tiles = (padded + kct::kPartTile - 1) / kct::kPartTile;
+                hipLaunchKernelGGL(kct::stage_stream_kernel, dim3((unsigned)std::min<u64>(tiles, 4 * (u64)t->num_cus)), dim3(kct::kPartThreads), 0, t->stream,
+                                   d_stream, (u64)nbytes, (int)t->k, (unsigned char *)t->d_defer.p + t->defer_used, padded, d_good);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(t->h_counters, d_good, 8, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));   // (the caller may reuse its buffer when this returns; n is wanted now)
+            *n_total = t->h_counters[0];
+            t->defer_used += padded;
+            t->defer_windows += npos;
+            if (t->defer_windows >= 32 * t->cap) KCT_TRY(flush_deferred_device(t));
+            return KCT_OK;
+        }
+    }
+    if (t->defer_used) KCT_TRY(flush_deferred_device(t));
+    return consume_stream(t, d_stream, nbytes, n_total);
+}
+
+}  // namespace kcth
+
 using namespace kcth;
 
 extern "C" {
@@ -632,52 +686,7 @@ kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes,
     if (t->pending_used) KCT_TRY(flush_pending(t));
     if (!n_total || (!d_stream && nbytes)) { set_err("null argument"); return KCT_ERR_ARG; }
     if (((uintptr_t)d_stream & 15) != 0) { set_err("d_stream must be 16-byte aligned"); return KCT_ERR_ARG; }
-    // A call that is small for the table is staged behind the earlier ones and counted with them (kct_internal.h defer_device): the
-    // table then sees ONE large pass -- its two-level paths, its dedupe probe -- where a caller feeds a large input in pieces.
-    // (Not the FIRST call into an empty table if it brings a window start per slot or more: whoever makes one large call and then reads
-    // the table should not pay a copy for the calls that might have followed -- 4 % of such a call; a stream of calls of that size has
-    // its first one counted by itself and the rest together.)
-    const u64 npos = nbytes >= (u64)t->k ? (u64)nbytes - t->k + 1 : 0;
-    const bool untouched = t->n_keys == 0 && !t->defer_used && !t->shadow_dirty && !t->s32_dirty && !t->s128_dirty;
-    // Nor a call that by itself fills the passes HBM has room for: a pass is bounded by its scratch (~12.5 B per window start on the 64-bit
-    // two-level path), so beside a table that takes most of the GPU -- whole C5's 128 GiB one -- gathering calls cannot make passes larger,
-    // and the copy's buffer would only take room from the scratch (every pass re-reads and re-writes the whole table: fewer passes matter).
-    bool fills_a_pass = false;
-    size_t free_b = 0, total_b = 0;
-    const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-    if (have_mem && (t->cap >> t->block_bits) > 1024) {
-        const double avail = (double)free_b + (double)(t->d_scratch.cap + t->d_scratch2.cap + t->d_irr.cap + t->d_irr2.cap + t->d_defer.cap);
-        fills_a_pass = (double)npos * 12.5 >= 0.5 * 0.8 * avail;
-    }
-    if (fills_a_pass && t->defer_used) KCT_TRY(flush_deferred_device(t));
-    if (t->defer_device && t->k <= 255 && npos && npos < 4 * t->cap && !(untouched && npos >= t->cap) && !fills_a_pass) {
-        const u64 padded = (((u64)nbytes + 15) & ~15ULL) + 16;   // (the stream, separators up to a 16-byte boundary, one unit of separators)
-        u64 limit = 32ULL << 30;
-        if (have_mem) limit = std::min<u64>(limit, ((u64)free_b + t->d_defer.cap) / 4);
-        if (t->defer_used + padded > limit && t->defer_used) KCT_TRY(flush_deferred_device(t));
-        if (padded <= limit) {
-            KCT_TRY(t->d_defer.reserve_keep(t->defer_used + padded, t->defer_used, t->stream));
-            du64 *d_good = t->d_counters + kNumCounters + 2;   // scratch word 2
-            HIP_TRY(hipMemsetAsync(d_good, 0, 8, t->stream));
-            {
-                ProfScope ps(t, "stage_stream_kernel");
-                const u64 tiles = (padded + kct::kPartTile - 1) / kct::kPartTile;
-                hipLaunchKernelGGL(kct::stage_stream_kernel, dim3((unsigned)std::min<u64>(tiles, 4 * (u64)t->num_cus)), dim3(kct::kPartThreads), 0, t->stream,
-                                   (const unsigned char *)d_stream, (u64)nbytes, (int)t->k, (unsigned char *)t->d_defer.p + t->defer_used, padded, d_good);
-            }
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(t->h_counters, d_good, 8, hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipStreamSynchronize(t->stream));   // (the caller may reuse its buffer when this returns; n is wanted now)
-            *n_total = t->h_counters[0];
-            t->defer_used += padded;
-            t->defer_windows += npos;
-            t->consumed += consumed_bytes;
-            if (t->defer_windows >= 32 * t->cap) KCT_TRY(flush_deferred_device(t));
-            return KCT_OK;
-        }
-    }
-    if (t->defer_used) KCT_TRY(flush_deferred_device(t));
-    KCT_TRY(consume_stream(t, (const unsigned char *)d_stream, nbytes, n_total));
+    KCT_TRY(consume_device_staged(t, (const unsigned char *)d_stream, nbytes, n_total));
     t->consumed += consumed_bytes;
     return KCT_OK;
 }

@@ -535,7 +535,8 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
                 const size_t padded = (c->used + 15) & ~(size_t)15;
                 memset((char *)c->host->p + c->used, '\n', padded + 16 - c->used);
                 if (hipMemcpyAsync(t->d_stream.p, c->host->p, padded + 16, hipMemcpyHostToDevice, t->stream) != hipSuccess) { set_err("H2D copy failed"); ws = KCT_ERR_HIP; }
-                if (ws == KCT_OK) ws = consume_stream(t, (const unsigned char *)t->d_stream.p, c->used, &n);
+                // (staged behind the earlier chunks and counted with them in passes of the table's own choosing: kct_entry.hip)
+                if (ws == KCT_OK) ws = consume_device_staged(t, (const unsigned char *)t->d_stream.p, c->used, &n);
             }
             if (ws != KCT_OK) queue.fail(ws, g_err);
             { std::lock_guard<std::mutex> lk(queue.mu); queue.counted += n; c->in_flight = false; }

@@ -344,6 +344,7 @@ kct_status consume_stream_packed(kct_table *t, const unsigned int *d_codes, cons
 kct_status unpack_stream(kct_table *t, const unsigned int *d_codes, const unsigned short *d_valid, u64 ng);  // kct_entry.hip
 kct_status consume_stream_runs(kct_table *t, const kct::RunsInput &in, u64 ngroups, u64 *n_out);  // received super-k-mers (kct_route.hip)
 // kct_runs.hip: K1's super-k-mer instantiations and the early route's own kernels
+kct_status consume_device_staged(kct_table *t, const unsigned char *d_stream, size_t nbytes, u64 *n_total);   // kct_entry.hip
 void launch_partition_runs(kct_table *t, int mode, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa);
 bool launch_partition_ws(kct_table *t, int mode, const unsigned char *d_stream, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa);   // kct_k1ws.hip
 void launch_split(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 ntiles, const kct::SplitArgs &sa);
