@@ -850,7 +850,16 @@ def main():
                             entry["zlib_fallback_kmers_per_s"] = kmers_per_step / dtz
                             entry["gate"]["zlib_fallback_same_table"] = okz
                         if name == "file_gz":
-                            entry["note"] = "one deflate stream is inflated by ONE thread whatever follows it (0.4 GB/s of text with zlib, ~0.8 with libdeflate): the bound of this entry"
+                            # round 6: the ONE member is inflated by several threads (csrc/parallel_inflate.h); beside it, the same file with
+                            # that switched off -- one thread's libdeflate, the bound of this entry until round 5
+                            os.environ["KCT_NO_PARALLEL_GZIP"] = "1"
+                            dt1, _p1, ok1, _n1 = measure(2)
+                            del os.environ["KCT_NO_PARALLEL_GZIP"]
+                            entry["single_thread_inflate_kmers_per_s"] = kmers_per_step / dt1
+                            entry["gate"]["single_thread_inflate_same_table"] = ok1
+                            entry["inflater"] += " / parallel_inflate.h (several threads on the one member, verified by length and CRC-32)"
+                            entry["note"] = ("one deflate stream was one thread's work until round 5 (0.4 GB/s of text with zlib, ~0.8 with libdeflate): "
+                                             "`single_thread_inflate_kmers_per_s`; `kmers_per_s` = the member entered at block boundaries by up to 64 threads")
                     configs[name] = entry
                     log(f"{name}: {entry['kmers_per_s']:.3g} k-mers/s ({entry.get('inflater', 'plain text')}), gate {entry['gate']}")
                     assert ablate or all(entry["gate"].values()), (name, entry["gate"])

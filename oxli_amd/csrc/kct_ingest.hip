@@ -1,5 +1,6 @@
 // kct_ingest.hip -- FASTA / FASTQ file ingestion (kct_consume_file): the caller side of the path.
 #include "kct_internal.h"
+#include "parallel_inflate.h"
 
 #include <deque>
 #include <dlfcn.h>
@@ -454,7 +455,9 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
     Mapping whole;   // (anonymous pages, unmapped when the call returns)
     const unsigned char *text_p = map.p;
     size_t text_size = map.size;
-    if (gz && !bgzf && gzmap.p && gzmap.size > 18 && deflate_lib().ok() && deflate_lib().gzip_ex && !getenv("KCT_NO_LIBDEFLATE")) {
+    const bool have_ld = deflate_lib().ok() && deflate_lib().gzip_ex && !getenv("KCT_NO_LIBDEFLATE");
+    const bool try_parallel = gzmap.size >= ((size_t)4 << 20) && !getenv("KCT_NO_PARALLEL_GZIP");
+    if (gz && !bgzf && gzmap.p && gzmap.size > 18 && (have_ld || try_parallel)) {
         unsigned isize;
         memcpy(&isize, gzmap.p + gzmap.size - 4, 4);
         size_t limit = (size_t)2 << 30;
@@ -474,11 +477,24 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
                         if (madvise((char *)m + off, n, 23 /* MADV_POPULATE_WRITE */) != 0)
                             for (size_t i = 0; i < n; i += 4096) ((volatile char *)m)[off + i] = 0;
                     });
-                const Deflate &ld = deflate_lib();
-                void *dec = ld.alloc();
-                size_t n_in = 0, n_out = 0;
-                const bool ok = dec && ld.gzip_ex(dec, gzmap.p, gzmap.size, m, isize, &n_in, &n_out) == 0 && n_in == gzmap.size && n_out == isize;
-                if (dec) ld.free_(dec);
+                // Several threads on the ONE member where it is large enough (parallel_inflate.h: entered at block boundaries found by
+                // search, the unknown 32 KiB in front of each piece resolved afterwards, length and CRC-32 verified); declined or failed:
+                // libdeflate inflates it in one piece, as before.
+                bool ok = false;
+                if (try_parallel) {
+                    const unsigned hw = std::thread::hardware_concurrency();
+                    unsigned nth = std::max(2u, std::min(64u, hw / 2));
+                    if (const char *e = getenv("KCT_GZIP_THREADS")) nth = (unsigned)std::max(2, atoi(e));
+                    ok = pgz::gunzip_parallel(gzmap.p, gzmap.size, (uint8_t *)m, isize, nth);
+                    KCT_DBG(t, "file: parallel inflate of %zu -> %u bytes on %u threads: %s\n", gzmap.size, isize, nth, ok ? "ok" : "declined");
+                }
+                if (!ok && have_ld) {
+                    const Deflate &ld = deflate_lib();
+                    void *dec = ld.alloc();
+                    size_t n_in = 0, n_out = 0;
+                    ok = dec && ld.gzip_ex(dec, gzmap.p, gzmap.size, m, isize, &n_in, &n_out) == 0 && n_in == gzmap.size && n_out == isize;
+                    if (dec) ld.free_(dec);
+                }
                 for (auto &th : toucher) th.join();
                 if (ok) { text_p = whole.p; text_size = isize; }
                 // (else: more members, a size field that wrapped, or a corrupt file -- the streaming reader finds out)

@@ -1,0 +1,96 @@
+"""oxli_amd/csrc/parallel_inflate.h (one gzip member inflated by several threads: kct_consume_file's single-member .fastq.gz path) against
+zlib, on the CPU: FASTQ-like text at levels 1 / 6 / 9, incompressible bytes (stored blocks), long-range repeats (copies that reach far back
+across piece boundaries), a stream with full flushes (what pigz writes), a member with a file name in its header -- each with several
+thread counts and chunk sizes down to 20 kB (hundreds of pieces, starts that are look-alikes, chunks without any block start); a file of two
+members and a tiny one must be DECLINED (the caller then inflates them the ordinary way).  The header is compiled alone with g++."""
+import gzip
+import io
+import os
+import random
+import shutil
+import subprocess
+import zlib
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+MAIN = r"""
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+int main(int argc, char **argv) {
+    if (argc < 4) return 2;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> gz(n);
+    if (fread(gz.data(), 1, n, f) != (size_t)n) return 2;
+    fclose(f);
+    std::vector<uint8_t> ref;
+    {
+        gzFile g = gzopen(argv[1], "rb");
+        std::vector<uint8_t> buf(1 << 20);
+        int r;
+        while ((r = gzread(g, buf.data(), (unsigned)buf.size())) > 0) ref.insert(ref.end(), buf.begin(), buf.begin() + r);
+        gzclose(g);
+    }
+    uint32_t isize; memcpy(&isize, gz.data() + n - 4, 4);
+    std::vector<uint8_t> out((size_t)isize + 16);
+    const bool ok = pgz::gunzip_parallel(gz.data(), gz.size(), out.data(), isize, (unsigned)atoi(argv[2]), (size_t)atoll(argv[3]));
+    if (!ok) { puts("declined"); return 0; }
+    if (ref.size() != isize || memcmp(ref.data(), out.data(), isize) != 0) { puts("MISMATCH"); return 3; }
+    puts("ok");
+    return 0;
+}
+"""
+
+
+def fastq(rng, n):
+    out = []
+    for i in range(n):
+        s = "".join(rng.choice("ACGT") for _ in range(150))
+        q = "".join(rng.choice("FFFFFFFF:,#") for _ in range(150))
+        out.append(f"@read{i} some/description\n{s}\n+\n{q}\n")
+    return "".join(out).encode()
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_parallel_inflate_equals_zlib(tmp_path):
+    cpp = tmp_path / "pgz.cpp"
+    cpp.write_text(f'#include "{ROOT}/oxli_amd/csrc/parallel_inflate.h"\n' + MAIN)
+    exe = tmp_path / "pgz"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(exe), str(cpp), "-lz", "-lpthread"], check=True)
+    rng = random.Random(5)
+    data = fastq(rng, 12000)
+    cases = {f"fq_l{lvl}": gzip.compress(data, compresslevel=lvl) for lvl in (1, 6, 9)}
+    cases["random"] = gzip.compress(rng.randbytes(600_000), compresslevel=6)
+    cases["repeat"] = gzip.compress((b"ACGTTGCA" * 50 + b"N") * 20000, compresslevel=6)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    parts = []
+    for i in range(0, len(data), 65536):
+        parts += [co.compress(data[i:i + 65536]), co.flush(zlib.Z_FULL_FLUSH)]
+    parts.append(co.flush())
+    cases["flushed"] = b"".join(parts)
+    bio = io.BytesIO()
+    with gzip.GzipFile(filename="reads.fastq", mode="wb", fileobj=bio, compresslevel=6) as g:
+        g.write(data)
+    cases["named"] = bio.getvalue()
+    # lower-case / N-rich text mixed with binary: dynamic, fixed and stored blocks in one stream
+    mixed = b"".join(rng.choice([data[i:i + 5000], rng.randbytes(3000), b"n" * 4000]) for i in range(0, len(data), 5000))
+    cases["mixed"] = gzip.compress(mixed, compresslevel=4)
+    must_decline = {"two_members": gzip.compress(data[:len(data) // 2], 6) + gzip.compress(data[len(data) // 2:], 6), "tiny": gzip.compress(b"hello world\n")}
+    done = 0
+    for name, blob in {**cases, **must_decline}.items():
+        path = tmp_path / (name + ".gz")
+        path.write_bytes(blob)
+        for threads, chunk in ((8, 65536), (3, 150_000), (16, 20_000)):
+            r = subprocess.run([str(exe), str(path), str(threads), str(chunk)], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, (name, threads, chunk, r.stdout, r.stderr)
+            verdict = r.stdout.strip()
+            if name in must_decline:
+                assert verdict == "declined", (name, verdict)
+            else:
+                assert verdict in ("ok", "declined"), (name, verdict)
+                done += verdict == "ok"
+    assert done >= 3 * 5, done   # the FASTQ-like cases are really inflated in parallel (a decline is legal, not the rule)
