@@ -467,6 +467,7 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
             void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
             if (m != MAP_FAILED) {
                 whole.p = (const unsigned char *)m; whole.size = bytes;
+                (void)madvise(m, bytes, MADV_HUGEPAGE);   // (where transparent huge pages are on request: 512x fewer faults for the inflaters)
                 // the pages are faulted in by four helper threads while the inflater runs (a fresh page costs about as much as inflating
                 // it: left to the inflater, the faults were a sixth of the call)
                 std::vector<std::thread> toucher;
@@ -483,7 +484,7 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
                 bool ok = false;
                 if (try_parallel) {
                     const unsigned hw = std::thread::hardware_concurrency();
-                    unsigned nth = std::max(2u, std::min(64u, hw / 2));
+                    unsigned nth = std::max(2u, std::min(32u, hw / 2));   // (64 threads: no faster inflating and an erratic last phase, tools/gz_diag.py)
                     if (const char *e = getenv("KCT_GZIP_THREADS")) nth = (unsigned)std::max(2, atoi(e));
                     ok = pgz::gunzip_parallel(gzmap.p, gzmap.size, (uint8_t *)m, isize, nth);
                     KCT_DBG(t, "file: parallel inflate of %zu -> %u bytes on %u threads: %s\n", gzmap.size, isize, nth, ok ? "ok" : "declined");

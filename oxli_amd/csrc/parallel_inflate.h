@@ -17,6 +17,10 @@
 //      chain that does not close, a length or CRC that differs -- makes the call return false and the caller inflates the member the
 //      ordinary way: nothing this file produces is used unverified.
 #pragma once
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE   // mremap
+#endif
+#include <sys/mman.h>
 #include <zlib.h>   // crc32, crc32_combine
 #if defined(__SSE2__)
 #include <emmintrin.h>
@@ -194,19 +198,23 @@ struct ByteOut {
 // output with an UNKNOWN 32 KiB in front: 16-bit symbols, 0x8000 + j = byte j of that window (j = 32768 - distance before the chunk)
 struct MarkOut {
     uint16_t *v = nullptr;
-    size_t n = 0, cap = 0, limit = 0;
+    size_t n = 0, cap = 0, limit = 0, mapped = 0;
     MarkOut() = default;
     MarkOut(const MarkOut &) = delete;
     MarkOut &operator=(const MarkOut &) = delete;
-    ~MarkOut() { free(v); }
+    ~MarkOut() { if (v) munmap(v, mapped); }
+    // The buffers of all pieces together are twice the text: anonymous mappings that ask for huge pages and grow by mremap (with 4 KiB
+    // pages, sixty-four threads faulting in 1.2 GB at once spent more time in the kernel's address-space lock than inflating).
     bool room(size_t more) {   // (258 symbols of slack are kept beyond n: lit() and copy() of one code never check again)
         if (n + more + 258 <= cap) return true;
         if (n + more > limit) return false;
         size_t want = std::max<size_t>(cap * 2, n + more + 258 + 65536);
         if (want > limit + 258 + 65536) want = limit + 258 + 65536;
-        uint16_t *q = (uint16_t *)realloc(v, want * sizeof(uint16_t));
-        if (!q) return false;
-        v = q; cap = want;
+        const size_t bytes = (want * sizeof(uint16_t) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        void *q = v ? mremap(v, mapped, bytes, MREMAP_MAYMOVE) : mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) return false;
+        (void)madvise(q, bytes, MADV_HUGEPAGE);
+        v = (uint16_t *)q; mapped = bytes; cap = bytes / sizeof(uint16_t);
         return true;
     }
     inline bool lit(unsigned c) { if (n + 259 > cap && !room(1)) return false; v[n++] = (uint16_t)c; return true; }
@@ -371,7 +379,7 @@ inline bool gunzip_parallel(const uint8_t *gz, size_t gz_size, uint8_t *out, siz
     memcpy(&want_crc, gz + gz_size - 8, 4);
     memcpy(&want_size, gz + gz_size - 4, 4);
     if ((uint32_t)out_size != want_size) return false;
-    if (!chunk_bytes) chunk_bytes = std::max<size_t>(1 << 20, def_size / (4 * (size_t)std::max(1u, nthreads)));
+    if (!chunk_bytes) chunk_bytes = std::max<size_t>(256 << 10, def_size / (2 * (size_t)std::max(1u, nthreads)));   // two even rounds of pieces
     const size_t nchunks = (def_size + chunk_bytes - 1) / chunk_bytes;
     if (nchunks < 2 || nthreads < 2) return false;
     nthreads = (unsigned)std::min<size_t>(nthreads, nchunks);
@@ -418,7 +426,8 @@ inline bool gunzip_parallel(const uint8_t *gz, size_t gz_size, uint8_t *out, siz
                         pc.bytes0 = bo.pos;
                     } else {
                         pc.marks.limit = out_size;
-                        (void)pc.marks.room(std::min<size_t>(out_size, 5 * chunk_bytes));
+                        // (room for this piece's text at the member's overall ratio + a quarter: one mapping, rarely a second)
+                        (void)pc.marks.room(std::min<size_t>(out_size, (size_t)((double)out_size / (double)def_size * 1.25 * (double)chunk_bytes) + 65536));
                         pc.status = run_blocks(b, pc.marks, tg, ntg, &reached, &pc.end_bit);
                     }
                     pc.next = i + 1 + reached;
