@@ -496,7 +496,9 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
                     ok = dec && ld.gzip_ex(dec, gzmap.p, gzmap.size, m, isize, &n_in, &n_out) == 0 && n_in == gzmap.size && n_out == isize;
                     if (dec) ld.free_(dec);
                 }
+                KCT_DBG(t, "file: inflated\n");
                 for (auto &th : toucher) th.join();
+                KCT_DBG(t, "file: output pages populated\n");
                 if (ok) { text_p = whole.p; text_size = isize; }
                 // (else: more members, a size field that wrapped, or a corrupt file -- the streaming reader finds out)
             }
@@ -591,6 +593,7 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
             for (size_t i = 1; i < nparsers; ++i) pool.emplace_back(parser, i);
             parser(0);
             for (auto &th : pool) th.join();
+            KCT_DBG(t, "file: parsers done\n");
         }
     } else if (bgzf) {
         // the file's first byte of text says FASTA or FASTQ (the slot threads need to know before they meet it)
@@ -685,6 +688,7 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
             { std::lock_guard<std::mutex> lk(frags.mu); slot_failed = frags.failed; slot_msg = frags.msg; }
             frags.fail("the parser is done");   // (lets slot threads go that still wait for their turn: the parser stopped early)
             for (auto &th : pool) th.join();
+            KCT_DBG(t, "file: parsers done\n");
             if (st == KCT_OK && slot_failed) { set_err("%s: %s", path, slot_msg.c_str()); st = KCT_ERR_ARG; }
         }
     } else {
@@ -731,6 +735,7 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
     { std::lock_guard<std::mutex> lk(queue.mu); queue.done = true; }
     queue.cv.notify_all();
     worker.join();
+    KCT_DBG(t, "file: chunks uploaded and counted (or staged)\n");
     if (st == KCT_OK && queue.status != KCT_OK) { st = queue.status; set_err("%s", queue.msg.c_str()); }
     if (st != KCT_OK) return st;
     t->consumed += bases;

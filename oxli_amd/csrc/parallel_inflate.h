@@ -202,7 +202,8 @@ struct MarkOut {
     MarkOut() = default;
     MarkOut(const MarkOut &) = delete;
     MarkOut &operator=(const MarkOut &) = delete;
-    ~MarkOut() { if (v) munmap(v, mapped); }
+    ~MarkOut() { release(); }
+    void release() { if (v) munmap(v, mapped); v = nullptr; n = cap = mapped = 0; }
     // The buffers of all pieces together are twice the text: anonymous mappings that ask for huge pages and grow by mremap (with 4 KiB
     // pages, sixty-four threads faulting in 1.2 GB at once spent more time in the kernel's address-space lock than inflating).
     bool room(size_t more) {   // (258 symbols of slack are kept beyond n: lit() and copy() of one code never check again)
@@ -473,7 +474,10 @@ inline bool gunzip_parallel(const uint8_t *gz, size_t gz_size, uint8_t *out, siz
         for (unsigned t = 0; t < nthreads; ++t)
             th.emplace_back([&] {
                 for (size_t j; (j = next.fetch_add(1)) < chain.size();) {
-                    if (j) resolve(piece[chain[j]].marks.v, piece[chain[j]].marks.n, win[j].data(), out + off[j]);
+                    if (j) {
+                        resolve(piece[chain[j]].marks.v, piece[chain[j]].marks.n, win[j].data(), out + off[j]);
+                        piece[chain[j]].marks.release();   // (here, by this thread: unmapping every piece's buffer at the end, one after the other, was a third of the call)
+                    }
                     uint32_t c = 0;
                     for (size_t a = off[j]; a < off[j + 1];) {   // (zlib's crc32 takes a uInt length)
                         const size_t n = std::min<size_t>(off[j + 1] - a, 1u << 30);
