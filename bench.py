@@ -58,7 +58,7 @@ same weak-scaled C2 job per rank + the late merge, and
 `roofline`: bound "hbm"; `achieved` = ALGORITHMIC bytes per step (k-mers x (L/(L-k+1) + 24) B) / the summed
 device time of every kernel of the step (HIP events on the table's stream, in an instrumented repetition of the job;
 `value` is taken with the events off); `traffic` / `measured_frac` = PMC-measured HBM bytes per step (profiles/
-pmc_r05.json, only if it was collected from THIS source tree -- stamped with a hash of the kernel sources -- else null);
+pmc_r06.json, only if it was collected from THIS source tree -- stamped with a hash of the kernel sources -- else null);
 `valu` = the ceiling that actually binds K1 (VALU instructions per window and issue-slot use from the same PMC file).
 `cpu_baseline`: the CPU restatement of the reference path (oracle/, "port") on this host: 1 thread (the reference's
 consume is single-threaded under the GIL), reads sharded over threads with a tree merge (reference-shaped "rayon"), and
@@ -143,16 +143,16 @@ def source_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "oxli_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith(".h") and name not in ("kct_internal.h", "path_policy.h"):  # (host-only headers do not change what was measured)
+        if name.endswith(".h") and name not in ("kct_internal.h", "path_policy.h", "parallel_inflate.h"):  # (host-only headers do not change what was measured)
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 
 def pmc_summary():
-    """profiles/pmc_r05.json (tools/collect_r05.sh) if it was collected from this source tree, else {} (every PMC-derived field becomes null)."""
+    """profiles/pmc_r06.json (tools/collect_r06.sh) if it was collected from this source tree, else {} (every PMC-derived field becomes null)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_r05.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_r06.json")) as f:
             d = json.load(f)
         return d if d.get("source_sha") == source_sha() else {}
     except (OSError, ValueError):
@@ -224,7 +224,8 @@ def compact(res):
         out["roofline"]["kernels_ms_per_step"] = f.get("kernels_ms_per_step")
         if f.get("valu"):
             out["roofline"]["valu"] = {"kernel": f["valu"]["kernel"], "insts_per_kmer": r(f["valu"]["valu_insts_per_window"], 1),
-                                       "issue_share_floor": r(f["valu"]["valu_issue_share_floor"], 3), "wave_wait_share": r(f["valu"]["wave_wait_share"], 3)}
+                                       "busy_range": [r(x_, 3) for x_ in (f["valu"].get("valu_busy_range") or [None, None])], "clock_GHz": r(f["valu"].get("clock_GHz"), 3),
+                                       "wave_wait_share": r(f["valu"]["wave_wait_share"], 3), "wave_issue_stall_share": r(f["valu"].get("wave_issue_stall_share"), 3)}
         if f.get("atomics"):
             out["roofline"]["atomics_direct_path"] = {"per_kmer": r(f["atomics"]["per_kmer"], 3), "per_second": r(f["atomics"]["per_second"], 0)}
     if "cpu_baseline" in res:
@@ -593,7 +594,7 @@ def main():
                     "measured_frac": (traffic_job / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_job and all_ms else None,
                     "basis": "achieved = algorithmic bytes per step (25.15 B/k-mer x k-mers) / summed device time of every kernel of the step (HIP "
                              "events, instrumented repetition); traffic = PMC HBM bytes per step and measured_frac = traffic / kernel time / peak, "
-                             "from profiles/pmc_r05.json when it matches this source tree (else null)",
+                             "from profiles/pmc_r06.json when it matches this source tree (else null)",
                     "alg_bytes_per_kmer": b_alg, "kmers_per_step": kmers_per_step, "kernels_total_ms_per_step": all_ms / args.steps,
                     "dominant_kernel_ms_per_step": ms / args.steps,
                     "frac_of_wall": kmers_per_step * b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,

@@ -24,7 +24,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 on_box = "--on-box" in sys.argv
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
@@ -84,8 +84,14 @@ def summarize(wdir):
             if "hbm_bytes_per_launch" in e:
                 e["hbm_GBs"] = e["hbm_bytes_per_launch"] / e["avg_launch_ns"]
             if "SQ_INSTS_VALU" in mean:
-                # every wave instruction takes at least 4 cycles of its SIMD: a floor of the VALU pipes' busy share
-                e["valu_issue_share_floor"] = mean["SQ_INSTS_VALU"] * 4 / (SIMDS * e["avg_launch_ns"] * 1e-9 * CLOCK_HZ)
+                # Round 6: no "floor" any more.  The launch's cycles come from GRBM_GUI_ACTIVE / 8 XCDs where it was
+                # collected (the chip clocks down under load: ~2.2 GHz, not 2.4), and a VALU wave instruction occupies its SIMD for ~2
+                # cycles (VOP2 adds / xors) to ~4 (multiplies, VOP3: tools/valu_rate.hip, 4 waves per SIMD) -- SQ_ACTIVE_INST_VALU is no
+                # measurement of that: it charges every instruction one quad-cycle.  Hence a RANGE, not a figure.
+                cycles = mean["GRBM_GUI_ACTIVE"] / 8 if mean.get("GRBM_GUI_ACTIVE") else e["avg_launch_ns"] * 1e-9 * CLOCK_HZ
+                e["launch_cycles"] = cycles
+                e["clock_GHz"] = cycles / e["avg_launch_ns"] if mean.get("GRBM_GUI_ACTIVE") else None
+                e["valu_busy_range"] = [mean["SQ_INSTS_VALU"] * 2 / (SIMDS * cycles), mean["SQ_INSTS_VALU"] * 4 / (SIMDS * cycles)]
         out[k] = e
     return out, (sf[-1] if sf else None)
 
@@ -132,10 +138,13 @@ def main():
         if k1 and "SQ_INSTS_VALU" in kernels[k1]["mean"] and w in windows:
             m = kernels[k1]["mean"]
             e["valu"] = {"kernel": k1, "valu_insts_per_window": m["SQ_INSTS_VALU"] * 64 / windows[w], "salu_insts_per_window": m["SQ_INSTS_SALU"] * 64 / windows[w],
-                         "lds_insts_per_window": m["SQ_INSTS_LDS"] * 64 / windows[w], "valu_issue_share_floor": kernels[k1].get("valu_issue_share_floor"),
+                         "lds_insts_per_window": m["SQ_INSTS_LDS"] * 64 / windows[w], "valu_busy_range": kernels[k1].get("valu_busy_range"),
+                         "clock_GHz": kernels[k1].get("clock_GHz"),
+                         "wave_issue_stall_share": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") and m.get("SQ_WAIT_INST_ANY") else None,
                          "wave_wait_share": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None,
-                         "note": "per window = wave instructions x 64 lanes / window starts of a launch; issue share floor = VALU wave instructions x 4 cycles / "
-                                 "(1024 SIMDs x launch duration x 2.4 GHz): multiplies and other multi-pass ops take longer than 4 cycles, so the pipes are busier than this"}
+                         "note": "per window = wave instructions x 64 lanes / window starts of a launch; valu_busy_range = VALU wave instructions x [2, 4] cycles / "
+                                 "(1024 SIMDs x the launch's cycles, GRBM_GUI_ACTIVE / 8): ~2 cycles for VOP2 adds / xors, ~4 for multiplies and VOP3 forms (tools/valu_rate.hip); "
+                                 "wave_wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES (parked at s_waitcnt or a barrier); profiles/r06_k1_wait_split.json says what the waits are"}
         if w == "C2_direct" and "count_windows_kernel" in kernels and "TCC_EA0_ATOMIC_sum" in kernels["count_windows_kernel"]["mean"]:
             m = kernels["count_windows_kernel"]
             e["atomics"] = {"kernel": "count_windows_kernel", "memory_side_atomics_per_launch": m["mean"]["TCC_EA0_ATOMIC_sum"],
