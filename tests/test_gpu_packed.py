@@ -145,6 +145,12 @@ def test_batch_packed_upload_equals_ascii_upload_and_oracle(gpu, k):
         t.set_packed_upload(packed)
         t.profile(True)
         assert t.consume_batch(recs) == n_ref
+        tl = t.batch_timeline()     # kct_batch_timeline: filled by the packed-upload route only
+        if packed:
+            assert tl["threads"] >= 2 and tl["source_bytes"] == sum(len(r.encode()) for r in recs) and tl["packed_bytes"] > 0
+            assert 0 <= tl["first_packer_start_ms"] <= tl["last_packer_end_ms"] <= tl["submitted_ms"] and tl["threads_busy_ms_sum"] >= tl["thread_busy_ms_max"] > 0
+        else:
+            assert tl["threads"] == 0 and tl["submitted_ms"] == 0
         dk, dc = t.dump_arrays(1)
         assert np.array_equal(dk, rk) and np.array_equal(dc, rc), packed
         assert t.consumed == ref.consumed

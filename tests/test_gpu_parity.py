@@ -884,6 +884,45 @@ def _bgzf(data, rng):
     return bytes(out)
 
 
+def test_large_single_member_gzip_goes_through_the_parallel_inflater(KCT, tmp_path, monkeypatch, capfd):
+    """A single-member FASTQ .gz of more than 4 MiB is inflated by several threads (csrc/parallel_inflate.h: entered at block boundaries
+    found by search, the unknown 32 KiB in front of every piece resolved afterwards, length and CRC-32 verified); the table must be the
+    oracle's -- and the same with the parallel inflater switched off, and for a file whose second half is CORRUPT (the CRC check sends
+    it to the ordinary inflater, which reports the error)."""
+    import gzip
+    import os
+    rng = random.Random(77)
+    L, k = 150, 21
+    genome = rand_dna(rng, 400_000, "ACGT")
+    recs = [genome[i:i + L] for i in (rng.randrange(0, len(genome) - L) for _ in range(70_000))]
+    recs += [rand_dna(rng, rng.choice([0, 20, 300]), "ACGTNacgt") for _ in range(300)]
+    fq = "".join(f"@read{i} lane:1\n{s}\n+\n{''.join(rng.choice('FFFFFF:,#') for _ in s)}\n" for i, s in enumerate(recs)).encode()
+    blob = gzip.compress(fq, 6)
+    assert len(blob) > (4 << 20), len(blob)
+    path = tmp_path / "big.fastq.gz"
+    path.write_bytes(blob)
+    ref = OracleTable(k)
+    n_ref = sum(ref.consume(r) for r in recs)
+    monkeypatch.setenv("KCT_DEBUG", "1")
+    dev = KCT(k, capacity=1_000_000)
+    assert dev.consume_file(str(path)) == n_ref
+    assert dev.last_file_records == len(recs)
+    assert_same_table(dev, ref)
+    err = capfd.readouterr().err
+    assert "parallel inflate" in err and ": ok" in err.split("parallel inflate", 1)[1].split("\n", 1)[0], err[-600:]   # (it really took that route)
+    monkeypatch.delenv("KCT_DEBUG")
+    monkeypatch.setenv("KCT_NO_PARALLEL_GZIP", "1")
+    dev = KCT(k, capacity=1_000_000)
+    assert dev.consume_file(str(path)) == n_ref
+    assert_same_table(dev, ref)
+    monkeypatch.delenv("KCT_NO_PARALLEL_GZIP")
+    bad = bytearray(blob)
+    bad[len(bad) * 3 // 4] ^= 0x21
+    (tmp_path / "bad.fastq.gz").write_bytes(bytes(bad))
+    with pytest.raises((RuntimeError, ValueError, OSError)):
+        KCT(k).consume_file(str(tmp_path / "bad.fastq.gz"))
+
+
 def test_consume_file_formats_match_oracle(KCT, tmp_path, monkeypatch):
     import gzip
     rng = random.Random(31)
