@@ -554,6 +554,23 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
             o[6] = (double)cpus.size() ? (double)std::count_if(lines.begin(), lines.end(), [](const ThreadLine &l) { return l.last != 0; }) : 0; o[7] = busy; o[8] = busy_max;
             o[9] = (double)total; o[10] = (double)(ng * 6); o[11] = (double)(ru1.ru_minflt - ru0.ru_minflt);
             o[12] = (double)cpus.size(); o[13] = (double)nodes.size(); o[14] = (double)sched_getcpu(); o[15] = pool.pinned() ? 1 : 0;
+            if (t->debug) {   // where the batch, the staging and the packers were (NUMA nodes): one line
+                auto node_of_cpu = [](int c) { for (int nd = 0; nd < 16; ++nd) { char path[128]; snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/node%d", c, nd); if (access(path, F_OK) == 0) return nd; } return -1; };
+                auto pages_on = [&](const void *base, size_t bytes, int out_[4]) {
+                    const long psz = sysconf(_SC_PAGESIZE);
+                    void *pg[64]; int stt[64];
+                    for (int i = 0; i < 64; ++i) { pg[i] = (void *)(((uintptr_t)base + (bytes / 64) * i) & ~(uintptr_t)(psz - 1)); stt[i] = -1; }
+                    for (int i = 0; i < 4; ++i) out_[i] = 0;
+                    if (syscall(SYS_move_pages, 0, 64UL, pg, nullptr, stt, 0) == 0) for (int i = 0; i < 64; ++i) ++out_[stt[i] >= 0 && stt[i] < 3 ? stt[i] : 3];
+                };
+                int src_n[4], stg_n[4];
+                pages_on(bytes + offsets[0], (size_t)total, src_n);
+                pages_on(h_codes, (size_t)ng * 4, stg_n);
+                double busy_n[4] = {0, 0, 0, 0}; int thr_n[4] = {0, 0, 0, 0};
+                for (const ThreadLine &ln : lines) if (ln.last != 0) { const int nd = node_of_cpu(ln.cpu); busy_n[nd >= 0 && nd < 3 ? nd : 3] += ln.busy; ++thr_n[nd >= 0 && nd < 3 ? nd : 3]; }
+                KCT_DBG(t, "batch: source pages on nodes [%d %d %d ?%d] of 64 samples, staging [%d %d %d ?%d]; packers node0: %d threads busy %.2f ms, node1: %d threads busy %.2f ms; caller cpu %d (node %d)\n",
+                        src_n[0], src_n[1], src_n[2], src_n[3], stg_n[0], stg_n[1], stg_n[2], stg_n[3], thr_n[0], busy_n[0], thr_n[1], busy_n[1], sched_getcpu(), node_of_cpu(sched_getcpu()));
+            }
         }
         return KCT_OK;
     }

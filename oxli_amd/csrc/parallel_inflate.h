@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace pgz {
@@ -474,10 +475,7 @@ inline bool gunzip_parallel(const uint8_t *gz, size_t gz_size, uint8_t *out, siz
         for (unsigned t = 0; t < nthreads; ++t)
             th.emplace_back([&] {
                 for (size_t j; (j = next.fetch_add(1)) < chain.size();) {
-                    if (j) {
-                        resolve(piece[chain[j]].marks.v, piece[chain[j]].marks.n, win[j].data(), out + off[j]);
-                        piece[chain[j]].marks.release();   // (here, by this thread: unmapping every piece's buffer at the end, one after the other, was a third of the call)
-                    }
+                    if (j) resolve(piece[chain[j]].marks.v, piece[chain[j]].marks.n, win[j].data(), out + off[j]);
                     uint32_t c = 0;
                     for (size_t a = off[j]; a < off[j + 1];) {   // (zlib's crc32 takes a uInt length)
                         const size_t n = std::min<size_t>(off[j + 1] - a, 1u << 30);
@@ -488,6 +486,14 @@ inline bool gunzip_parallel(const uint8_t *gz, size_t gz_size, uint8_t *out, siz
                 }
             });
         for (auto &x : th) x.join();
+    }
+    // The pieces' buffers (twice the text in all) are unmapped by a thread of their own that nobody waits for: giving 1.2 GB back to the kernel
+    // takes ~45 ms whether one thread does it or thirty-two (the address-space lock serialises them).  (The whole kct_consume_file call did not
+    // get shorter by it -- the parsers behind it take their page faults under the same lock -- but the inflater's own phases are what they look like.)
+    {
+        std::vector<std::pair<void *, size_t>> gone;
+        for (Piece &pc : piece) if (pc.marks.v) { gone.emplace_back(pc.marks.v, pc.marks.mapped); pc.marks.v = nullptr; pc.marks.n = pc.marks.cap = pc.marks.mapped = 0; }
+        if (!gone.empty()) std::thread([gone] { for (const auto &g : gone) munmap(g.first, g.second); }).detach();
     }
     if (timing) fprintf(stderr, "pgz: %zu chunks, %zu starts, %zu pieces in the chain; search %.1f ms, inflate %.1f ms, windows %.1f ms, bytes + crc %.1f ms\n", nchunks, cand.size(),
                         chain.size(), t_found - t_begin, t_inflated - t_found, t_windows - t_inflated, now() - t_windows);
