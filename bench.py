@@ -262,6 +262,8 @@ def compact(res):
                     e[k] = c[k]
             if "zlib_fallback_kmers_per_s" in c:
                 e["zlib_fallback_kmers_per_s"] = r(c["zlib_fallback_kmers_per_s"], 0)
+            if "single_thread_inflate_kmers_per_s" in c:
+                e["single_thread_inflate_kmers_per_s"] = r(c["single_thread_inflate_kmers_per_s"], 0)
             if "partitioned_path_kmers_per_s" in c:
                 e["partitioned_path_kmers_per_s"] = r(c["partitioned_path_kmers_per_s"], 0)
             if "routes" in c:
