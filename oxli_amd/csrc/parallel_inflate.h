@@ -350,7 +350,8 @@ inline uint64_t find_block(const uint8_t *p, size_t n, uint64_t from, uint64_t t
             if (b2 + 9 > n) break;
             uint64_t lo;
             memcpy(&lo, p + b2, 8);
-            lo = (lo >> (q2 & 7)) | ((uint64_t)p[b2 + 8] << (64 - (q2 & 7))) * ((q2 & 7) != 0);
+            const unsigned sh = (unsigned)(q2 & 7);
+            if (sh) lo = (lo >> sh) | ((uint64_t)p[b2 + 8] << (64 - sh));
             unsigned kraft = 0;
             for (unsigned i = 0; i < hclen; ++i) {
                 const unsigned l = (unsigned)(lo >> (3 * i)) & 7u;   // (57 bits at most)
