@@ -124,7 +124,11 @@ __device__ __forceinline__ bool ring_flush(T *ring, u64 *cur, u32 *flist, u32 *f
 // lane -- 256 lanes take four code words each, 128 lanes eight validity halves, six more the halo -- straight into the places of tcodes /
 // tvalid they land in anyway: one wide load per lane of six waves instead of a 4-byte and a 2-byte load per lane of all sixteen.  (An
 // instantiation without PACKED still reads packed arrays when pcodes is set, with the two narrow loads: k without a PACKED instantiation.)
-template <int KW, int KC, int MODE = 0, bool RUNS = false, bool PACKED = false>
+// FE: windows between two flushes of the ring (0 = the mode's default: a quarter of the ring per interval -- 8 in compact mode, 4 with 8-byte entries,
+// 2 with 16-byte ones).  FE = 4 in compact mode (an eighth of the ring per interval) is for inputs whose k-mers arrive in BURSTS -- position-sorted reads:
+// every k-mer of a tile ~25 times within a few hundred windows -- which overflow a bin's 32-entry stretch between two flushes (round 6: the overflow
+// route was half of such a pass); it costs the flush's fixed work twice as often.
+template <int KW, int KC, int MODE = 0, bool RUNS = false, bool PACKED = false, int FE = 0>
 __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const unsigned char *__restrict__ stream, u64 nbytes, int k,
                                                                          u64 ntiles, PartitionArgs a) {
     static_assert(!RUNS || KW != 0, "super-k-mer input needs k <= 64");
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_windows_kernel(const u
     using T = typename std::conditional<MODE == 2, u32, typename std::conditional<MODE == 3, ulonglong2, u64>::type>::type;
     using PH = typename std::conditional<MODE == 3, u64, T>::type;  // the pending append's (first) word
     constexpr int kEntries = kRingEntries * 8 / sizeof(T);  // the ring is 128 KiB either way
-    constexpr int kFlushEvery = MODE == 2 ? 8 : MODE == 3 ? 2 : 4;  // windows between flushes: a quarter of the ring per interval
+    constexpr int kFlushEvery = FE > 0 ? FE : MODE == 2 ? 8 : MODE == 3 ? 2 : 4;  // windows between flushes: a quarter of the ring per interval
     __shared__ __attribute__((aligned(16))) T ring[kEntries];
     __shared__ u64 cur[1024];  // per bin: fill (low half) | flushed (high half)
     constexpr u32 kListCap = KW == 0 ? 1792 : 2048;  // the bytewise path's raw tile leaves a little less LDS

@@ -96,7 +96,10 @@ static void k1_packed(kct_table *t, int nwg, u64 chunk_bytes, int k, u64 ntiles,
 static bool launch_partition_packed(kct_table *t, int mode, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa) {
     const int k = t->k, nwg = t->num_cus;
     if ((((uintptr_t)pa.pcodes | (uintptr_t)pa.pvalid) & 15) != 0 || k > 64) return false;
-    if (mode == 2) {
+    if (mode == 2 && t->compact_bursty) {   // (flush every 4 windows: k1_kernel.h FE)
+        if (k == 21) hipLaunchKernelGGL((kct::partition_windows_kernel<1, 21, 2, false, true, 4>), dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, (const unsigned char *)nullptr, chunk_bytes, k, ntiles, pa);
+        else hipLaunchKernelGGL((kct::partition_windows_kernel<1, 0, 2, false, true, 4>), dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, (const unsigned char *)nullptr, chunk_bytes, k, ntiles, pa);
+    } else if (mode == 2) {
         if (k == 21) k1_packed<1, 21, 2>(t, nwg, chunk_bytes, k, ntiles, pa);
         else k1_packed<1, 0, 2>(t, nwg, chunk_bytes, k, ntiles, pa);
     } else if (mode == 1) {
@@ -171,7 +174,10 @@ void launch_partition(kct_table *t, int mode, const unsigned char *d_stream, u64
 #endif
     if (mode != 3 && launch_partition_ws(t, mode, d_stream, chunk_bytes, ntiles, pa_)) return;   // the wave-specialised K1 (kct_k1ws.hip)
     if (pa_.pcodes && launch_partition_packed(t, mode, chunk_bytes, ntiles, pa_)) return;
-    if (mode == 2) PartitionCompactByK<21>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa_);
+    if (mode == 2 && t->compact_bursty) {   // (flush every 4 windows: k1_kernel.h FE; k = 21 at compile time, every other k at run time)
+        if (k == 21) hipLaunchKernelGGL((kct::partition_windows_kernel<1, 21, 2, false, false, 4>), dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, d_stream, chunk_bytes, k, ntiles, pa_);
+        else hipLaunchKernelGGL((kct::partition_windows_kernel<1, 0, 2, false, false, 4>), dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, d_stream, chunk_bytes, k, ntiles, pa_);
+    } else if (mode == 2) PartitionCompactByK<21>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa_);
     else if (mode == 1) PartitionRawByK<32>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa_);
     else PartitionByK<64>::run(k, t->stream, nwg, d_stream, chunk_bytes, ntiles, pa_);
 }
@@ -705,6 +711,15 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
             (unsigned long long)t->s32_keys, (unsigned long long)nfailed, (unsigned long long)blocked, (unsigned long long)c2[kct::CTR_TOTAL_ADDED],
             (unsigned long long)spilled2);
     *n_out += counted + c2[kct::CTR_TOTAL_ADDED];  // (see consume_partitioned about n and a MurmurHash3 value of 0)
+    // K-mers that arrive in bursts (position-sorted reads) overflow a bin's stretch of the ring between two flushes: when more than 2 % of a
+    // pass took the overflow route (C2 sorted by position: 4.4 % of the probe, 6.6 % of the pass), K1 flushes twice as often from the next
+    // pass on (k1_kernel.h FE = 4: 0.35 % there).  It stays that way for the table's life: what a pass with FE = 4 overflows says nothing about
+    // what the same input would do to FE = 8 (an "until a pass stays under 0.25 %" rule flipped back and forth between the probe and the
+    // pass of every call), and the price on input that would not have needed it is 3 % of K1.
+    {
+        const u64 over = c2[kct::CTR_TOTAL_ADDED], all = counted + over;
+        if (all >= (1ULL << 20) && over * 50 > all) t->compact_bursty = true;
+    }
     t->n_keys += c2[kct::CTR_NEWKEYS];
     u64 new_in_table = c2[kct::CTR_NEWKEYS];
     if (spilled2) {

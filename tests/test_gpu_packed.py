@@ -199,3 +199,37 @@ def test_wave_specialised_k1_equals_oracle(gpu, k, flushers, cap, monkeypatch):
         assert "partition_windows_kernel<compact>" in prof, prof
         assert np.array_equal(dk, rk) and np.array_equal(dc, 2 * rc), (packed,)
         assert t.sum_counts == 2 * n_ref
+
+
+@pytest.mark.parametrize("k", [21, 17])
+def test_position_sorted_reads_switch_k1_to_the_short_flush_interval(gpu, k):
+    """Position-sorted reads bring every k-mer ~30 times within a few hundred windows: the compact K1's rings overflow between two flushes (6.6 % of
+    C2 sorted), the pass notices (more than 2 % over the overflow route) and the table's later passes run the FE = 4 instantiation of K1
+    (k1_kernel.h: a flush every 4 windows; k = 21 at compile time, k = 17 at run time; ASCII and packed input).  Every pass must equal the oracle."""
+    torch, KCT, lib = gpu
+    rng = random.Random(4000 + k)
+    genome = "".join(rng.choice("ACGT") for _ in range(330_000))
+    recs = [genome[p:p + 150] for p in range(0, len(genome) - 150, 5)]          # 66 k reads, sorted, 30x
+    ref = OracleTable(k)
+    n_ref = sum(ref.consume(r) for r in recs)
+    rk, rc = ref.dump_arrays()
+    stream = "".join(r + "\n" for r in recs).encode()
+    dev = torch.frombuffer(bytearray(stream + b"\n" * ((-len(stream)) % 16) + b"\n" * 64), dtype=torch.uint8).cuda()
+    ng = (len(stream) + 15) // 16
+    codes = torch.zeros(ng + 4, dtype=torch.int32, device="cuda")
+    valid = torch.zeros(ng + 8, dtype=torch.int16, device="cuda")
+    assert lib.kct_pack_stream_device(dev.data_ptr(), len(stream), codes.data_ptr(), valid.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    consumed = sum(len(r) for r in recs)
+    t = KCT(k, capacity=400_000)
+    t.set_path("dedupe")
+    t.profile(True)
+    total = 0
+    for i in range(4):   # pass 0 overflows and sets the switch; passes 1-3 run with the short interval (ASCII, packed, ASCII)
+        n = t.consume_device_packed(codes.data_ptr(), valid.data_ptr(), len(stream), consumed) if i == 2 else t.consume_device(dev.data_ptr(), len(stream), consumed)
+        assert n == n_ref
+        total += n
+        dk, dc = t.dump_arrays(1)
+        assert np.array_equal(dk, rk) and np.array_equal(dc, (i + 1) * rc), i
+    prof = t.profile_read()
+    assert "merge_overflow_kernel" in prof and t.sum_counts == total
