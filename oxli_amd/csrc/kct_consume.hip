@@ -577,8 +577,9 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
         KCT_TRY(ensure_shadow32(t, probe ? kCompactBlockBits : compact_sbits_for(t), &ok));  // (the probe's shadow is the small one, swapped in by the caller)
         if (!ok) { t->compact_off = true; return KCT_OK; }
     }
-    // u32 counts: a pending count grows by at most 1/256 of the window starts consumed (aggregate_blocks32_kernel)
-    if (t->s32_dirty && t->s32_windows + npos >= (1ULL << 39)) KCT_TRY(flush_compact(t));
+    // u32 counts: a pending count grows by at most 1/256 of the window starts consumed (aggregate_blocks32_kernel) -- 1/128 with the short flush
+    // interval of bursty input (a bin's 32-entry stretch per 4096 appends): converted before 2^38 window starts either way
+    if (t->s32_dirty && t->s32_windows + npos >= (1ULL << 38)) KCT_TRY(flush_compact(t));
     const int sbits = t->s32_sbits;
     const bool two_level = sbits > kCompactBlockBits;
     const int pbits = kCompactBlockBits;                             // K1's bins are always the value's top 10 bits
@@ -652,6 +653,8 @@ kct_status consume_compact(kct_table *t, const unsigned char *d_stream, u64 chun
         // the next workgroup's start (K2-32 -1.3 %)
         aa.nblocks = (unsigned int)B;
         const unsigned grid2 = t->tune.k2_nopersist ? (unsigned)B : (unsigned)std::min<u64>(B, 2 * (u64)t->num_cus);
+        // (bursty input: folding equal neighbours among the four entries a lane holds before the LDS add was measured -- K2-32 0.581 against
+        // 0.489 ms on position-sorted C2: the same k-mer's entries lie a lane apart, not inside one lane's four -- and is not kept)
         if (two_level) hipLaunchKernelGGL(kct::aggregate_blocks32_kernel<true>, dim3(grid2), dim3(kct::kPartThreads), 0, t->stream, aa);
         else hipLaunchKernelGGL(kct::aggregate_blocks32_kernel<false>, dim3(grid2), dim3(kct::kPartThreads), 0, t->stream, aa);
     }
