@@ -486,7 +486,8 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
                     const unsigned hw = std::thread::hardware_concurrency();
                     unsigned nth = std::max(2u, std::min(32u, hw / 2));   // (64 threads: no faster inflating and an erratic last phase, tools/gz_diag.py)
                     if (const char *e = getenv("KCT_GZIP_THREADS")) nth = (unsigned)std::max(2, atoi(e));
-                    ok = pgz::gunzip_parallel(gzmap.p, gzmap.size, (uint8_t *)m, isize, nth);
+                    try { ok = pgz::gunzip_parallel(gzmap.p, gzmap.size, (uint8_t *)m, isize, nth); }
+                    catch (...) { ok = false; }   // (no thread, no memory: the ordinary inflater takes the member; nothing unwinds across the C ABI)
                     KCT_DBG(t, "file: parallel inflate of %zu -> %u bytes on %u threads: %s\n", gzmap.size, isize, nth, ok ? "ok" : "declined");
                 }
                 if (!ok && have_ld) {
