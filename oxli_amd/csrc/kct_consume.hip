@@ -173,6 +173,20 @@ void launch_partition(kct_table *t, int mode, const unsigned char *d_stream, u64
     const kct::PartitionArgs &pa_ = pa;
 #endif
     if (mode != 3 && launch_partition_ws(t, mode, d_stream, chunk_bytes, ntiles, pa_)) return;   // the wave-specialised K1 (kct_k1ws.hip)
+    if (mode != 2 && t->wide_bursty && k <= 64) {
+        // bursty input on the 8-byte-entry modes: a flush every 2 windows instead of 4 (k1_kernel.h FE; the popular k at compile time, the rest at run
+        // time; packed arrays through the ordinary instantiation's narrow loads)
+        const dim3 g(nwg), b(kct::kPartThreads);
+        if (mode == 1) {
+            if (k == 31) hipLaunchKernelGGL((kct::partition_windows_kernel<1, 31, 1, false, false, 2>), g, b, 0, t->stream, d_stream, chunk_bytes, k, ntiles, pa_);
+            else hipLaunchKernelGGL((kct::partition_windows_kernel<1, 0, 1, false, false, 2>), g, b, 0, t->stream, d_stream, chunk_bytes, k, ntiles, pa_);
+        } else if (k == 21) hipLaunchKernelGGL((kct::partition_windows_kernel<1, 21, 0, false, false, 2>), g, b, 0, t->stream, d_stream, chunk_bytes, k, ntiles, pa_);
+        else if (k == 31) hipLaunchKernelGGL((kct::partition_windows_kernel<1, 31, 0, false, false, 2>), g, b, 0, t->stream, d_stream, chunk_bytes, k, ntiles, pa_);
+        else if (k == 51) hipLaunchKernelGGL((kct::partition_windows_kernel<2, 51, 0, false, false, 2>), g, b, 0, t->stream, d_stream, chunk_bytes, k, ntiles, pa_);
+        else if (k <= 32) hipLaunchKernelGGL((kct::partition_windows_kernel<1, 0, 0, false, false, 2>), g, b, 0, t->stream, d_stream, chunk_bytes, k, ntiles, pa_);
+        else hipLaunchKernelGGL((kct::partition_windows_kernel<2, 0, 0, false, false, 2>), g, b, 0, t->stream, d_stream, chunk_bytes, k, ntiles, pa_);
+        return;
+    }
     if (pa_.pcodes && launch_partition_packed(t, mode, chunk_bytes, ntiles, pa_)) return;
     if (mode == 2 && t->compact_bursty) {   // (flush every 4 windows: k1_kernel.h FE; k = 21 at compile time, every other k at run time)
         if (k == 21) hipLaunchKernelGGL((kct::partition_windows_kernel<1, 21, 2, false, false, 4>), dim3(nwg), dim3(kct::kPartThreads), 0, t->stream, d_stream, chunk_bytes, k, ntiles, pa_);
@@ -1043,6 +1057,10 @@ kct_status consume_partitioned(kct_table *t, const unsigned char *d_stream, u64 
             (unsigned long long)failed_entries, (unsigned long long)t->h_counters[kNumCounters + 6]);
     if (t->h_counters[kNumCounters + 6] != 0) return KCT_OK;  // abandoned: K2 and the merges exited early, nothing was touched
     *handled = true;
+    {   // bursty input (consume_compact has the story): more than 2 % of the pass over the overflow route -> K1 flushes every 2 windows from now on
+        const u64 over = c2[kct::CTR_TOTAL_ADDED], all = (raw ? c[kct::CTR_COUNTED] : c2[kct::CTR_COUNTED]) + over;
+        if (all >= (1ULL << 20) && over * 50 > all) t->wide_bursty = true;
+    }
     if (pend.pairs) t->pending_pairs = t->h_counters[kNumCounters + 8];
     if (!raw) {
         t->lazy_empty = false;

@@ -238,6 +238,7 @@ struct kct_table {
     u64 pending_pairs = 0;
     u64 windows_since_read = 0; // window starts consumed since anything last read the table (use()): how long the caller's runs are
     u64 call_windows_left = 0;  // window starts the running consume call still has to count (no read can come before them)
+    bool wide_bursty = false;      // ... the same for the 8-byte-entry modes (hashing, 64-bit dedupe-first): a flush every 2 windows instead of 4
     bool compact_bursty = false;   // a compact dedupe-first pass sent more than 2 % of its entries over the overflow route (k-mers arriving in bursts:
                                    // position-sorted reads): K1 flushes its ring every 4 windows instead of 8 from then on (kct_consume.hip)
     int fault_point = 0;        // kct_debug_inject_fault: the next routed call fails once at this point (kct_route.hip) ...

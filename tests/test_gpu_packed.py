@@ -201,11 +201,13 @@ def test_wave_specialised_k1_equals_oracle(gpu, k, flushers, cap, monkeypatch):
         assert t.sum_counts == 2 * n_ref
 
 
-@pytest.mark.parametrize("k", [21, 17])
-def test_position_sorted_reads_switch_k1_to_the_short_flush_interval(gpu, k):
+@pytest.mark.parametrize("k,path", [(21, "dedupe"), (17, "dedupe"), (31, "dedupe"), (31, "partitioned"), (25, "partitioned"), (51, "partitioned")])
+def test_position_sorted_reads_switch_k1_to_the_short_flush_interval(gpu, k, path):
     """Position-sorted reads bring every k-mer ~30 times within a few hundred windows: the compact K1's rings overflow between two flushes (6.6 % of
     C2 sorted), the pass notices (more than 2 % over the overflow route) and the table's later passes run the FE = 4 instantiation of K1
-    (k1_kernel.h: a flush every 4 windows; k = 21 at compile time, k = 17 at run time; ASCII and packed input).  Every pass must equal the oracle."""
+    (k1_kernel.h: a flush every 4 windows; k = 21 at compile time, k = 17 at run time; ASCII and packed input) -- and the 8-byte-entry modes likewise
+    (a flush every 2 windows: the 64-bit dedupe-first mode at k = 31, the hashing mode at k = 31 / 51 at compile time and k = 25 at run time).
+    Every pass must equal the oracle."""
     torch, KCT, lib = gpu
     rng = random.Random(4000 + k)
     genome = "".join(rng.choice("ACGT") for _ in range(330_000))
@@ -221,8 +223,8 @@ def test_position_sorted_reads_switch_k1_to_the_short_flush_interval(gpu, k):
     assert lib.kct_pack_stream_device(dev.data_ptr(), len(stream), codes.data_ptr(), valid.data_ptr(), None) == 0
     torch.cuda.synchronize()
     consumed = sum(len(r) for r in recs)
-    t = KCT(k, capacity=400_000)
-    t.set_path("dedupe")
+    t = KCT(k, capacity=5_000_000)   # (2^23 slots = 1024 blocks: K1 fans out to 1024 bins of 32 / 16 ring entries, as for C2)
+    t.set_path(path)
     t.profile(True)
     total = 0
     for i in range(4):   # pass 0 overflows and sets the switch; passes 1-3 run with the short interval (ASCII, packed, ASCII)
