@@ -701,7 +701,71 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
                             "BGZF input (bgzip) is inflated on many threads, libdeflate doubles a single stream's rate\n", path);
         // a plain gzip stream: one inflater thread -> a ring of text slots -> this thread's parser (see the top of the file)
         TextRing ring(4, slot_bytes);
+        // Round 6: a gzip file of 4 MiB or more is inflated by several threads here too (parallel_inflate.h's streaming form: 32 MiB of compressed
+        // bytes at a time, entered at searched block boundaries, the next window inflated while this one's text is handed to the parser; every
+        // member's CRC-32 and length checked at its end -- a mismatch fails the call there, as gzread's would).  Smaller files, or
+        // KCT_NO_PARALLEL_GZIP: the one zlib thread below.
+        const bool stream_parallel = gzmap.p && gzmap.size >= ((size_t)4 << 20) && !getenv("KCT_NO_PARALLEL_GZIP") && pgz::gzip_header(gzmap.p, gzmap.size) != 0;
+        KCT_DBG(t, "file: gzip stream through %s\n", stream_parallel ? "the parallel inflater (windows of 32 MiB)" : "one zlib thread");
         std::thread inflater([&] {
+            if (stream_parallel) {
+                try {
+                    const unsigned hw = std::thread::hardware_concurrency();
+                    unsigned nth = std::max(2u, std::min(32u, hw / 2));
+                    if (const char *e = getenv("KCT_GZIP_THREADS")) nth = (unsigned)std::max(2, atoi(e));
+                    size_t span = (size_t)32 << 20;
+                    if (const char *e = getenv("KCT_GZIP_WINDOW")) span = std::max<size_t>(65536, (size_t)atoll(e));   // (tests: many windows of a small file)
+                    size_t off = 0;
+                    u64 seq = 0;
+                    pgz::MemberStream st;
+                    bool in_member = false;
+                    // the next window's text (members follow one another; what is no gzip header behind a member's trailer is ignored, as zlib does)
+                    auto next_text = [&](std::vector<uint8_t> &text) -> int {   // 1 = text, 0 = the end, -1 = failed (ring.fail called)
+                        for (;;) {
+                            if (!in_member) {
+                                const size_t h = off < gzmap.size ? pgz::gzip_header(gzmap.p + off, gzmap.size - off) : 0;
+                                if (!h) return 0;
+                                st = pgz::MemberStream();
+                                st.def = gzmap.p + off + h; st.def_size = gzmap.size - off - h;
+                                off += h;
+                                in_member = true;
+                            }
+                            if (!pgz::inflate_window(st, span, nth, text)) { ring.fail("corrupt gzip stream"); return -1; }
+                            if (st.done) {
+                                const size_t end = (size_t)((st.bit + 7) / 8);
+                                unsigned crc = 0, isz = 0;
+                                if (end + 8 > st.def_size) { ring.fail("truncated gzip stream"); return -1; }
+                                memcpy(&crc, st.def + end, 4); memcpy(&isz, st.def + end + 4, 4);
+                                if (crc != st.crc || isz != (unsigned)st.total) { ring.fail("corrupt gzip stream (CRC-32 / length of a member)"); return -1; }
+                                off += end + 8;
+                                in_member = false;
+                            }
+                            if (!text.empty()) return 1;
+                        }
+                    };
+                    std::vector<uint8_t> cur, nxt;
+                    int have = next_text(cur);
+                    while (have == 1) {
+                        int have_next = 0;
+                        std::thread ahead([&] { try { have_next = next_text(nxt); } catch (...) { ring.fail("out of memory in the parallel inflater"); have_next = -1; } });
+                        bool abandoned = false;
+                        for (size_t p0 = 0; p0 < cur.size() && !abandoned;) {
+                            TextRing::Slot *sl = ring.acquire(seq);
+                            if (!sl) { abandoned = true; break; }
+                            const size_t n = std::min(sl->buf.size(), cur.size() - p0);
+                            memcpy(sl->buf.data(), cur.data() + p0, n);
+                            ring.publish(sl, n);
+                            ++seq; p0 += n;
+                        }
+                        ahead.join();
+                        if (abandoned) return;
+                        cur.swap(nxt);
+                        have = have_next;
+                    }
+                    if (have == 0) ring.finish(seq);
+                } catch (...) { ring.fail("out of memory in the parallel inflater"); }
+                return;
+            }
             gzFile f = gzopen(path, "rb");
             if (!f) { ring.fail("cannot open the gzip stream"); return; }
             gzbuffer(f, 1 << 20);

@@ -196,6 +196,27 @@ struct ByteOut {
     size_t size() const { return pos; }
 };
 
+// output with a KNOWN 32 KiB in front and no known size (the streaming form's first piece, and its serial fall-back): v = the window, then the text
+struct ByteOutW {
+    std::vector<uint8_t> v;      // [0, 32768) = the window in front (zeros where the stream is younger than that), text behind it
+    size_t limit = ~(size_t)0;
+    explicit ByteOutW(const uint8_t *window) : v(window, window + 32768) {}
+    inline bool lit(unsigned c) { if (v.size() - 32768 >= limit) return false; v.push_back((uint8_t)c); return true; }
+    inline bool copy(unsigned len, unsigned dist) {
+        const size_t pos = v.size();
+        if (dist > pos || pos - 32768 + len > limit) return false;
+        v.resize(pos + len);
+        uint8_t *d = v.data() + pos;
+        const uint8_t *s = d - dist;
+        if (dist >= len) memcpy(d, s, len);
+        else for (unsigned i = 0; i < len; ++i) d[i] = s[i];
+        return true;
+    }
+    inline bool raw(const uint8_t *s, size_t n) { if (v.size() - 32768 + n > limit) return false; v.insert(v.end(), s, s + n); return true; }
+    size_t size() const { return v.size() - 32768; }
+    const uint8_t *text() const { return v.data() + 32768; }
+};
+
 // output with an UNKNOWN 32 KiB in front: 16-bit symbols, 0x8000 + j = byte j of that window (j = 32768 - distance before the chunk)
 struct MarkOut {
     uint16_t *v = nullptr;
@@ -292,13 +313,14 @@ inline bool block_codes(Bits &b, const LitLen &ll, const Dist &dd, Out &out) {
     }
 }
 
-enum { RUN_ERROR = 0, RUN_REACHED = 1, RUN_FINAL = 2 };
+enum { RUN_ERROR = 0, RUN_REACHED = 1, RUN_FINAL = 2, RUN_STOPPED = 3 };
 
 // Inflates whole blocks from the reader's position.  targets[ti...] are bit positions (ascending) of later block-start candidates: the
 // run ends when a block boundary falls EXACTLY on one (*reached = its index); candidates that are passed are skipped.  Also ends behind
 // the final block (*end_bit = the position behind it).
+// stop_at (the streaming form): the run also ends at the first block boundary at or behind this bit position (*end_bit = the boundary).
 template <class Out>
-inline int run_blocks(Bits &b, Out &out, const uint64_t *targets, size_t ntargets, size_t *reached, uint64_t *end_bit) {
+inline int run_blocks(Bits &b, Out &out, const uint64_t *targets, size_t ntargets, size_t *reached, uint64_t *end_bit, uint64_t stop_at = ~0ULL) {
     size_t ti = 0;
     LitLen ll;
     Dist dd;
@@ -306,6 +328,7 @@ inline int run_blocks(Bits &b, Out &out, const uint64_t *targets, size_t ntarget
         const uint64_t at = b.pos();
         while (ti < ntargets && targets[ti] < at) ++ti;
         if (ti < ntargets && targets[ti] == at) { *reached = ti; return RUN_REACHED; }
+        if (at >= stop_at) { *end_bit = at; return RUN_STOPPED; }
         b.refill();
         const unsigned final = b.get(1), type = b.get(2);
         if (type == 0) {
@@ -501,6 +524,154 @@ inline bool gunzip_parallel(const uint8_t *gz, size_t gz_size, uint8_t *out, siz
     uint32_t crc = crcs[0];
     for (size_t j = 1; j < chain.size(); ++j) crc = (uint32_t)crc32_combine(crc, crcs[j], (z_off_t)(off[j + 1] - off[j]));
     return crc == want_crc;
+}
+
+
+// ---- the streaming form: a member of any size, a WINDOW of its compressed bytes at a time (kct_ingest.hip's producer for texts beyond what the
+// one-piece form above may hold in memory) --------------------------------------------------------------------------------------------------
+// The state between windows is a block boundary and the 32 KiB of text in front of it; a window is the blocks that start in the next `span` compressed
+// bytes, inflated like a whole member above -- piece 0 begins at the known boundary with the known window and is decoded as bytes, the other
+// pieces begin at searched starts with unknown windows -- except that nothing can be verified until the member's trailer: a window whose pieces do
+// not chain up is inflated again by ONE thread from its known boundary (always possible), and the CRC-32 of everything is checked at the end of the
+// member, where a mismatch is an error (as it is for zlib): text has been handed on by then.
+struct MemberStream {
+    const uint8_t *def = nullptr;     // the member's deflate data
+    size_t def_size = 0;              // ... up to the end of the FILE (the member's own end is found by inflating)
+    uint64_t bit = 0;                 // the next block boundary
+    uint8_t window[32768];            // the text in front of it
+    bool done = false;                // the final block has been inflated: `bit` is the position behind it
+    uint32_t crc = 0;
+    uint64_t total = 0;
+    unsigned windows = 0, serial_windows = 0;   // statistics: windows inflated, windows that fell back to one thread
+    MemberStream() { memset(window, 0, sizeof window); }
+};
+
+// inflates the next window of `st` into `text` (replaced); false = the stream is corrupt (or out of memory)
+inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, std::vector<uint8_t> &text) {
+    text.clear();
+    if (st.done) return true;
+    constexpr size_t W = 32768;
+    const uint64_t stop_at = st.bit + 8ULL * span;
+    const size_t byte0 = (size_t)(st.bit >> 3);
+    const size_t chunk_bytes = std::max<size_t>(256 << 10, span / (2 * (size_t)std::max(1u, nthreads)));
+    const size_t nchunks = std::max<size_t>(1, (std::min(span, st.def_size - std::min(st.def_size, byte0)) + chunk_bytes - 1) / chunk_bytes);
+    ++st.windows;
+    bool chained = false;
+    std::vector<uint64_t> cstart{st.bit};
+    if (nthreads >= 2 && nchunks >= 2) {
+        std::vector<uint64_t> start(nchunks, ~0ULL);
+        {
+            std::atomic<size_t> next{1};
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < std::min<size_t>(nthreads, nchunks); ++t)
+                th.emplace_back([&] {
+                    for (size_t c; (c = next.fetch_add(1)) < nchunks;) {
+                        const uint64_t from = 8ULL * (byte0 + c * chunk_bytes), to = std::min<uint64_t>(8ULL * st.def_size, std::min<uint64_t>(stop_at, from + 8ULL * chunk_bytes));
+                        if (from < to) start[c] = find_block(st.def, st.def_size, from, to);
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
+        for (size_t c = 1; c < nchunks; ++c) if (start[c] != ~0ULL && start[c] > st.bit) cstart.push_back(start[c]);
+    }
+    struct Piece { MarkOut marks; int status = RUN_ERROR; size_t next = 0; uint64_t end_bit = 0; };
+    std::vector<Piece> piece(cstart.size());
+    ByteOutW first(st.window);
+    if (cstart.size() > 1) {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < std::min<size_t>(nthreads, cstart.size()); ++t)
+            th.emplace_back([&] {
+                for (size_t i; (i = next.fetch_add(1)) < cstart.size();) {
+                    Piece &pc = piece[i];
+                    Bits b(st.def, st.def_size);
+                    b.seek(cstart[i]);
+                    size_t reached = 0;
+                    const uint64_t *tg = cstart.data() + i + 1;
+                    const size_t ntg = cstart.size() - i - 1;
+                    if (i == 0) pc.status = run_blocks(b, first, tg, ntg, &reached, &pc.end_bit, stop_at);
+                    else {
+                        pc.marks.limit = 1032 * (span + chunk_bytes) + 65536;   // (deflate cannot expand further)
+                        (void)pc.marks.room(6 * chunk_bytes);
+                        pc.status = run_blocks(b, pc.marks, tg, ntg, &reached, &pc.end_bit, stop_at);
+                    }
+                    pc.next = i + 1 + reached;
+                }
+            });
+        for (auto &x : th) x.join();
+        // the chain: piece 0, the piece it arrived at, ...; it ends where a piece stopped at the window's end or behind the final block
+        std::vector<size_t> chain;
+        bool ok = true, fin = false;
+        uint64_t end_bit = 0;
+        for (size_t i = 0;;) {
+            chain.push_back(i);
+            if (piece[i].status == RUN_FINAL || piece[i].status == RUN_STOPPED) { fin = piece[i].status == RUN_FINAL; end_bit = piece[i].end_bit; break; }
+            if (piece[i].status != RUN_REACHED || piece[i].next >= cstart.size()) { ok = false; break; }
+            i = piece[i].next;
+        }
+        if (ok) {
+            std::vector<size_t> off(chain.size() + 1, 0);
+            for (size_t j = 0; j < chain.size(); ++j) off[j + 1] = off[j] + (j == 0 ? first.size() : piece[chain[j]].marks.size());
+            text.resize(off[chain.size()]);
+            memcpy(text.data(), first.text(), first.size());
+            // the window in front of every piece, front to back: the last 32 KiB of (what lay in front of the previous piece ++ that piece's text)
+            std::vector<std::vector<uint8_t>> win(chain.size());
+            for (size_t j = 1; j < chain.size(); ++j) {
+                win[j].assign(W, 0);
+                if (j == 1) memcpy(win[j].data(), first.v.data() + first.v.size() - W, W);   // (first.v begins with the stream's own window: always >= W bytes)
+                else {
+                    const MarkOut &m = piece[chain[j - 1]].marks;
+                    const size_t n = std::min(W, m.n);
+                    resolve(m.v + (m.n - n), n, win[j - 1].data(), win[j].data() + (W - n));
+                    if (n < W) memcpy(win[j].data(), win[j - 1].data() + n, W - n);
+                }
+            }
+            std::atomic<size_t> nx{1};
+            std::vector<std::thread> th2;
+            for (unsigned t = 0; t < std::min<size_t>(nthreads, chain.size()); ++t)
+                th2.emplace_back([&] { for (size_t j; (j = nx.fetch_add(1)) < chain.size();) resolve(piece[chain[j]].marks.v, piece[chain[j]].marks.n, win[j].data(), text.data() + off[j]); });
+            for (auto &x : th2) x.join();
+            st.bit = end_bit; st.done = fin;
+            chained = true;
+        }
+    }
+    if (!chained) {   // one piece, or pieces that did not chain up: one thread from the known boundary
+        ++st.serial_windows;
+        ByteOutW bo(st.window);
+        Bits b(st.def, st.def_size);
+        b.seek(st.bit);
+        size_t reached = 0;
+        uint64_t end_bit = 0;
+        const int rc = run_blocks(b, bo, nullptr, 0, &reached, &end_bit, stop_at);
+        if (rc != RUN_FINAL && rc != RUN_STOPPED) return false;
+        text.assign(bo.text(), bo.text() + bo.size());
+        st.bit = end_bit; st.done = rc == RUN_FINAL;
+    }
+    // the state for the next window: the last 32 KiB of (window ++ text), the running CRC and length
+    if (text.size() >= W) memcpy(st.window, text.data() + text.size() - W, W);
+    else if (!text.empty()) { memmove(st.window, st.window + text.size(), W - text.size()); memcpy(st.window + W - text.size(), text.data(), text.size()); }
+    {
+        const size_t n = text.size(), parts = std::max<size_t>(1, std::min<size_t>(nthreads, n >> 20));
+        std::vector<uint32_t> cr(parts, 0);
+        std::vector<std::thread> th;
+        for (size_t q = 0; q < parts; ++q) th.emplace_back([&, q] { const size_t a = n * q / parts, e = n * (q + 1) / parts; uint32_t c = 0; for (size_t x = a; x < e;) { const size_t m = std::min<size_t>(e - x, 1u << 30); c = (uint32_t)crc32(c, text.data() + x, (uInt)m); x += m; } cr[q] = c; });
+        for (auto &x : th) x.join();
+        for (size_t q = 0; q < parts; ++q) st.crc = (uint32_t)crc32_combine(st.crc, cr[q], (z_off_t)(n * (q + 1) / parts - n * q / parts));
+        st.total += n;
+    }
+    return true;
+}
+
+// the length of a gzip member's header at p (RFC 1952), 0 if it is none
+inline size_t gzip_header(const uint8_t *p, size_t n) {
+    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return 0;
+    size_t h = 10;
+    const unsigned flg = p[3];
+    if (flg & 4) { if (h + 2 > n) return 0; h += 2 + (p[h] | (p[h + 1] << 8)); }
+    if (flg & 8) { while (h < n && p[h]) ++h; ++h; }
+    if (flg & 16) { while (h < n && p[h]) ++h; ++h; }
+    if (flg & 2) h += 2;
+    return h + 8 <= n ? h : 0;
 }
 
 }  // namespace pgz

@@ -916,11 +916,30 @@ def test_large_single_member_gzip_goes_through_the_parallel_inflater(KCT, tmp_pa
     assert dev.consume_file(str(path)) == n_ref
     assert_same_table(dev, ref)
     monkeypatch.delenv("KCT_NO_PARALLEL_GZIP")
+    # the STREAMING form (texts too large to inflate in one piece -- forced here by KCT_GZIP_WHOLE_MAX=0): windows of 1 MiB of compressed bytes, the
+    # text handed to the parser through the ring of slots; and the same reads as TWO members in one file
+    monkeypatch.setenv("KCT_GZIP_WHOLE_MAX", "0")
+    monkeypatch.setenv("KCT_GZIP_WINDOW", str(1 << 20))
+    monkeypatch.setenv("KCT_DEBUG", "1")
+    two = tmp_path / "two.fastq.gz"
+    cut = fq.index(b"\n@read35000 ") + 1
+    two.write_bytes(gzip.compress(fq[:cut], 6) + gzip.compress(fq[cut:], 1))
+    for pth in (path, two):
+        dev = KCT(k, capacity=1_000_000)
+        assert dev.consume_file(str(pth)) == n_ref
+        assert dev.last_file_records == len(recs)
+        assert_same_table(dev, ref)
+        assert "through the parallel inflater" in capfd.readouterr().err
+    monkeypatch.delenv("KCT_DEBUG"); monkeypatch.delenv("KCT_GZIP_WHOLE_MAX"); monkeypatch.delenv("KCT_GZIP_WINDOW")
     bad = bytearray(blob)
     bad[len(bad) * 3 // 4] ^= 0x21
     (tmp_path / "bad.fastq.gz").write_bytes(bytes(bad))
     with pytest.raises((RuntimeError, ValueError, OSError)):
         KCT(k).consume_file(str(tmp_path / "bad.fastq.gz"))
+    monkeypatch.setenv("KCT_GZIP_WHOLE_MAX", "0")     # ... and the streaming form meets the corruption in a window, or at the member's CRC
+    with pytest.raises((RuntimeError, ValueError, OSError)):
+        KCT(k).consume_file(str(tmp_path / "bad.fastq.gz"))
+    monkeypatch.delenv("KCT_GZIP_WHOLE_MAX")
 
 
 def test_consume_file_formats_match_oracle(KCT, tmp_path, monkeypatch):

@@ -46,6 +46,53 @@ int main(int argc, char **argv) {
 """
 
 
+STREAM_MAIN = r"""
+#include <cstdio>
+#include <cstdlib>
+// usage: pgz_stream file.gz threads span_bytes -> every member through inflate_window, compared with zlib's gzread
+int main(int argc, char **argv) {
+    if (argc < 4) return 2;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> gz(n);
+    if (fread(gz.data(), 1, n, f) != (size_t)n) return 2;
+    fclose(f);
+    std::vector<uint8_t> ref;
+    {
+        gzFile g = gzopen(argv[1], "rb");
+        std::vector<uint8_t> buf(1 << 20);
+        int r;
+        while ((r = gzread(g, buf.data(), (unsigned)buf.size())) > 0) ref.insert(ref.end(), buf.begin(), buf.begin() + r);
+        gzclose(g);
+    }
+    std::vector<uint8_t> out, text;
+    size_t off = 0;
+    unsigned windows = 0, serial = 0, members = 0;
+    while (off < gz.size()) {
+        const size_t h = pgz::gzip_header(gz.data() + off, gz.size() - off);
+        if (!h) break;
+        pgz::MemberStream st;
+        st.def = gz.data() + off + h; st.def_size = gz.size() - off - h;
+        while (!st.done) {
+            if (!pgz::inflate_window(st, (size_t)atoll(argv[3]), (unsigned)atoi(argv[2]), text)) { puts("CORRUPT"); return 3; }
+            out.insert(out.end(), text.begin(), text.end());
+        }
+        const size_t end = (size_t)((st.bit + 7) / 8);
+        uint32_t crc, isz;
+        if (end + 8 > st.def_size) { puts("TRUNCATED"); return 3; }
+        memcpy(&crc, st.def + end, 4); memcpy(&isz, st.def + end + 4, 4);
+        if (crc != st.crc || isz != (uint32_t)st.total) { puts("CRC MISMATCH"); return 3; }
+        windows += st.windows; serial += st.serial_windows; ++members;
+        off += h + end + 8;
+    }
+    if (out.size() != ref.size() || memcmp(out.data(), ref.data(), out.size()) != 0) { printf("MISMATCH %zu %zu\n", out.size(), ref.size()); return 3; }
+    printf("ok %u members, %u windows (%u serial)\n", members, windows, serial);
+    return 0;
+}
+"""
+
+
 def fastq(rng, n):
     out = []
     for i in range(n):
@@ -94,3 +141,19 @@ def test_parallel_inflate_equals_zlib(tmp_path):
                 assert verdict in ("ok", "declined"), (name, verdict)
                 done += verdict == "ok"
     assert done >= 3 * 5, done   # the FASTQ-like cases are really inflated in parallel (a decline is legal, not the rule)
+    # the STREAMING form (inflate_window: a window of compressed bytes at a time, the state between windows a block boundary + 32 KiB): every file
+    # above, member after member, windows of 300 kB (two pieces each), 1 MB and 100 kB (one thread per window), against gzread; CRC and length of
+    # every member checked by the harness as kct_ingest.hip's producer checks them
+    cpp2 = tmp_path / "pgz_stream.cpp"
+    cpp2.write_text(f'#include "{ROOT}/oxli_amd/csrc/parallel_inflate.h"\n' + STREAM_MAIN)
+    exe2 = tmp_path / "pgz_stream"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(exe2), str(cpp2), "-lz", "-lpthread"], check=True)
+    parallel_windows = 0
+    for name in {**cases, **must_decline}:
+        for threads, span in ((8, 300_000), (4, 1_000_000), (16, 100_000)):
+            r = subprocess.run([str(exe2), str(tmp_path / (name + ".gz")), str(threads), str(span)], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0 and r.stdout.startswith("ok "), (name, threads, span, r.stdout, r.stderr)
+            _ok, members, _m, windows, _w, serial, _s = r.stdout.replace("(", "").replace(")", "").replace(",", "").split()
+            assert int(members) == (2 if name == "two_members" else 1)
+            parallel_windows += int(windows) - int(serial)
+    assert parallel_windows > 20, parallel_windows
