@@ -524,11 +524,15 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
     }
     const size_t ntasks = bgzf ? task_first.size() - 1 : 0;
     size_t nparsers = 1, nslot_threads = 0;
+    // Round 6: a gzip file of 4 MiB or more that was not inflated in one piece goes through parallel_inflate.h's streaming form (below)
+    const bool stream_parallel = gz && !bgzf && !text_p && gzmap.p && gzmap.size >= ((size_t)4 << 20) && !getenv("KCT_NO_PARALLEL_GZIP") &&
+                                 pgz::gzip_header(gzmap.p, gzmap.size) != 0;
     if (text_p) nparsers = std::max<size_t>(1, std::min<size_t>({(size_t)8, hw ? hw : 1, (text_size + segment - 1) / segment}));
+    if (stream_parallel) nparsers = std::max<size_t>(1, std::min<size_t>((size_t)8, hw ? hw : 1));
     if (bgzf) nslot_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, hw ? hw / 2 : 1, ntasks}));
     if (const char *e = getenv("KCT_FILE_THREADS")) {
         const size_t want = std::max<size_t>(1, std::min<size_t>(64, (size_t)atoll(e)));
-        if (text_p) nparsers = want;
+        if (text_p || stream_parallel) nparsers = want;
         if (bgzf) nslot_threads = want;
     }
     if (bgzf) nparsers = nslot_threads + 1;   // (+ the calling thread, which parses the fragments between the slots)
@@ -566,34 +570,39 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
 
     u64 records = 0, bases = 0;
     kct_status st = KCT_OK;
+    // [p, p + size) holds whole records (it begins at a record start): parsed by nparsers threads that take `segment`-sized stretches (record
+    // starts found without context) -- a mapped file, the one-piece inflate of a .gz, or one window of the streaming inflater's text
+    auto parse_text = [&](const unsigned char *p, size_t size, int fmt) {
+        const size_t nseg = (size + segment - 1) / segment;
+        std::atomic<size_t> next_seg{0};
+        std::mutex tally_mu;
+        auto parser = [&](size_t id) {
+            ChunkWriter w(&queue, &t->h_file[2 * id], &t->h_file[2 * id + 1], chunk_cap, k);
+            for (;;) {
+                const size_t sg = next_seg.fetch_add(1);
+                if (sg >= nseg || queue.failed()) break;
+                const size_t lo = find_record_start(p, size, sg * segment, fmt);
+                const size_t hi = sg + 1 == nseg ? size : find_record_start(p, size, (sg + 1) * segment, fmt);
+                if (lo >= hi) continue;  // no record starts in this segment
+                MemSource src{p, p + lo, p + size};
+                if (!parse_records(src, w, fmt, hi, queue, path)) { queue.fail(KCT_ERR_ARG, g_err); break; }
+            }
+            w.finish();
+            std::lock_guard<std::mutex> lk(tally_mu);
+            records += w.records; bases += w.bases;
+        };
+        std::vector<std::thread> pool;
+        for (size_t i = 1; i < nparsers; ++i) pool.emplace_back(parser, i);
+        parser(0);
+        for (auto &th : pool) th.join();
+    };
     if (text_p) {
         size_t first = 0;
         while (first < text_size && (text_p[first] == '\n' || text_p[first] == '\r' || text_p[first] == ' ' || text_p[first] == '\t')) ++first;
         const int fmt = first < text_size ? text_p[first] : '>';
         if (first < text_size && fmt != '>' && fmt != '@') { set_err("%s: neither FASTA nor FASTQ (starts with 0x%02x)", path, fmt); st = KCT_ERR_ARG; }
         if (st == KCT_OK && first < text_size) {
-            const size_t nseg = (text_size + segment - 1) / segment;
-            std::atomic<size_t> next_seg{0};
-            std::mutex tally_mu;
-            auto parser = [&](size_t id) {
-                ChunkWriter w(&queue, &t->h_file[2 * id], &t->h_file[2 * id + 1], chunk_cap, k);
-                for (;;) {
-                    const size_t sg = next_seg.fetch_add(1);
-                    if (sg >= nseg || queue.failed()) break;
-                    const size_t lo = find_record_start(text_p, text_size, sg * segment, fmt);
-                    const size_t hi = sg + 1 == nseg ? text_size : find_record_start(text_p, text_size, (sg + 1) * segment, fmt);
-                    if (lo >= hi) continue;  // no record starts in this segment
-                    MemSource src{text_p, text_p + lo, text_p + text_size};
-                    if (!parse_records(src, w, fmt, hi, queue, path)) { queue.fail(KCT_ERR_ARG, g_err); break; }
-                }
-                w.finish();
-                std::lock_guard<std::mutex> lk(tally_mu);
-                records += w.records; bases += w.bases;
-            };
-            std::vector<std::thread> pool;
-            for (size_t i = 1; i < nparsers; ++i) pool.emplace_back(parser, i);
-            parser(0);
-            for (auto &th : pool) th.join();
+            parse_text(text_p, text_size, fmt);
             KCT_DBG(t, "file: parsers done\n");
         }
     } else if (bgzf) {
@@ -692,6 +701,98 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
             KCT_DBG(t, "file: parsers done\n");
             if (st == KCT_OK && slot_failed) { set_err("%s: %s", path, slot_msg.c_str()); st = KCT_ERR_ARG; }
         }
+    } else if (stream_parallel) {
+        // A plain gzip stream too large (or of too many members) for the one-piece route: 32 MiB of compressed bytes at a time are inflated by
+        // several threads (entered at searched block boundaries; every member's CRC-32 and length checked at its end -- a mismatch fails the
+        // call there, as gzread's would), the next window while this one's text is parsed by nparsers threads like a mapped file.  What
+        // follows a window's last record start -- an unfinished record -- is carried in front of the next window's text.
+        KCT_DBG(t, "file: gzip stream through the parallel inflater (windows of 32 MiB), %zu parser threads\n", nparsers);
+        std::string fail_msg;
+        try {
+            unsigned nth = std::max(2u, std::min(32u, hw / 2));
+            if (const char *e = getenv("KCT_GZIP_THREADS")) nth = (unsigned)std::max(2, atoi(e));
+            size_t span = (size_t)32 << 20;
+            if (const char *e = getenv("KCT_GZIP_WINDOW")) span = std::max<size_t>(65536, (size_t)atoll(e));   // (tests: many windows of a small file)
+            size_t off = 0;
+            pgz::MemberStream ms;
+            bool in_member = false;
+            // the next window's text (members follow one another; what is no gzip header behind a member's trailer is ignored, as zlib does)
+            // (the window buffers -- some 700 MB of mappings by the end -- are unmapped by a thread of their own after the call: 45 ms otherwise)
+            struct Buffers { pgz::WindowScratch scratch; pgz::TextBuf text, nxt; };
+            std::shared_ptr<Buffers> bufs = std::make_shared<Buffers>();
+            struct Release { std::shared_ptr<Buffers> &b; ~Release() { try { std::thread([q = std::move(b)]() mutable { q.reset(); }).detach(); } catch (...) {} } } release{bufs};
+            pgz::WindowScratch &scratch = bufs->scratch;
+            auto next_text = [&](pgz::TextBuf &text, std::string &msg) -> int {   // 1 = text, 0 = the end, -1 = failed
+                for (;;) {
+                    if (!in_member) {
+                        const size_t h = off < gzmap.size ? pgz::gzip_header(gzmap.p + off, gzmap.size - off) : 0;
+                        if (!h) return 0;
+                        ms = pgz::MemberStream();
+                        ms.def = gzmap.p + off + h; ms.def_size = gzmap.size - off - h;
+                        off += h;
+                        in_member = true;
+                    }
+                    if (!pgz::inflate_window(ms, span, nth, text, scratch)) { msg = "corrupt gzip stream"; return -1; }
+                    if (ms.done) {
+                        const size_t end = (size_t)((ms.bit + 7) / 8);
+                        unsigned crc = 0, isz = 0;
+                        if (end + 8 > ms.def_size) { msg = "truncated gzip stream"; return -1; }
+                        memcpy(&crc, ms.def + end, 4); memcpy(&isz, ms.def + end + 4, 4);
+                        if (crc != ms.crc || isz != (unsigned)ms.total) { msg = "corrupt gzip stream (CRC-32 / length of a member)"; return -1; }
+                        off += end + 8;
+                        in_member = false;
+                    }
+                    if (!text.empty()) return 1;
+                }
+            };
+            // Two text buffers take turns (their pages stay); what a window leaves unparsed -- the bytes from its last record start on -- is
+            // copied into the free `lead` in front of the next window's text, or, where a record is longer than that, joined with it aside.
+            pgz::TextBuf &text = bufs->text, &nxt = bufs->nxt;
+            text.lead = nxt.lead = (size_t)1 << 20;
+            if (const char *e = getenv("KCT_GZIP_LEAD")) text.lead = nxt.lead = (size_t)atoll(e);   // (tests: the joined route)
+            std::vector<unsigned char> carry, joined;
+            int fmt = -1;
+            int have = next_text(text, fail_msg);
+            while (have == 1 && !queue.failed()) {
+                int have_next = 0;
+                std::string next_msg;
+                std::thread ahead([&] { try { have_next = next_text(nxt, next_msg); } catch (...) { next_msg = "out of memory in the parallel inflater"; have_next = -1; } });
+                struct Joiner { std::thread &th; ~Joiner() { if (th.joinable()) th.join(); } } joiner{ahead};   // (an exception below must not leave it running)
+                const unsigned char *p = text.data();
+                size_t size = text.size();
+                if (!carry.empty()) {
+                    if (carry.size() <= text.lead) { p -= carry.size(); memcpy(text.data() - carry.size(), carry.data(), carry.size()); }
+                    else { joined.assign(carry.begin(), carry.end()); joined.insert(joined.end(), text.data(), text.data() + text.size()); p = joined.data(); }
+                    size += carry.size();
+                }
+                if (fmt < 0) {
+                    while (size && (*p == '\n' || *p == '\r' || *p == ' ' || *p == '\t')) { ++p; --size; }
+                    if (size) {
+                        fmt = *p;
+                        if (fmt != '>' && fmt != '@') { set_err("%s: neither FASTA nor FASTQ (starts with 0x%02x)", path, fmt); st = KCT_ERR_ARG; }
+                    }
+                }
+                if (st == KCT_OK && fmt >= 0) {
+                    const size_t hi = find_last_record_start(p, size, 0, fmt);
+                    if (hi > 0) {
+                        KCT_DBG(t, "file: window of %zu text bytes to the parsers\n", hi);
+                        parse_text(p, hi, fmt);
+                        KCT_DBG(t, "file: window parsed\n");
+                    }
+                    std::vector<unsigned char> rest(p + hi, p + size);
+                    carry.swap(rest);
+                } else carry.clear();   // (white space only so far)
+                ahead.join();
+                KCT_DBG(t, "file: next window inflated\n");
+                if (st != KCT_OK) { have = -2; break; }
+                std::swap(text.p, nxt.p); std::swap(text.cap, nxt.cap); std::swap(text.n, nxt.n);
+                have = have_next;
+                fail_msg = next_msg;
+            }
+            if (have == 0 && st == KCT_OK && fmt >= 0 && !carry.empty() && !queue.failed()) parse_text(carry.data(), carry.size(), fmt);   // the last record(s)
+            if (have == -1 && st == KCT_OK) { set_err("%s: %s", path, fail_msg.c_str()); st = KCT_ERR_ARG; }
+        } catch (...) { if (st == KCT_OK) { set_err("%s: out of memory in the parallel inflater", path); st = KCT_ERR_ARG; } }
+        KCT_DBG(t, "file: parsers done\n");
     } else {
         // (said ONCE per process, loudly: without libdeflate.so.0 a gzip file is inflated by one zlib thread at ~0.4 GB/s of text -- below
         // what the CPU reference path reads -- and nothing downstream can make up for it; bgzip the file, or install libdeflate)
@@ -699,73 +800,9 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
         if (!(deflate_lib().ok() && !libdeflate_disabled()) && gzmap.size > (64u << 20) && !said.exchange(true))
             fprintf(stderr, "kct_consume_file: libdeflate.so.0 not found -- %s is inflated by zlib on one thread (~0.4 GB/s of text); "
                             "BGZF input (bgzip) is inflated on many threads, libdeflate doubles a single stream's rate\n", path);
-        // a plain gzip stream: one inflater thread -> a ring of text slots -> this thread's parser (see the top of the file)
+        // a small plain gzip stream: one zlib thread -> a ring of text slots -> this thread's parser (see the top of the file)
         TextRing ring(4, slot_bytes);
-        // Round 6: a gzip file of 4 MiB or more is inflated by several threads here too (parallel_inflate.h's streaming form: 32 MiB of compressed
-        // bytes at a time, entered at searched block boundaries, the next window inflated while this one's text is handed to the parser; every
-        // member's CRC-32 and length checked at its end -- a mismatch fails the call there, as gzread's would).  Smaller files, or
-        // KCT_NO_PARALLEL_GZIP: the one zlib thread below.
-        const bool stream_parallel = gzmap.p && gzmap.size >= ((size_t)4 << 20) && !getenv("KCT_NO_PARALLEL_GZIP") && pgz::gzip_header(gzmap.p, gzmap.size) != 0;
-        KCT_DBG(t, "file: gzip stream through %s\n", stream_parallel ? "the parallel inflater (windows of 32 MiB)" : "one zlib thread");
         std::thread inflater([&] {
-            if (stream_parallel) {
-                try {
-                    const unsigned hw = std::thread::hardware_concurrency();
-                    unsigned nth = std::max(2u, std::min(32u, hw / 2));
-                    if (const char *e = getenv("KCT_GZIP_THREADS")) nth = (unsigned)std::max(2, atoi(e));
-                    size_t span = (size_t)32 << 20;
-                    if (const char *e = getenv("KCT_GZIP_WINDOW")) span = std::max<size_t>(65536, (size_t)atoll(e));   // (tests: many windows of a small file)
-                    size_t off = 0;
-                    u64 seq = 0;
-                    pgz::MemberStream st;
-                    bool in_member = false;
-                    // the next window's text (members follow one another; what is no gzip header behind a member's trailer is ignored, as zlib does)
-                    auto next_text = [&](std::vector<uint8_t> &text) -> int {   // 1 = text, 0 = the end, -1 = failed (ring.fail called)
-                        for (;;) {
-                            if (!in_member) {
-                                const size_t h = off < gzmap.size ? pgz::gzip_header(gzmap.p + off, gzmap.size - off) : 0;
-                                if (!h) return 0;
-                                st = pgz::MemberStream();
-                                st.def = gzmap.p + off + h; st.def_size = gzmap.size - off - h;
-                                off += h;
-                                in_member = true;
-                            }
-                            if (!pgz::inflate_window(st, span, nth, text)) { ring.fail("corrupt gzip stream"); return -1; }
-                            if (st.done) {
-                                const size_t end = (size_t)((st.bit + 7) / 8);
-                                unsigned crc = 0, isz = 0;
-                                if (end + 8 > st.def_size) { ring.fail("truncated gzip stream"); return -1; }
-                                memcpy(&crc, st.def + end, 4); memcpy(&isz, st.def + end + 4, 4);
-                                if (crc != st.crc || isz != (unsigned)st.total) { ring.fail("corrupt gzip stream (CRC-32 / length of a member)"); return -1; }
-                                off += end + 8;
-                                in_member = false;
-                            }
-                            if (!text.empty()) return 1;
-                        }
-                    };
-                    std::vector<uint8_t> cur, nxt;
-                    int have = next_text(cur);
-                    while (have == 1) {
-                        int have_next = 0;
-                        std::thread ahead([&] { try { have_next = next_text(nxt); } catch (...) { ring.fail("out of memory in the parallel inflater"); have_next = -1; } });
-                        bool abandoned = false;
-                        for (size_t p0 = 0; p0 < cur.size() && !abandoned;) {
-                            TextRing::Slot *sl = ring.acquire(seq);
-                            if (!sl) { abandoned = true; break; }
-                            const size_t n = std::min(sl->buf.size(), cur.size() - p0);
-                            memcpy(sl->buf.data(), cur.data() + p0, n);
-                            ring.publish(sl, n);
-                            ++seq; p0 += n;
-                        }
-                        ahead.join();
-                        if (abandoned) return;
-                        cur.swap(nxt);
-                        have = have_next;
-                    }
-                    if (have == 0) ring.finish(seq);
-                } catch (...) { ring.fail("out of memory in the parallel inflater"); }
-                return;
-            }
             gzFile f = gzopen(path, "rb");
             if (!f) { ring.fail("cannot open the gzip stream"); return; }
             gzbuffer(f, 1 << 20);

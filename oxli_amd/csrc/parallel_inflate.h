@@ -34,6 +34,7 @@
 #include <cstring>
 #include <thread>
 #include <utility>
+#include <deque>
 #include <vector>
 
 namespace pgz {
@@ -546,8 +547,40 @@ struct MemberStream {
     MemberStream() { memset(window, 0, sizeof window); }
 };
 
+// A window's text: storage that is not initialised and is kept, with its pages, from one window to the next (a std::vector's resize
+// wrote 146 MB of zeros per window on one thread -- more time than the inflating took); `lead` bytes stay free in front of the text
+// for what the caller carries over from the window before.
+struct TextBuf {
+    uint8_t *p = nullptr;
+    size_t cap = 0, lead = 0, n = 0;
+    TextBuf() = default;
+    TextBuf(const TextBuf &) = delete;
+    TextBuf &operator=(const TextBuf &) = delete;
+    ~TextBuf() { if (p) munmap(p, cap); }
+    uint8_t *data() const { return p + lead; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void clear() { n = 0; }
+    bool resize(size_t m) {   // (what was there is NOT kept)
+        if (!p || lead + m > cap) {
+            if (p) munmap(p, cap);
+            p = nullptr;
+            const size_t bytes = (lead + m + m / 8 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+            void *q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q == MAP_FAILED) { cap = n = 0; return false; }
+            (void)madvise(q, bytes, MADV_HUGEPAGE);
+            p = (uint8_t *)q; cap = bytes;
+        }
+        n = m;
+        return true;
+    }
+};
+
+// the 16-bit piece buffers of a window, kept for the next one (mapping, faulting in and unmapping ~300 MB per window otherwise)
+struct WindowScratch { std::deque<MarkOut> marks; };
+
 // inflates the next window of `st` into `text` (replaced); false = the stream is corrupt (or out of memory)
-inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, std::vector<uint8_t> &text) {
+inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, TextBuf &text, WindowScratch &scratch) {
     text.clear();
     if (st.done) return true;
     constexpr size_t W = 32768;
@@ -556,6 +589,10 @@ inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, std
     const size_t chunk_bytes = std::max<size_t>(256 << 10, span / (2 * (size_t)std::max(1u, nthreads)));
     const size_t nchunks = std::max<size_t>(1, (std::min(span, st.def_size - std::min(st.def_size, byte0)) + chunk_bytes - 1) / chunk_bytes);
     ++st.windows;
+    const bool timing = getenv("PGZ_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    double t_find = t0, t_dec = t0, t_res = t0;
     bool chained = false;
     std::vector<uint64_t> cstart{st.bit};
     if (nthreads >= 2 && nchunks >= 2) {
@@ -574,8 +611,11 @@ inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, std
         }
         for (size_t c = 1; c < nchunks; ++c) if (start[c] != ~0ULL && start[c] > st.bit) cstart.push_back(start[c]);
     }
-    struct Piece { MarkOut marks; int status = RUN_ERROR; size_t next = 0; uint64_t end_bit = 0; };
+    t_find = now();
+    struct Piece { MarkOut *marks = nullptr; int status = RUN_ERROR; size_t next = 0; uint64_t end_bit = 0; };
     std::vector<Piece> piece(cstart.size());
+    while (scratch.marks.size() < cstart.size()) scratch.marks.emplace_back();
+    for (size_t i = 0; i < cstart.size(); ++i) { piece[i].marks = &scratch.marks[i]; piece[i].marks->n = 0; }
     ByteOutW first(st.window);
     if (cstart.size() > 1) {
         std::atomic<size_t> next{0};
@@ -591,14 +631,15 @@ inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, std
                     const size_t ntg = cstart.size() - i - 1;
                     if (i == 0) pc.status = run_blocks(b, first, tg, ntg, &reached, &pc.end_bit, stop_at);
                     else {
-                        pc.marks.limit = 1032 * (span + chunk_bytes) + 65536;   // (deflate cannot expand further)
-                        (void)pc.marks.room(6 * chunk_bytes);
-                        pc.status = run_blocks(b, pc.marks, tg, ntg, &reached, &pc.end_bit, stop_at);
+                        pc.marks->limit = 1032 * (span + chunk_bytes) + 65536;   // (deflate cannot expand further)
+                        (void)pc.marks->room(6 * chunk_bytes);
+                        pc.status = run_blocks(b, *pc.marks, tg, ntg, &reached, &pc.end_bit, stop_at);
                     }
                     pc.next = i + 1 + reached;
                 }
             });
         for (auto &x : th) x.join();
+        t_dec = now();
         // the chain: piece 0, the piece it arrived at, ...; it ends where a piece stopped at the window's end or behind the final block
         std::vector<size_t> chain;
         bool ok = true, fin = false;
@@ -611,8 +652,8 @@ inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, std
         }
         if (ok) {
             std::vector<size_t> off(chain.size() + 1, 0);
-            for (size_t j = 0; j < chain.size(); ++j) off[j + 1] = off[j] + (j == 0 ? first.size() : piece[chain[j]].marks.size());
-            text.resize(off[chain.size()]);
+            for (size_t j = 0; j < chain.size(); ++j) off[j + 1] = off[j] + (j == 0 ? first.size() : piece[chain[j]].marks->size());
+            if (!text.resize(off[chain.size()])) return false;
             memcpy(text.data(), first.text(), first.size());
             // the window in front of every piece, front to back: the last 32 KiB of (what lay in front of the previous piece ++ that piece's text)
             std::vector<std::vector<uint8_t>> win(chain.size());
@@ -620,7 +661,7 @@ inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, std
                 win[j].assign(W, 0);
                 if (j == 1) memcpy(win[j].data(), first.v.data() + first.v.size() - W, W);   // (first.v begins with the stream's own window: always >= W bytes)
                 else {
-                    const MarkOut &m = piece[chain[j - 1]].marks;
+                    const MarkOut &m = *piece[chain[j - 1]].marks;
                     const size_t n = std::min(W, m.n);
                     resolve(m.v + (m.n - n), n, win[j - 1].data(), win[j].data() + (W - n));
                     if (n < W) memcpy(win[j].data(), win[j - 1].data() + n, W - n);
@@ -629,7 +670,7 @@ inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, std
             std::atomic<size_t> nx{1};
             std::vector<std::thread> th2;
             for (unsigned t = 0; t < std::min<size_t>(nthreads, chain.size()); ++t)
-                th2.emplace_back([&] { for (size_t j; (j = nx.fetch_add(1)) < chain.size();) resolve(piece[chain[j]].marks.v, piece[chain[j]].marks.n, win[j].data(), text.data() + off[j]); });
+                th2.emplace_back([&] { for (size_t j; (j = nx.fetch_add(1)) < chain.size();) resolve(piece[chain[j]].marks->v, piece[chain[j]].marks->n, win[j].data(), text.data() + off[j]); });
             for (auto &x : th2) x.join();
             st.bit = end_bit; st.done = fin;
             chained = true;
@@ -644,9 +685,11 @@ inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, std
         uint64_t end_bit = 0;
         const int rc = run_blocks(b, bo, nullptr, 0, &reached, &end_bit, stop_at);
         if (rc != RUN_FINAL && rc != RUN_STOPPED) return false;
-        text.assign(bo.text(), bo.text() + bo.size());
+        if (!text.resize(bo.size())) return false;
+        memcpy(text.data(), bo.text(), bo.size());
         st.bit = end_bit; st.done = rc == RUN_FINAL;
     }
+    t_res = now();
     // the state for the next window: the last 32 KiB of (window ++ text), the running CRC and length
     if (text.size() >= W) memcpy(st.window, text.data() + text.size() - W, W);
     else if (!text.empty()) { memmove(st.window, st.window + text.size(), W - text.size()); memcpy(st.window + W - text.size(), text.data(), text.size()); }
@@ -659,6 +702,18 @@ inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, std
         for (size_t q = 0; q < parts; ++q) st.crc = (uint32_t)crc32_combine(st.crc, cr[q], (z_off_t)(n * (q + 1) / parts - n * q / parts));
         st.total += n;
     }
+    (void)t_find; (void)t_dec;
+    if (timing) fprintf(stderr, "pgz window %llu: %zu pieces, text %zu: find %.1f decode %.1f resolve %.1f crc %.1f ms%s\n", (unsigned long long)st.windows, cstart.size(),
+                        text.size(), t_find - t0, t_dec - t_find, t_res - t_dec, now() - t_res, chained ? "" : " (one thread)");
+    return true;
+}
+
+// (the same into a std::vector, with scratch of its own: tests)
+inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, std::vector<uint8_t> &text) {
+    TextBuf tb;
+    WindowScratch sc;
+    if (!inflate_window(st, span, nthreads, tb, sc)) return false;
+    text.assign(tb.data(), tb.data() + tb.size());
     return true;
 }
 

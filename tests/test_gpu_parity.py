@@ -917,19 +917,39 @@ def test_large_single_member_gzip_goes_through_the_parallel_inflater(KCT, tmp_pa
     assert_same_table(dev, ref)
     monkeypatch.delenv("KCT_NO_PARALLEL_GZIP")
     # the STREAMING form (texts too large to inflate in one piece -- forced here by KCT_GZIP_WHOLE_MAX=0): windows of 1 MiB of compressed bytes, the
-    # text handed to the parser through the ring of slots; and the same reads as TWO members in one file
+    # text parsed by several threads, the unfinished record carried into the next window; and the same reads as TWO members in one file
     monkeypatch.setenv("KCT_GZIP_WHOLE_MAX", "0")
     monkeypatch.setenv("KCT_GZIP_WINDOW", str(1 << 20))
     monkeypatch.setenv("KCT_DEBUG", "1")
     two = tmp_path / "two.fastq.gz"
     cut = fq.index(b"\n@read35000 ") + 1
     two.write_bytes(gzip.compress(fq[:cut], 6) + gzip.compress(fq[cut:], 1))
-    for pth in (path, two):
+    # (KCT_GZIP_LEAD=0: no room in front of a window's text for the unfinished record of the window before -- the two are joined aside)
+    for pth, lead in ((path, None), (two, None), (path, "0")):
+        if lead is not None:
+            monkeypatch.setenv("KCT_GZIP_LEAD", lead)
         dev = KCT(k, capacity=1_000_000)
         assert dev.consume_file(str(pth)) == n_ref
         assert dev.last_file_records == len(recs)
         assert_same_table(dev, ref)
         assert "through the parallel inflater" in capfd.readouterr().err
+    monkeypatch.delenv("KCT_GZIP_LEAD")
+    # FASTA records of 2.5 Mbases in lines of 70: longer than a window's text, so whole windows are carried forward until a record ends
+    nrng = np.random.default_rng(78)
+    long_recs = [np.frombuffer(b"ACGT", dtype=np.uint8)[nrng.integers(0, 4, size=2_500_000)].tobytes().decode() for _ in range(7)]
+    fa = "".join(f">chr{i}\n" + "\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + "\n" for i, s in enumerate(long_recs)).encode()
+    fa_blob = gzip.compress(fa, 6)
+    assert len(fa_blob) > (4 << 20), len(fa_blob)
+    (tmp_path / "long.fa.gz").write_bytes(fa_blob)
+    ref_fa = OracleTable(k)
+    n_fa = sum(ref_fa.consume(r) for r in long_recs)
+    for lead in ("1048576", "0"):
+        monkeypatch.setenv("KCT_GZIP_LEAD", lead)
+        dev = KCT(k, capacity=40_000_000)
+        assert dev.consume_file(str(tmp_path / "long.fa.gz")) == n_fa
+        assert dev.last_file_records == len(long_recs)
+        assert_same_table(dev, ref_fa)
+    monkeypatch.delenv("KCT_GZIP_LEAD")
     monkeypatch.delenv("KCT_DEBUG"); monkeypatch.delenv("KCT_GZIP_WHOLE_MAX"); monkeypatch.delenv("KCT_GZIP_WINDOW")
     bad = bytearray(blob)
     bad[len(bad) * 3 // 4] ^= 0x21
