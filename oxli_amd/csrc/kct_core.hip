@@ -480,6 +480,7 @@ void kct_destroy(kct_table *t) {
     for (kcth::DevBuf *b : {&t->d_sk_bases, &t->d_sk_starts, &t->d_sk_meta, &t->d_sk_lists, &t->d_sk_dir, &t->d_sk_send, &t->d_sk_recv, &t->d_sk_inbox}) b->release();
     for (auto &b : t->h_file) b.release();
     if (t->own_stream && t->stream) (void)hipStreamDestroy(t->stream);
+    if (t->copy_stream) (void)hipStreamDestroy(t->copy_stream);
     delete t;
 }
 

@@ -229,29 +229,43 @@ namespace kcth {
 // (Not the FIRST piece into an empty table if it brings a window start per slot or more: whoever makes one large call and then reads
 // the table should not pay a copy for the calls that might have followed -- 4 % of such a call; a stream of calls of that size has
 // its first one counted by itself and the rest together.)
-kct_status consume_device_staged(kct_table *t, const unsigned char *d_stream, size_t nbytes, u64 *n_total) {
+du64 *staged_good_word(kct_table *t);
+// The staging itself.  `wait`: the caller wants the piece's good windows now (*n_total) and its buffer back -- the stream is waited for; otherwise
+// they are ADDED to the device word staged_good_word(t) and nothing is waited for (kct_consume_file's worker: it zeroes the word before its first
+// piece and reads it after its last).  *staged = false: the table does not take this piece that way now (see above; or, without `wait`, staging it
+// would first need the earlier pieces counted) -- nothing was done.
+static kct_status try_stage(kct_table *t, const unsigned char *d_stream, size_t nbytes, bool wait, u64 *n_total, bool *staged) {
+    *staged = false;
     const u64 npos = nbytes >= (u64)t->k ? (u64)nbytes - t->k + 1 : 0;
     const bool untouched = t->n_keys == 0 && !t->defer_used && !t->shadow_dirty && !t->s32_dirty && !t->s128_dirty;
     // Nor a call that by itself fills the passes HBM has room for: a pass is bounded by its scratch (~12.5 B per window start on the 64-bit
     // two-level path), so beside a table that takes most of the GPU -- whole C5's 128 GiB one -- gathering calls cannot make passes larger,
     // and the copy's buffer would only take room from the scratch (every pass re-reads and re-writes the whole table: fewer passes matter).
     bool fills_a_pass = false;
-    size_t free_b = 0, total_b = 0;
-    const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    // (hipMemGetInfo asks the driver -- tens of microseconds, as long as a 4 MiB chunk's copy: the file reader's worker, which stages a chunk
+    // every ~0.1 ms and whose pieces alone change the figure, goes by an answer up to 20 ms old)
+    size_t free_b = t->mem_free_seen, total_b = 0;
+    bool have_mem = !wait && t->mem_free_seen && now_ms() - t->mem_free_seen_ms < 20.0;
+    if (!have_mem) {
+        have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+        t->mem_free_seen = have_mem ? free_b : 0;
+        t->mem_free_seen_ms = now_ms();
+    }
     if (have_mem && (t->cap >> t->block_bits) > 1024) {
         const double avail = (double)free_b + (double)(t->d_scratch.cap + t->d_scratch2.cap + t->d_irr.cap + t->d_irr2.cap + t->d_defer.cap);
         fills_a_pass = (double)npos * 12.5 >= 0.5 * 0.8 * avail;
     }
-    if (fills_a_pass && t->defer_used) KCT_TRY(flush_deferred_device(t));
+    if (fills_a_pass && t->defer_used) { if (!wait) return KCT_OK; KCT_TRY(flush_deferred_device(t)); }
     if (t->defer_device && t->k <= 255 && npos && npos < 4 * t->cap && !(untouched && npos >= t->cap) && !fills_a_pass) {
         const u64 padded = (((u64)nbytes + 15) & ~15ULL) + 16;   // (the stream, separators up to a 16-byte boundary, one unit of separators)
         u64 limit = 32ULL << 30;
         if (have_mem) limit = std::min<u64>(limit, ((u64)free_b + t->d_defer.cap) / 4);
-        if (t->defer_used + padded > limit && t->defer_used) KCT_TRY(flush_deferred_device(t));
+        if (t->defer_used + padded > limit && t->defer_used) { if (!wait) return KCT_OK; KCT_TRY(flush_deferred_device(t)); }
+        if (!wait && t->defer_windows + npos >= 32 * t->cap) return KCT_OK;   // (the pieces are due to be counted after this one: the waiting form does that)
         if (padded <= limit) {
             KCT_TRY(t->d_defer.reserve_keep(t->defer_used + padded, t->defer_used, t->stream));
-            du64 *d_good = t->d_counters + kNumCounters + 2;   // scratch word 2
-            HIP_TRY(hipMemsetAsync(d_good, 0, 8, t->stream));
+            du64 *d_good = staged_good_word(t);
+            if (wait) HIP_TRY(hipMemsetAsync(d_good, 0, 8, t->stream));
             {
                 ProfScope ps(t, "stage_stream_kernel");
                 const u64 tiles = (padded + kct::kPartTile - 1) / kct::kPartTile;
@@ -259,17 +273,34 @@ kct_status consume_device_staged(kct_table *t, const unsigned char *d_stream, si
                                    d_stream, (u64)nbytes, (int)t->k, (unsigned char *)t->d_defer.p + t->defer_used, padded, d_good);
             }
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(t->h_counters, d_good, 8, hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipStreamSynchronize(t->stream));   // (the caller may reuse its buffer when this returns; n is wanted now)
-            *n_total = t->h_counters[0];
+            if (wait) {
+                HIP_TRY(hipMemcpyAsync(t->h_counters, d_good, 8, hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipStreamSynchronize(t->stream));   // (the caller may reuse its buffer when this returns; n is wanted now)
+                *n_total = t->h_counters[0];
+            }
             t->defer_used += padded;
             t->defer_windows += npos;
-            if (t->defer_windows >= 32 * t->cap) KCT_TRY(flush_deferred_device(t));
+            *staged = true;
+            if (wait && t->defer_windows >= 32 * t->cap) KCT_TRY(flush_deferred_device(t));
             return KCT_OK;
         }
     }
+    return KCT_OK;
+}
+
+du64 *staged_good_word(kct_table *t) { return t->d_counters + kNumCounters + 2; }   // scratch word 2
+
+kct_status consume_device_staged(kct_table *t, const unsigned char *d_stream, size_t nbytes, u64 *n_total) {
+    bool staged = false;
+    KCT_TRY(try_stage(t, d_stream, nbytes, true, n_total, &staged));
+    if (staged) return KCT_OK;
     if (t->defer_used) KCT_TRY(flush_deferred_device(t));
     return consume_stream(t, d_stream, nbytes, n_total);
+}
+
+kct_status stage_piece_async(kct_table *t, const unsigned char *d_stream, size_t nbytes, bool *staged) {
+    u64 unused = 0;
+    return try_stage(t, d_stream, nbytes, false, &unused, staged);
 }
 
 }  // namespace kcth

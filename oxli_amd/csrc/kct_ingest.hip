@@ -5,6 +5,7 @@
 #include <deque>
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <functional>
 #include <memory>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -67,12 +68,14 @@ struct ChunkWriter {
     ChunkQueue *queue;
     FileChunk chunk[2];
     int cur = 0;
-    size_t cap, k;
+    size_t cap, full_cap, k;
     unsigned char *out;
     size_t used = 0, rec_len = 0;  // rec_len = bases of the current record already in this chunk
     u64 records = 0, bases = 0;
 
-    ChunkWriter(ChunkQueue *q, PinnedBuf *a, PinnedBuf *b, size_t chunk_cap, size_t ksize) : queue(q), cap(chunk_cap), k(ksize) {
+    // (a writer's FIRST chunk is cut at 2 MiB: the uploads start 0.3 ms into the call instead of 2.2 -- the link is the bound of a plain file)
+    ChunkWriter(ChunkQueue *q, PinnedBuf *a, PinnedBuf *b, size_t chunk_cap, size_t ksize)
+        : queue(q), cap(chunk_cap > ((size_t)8 << 20) ? chunk_cap : std::min<size_t>(chunk_cap, (size_t)2 << 20)), full_cap(chunk_cap), k(ksize) {   // (not a small table's 16 MiB chunks: each is a pass there)
         chunk[0].host = a; chunk[1].host = b;
         out = (unsigned char *)a->p;
     }
@@ -83,6 +86,7 @@ struct ChunkWriter {
         chunk[cur].used = used;
         queue->submit(&chunk[cur]);
         cur ^= 1;
+        cap = full_cap;
         queue->wait_free(&chunk[cur]);
         out = (unsigned char *)chunk[cur].host->p;
         memcpy(out, tail, ntail);
@@ -400,8 +404,44 @@ bool libdeflate_disabled() { return getenv("KCT_NO_LIBDEFLATE") != nullptr; }   
 struct Mapping {
     const unsigned char *p = nullptr;
     size_t size = 0;
-    ~Mapping() { if (p) munmap((void *)p, size); }
+    // (unmapping 160 MB of page-cache pages takes 2.2 ms: a thread of its own does it behind the call's return)
+    ~Mapping() {
+        if (!p) return;
+        if (size >= ((size_t)8 << 20)) {
+            try { std::thread([q = (void *)p, n = size] { munmap(q, n); }).detach(); return; } catch (...) {}
+        }
+        munmap((void *)p, size);
+    }
 };
+
+// The file reader's device calls (uploads, the staging kernel) are made by ONE long-lived thread: a thread that has made HIP calls
+// takes ~3.5 ms to exit (its runtime state is torn down), which a worker thread per call paid inside every call.  A second caller at
+// the same time (another table, another thread) gets a thread of its own, as before.
+struct DeviceThread {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool busy = false, has_job = false, started = false;
+    void loop() {
+        for (;;) {
+            std::function<void()> f;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return has_job; }); f = std::move(job); has_job = false; }
+            f();
+            { std::lock_guard<std::mutex> lk(mu); busy = false; }
+            cv.notify_all();
+        }
+    }
+    bool start(std::function<void()> f) {   // false: busy with another call (or no thread to be had)
+        std::lock_guard<std::mutex> lk(mu);
+        if (busy) return false;
+        if (!started) { try { std::thread([this] { loop(); }).detach(); } catch (...) { return false; } started = true; }
+        job = std::move(f); has_job = true; busy = true;
+        cv.notify_all();
+        return true;
+    }
+    void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !busy; }); }
+};
+DeviceThread &device_thread() { static DeviceThread *d = new DeviceThread; return *d; }   // (never destroyed: its thread outlives main)
 
 }  // namespace
 
@@ -437,6 +477,7 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
         close(fd);
     }
     const size_t k = t->k;
+    KCT_DBG(t, "file: opened%s\n", map.p ? " and mapped" : "");
     // gzip: BGZF or a plain stream?
     Mapping gzmap;
     std::vector<BgzfBlock> blocks;
@@ -505,7 +546,11 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
             }
         }
     }
-    size_t chunk_cap = (size_t)(bgzf ? 8 : 16) << 20;  // stream bytes per chunk
+    // stream bytes per chunk (16 / 8 MiB until round 6, when every chunk cost a wait: with 4 MiB the link has work 0.3 ms into the call and never idles)
+    // -- unless the table is so small that it will not stage a chunk of that size behind the others but count it by itself (kct_entry.hip:
+    // a piece of four window starts per slot or more): 16 MiB then, as before, for passes worth their launches
+    const bool small_table = 4 * (size_t)t->cap <= ((size_t)4 << 20);
+    size_t chunk_cap = (size_t)(small_table ? 16 : 4) << 20;
     if (const char *e = getenv("KCT_FILE_CHUNK")) chunk_cap = std::max<size_t>(1024, (size_t)atoll(e));  // tests shrink it to exercise record splitting
     size_t segment = (size_t)8 << 20;     // file bytes a parser thread takes at a time
     if (const char *e = getenv("KCT_FILE_SEGMENT")) segment = std::max<size_t>(64, (size_t)atoll(e));
@@ -529,7 +574,7 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
                                  pgz::gzip_header(gzmap.p, gzmap.size) != 0;
     if (text_p) nparsers = std::max<size_t>(1, std::min<size_t>({(size_t)8, hw ? hw : 1, (text_size + segment - 1) / segment}));
     if (stream_parallel) nparsers = std::max<size_t>(1, std::min<size_t>((size_t)8, hw ? hw : 1));
-    if (bgzf) nslot_threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, hw ? hw / 2 : 1, ntasks}));
+    if (bgzf) nslot_threads = std::max<size_t>(1, std::min<size_t>({(size_t)32, hw ? hw / 2 : 1, ntasks}));   // (16 until round 6: 5.8x10^9 k-mers/s on the C2 file against 9.1 with 32)
     if (const char *e = getenv("KCT_FILE_THREADS")) {
         const size_t want = std::max<size_t>(1, std::min<size_t>(64, (size_t)atoll(e)));
         if (text_p || stream_parallel) nparsers = want;
@@ -540,38 +585,120 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
     // chunk buffers stay with the table: pinning memory costs more than parsing a small file
     if (t->h_file.size() < 2 * nparsers) t->h_file.resize(2 * nparsers);
     for (size_t i = 0; i < 2 * nparsers; ++i) KCT_TRY(t->h_file[i].reserve(chunk_cap + 64));
-    KCT_TRY(t->d_stream.reserve(chunk_cap + 64));
+    // (the device side of a chunk: two halves that take turns -- chunk i + 1 is copied while chunk i is staged)
+    const size_t half = (chunk_cap + 64 + 255) & ~(size_t)255;
+    KCT_TRY(t->d_stream.reserve(2 * half));
+    if (!t->copy_stream && hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return KCT_ERR_HIP; }
 
     ChunkQueue queue;
-    std::thread worker([&] {  // uploads and counts finished chunks, one at a time
+    auto worker_fn = [&] {  // uploads finished chunks and stages them behind one another on the device, one at a time
         (void)hipSetDevice(t->device);
+        // Nothing is waited for per chunk (0.05 ms of round trips each, as much as a 2 MiB chunk's copy): a chunk's pinned buffer goes back to
+        // its parser when the event behind its copy has passed -- looked at after the NEXT chunk's copy is under way -- and the chunks' good
+        // windows add up in a device word read once at the end.  (A chunk the table will not stage right now -- the staged pieces are due
+        // to be counted first -- takes the waiting form.)
+        // The copies run on a stream of their own into the two halves of d_stream in turn: a half is copied into once the staging
+        // kernel that read it last has run (staged_ev), and a chunk is staged once its copy has run (the event that also releases its buffer).
+        std::deque<std::pair<FileChunk *, hipEvent_t>> pending;
+        std::vector<hipEvent_t> spare;
+        hipEvent_t staged_ev[2] = {nullptr, nullptr};
+        bool staged_set[2] = {false, false};
+        u64 total = 0, nchunk = 0;
+        kct_status ws = KCT_OK;
+        for (auto &e : staged_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); ws = KCT_ERR_HIP; }
+        auto release_oldest = [&] {
+            auto pr = pending.front(); pending.pop_front();
+            if (hipEventSynchronize(pr.second) != hipSuccess && ws == KCT_OK) { set_err("waiting for an upload failed"); ws = KCT_ERR_HIP; }
+            spare.push_back(pr.second);
+            { std::lock_guard<std::mutex> lk(queue.mu); pr.first->in_flight = false; }
+            queue.cv.notify_all();
+        };
+        auto collect = [&] {   // the device word into `total` (everything enqueued so far has run), and zero again
+            if (ws != KCT_OK) return;
+            if (hipMemcpyAsync(t->h_counters, staged_good_word(t), 8, hipMemcpyDeviceToHost, t->stream) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess ||
+                hipMemsetAsync(staged_good_word(t), 0, 8, t->stream) != hipSuccess) { set_err("reading the staged windows' count failed"); ws = KCT_ERR_HIP; return; }
+            total += t->h_counters[0];
+        };
+        if (hipMemsetAsync(staged_good_word(t), 0, 8, t->stream) != hipSuccess) { set_err("hipMemsetAsync failed"); ws = KCT_ERR_HIP; }
         for (;;) {
-            FileChunk *c;
+            FileChunk *c = nullptr;
             {
                 std::unique_lock<std::mutex> lk(queue.mu);
+                if (queue.q.empty() && !queue.done && !pending.empty()) {   // (before sleeping: a parser may be waiting for one of these)
+                    lk.unlock();
+                    while (!pending.empty()) release_oldest();
+                    continue;
+                }
                 queue.cv.wait(lk, [&] { return !queue.q.empty() || queue.done; });
-                if (queue.q.empty()) return;
+                if (queue.q.empty()) break;
                 c = queue.q.front(); queue.q.pop_front();
             }
-            kct_status ws = KCT_OK;
-            u64 n = 0;
-            if (!queue.failed()) {
+            const double t_take = now_ms();
+            bool queued = false;
+            static const bool dry = getenv("KCT_FILE_DRY") != nullptr;   // (measurement: the parsers alone -- nothing is uploaded or counted)
+            if (ws == KCT_OK && !queue.failed() && !dry) {
                 const size_t padded = (c->used + 15) & ~(size_t)15;
                 memset((char *)c->host->p + c->used, '\n', padded + 16 - c->used);
-                if (hipMemcpyAsync(t->d_stream.p, c->host->p, padded + 16, hipMemcpyHostToDevice, t->stream) != hipSuccess) { set_err("H2D copy failed"); ws = KCT_ERR_HIP; }
+                hipEvent_t ev = nullptr;
+                if (!spare.empty()) { ev = spare.back(); spare.pop_back(); }
+                else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); ws = KCT_ERR_HIP; }
+                const int hb = (int)(nchunk++ & 1);
+                const unsigned char *d_half = (const unsigned char *)t->d_stream.p + hb * half;
+                if (ws == KCT_OK && ((staged_set[hb] && hipStreamWaitEvent(t->copy_stream, staged_ev[hb], 0) != hipSuccess) ||
+                                     hipMemcpyAsync((void *)d_half, c->host->p, padded + 16, hipMemcpyHostToDevice, t->copy_stream) != hipSuccess ||
+                                     hipEventRecord(ev, t->copy_stream) != hipSuccess ||
+                                     hipStreamWaitEvent(t->stream, ev, 0) != hipSuccess)) { set_err("H2D copy failed"); ws = KCT_ERR_HIP; }
+                if (ev) { pending.emplace_back(c, ev); queued = true; }
                 // (staged behind the earlier chunks and counted with them in passes of the table's own choosing: kct_entry.hip)
-                if (ws == KCT_OK) ws = consume_device_staged(t, (const unsigned char *)t->d_stream.p, c->used, &n);
+                bool staged = false;
+                if (ws == KCT_OK) ws = stage_piece_async(t, d_half, c->used, &staged);
+                if (ws == KCT_OK && !staged) {
+                    collect();
+                    u64 n = 0;
+                    if (ws == KCT_OK) ws = consume_device_staged(t, d_half, c->used, &n);
+                    total += n;
+                    if (ws == KCT_OK && hipMemsetAsync(staged_good_word(t), 0, 8, t->stream) != hipSuccess) { set_err("hipMemsetAsync failed"); ws = KCT_ERR_HIP; }
+                }
+                if (ws == KCT_OK) { if (hipEventRecord(staged_ev[hb], t->stream) != hipSuccess) { set_err("hipEventRecord failed"); ws = KCT_ERR_HIP; } else staged_set[hb] = true; }
+                if (ws != KCT_OK) queue.fail(ws, g_err);
             }
-            if (ws != KCT_OK) queue.fail(ws, g_err);
-            { std::lock_guard<std::mutex> lk(queue.mu); queue.counted += n; c->in_flight = false; }
-            queue.cv.notify_all();
+            if (!queued) {
+                { std::lock_guard<std::mutex> lk(queue.mu); c->in_flight = false; }
+                queue.cv.notify_all();
+            }
+            const double t_enq = now_ms();
+            while (pending.size() > 2) release_oldest();   // (two copies stay enqueued: the link always has the next one)
+            KCT_DBG(t, "file: worker took a chunk of %zu bytes at %.3f: enqueued in %.0f us, then waited %.0f us for an older copy\n", c->used, t_take, (t_enq - t_take) * 1e3,
+                    (now_ms() - t_enq) * 1e3);
         }
-    });
+        while (!pending.empty()) release_oldest();
+        collect();
+        if (ws != KCT_OK) queue.fail(ws, g_err);
+        for (hipEvent_t e : spare) (void)hipEventDestroy(e);
+        for (hipEvent_t e : staged_ev) if (e) (void)hipEventDestroy(e);
+        { std::lock_guard<std::mutex> lk(queue.mu); queue.counted += total; }
+        KCT_DBG(t, "file: worker is through\n");
+    };
+    std::thread own_worker;   // (only when the long-lived device thread is taken by another call)
+    const bool shared_worker = device_thread().start(worker_fn);
+    if (!shared_worker) own_worker = std::thread(worker_fn);
+    struct WorkerEnd {   // whatever way this scope is left, the worker has ended before `queue` and the rest go away
+        ChunkQueue &q; std::thread &own; bool shared, ended = false;
+        void end() {
+            if (ended) return;
+            ended = true;
+            { std::lock_guard<std::mutex> lk(q.mu); q.done = true; }
+            q.cv.notify_all();
+            if (shared) device_thread().wait(); else if (own.joinable()) own.join();
+        }
+        ~WorkerEnd() { end(); }
+    } worker_end{queue, own_worker, shared_worker};
 
     u64 records = 0, bases = 0;
     kct_status st = KCT_OK;
     // [p, p + size) holds whole records (it begins at a record start): parsed by nparsers threads that take `segment`-sized stretches (record
     // starts found without context) -- a mapped file, the one-piece inflate of a .gz, or one window of the streaming inflater's text
+    // (MADV_POPULATE_READ on a mapped file's segments before they are parsed: measured, no gain -- the page faults are not what holds the parsers)
     auto parse_text = [&](const unsigned char *p, size_t size, int fmt) {
         const size_t nseg = (size + segment - 1) / segment;
         std::atomic<size_t> next_seg{0};
@@ -834,9 +961,7 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
         ring.fail("the parser is done");   // (lets the inflater go if it still waits for a slot: the parser stopped early, or the input is read)
         inflater.join();
     }
-    { std::lock_guard<std::mutex> lk(queue.mu); queue.done = true; }
-    queue.cv.notify_all();
-    worker.join();
+    worker_end.end();
     KCT_DBG(t, "file: chunks uploaded and counted (or staged)\n");
     if (st == KCT_OK && queue.status != KCT_OK) { st = queue.status; set_err("%s", queue.msg.c_str()); }
     if (st != KCT_OK) return st;

@@ -162,6 +162,9 @@ struct kct_table {
     uint8_t k = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    size_t mem_free_seen = 0;            // hipMemGetInfo's last answer and when it was given (try_stage, kct_entry.hip)
+    double mem_free_seen_ms = 0;
+    hipStream_t copy_stream = nullptr;   // kct_consume_file's uploads (made at the first file; two staging halves take turns)
 
     du64 *slots = nullptr;  // 2 * cap words (device)
     u64 slots_alloc = 0;    // slots the allocation has room for (>= cap: kct_resize makes an EMPTY table smaller or larger in place)
@@ -348,6 +351,8 @@ kct_status unpack_stream(kct_table *t, const unsigned int *d_codes, const unsign
 kct_status consume_stream_runs(kct_table *t, const kct::RunsInput &in, u64 ngroups, u64 *n_out);  // received super-k-mers (kct_route.hip)
 // kct_runs.hip: K1's super-k-mer instantiations and the early route's own kernels
 kct_status consume_device_staged(kct_table *t, const unsigned char *d_stream, size_t nbytes, u64 *n_total);   // kct_entry.hip
+kct_status stage_piece_async(kct_table *t, const unsigned char *d_stream, size_t nbytes, bool *staged);   // (no waiting; good windows added to ...
+du64 *staged_good_word(kct_table *t);                                                                       // ... this device word)
 void launch_partition_runs(kct_table *t, int mode, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa);
 bool launch_partition_ws(kct_table *t, int mode, const unsigned char *d_stream, u64 chunk_bytes, u64 ntiles, const kct::PartitionArgs &pa);   // kct_k1ws.hip
 void launch_split(kct_table *t, const unsigned char *d_stream, u64 nbytes, u64 ntiles, const kct::SplitArgs &sa);

@@ -636,7 +636,7 @@ def test_compact_dedupe_path_over_many_passes_and_when_outgrown(KCT):
 
 
 def test_consume_file_through_the_dedupe_first_paths(KCT, tmp_path):
-    """File ingestion feeds 16 MiB chunks to the same pass machinery: with the dedupe-first paths forced, a FASTA of deep
+    """File ingestion feeds chunks (16 MiB here: the table is too small to stage them) to the same pass machinery: with the dedupe-first paths forced, a FASTA of deep
     coverage must give the table the standard path gives (several parser threads, chunks counted in any order)."""
     import torch
 
