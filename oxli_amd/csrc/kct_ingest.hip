@@ -405,16 +405,8 @@ bool libdeflate_disabled() { return getenv("KCT_NO_LIBDEFLATE") != nullptr; }   
 struct Mapping {
     const unsigned char *p = nullptr;
     size_t size = 0;
-    // (the anonymous text of a .gz inflated in one piece: unmapped by a thread of its own behind the call's return; a mapped FILE's
-    // pages were dropped by the parsers, segment by segment -- see parse_text)
-    bool anonymous = false;
-    ~Mapping() {
-        if (!p) return;
-        if (anonymous && size >= ((size_t)8 << 20)) {
-            try { std::thread([q = (void *)p, n = size] { munmap(q, n); }).detach(); return; } catch (...) {}
-        }
-        munmap((void *)p, size);
-    }
+    // (cheap by the time it runs: the pages were dropped by the parsers, segment by segment -- see parse_text)
+    ~Mapping() { if (p) munmap((void *)p, size); }
 };
 
 // The file reader's device calls (uploads, the staging kernel) are made by ONE long-lived thread: a thread that has made HIP calls
@@ -518,7 +510,7 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
             const size_t bytes = ((size_t)isize + 16 + 4095) & ~(size_t)4095;
             void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
             if (m != MAP_FAILED) {
-                whole.p = (const unsigned char *)m; whole.size = bytes; whole.anonymous = true;
+                whole.p = (const unsigned char *)m; whole.size = bytes;
                 (void)madvise(m, bytes, MADV_HUGEPAGE);   // (where transparent huge pages are on request: 512x fewer faults for the inflaters)
                 // the pages are faulted in by four helper threads while the inflater runs (a fresh page costs about as much as inflating
                 // it: left to the inflater, the faults were a sixth of the call)
@@ -727,7 +719,8 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
                 // A mapped file's pages leave the page table here, segment by segment and thread by thread (MADV_DONTNEED takes the address
                 // space's lock for reading): unmapping the 160 MB of the C2 file in one piece took 2.2 ms inside the call -- or, handed to a
                 // thread, held the lock against the NEXT call's mmap for 5.9 ms.  [lo, hi) is read by this thread only.
-                if (p == map.p && hi > lo) {
+                // (the anonymous text of a .gz inflated in one piece likewise: its pages are freed here; file_gz's 627 MB sample -8 %)
+                if ((p == map.p || p == whole.p) && hi > lo) {
                     const uintptr_t a0 = ((uintptr_t)p + lo + 4095) & ~(uintptr_t)4095, a1 = ((uintptr_t)p + hi) & ~(uintptr_t)4095;
                     if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_DONTNEED);
                 }
@@ -773,12 +766,16 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
             if (st == KCT_OK && fmt >= 0 && fmt != '>' && fmt != '@') { set_err("%s: neither FASTA nor FASTQ (starts with 0x%02x)", path, fmt); st = KCT_ERR_ARG; }
         }
         if (st == KCT_OK && fmt >= 0) {
+            if (t->file_text.size() < nparsers) t->file_text.resize(nparsers);   // (indexed like h_file: by the thread's id)
+            for (size_t i = 0; i < nparsers; ++i) if (t->file_text[i].size() < slot_bytes + 65536 + 16) t->file_text[i].resize(slot_bytes + 65536 + 16);
             Fragments frags(2 * nslot_threads + 2, ntasks);
             std::atomic<size_t> next_task{0};
             std::mutex tally_mu;
             auto slot_thread = [&](size_t id) {
                 ChunkWriter w(&queue, &t->h_file[2 * id], &t->h_file[2 * id + 1], chunk_cap, k);
-                std::vector<unsigned char> text(slot_bytes + 65536 + 16);
+                // (the slot's text buffer stays with the table: thirty-two threads each mapping, zero-filling and unmapping 2 MiB per call
+                // met in the address space's lock)
+                std::vector<unsigned char> &text = t->file_text[id];
                 const Deflate &ld = deflate_lib();
                 void *dec = ld.ok() && !getenv("KCT_NO_LIBDEFLATE") ? ld.alloc() : nullptr;   // (the switch: tests run zlib's inflate too)
                 z_stream zs;

@@ -265,6 +265,7 @@ struct kct_table {
     kcth::PinnedBuf h_stage;
     double batch_tl[16] = {0};  // kct_batch_timeline: the last packed-upload batch
     std::vector<kcth::PinnedBuf> h_file;  // kct_consume_file's chunk buffers (two per parser thread), kept between calls
+    std::vector<std::vector<unsigned char>> file_text;   // ... and its BGZF slot threads' text buffers
 
     bool prof_on = false;
     std::vector<kcth::ProfEntry> prof;

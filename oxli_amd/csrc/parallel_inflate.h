@@ -226,7 +226,9 @@ struct MarkOut {
     MarkOut(const MarkOut &) = delete;
     MarkOut &operator=(const MarkOut &) = delete;
     ~MarkOut() { release(); }
-    void release() { if (v) munmap(v, mapped); v = nullptr; n = cap = mapped = 0; }
+    // (pages first, under the address-space lock held for reading; the munmap behind it -- the write lock, which stops every other thread's
+    // page faults and mmaps -- then has nothing to free)
+    void release() { if (v) { (void)madvise(v, mapped, MADV_DONTNEED); munmap(v, mapped); } v = nullptr; n = cap = mapped = 0; }
     // The buffers of all pieces together are twice the text: anonymous mappings that ask for huge pages and grow by mremap (with 4 KiB
     // pages, sixty-four threads faulting in 1.2 GB at once spent more time in the kernel's address-space lock than inflating).
     bool room(size_t more) {   // (258 symbols of slack are kept beyond n: lit() and copy() of one code never check again)
@@ -508,17 +510,16 @@ inline bool gunzip_parallel(const uint8_t *gz, size_t gz_size, uint8_t *out, siz
                         a += n;
                     }
                     crcs[j] = c;
+                    // The piece's 16-bit buffer (twice its text) goes back to the kernel here, by the thread that is done with it:
+                    // MADV_DONTNEED takes the address-space lock for READING, so the threads do it side by side, and the munmap that
+                    // follows finds nothing left to do.  (munmap itself -- 1.2 GB, ~45 ms under the write lock whether one thread did
+                    // it or thirty-two -- was first given to a thread nobody waited for, which held that lock against the page faults
+                    // of the parsers behind the inflater.)
+                    MarkOut &mk = piece[chain[j]].marks;
+                    if (mk.v) (void)madvise(mk.v, mk.mapped, MADV_DONTNEED);
                 }
             });
         for (auto &x : th) x.join();
-    }
-    // The pieces' buffers (twice the text in all) are unmapped by a thread of their own that nobody waits for: giving 1.2 GB back to the kernel
-    // takes ~45 ms whether one thread does it or thirty-two (the address-space lock serialises them).  (The whole kct_consume_file call did not
-    // get shorter by it -- the parsers behind it take their page faults under the same lock -- but the inflater's own phases are what they look like.)
-    {
-        std::vector<std::pair<void *, size_t>> gone;
-        for (Piece &pc : piece) if (pc.marks.v) { gone.emplace_back(pc.marks.v, pc.marks.mapped); pc.marks.v = nullptr; pc.marks.n = pc.marks.cap = pc.marks.mapped = 0; }
-        if (!gone.empty()) std::thread([gone] { for (const auto &g : gone) munmap(g.first, g.second); }).detach();
     }
     if (timing) fprintf(stderr, "pgz: %zu chunks, %zu starts, %zu pieces in the chain; search %.1f ms, inflate %.1f ms, windows %.1f ms, bytes + crc %.1f ms\n", nchunks, cand.size(),
                         chain.size(), t_found - t_begin, t_inflated - t_found, t_windows - t_inflated, now() - t_windows);
@@ -556,7 +557,7 @@ struct TextBuf {
     TextBuf() = default;
     TextBuf(const TextBuf &) = delete;
     TextBuf &operator=(const TextBuf &) = delete;
-    ~TextBuf() { if (p) munmap(p, cap); }
+    ~TextBuf() { if (p) { (void)madvise(p, cap, MADV_DONTNEED); munmap(p, cap); } }
     uint8_t *data() const { return p + lead; }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
