@@ -962,6 +962,40 @@ def test_large_single_member_gzip_goes_through_the_parallel_inflater(KCT, tmp_pa
     monkeypatch.delenv("KCT_GZIP_WHOLE_MAX")
 
 
+def test_two_threads_read_files_into_their_tables_at_the_same_time(KCT, tmp_path):
+    """kct_consume_file's device calls are made by one long-lived thread per process; a second call that arrives while it is taken (another
+    table, another caller thread -- ctypes releases the GIL) gets a thread of its own.  Both tables must be the oracle's, call after call."""
+    import threading
+    rng = random.Random(91)
+    files, refs = [], []
+    for j, k in enumerate((21, 31, 25)):
+        recs = [rand_dna(rng, rng.choice([30, 150, 151, 4000]), "ACGTACGTN") for _ in range(3000)]
+        path = tmp_path / f"t{j}.fa"
+        _write_fasta(path, recs, width=80)
+        ref = OracleTable(k)
+        n_ref = sum(ref.consume(r) for r in recs)
+        files.append((str(path), k, n_ref)); refs.append(ref)
+    tables = [KCT(k, capacity=2_000_000) for _p, k, _n in files]
+    errors = []
+
+    def job(i):
+        try:
+            for _ in range(4):
+                tables[i].clear()
+                assert tables[i].consume_file(files[i][0]) == files[i][2]
+        except Exception as e:   # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=job, args=(i,)) for i in range(len(files))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    assert not errors and not any(th.is_alive() for th in threads), errors
+    for tbl, ref in zip(tables, refs):
+        assert_same_table(tbl, ref)
+
+
 def test_consume_file_formats_match_oracle(KCT, tmp_path, monkeypatch):
     import gzip
     rng = random.Random(31)
