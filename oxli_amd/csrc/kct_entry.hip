@@ -116,6 +116,101 @@ static void encode_groups(const unsigned char *p, size_t ngroups, unsigned int *
     else for (size_t g = 0; g < ngroups; ++g) encode16_scalar(p + 16 * g, codes + g, valid + g);
 }
 
+// Records r0 .. r1 of a CSR batch (each followed by one separator, the part padded with separators to whole groups) -> groups from *codes /
+// *valid on; returns the number of groups written.  A record's groups are encoded STRAIGHT from the caller's memory wherever sixteen stream
+// bytes lie inside one record (nine of ten groups of a 150 bp read); only the group across a record boundary -- the record's tail, its
+// separator, the next record's head -- is assembled in a 16-byte carry.  (Until round 5 every byte went through a 4 KiB line buffer first.)
+static size_t pack_records_generic(const unsigned char *bytes, const unsigned long long *offsets, size_t r0, size_t r1, unsigned int *codes, unsigned short *valid) {
+    unsigned char carry[16];
+    size_t g = 0, fill = 0;
+    for (size_t r = r0; r < r1; ++r) {
+        const unsigned char *src = bytes + offsets[r];
+        size_t n = (size_t)(offsets[r + 1] - offsets[r]);
+        if (fill) {   // finish the group the previous record (and its separator) began
+            const size_t take = n < 16 - fill ? n : 16 - fill;
+            memcpy(carry + fill, src, take);
+            fill += take; src += take; n -= take;
+            if (fill == 16) { encode_groups(carry, 1, codes + g, valid + g); ++g; fill = 0; }
+        }
+        const size_t whole = n >> 4;
+        if (whole) { encode_groups(src, whole, codes + g, valid + g); g += whole; src += 16 * whole; n -= 16 * whole; }
+        if (n) { memcpy(carry + fill, src, n); fill += n; }   // (fill is 0 here unless the record ended inside the carried group)
+        carry[fill++] = '\n';
+        if (fill == 16) { encode_groups(carry, 1, codes + g, valid + g); ++g; fill = 0; }
+    }
+    if (fill) { while (fill < 16) carry[fill++] = '\n'; encode_groups(carry, 1, codes + g, valid + g); ++g; }
+    return g;
+}
+// The same with the record loop INSIDE the function that carries the target attribute: the encoders' constants stay in registers from record
+// to record and nothing is called (three calls per 150 bp read above, each reloading ten constants); the validity bits come out of the
+// movemask in stream order because the bytes are reversed within their 16-byte lane first (one shuffle where a 32-bit bit reversal took a
+// dozen scalar operations per 32 bases).
+__attribute__((target("avx2"))) static size_t pack_records_avx2(const unsigned char *bytes, const unsigned long long *offsets, size_t r0, size_t r1, unsigned int *codes,
+                                                                unsigned short *valid) {
+    const __m256i lower = _mm256_set1_epi8(0x20), ca = _mm256_set1_epi8('a'), cc = _mm256_set1_epi8('c'), cg = _mm256_set1_epi8('g'), ct = _mm256_set1_epi8('t');
+    const __m256i three = _mm256_set1_epi8(3), one = _mm256_set1_epi8(1), m2 = _mm256_set1_epi16(0x0104), m4 = _mm256_set1_epi32(0x00010010);
+    const __m256i pick = _mm256_set_epi8(-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12);
+    const __m256i rev = _mm256_set_epi8(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const __m128i lower1 = _mm256_castsi256_si128(lower), ca1 = _mm256_castsi256_si128(ca), cc1 = _mm256_castsi256_si128(cc), cg1 = _mm256_castsi256_si128(cg),
+                  ct1 = _mm256_castsi256_si128(ct), three1 = _mm256_castsi256_si128(three), one1 = _mm256_castsi256_si128(one), m21 = _mm256_castsi256_si128(m2),
+                  m41 = _mm256_castsi256_si128(m4), pick1 = _mm256_castsi256_si128(pick), rev1 = _mm256_castsi256_si128(rev);
+    // (macros, not lambdas: a lambda's operator() does not inherit the target attribute)
+#define KCT_ENC32(q, c, v)                                                                                                                            \
+    do {                                                                                                                                              \
+        const __m256i x0_ = _mm256_loadu_si256((const __m256i *)(q)), up_ = _mm256_or_si256(x0_, lower);                                               \
+        const __m256i ok_ = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(up_, ca), _mm256_cmpeq_epi8(up_, cc)),                                   \
+                                            _mm256_or_si256(_mm256_cmpeq_epi8(up_, cg), _mm256_cmpeq_epi8(up_, ct)));                                  \
+        __m256i x_ = _mm256_and_si256(_mm256_srli_epi16(x0_, 1), three);                                                                               \
+        x_ = _mm256_xor_si256(x_, _mm256_and_si256(_mm256_srli_epi16(x_, 1), one));                                                                    \
+        x_ = _mm256_and_si256(x_, ok_);                                                                                                                \
+        const __m256i sh_ = _mm256_shuffle_epi8(_mm256_madd_epi16(_mm256_maddubs_epi16(x_, m2), m4), pick);                                            \
+        (c)[0] = (unsigned int)_mm256_extract_epi32(sh_, 0);                                                                                           \
+        (c)[1] = (unsigned int)_mm256_extract_epi32(sh_, 4);                                                                                           \
+        const unsigned int mk_ = (unsigned int)_mm256_movemask_epi8(_mm256_shuffle_epi8(ok_, rev)); /* byte j of a lane -> bit 15 - j of its half */   \
+        (v)[0] = (unsigned short)mk_;                                                                                                                  \
+        (v)[1] = (unsigned short)(mk_ >> 16);                                                                                                          \
+    } while (0)
+#define KCT_ENC16(q, c, v)                                                                                                                            \
+    do {                                                                                                                                              \
+        const __m128i x0_ = _mm_loadu_si128((const __m128i *)(q)), up_ = _mm_or_si128(x0_, lower1);                                                    \
+        const __m128i ok_ = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(up_, ca1), _mm_cmpeq_epi8(up_, cc1)),                                             \
+                                         _mm_or_si128(_mm_cmpeq_epi8(up_, cg1), _mm_cmpeq_epi8(up_, ct1)));                                            \
+        __m128i x_ = _mm_and_si128(_mm_srli_epi16(x0_, 1), three1);                                                                                    \
+        x_ = _mm_xor_si128(x_, _mm_and_si128(_mm_srli_epi16(x_, 1), one1));                                                                            \
+        x_ = _mm_and_si128(x_, ok_);                                                                                                                   \
+        const __m128i sh_ = _mm_shuffle_epi8(_mm_madd_epi16(_mm_maddubs_epi16(x_, m21), m41), pick1);                                                  \
+        *(c) = (unsigned int)_mm_cvtsi128_si32(sh_);                                                                                                   \
+        *(v) = (unsigned short)_mm_movemask_epi8(_mm_shuffle_epi8(ok_, rev1));                                                                         \
+    } while (0)
+    alignas(16) unsigned char carry[16];
+    size_t g = 0, fill = 0;
+    for (size_t r = r0; r < r1; ++r) {
+        const unsigned char *src = bytes + offsets[r];
+        size_t n = (size_t)(offsets[r + 1] - offsets[r]);
+        if (fill) {
+            const size_t take = n < 16 - fill ? n : 16 - fill;
+            memcpy(carry + fill, src, take);
+            fill += take; src += take; n -= take;
+            if (fill == 16) { KCT_ENC16(carry, codes + g, valid + g); ++g; fill = 0; }
+        }
+        size_t whole = n >> 4;
+        n -= 16 * whole;
+        for (; whole >= 2; whole -= 2, src += 32, g += 2) KCT_ENC32(src, codes + g, valid + g);
+        if (whole) { KCT_ENC16(src, codes + g, valid + g); ++g; src += 16; }
+        if (n) { memcpy(carry + fill, src, n); fill += n; }
+        carry[fill++] = '\n';
+        if (fill == 16) { KCT_ENC16(carry, codes + g, valid + g); ++g; fill = 0; }
+    }
+    if (fill) { while (fill < 16) carry[fill++] = '\n'; KCT_ENC16(carry, codes + g, valid + g); ++g; }
+    return g;
+#undef KCT_ENC32
+#undef KCT_ENC16
+}
+static size_t pack_records(const unsigned char *bytes, const unsigned long long *offsets, size_t r0, size_t r1, unsigned int *codes, unsigned short *valid) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    return avx2 ? pack_records_avx2(bytes, offsets, r0, r1, codes, valid) : pack_records_generic(bytes, offsets, r0, r1, codes, valid);
+}
+
 // [host-packer-end]
 
 // host bytes -> pinned staging -> device stream buffer (padded with '\n' to a multiple of 16)
@@ -508,11 +603,7 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
         pool.start(nthreads, [&](size_t tid) {
             ThreadLine &ln = lines[tid];
             ln.cpu = sched_getcpu();
-            // A record's groups are encoded STRAIGHT from the caller's memory wherever sixteen stream bytes lie inside one record (nine of
-            // ten groups of a 150 bp read); only the group across a record boundary -- the record's tail, its separator, the next record's
-            // head -- is assembled in a 16-byte carry.  (Until round 5 every byte went through a 4 KiB line buffer first: a second pass over
-            // the data, and one call per group into the SIMD encoder.)
-            unsigned char carry[16];
+            // (pack_records: a record's groups are encoded straight from the caller's memory; see the host packer above)
             for (;;) {
                 size_t it = nitems;
                 for (size_t d = 0; d < nn && it == nitems; ++d) {   // this worker's node first (worker i lives on node i % nn)
@@ -524,23 +615,8 @@ kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *of
                 if (it >= nitems) break;
                 const double it0 = now_ms() - tl0;
                 ln.first = std::min(ln.first, it0);
-                size_t g = pos[it] >> 4, fill = 0;
-                for (size_t r = cut[it]; r < cut[it + 1]; ++r) {
-                    const unsigned char *src = (const unsigned char *)bytes + offsets[r];
-                    size_t n = (size_t)(offsets[r + 1] - offsets[r]);
-                    if (fill) {   // finish the group the previous record (and its separator) began
-                        const size_t take = std::min(n, 16 - fill);
-                        memcpy(carry + fill, src, take);
-                        fill += take; src += take; n -= take;
-                        if (fill == 16) { encode_groups(carry, 1, h_codes + g, h_valid + g); ++g; fill = 0; }
-                    }
-                    const size_t whole = n >> 4;
-                    if (whole) { encode_groups(src, whole, h_codes + g, h_valid + g); g += whole; src += 16 * whole; n -= 16 * whole; }
-                    if (n) { memcpy(carry + fill, src, n); fill += n; }   // (fill is 0 here unless the record ended inside the carried group)
-                    carry[fill++] = '\n';
-                    if (fill == 16) { encode_groups(carry, 1, h_codes + g, h_valid + g); ++g; fill = 0; }
-                }
-                if (fill) { while (fill < 16) carry[fill++] = '\n'; encode_groups(carry, 1, h_codes + g, h_valid + g); ++g; }
+                size_t g = pos[it] >> 4;
+                g += pack_records((const unsigned char *)bytes, (const unsigned long long *)offsets, cut[it], cut[it + 1], h_codes + g, h_valid + g);
                 for (; g < (pos[it + 1] >> 4); ++g) { h_codes[g] = 0; h_valid[g] = 0; }  // (never: a part's groups are exactly its bytes, padded)
                 ln.last = now_ms() - tl0;
                 ln.busy += ln.last - it0;
