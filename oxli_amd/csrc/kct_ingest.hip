@@ -611,7 +611,8 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
     if (!t->copy_stream && hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return KCT_ERR_HIP; }
 
     ChunkQueue queue;
-    auto worker_fn = [&] {  // uploads finished chunks and stages them behind one another on the device, one at a time
+    std::deque<std::pair<FileChunk *, hipEvent_t>> pending;   // (the worker's: chunks whose copies are enqueued, oldest first)
+    auto worker_body = [&] {  // uploads finished chunks and stages them behind one another on the device, one at a time
         (void)hipSetDevice(t->device);
         // Nothing is waited for per chunk (0.05 ms of round trips each, as much as a 2 MiB chunk's copy): a chunk's pinned buffer goes back to
         // its parser when the event behind its copy has passed -- looked at after the NEXT chunk's copy is under way -- and the chunks' good
@@ -619,8 +620,8 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
         // to be counted first -- takes the waiting form.)
         // The copies run on a stream of their own into the two halves of d_stream in turn: a half is copied into once the staging
         // kernel that read it last has run (staged_ev), and a chunk is staged once its copy has run (the event that also releases its buffer).
-        std::deque<std::pair<FileChunk *, hipEvent_t>> pending;
         std::vector<hipEvent_t> spare;
+        spare.reserve(2 * nparsers + 8);   // (no more events than chunks exist: release_oldest's push_back never allocates)
         hipEvent_t staged_ev[2] = {nullptr, nullptr};
         bool staged_set[2] = {false, false};
         u64 total = 0, nchunk = 0;
@@ -698,6 +699,24 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
         for (hipEvent_t e : staged_ev) if (e) (void)hipEventDestroy(e);
         { std::lock_guard<std::mutex> lk(queue.mu); queue.counted += total; }
         KCT_DBG(t, "file: worker is through\n");
+    };
+    auto worker_fn = [&] {   // (nothing may leave a thread by exception: out of memory in the worker's few containers fails the call instead)
+        try { worker_body(); }
+        catch (...) {
+            queue.fail(KCT_ERR_HIP, "out of memory in the file reader's worker");
+            (void)hipStreamSynchronize(t->copy_stream);
+            (void)hipStreamSynchronize(t->stream);
+            for (;;) {   // the parsers' chunks come back unread until they have all stopped
+                std::unique_lock<std::mutex> lk(queue.mu);
+                for (auto &pr : pending) pr.first->in_flight = false;   // (their copies have ended: the streams were waited for)
+                pending.clear();
+                for (FileChunk *c : queue.q) c->in_flight = false;
+                queue.q.clear();
+                queue.cv.notify_all();
+                if (queue.done) break;
+                queue.cv.wait(lk, [&] { return !queue.q.empty() || queue.done; });
+            }
+        }
     };
     std::thread own_worker;   // (only when the long-lived device thread is taken by another call)
     const bool shared_worker = device_thread().start(worker_fn);
