@@ -130,15 +130,6 @@ KCT_API int kct_consume_will_defer(const kct_table *t, size_t len, int skip_bad)
 KCT_API kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint64_t *offsets, size_t nrec, int skip_bad,
                              uint64_t *n_total, uint64_t *bad_record, uint64_t *bad_position);
 
-/* Same, for input already resident in HBM: `d_stream` is a 16-byte-aligned device pointer to
- * `nbytes` bytes in which records are separated by at least one non-ACGT byte (e.g. '\n');
- * skip_bad semantics.  `consumed` grows by `consumed_bytes` (the caller knows the record
- * lengths).  Runs on the table's stream; the caller's buffer is free again when the call returns.
- * A call that is SMALL for the table (fewer than 4 window starts per slot; fewer than 1 if it is the first call into an empty
- * table) is, in deferred mode (the default, kct_set_deferred), copied behind the earlier ones in HBM and counted with them -- when anything else touches the table, when 32 window starts per
- * slot have gathered or the staging buffer (<= 32 GiB, a quarter of the free HBM) is full -- so that an input fed in pieces is
- * counted in the passes, and on the path, of ONE large call; *n_total then comes from the copy kernel's own validity scan (the
- * all-ACGT rule of lib.rs:586-600; it differs from the reference's n only if a window's true hash is 0, probability 2^-64). */
 /* Where the last kct_consume_batch call of this table spent its time (a large skip_bad batch through the host packer; not in the
  * reference): out[0..15], milliseconds since the call began unless said otherwise --
  *   0 argument checks done             1 parts cut, staging reserved        2 first packer thread started its first part
@@ -149,6 +140,15 @@ KCT_API kct_status kct_consume_batch(kct_table *t, const char *bytes, const uint
  * All zero when the last batch did not take the packed-upload route. */
 KCT_API kct_status kct_batch_timeline(kct_table *t, double *out16);
 
+/* Same, for input already resident in HBM: `d_stream` is a 16-byte-aligned device pointer to
+ * `nbytes` bytes in which records are separated by at least one non-ACGT byte (e.g. '\n');
+ * skip_bad semantics.  `consumed` grows by `consumed_bytes` (the caller knows the record
+ * lengths).  Runs on the table's stream; the caller's buffer is free again when the call returns.
+ * A call that is SMALL for the table (fewer than 4 window starts per slot; fewer than 1 if it is the first call into an empty
+ * table) is, in deferred mode (the default, kct_set_deferred), copied behind the earlier ones in HBM and counted with them -- when anything else touches the table, when 32 window starts per
+ * slot have gathered or the staging buffer (<= 32 GiB, a quarter of the free HBM) is full -- so that an input fed in pieces is
+ * counted in the passes, and on the path, of ONE large call; *n_total then comes from the copy kernel's own validity scan (the
+ * all-ACGT rule of lib.rs:586-600; it differs from the reference's n only if a window's true hash is 0, probability 2^-64). */
 KCT_API kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t nbytes, uint64_t consumed_bytes,
                               uint64_t *n_total);
 
@@ -156,13 +156,17 @@ KCT_API kct_status kct_consume_device(kct_table *t, const void *d_stream, size_t
  * for a FASTA or FASTQ file, plain or gzip: a host parser builds record-stream chunks in pinned
  * memory while the previous chunk is uploaded and counted.  skip_bad must be non-zero (the
  * reference's default); *n_total = sum of the per-record n, *n_records / *n_bases = records and
- * sequence bytes read (`consumed` grows by *n_bases).  Out-parameters other than n_total may be NULL. */
+ * sequence bytes read (`consumed` grows by *n_bases).  Out-parameters other than n_total may be NULL.
+ * (The uploads and the device calls behind them are made by ONE helper thread that the library keeps for the life of the process --
+ * a thread that has made HIP calls takes milliseconds to exit; a second kct_consume_file call that arrives while it is taken, on
+ * another table from another thread, gets a thread of its own for that call.) */
 KCT_API kct_status kct_consume_file(kct_table *t, const char *path, int skip_bad, uint64_t *n_total, uint64_t *n_records,
                             uint64_t *n_bases);
 /* Which inflater kct_consume_file uses for gzip / BGZF input in this process: "libdeflate" (the system's libdeflate.so.0, found at
  * run time: whole-buffer inflate at 2-3x zlib's rate, several threads for BGZF blocks) or "zlib" (the fallback linked into the
- * library: one streaming inflater thread for a plain gzip file -- a single deflate stream cannot be inflated in parallel).  What
- * bench.py records beside its file-input entries. */
+ * library).  A plain gzip file of 4 MiB or more is inflated by several threads of the library's own either way (round 6: its members'
+ * deflate streams are entered at block boundaries found by search, verified by length and CRC-32; KCT_NO_PARALLEL_GZIP=1 leaves them to
+ * one thread of the inflater named here).  What bench.py records beside its file-input entries. */
 KCT_API const char *kct_inflater_name(void);
 
 /* ---- table attributes ---------------------------------------------------------------------
