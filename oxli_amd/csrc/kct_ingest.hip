@@ -844,6 +844,11 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
                         used += b.isize;
                     }
                     if (!ok) { frags.fail("corrupt BGZF block"); break; }
+                    {   // (the task's compressed bytes leave the page table here, thread by thread: see parse_text)
+                        const BgzfBlock &b0 = blocks[task_first[task]], &b1 = blocks[task_first[task + 1] - 1];
+                        const uintptr_t a0 = ((uintptr_t)gzmap.p + b0.off + 4095) & ~(uintptr_t)4095, a1 = ((uintptr_t)gzmap.p + b1.off + b1.csize) & ~(uintptr_t)4095;
+                        if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_DONTNEED);
+                    }
                     const unsigned char *tx = text.data();
                     size_t lo = 0;
                     if (task == 0) { while (lo < used && (tx[lo] == '\n' || tx[lo] == '\r' || tx[lo] == ' ' || tx[lo] == '\t')) ++lo; }  // the file's first record
