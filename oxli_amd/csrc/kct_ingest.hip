@@ -416,7 +416,12 @@ struct Deflate {
     }
     bool ok() const { return alloc != nullptr; }
 };
-const Deflate &deflate_lib() { static Deflate d; return d; }
+const Deflate &deflate_lib() {
+    static Deflate d;
+    static const bool told = [] { if (d.ok() && !getenv("KCT_NO_LIBDEFLATE")) pgz::crc_impl() = d.crc; return true; }();   // (parallel_inflate.h's checksums)
+    (void)told;
+    return d;
+}
 bool libdeflate_disabled() { return getenv("KCT_NO_LIBDEFLATE") != nullptr; }   // (the switch: tests and bench run zlib's inflate too)
 
 struct Mapping {

@@ -39,6 +39,12 @@
 
 namespace pgz {
 
+// The CRC-32 of RFC 1952 over a piece of text (<= 1 GiB a call): zlib's unless the host has set a faster one of the same meaning -- kct_ingest.hip
+// hands over libdeflate's (carry-less multiplication: several GB/s where zlib's table walk does ~1) when libdeflate.so.0 is there.
+using crc_fn_t = unsigned (*)(unsigned, const void *, size_t);
+inline unsigned zlib_crc(unsigned c, const void *p, size_t n) { return (unsigned)crc32(c, (const Bytef *)p, (uInt)n); }
+inline crc_fn_t &crc_impl() { static crc_fn_t f = zlib_crc; return f; }
+
 struct Bits {   // LSB-first bit reader (RFC 1951 3.1.1); bytes beyond the end read as zero and set `over`
     const uint8_t *p;
     size_t n;
@@ -506,7 +512,7 @@ inline bool gunzip_parallel(const uint8_t *gz, size_t gz_size, uint8_t *out, siz
                     uint32_t c = 0;
                     for (size_t a = off[j]; a < off[j + 1];) {   // (zlib's crc32 takes a uInt length)
                         const size_t n = std::min<size_t>(off[j + 1] - a, 1u << 30);
-                        c = (uint32_t)crc32(c, out + a, (uInt)n);
+                        c = crc_impl()(c, out + a, n);
                         a += n;
                     }
                     crcs[j] = c;
@@ -698,7 +704,7 @@ inline bool inflate_window(MemberStream &st, size_t span, unsigned nthreads, Tex
         const size_t n = text.size(), parts = std::max<size_t>(1, std::min<size_t>(nthreads, n >> 20));
         std::vector<uint32_t> cr(parts, 0);
         std::vector<std::thread> th;
-        for (size_t q = 0; q < parts; ++q) th.emplace_back([&, q] { const size_t a = n * q / parts, e = n * (q + 1) / parts; uint32_t c = 0; for (size_t x = a; x < e;) { const size_t m = std::min<size_t>(e - x, 1u << 30); c = (uint32_t)crc32(c, text.data() + x, (uInt)m); x += m; } cr[q] = c; });
+        for (size_t q = 0; q < parts; ++q) th.emplace_back([&, q] { const size_t a = n * q / parts, e = n * (q + 1) / parts; uint32_t c = 0; for (size_t x = a; x < e;) { const size_t m = std::min<size_t>(e - x, 1u << 30); c = crc_impl()(c, text.data() + x, m); x += m; } cr[q] = c; });
         for (auto &x : th) x.join();
         for (size_t q = 0; q < parts; ++q) st.crc = (uint32_t)crc32_combine(st.crc, cr[q], (z_off_t)(n * (q + 1) / parts - n * q / parts));
         st.total += n;
