@@ -865,6 +865,7 @@ kct_status kct_release_scratch(kct_table *t) {
 
 kct_status kct_sync(kct_table *t) {
     KCT_BORROW(t);
+    KCT_DBG(t, "sync: call begins\n");
     KCT_TRY(use(t));  // flushes what deferred mode has buffered
     HIP_TRY(hipStreamSynchronize(t->stream));
     return KCT_OK;

@@ -428,7 +428,8 @@ struct Mapping {
     const unsigned char *p = nullptr;
     size_t size = 0;
     // (cheap by the time it runs: the pages were dropped by the parsers, segment by segment -- see parse_text)
-    ~Mapping() { if (p) munmap((void *)p, size); }
+    ~Mapping() { release(); }
+    void release() { if (p) munmap((void *)p, size); p = nullptr; size = 0; }
 };
 
 // The file reader's device calls (uploads, the staging kernel) are made by ONE long-lived thread: a thread that has made HIP calls
@@ -761,7 +762,8 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
                 // space's lock for reading): unmapping the 160 MB of the C2 file in one piece took 2.2 ms inside the call -- or, handed to a
                 // thread, held the lock against the NEXT call's mmap for 5.9 ms.  [lo, hi) is read by this thread only.
                 // (the anonymous text of a .gz inflated in one piece likewise: its pages are freed here; file_gz's 627 MB sample -8 %)
-                if ((p == map.p || p == whole.p) && hi > lo) {
+                static const bool no_zap = getenv("KCT_NO_ZAP") != nullptr;   // (measurement)
+                if (!no_zap && (p == map.p || p == whole.p) && hi > lo) {
                     const uintptr_t a0 = ((uintptr_t)p + lo + 4095) & ~(uintptr_t)4095, a1 = ((uintptr_t)p + hi) & ~(uintptr_t)4095;
                     if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_DONTNEED);
                 }
@@ -1024,6 +1026,11 @@ extern "C" kct_status kct_consume_file(kct_table *t, const char *path, int skip_
     }
     worker_end.end();
     KCT_DBG(t, "file: chunks uploaded and counted (or staged)\n");
+    whole.release();
+    KCT_DBG(t, "file: the inflated text unmapped\n");
+    gzmap.release();
+    map.release();
+    KCT_DBG(t, "file: the file unmapped\n");
     if (st == KCT_OK && queue.status != KCT_OK) { st = queue.status; set_err("%s", queue.msg.c_str()); }
     if (st != KCT_OK) return st;
     t->consumed += bases;

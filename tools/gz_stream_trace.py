@@ -2,7 +2,7 @@
 import os, sys, time, zlib
 sys.path.insert(0, ".")
 import numpy as np
-os.environ["KCT_GZIP_WHOLE_MAX"] = "0"
+os.environ.setdefault("KCT_GZIP_WHOLE_MAX", "0")   # (set it to 3000000000 to trace the one-piece route instead)
 from oxli_amd import KmerCountTable
 N = 2_000_000
 rng = np.random.default_rng(3)
